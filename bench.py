@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""
+bench.py -- from_differential solves/sec on the 1M-vertex plane (BASELINE.json metric, configs[3] / cfg4).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = one from_differential solve  M x = u  (M = I + 50 L_uniform of the 1000x1000 plane, u = M v,
+k = 3 right-hand sides, cold start x0 = 0, stop at ||r|| <= 1e-6 ||b|| per column), inputs resident in HBM.
+N = 1: the public API path (largesteps.parameterize.from_differential -> C ABI -> HIP PCG).
+N > 1: the same mesh cut into N contiguous vertex blocks, one rank per GPU, halo exchange + fused dot-product
+all-reduce over RCCL (largesteps.distributed); strong scaling (total work fixed).
+
+Prints ONE JSON line on rank 0 (contract: see the task description): metric/value/unit/... plus
+  "roofline":     HBM roofline of the dominant kernel (K1: SpMV + p.Ap), timed with HIP events on the solve's
+                  own stream in an extra profiled pass right after the timed region (same workload)
+  "cpu_baseline": the oracle's CPU "factor once / re-solve" direct solver (scipy SuperLU, fp64, 1 thread) on
+                  the same 1M-vertex system, rank 0 at N = 1 only (bounded: 1 factorisation + 3 solves)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "large-steps-pytorch_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured-achievable copy rate: 6290
+HBM_ACHIEVABLE_GBS = 6290.0
+WORKLOAD = "cfg4_plane1m"
+
+
+def algorithmic_bytes(V, nnz, k, iters, warm=False):
+    """CSR int32/fp32 contract format, k interleaved fp32 right-hand sides."""
+    b_spmv = 8 * nnz + 4 * (V + 1) + 2 * 4 * k * V              # K1: matrix + read p + write Ap
+    b_k2 = (4 * k + 1) * 4 * V + 2 * 4 * k * V                 # read x,p,Ap,r,dinv ; write x,r
+    b_k3 = (2 * k + 1) * 4 * V + 4 * k * V                     # read r,dinv,p ; write p
+    b_iter = b_spmv + b_k2 + b_k3
+    b_setup = (4 * k + 1) * 4 * V + (b_spmv if warm else 0)
+    return dict(k1=b_spmv, k2=b_k2, k3=b_k3, iter=b_iter, solve=b_setup + iters * b_iter)
+
+
+def cpu_baseline(v, f, lam, u_np, seconds_cap=120.0):
+    """Oracle direct solver timed on the host: factor once (reported, not counted), then re-solves."""
+    from oracle import laplacian as ol, solve as osv
+    r, c, val = ol.compute_matrix(v, f, lam)
+    t0 = time.perf_counter()
+    ds = osv.DirectSolver(r, c, val, v.shape[0])
+    t_factor = time.perf_counter() - t0
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        x = ds.solve(u_np)
+        times.append(time.perf_counter() - t0)
+        if sum(times) > seconds_cap:
+            break
+    err = float(np.abs(x - v).max())
+    t = float(np.median(times))
+    return dict(value=1.0 / t, unit="solves/s", cores=1, kind="port",
+                sample=f"oracle.DirectSolver (scipy SuperLU fp64, symmetric mode, 1 thread) on the same 1M-vertex system: "
+                       f"1 factorisation ({t_factor:.1f} s, not counted) + {len(times)} timed 3-RHS solves, median {t * 1e3:.0f} ms; "
+                       f"round-trip max-abs error {err:.1e}; host logical cores {os.cpu_count()}"), x
+
+
+def run_single(args):
+    from largesteps.geometry import compute_matrix
+    from largesteps.parameterize import to_differential, from_differential
+    from largesteps import parameterize, synthetic, _native
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    v, f, cfg = synthetic.config_mesh(args.workload)
+    lam = cfg["lambda_"]
+    tv, tf = torch.from_numpy(v).to(dev), torch.from_numpy(f).to(dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    M = compute_matrix(tv, tf, lam, alpha=cfg["alpha"], cotan=cfg["cotan"])
+    torch.cuda.synchronize()
+    t_assemble = time.perf_counter() - t0
+    u = to_differential(M, tv)
+    V, nnz, k = v.shape[0], M._nnz(), 3
+    method = "Cholesky"                                   # cold start, rtol 1e-6 (the package default)
+
+    x = None
+    for _ in range(args.warmup):
+        x = from_differential(M, u, method)
+    solver = parameterize._cache[(id(M), method)][0] if args.warmup else None
+    if solver is None:
+        x = from_differential(M, u, method)
+        solver = parameterize._cache[(id(M), method)][0]
+    if args.variant is not None:
+        solver.set_option("variant", args.variant)
+    if args.grid:
+        solver.set_option("grid", args.grid)
+    if args.check_every:
+        solver.set_option("check_every", args.check_every)
+    if args.variant is not None or args.grid or args.check_every:
+        x = from_differential(M, u, method)
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x = from_differential(M, u, method)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    info = dict(solver.last_info)
+    ms = elapsed / args.steps * 1e3
+
+    # profiled pass: HIP events around every kernel on the solve's own stream
+    solver.set_option("profile", 1)
+    prof = np.zeros(3)
+    piters = 0
+    for _ in range(max(1, min(args.steps, 5))):
+        from_differential(M, u, method)
+        a, b, c, it = solver.kernel_profile()
+        prof += (a, b, c)
+        piters += it
+    solver.set_option("profile", 0)
+    k_ms = prof / max(piters, 1)
+    bts = algorithmic_bytes(V, nnz, k, info["iterations"])
+    k1_gbs = bts["k1"] / (k_ms[0] * 1e-3) / 1e9
+    err = float((x - tv).abs().max())
+    out = dict(
+        metric="from_differential_solves_per_sec", value=1e3 / ms, unit="solves/s", n_gpus=1, steps=args.steps,
+        warmup=args.warmup, ms_per_step=ms, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32",
+        data="synthetic",
+        config=dict(workload=f"{args.workload}: 1000x1000 plane, V={V}, nnz(M)={nnz}, M=I+{lam:g}*L_uniform, u=M v, k=3, "
+                             f"cold start, rtol=1e-6", solver="HIP Jacobi-PCG (3 kernels/iteration, SELL-64)",
+                    iterations=info["iterations"], converged=info["converged"],
+                    rel_residual=[float(r / b) for r, b in zip(info["rnorm"], info["bnorm"])],
+                    max_abs_err_vs_v=err, assemble_ms=t_assemble * 1e3,
+                    solve_bytes=bts["solve"], solve_gbs=bts["solve"] / (ms * 1e-3) / 1e9,
+                    solve_frac_of_8tbs=bts["solve"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    kernel_us=dict(k1_spmv_dot=k_ms[0] * 1e3, k2_update=k_ms[1] * 1e3, k3_direction=k_ms[2] * 1e3),
+                    device=torch.cuda.get_device_name(0)),
+        roofline=dict(bound="hbm", kernel="k_spmv_dot<3,SELL-64> (K1: Ap = M p, partial p.Ap)", achieved=k1_gbs,
+                      peak=HBM_PEAK_GBS, unit="GB/s", frac=k1_gbs / HBM_PEAK_GBS, frac_of_achievable=k1_gbs / HBM_ACHIEVABLE_GBS,
+                      bytes_per_launch=bts["k1"], avg_launch_us=k_ms[0] * 1e3, launches_timed=int(piters), traffic=None),
+    )
+    if not args.no_cpu_baseline:
+        base, _ = cpu_baseline(v, f, lam, u.cpu().numpy())
+        out["cpu_baseline"] = base
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out), flush=True)
+
+
+def run_distributed(args):
+    import torch.distributed as dist
+    from largesteps import distributed as lsd
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist.init_process_group("nccl", device_id=dev)
+    out = lsd.bench_sharded(args.workload, dev, steps=args.steps, warmup=args.warmup)
+    if rank == 0:
+        bts = algorithmic_bytes(out["V"], out["nnz"], 3, out["iterations"])
+        ms = out["ms_per_step"]
+        res = dict(
+            metric="from_differential_solves_per_sec", value=1e3 / ms, unit="solves/s", n_gpus=world, steps=args.steps,
+            warmup=args.warmup, ms_per_step=ms, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32",
+            data="synthetic",
+            config=dict(workload=f"{args.workload}: V={out['V']}, nnz(M)={out['nnz']}, k=3, cold start, rtol=1e-6, "
+                                 f"{world} contiguous vertex blocks", solver=out["solver"], iterations=out["iterations"],
+                        converged=out["converged"], max_abs_err_vs_v=out["err"], halo_vertices=out["halo"],
+                        solve_bytes=bts["solve"], solve_gbs=bts["solve"] / (ms * 1e-3) / 1e9),
+            roofline=dict(bound="hbm", kernel=out["kernel"], achieved=out["k1_gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
+                          frac=out["k1_gbs"] / HBM_PEAK_GBS, traffic=None),
+            cpu_baseline=None,
+        )
+        print(json.dumps(res), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=WORKLOAD)
+    ap.add_argument("--variant", type=int, default=None, help="matrix access variant of K1 (0 CSR+LDS, 1 CSR direct, 2 SELL-64)")
+    ap.add_argument("--grid", type=int, default=0)
+    ap.add_argument("--check-every", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    if args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        run_distributed(args)
+    else:
+        run_single(args)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,131 @@
+/*
+ * largesteps_hip.h -- C ABI of liblargesteps_hip.so (MI355X / gfx950).
+ *
+ * The drop-in boundary of the `largesteps` parameterization hot path. Every entry point takes plain
+ * device pointers, sizes, a HIP device ordinal and a hipStream_t passed as void*; no torch types, no
+ * C++ types, nothing is thrown across the boundary. Every function returns an int status:
+ *       0            success
+ *      <0            LS_E_* (invalid argument / state, see below)
+ *      >0            a hipError_t raised by the runtime
+ * ls_last_error() returns a thread-local human readable message for the last non-zero status.
+ *
+ * All pointers are DEVICE pointers unless the parameter name starts with `h_` (host).
+ * Work is enqueued on `stream`; functions that have to return a size to the host (marked SYNC)
+ * synchronise that stream once.
+ *
+ * Reference interface each entry point replaces (paths relative to rgl-epfl/large-steps-pytorch):
+ *   ls_assemble_*        largesteps/geometry.py:65-94  (laplacian_uniform), :3-63 (laplacian_cot),
+ *                        :96-133 (compute_matrix: M = a I + b L, coalesced)
+ *   ls_csr_from_coo      the implicit COO->CSR conversion inside torch's sparse mm
+ *                        (largesteps/parameterize.py:30) for a matrix that was not built by ls_assemble_*
+ *   ls_spmv              largesteps/parameterize.py:30  (to_differential: u = M @ v)
+ *   ls_solver_*          largesteps/solvers.py:26-39 (CholeskySolver.__init__/solve -> cholespy) and
+ *                        :41-126 (ConjugateGradientSolver); one handle == one cached solver object of
+ *                        largesteps/parameterize.py:48-59
+ *   ls_adam_uniform_step largesteps/optimize.py:18-41
+ */
+#ifndef LARGESTEPS_HIP_H
+#define LARGESTEPS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LS_VERSION 100 /* 0.1.0 */
+
+#define LS_OK 0
+#define LS_E_INVALID (-1)      /* bad argument (null pointer, negative size, unsupported k, ...) */
+#define LS_E_INDEX (-2)        /* a face index is outside [0, V) */
+#define LS_E_WORKSPACE (-3)    /* workspace too small */
+#define LS_E_OVERFLOW (-4)     /* problem does not fit the int32 index space of the kernels */
+#define LS_E_STATE (-5)        /* call sequence violated (e.g. fill before pattern) */
+#define LS_E_NOT_CONVERGED (-6) /* solver hit max_iter or a non-finite residual; x holds the last iterate */
+
+#define LS_LAPLACIAN_UNIFORM 0
+#define LS_LAPLACIAN_COT 1
+
+int ls_version(void);
+const char* ls_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Assembly of M = a*I + b*L as CSR (int32 rowptr/col, fp32 val) + the row-major sorted, duplicate
+ * free COO index list torch's coalesce() would produce (geometry.py:133).
+ *
+ *   1. ls_assemble_workspace_bytes -> size the caller must allocate (device memory)
+ *   2. ls_assemble_pattern  (SYNC)  -> fills rowptr[V+1], returns nnz through h_nnz
+ *   3. caller allocates col[nnz], val[nnz], coo_idx[2*nnz] (int64: row indices then column indices)
+ *   4. ls_assemble_fill             -> writes them (same V, F, workspace); optionally dinv[V] = 1/M_ii
+ *
+ * faces: (F,3) row-major, index width idx_bytes in {4, 8}. verts: (V,3) fp32 row-major, only read
+ * for LS_LAPLACIAN_COT (may be NULL otherwise). `a` and `b` are the already fp32-rounded scalars
+ * (a=1,b=lambda  or  a=1-alpha,b=alpha).
+ * --------------------------------------------------------------------------------------------- */
+int ls_assemble_workspace_bytes(int64_t V, int64_t F, size_t* h_bytes);
+int ls_assemble_pattern(const void* faces, int idx_bytes, int64_t F, int64_t V, const float* verts,
+                        int kind, float a, float b, void* workspace, size_t workspace_bytes,
+                        int32_t* rowptr, int64_t* h_nnz, int device, void* stream);
+int ls_assemble_fill(const void* workspace, size_t workspace_bytes, int64_t V, int64_t F, const int32_t* rowptr,
+                     int32_t* col, float* val, int64_t* coo_idx, int64_t nnz, float* dinv, int device,
+                     void* stream);
+
+/* Foreign matrix: coalesced (row-major sorted, unique) COO int64 -> CSR int32. rowptr[V+1], col[nnz];
+ * val is shared with the COO tensor (same order) so only indices are produced. dinv[V] = 1/M_ii optional.
+ * scratch: >= 4*(V+1) + 4*((V+1)/2048+4) + 1024 bytes. SYNC (validates sortedness / index range). */
+int ls_csr_from_coo(const int64_t* coo_rows, const int64_t* coo_cols, const float* vals, int64_t nnz,
+                    int64_t V, int32_t* rowptr, int32_t* col, float* dinv, void* scratch,
+                    size_t scratch_bytes, int device, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * y[V,k] = M x[V,k]   (row-major, leading dimension = k, fp32). 1 <= k <= 64.
+ * variant: 0 = default (LDS-staged CSR), 1 = thread-per-row direct CSR (kept for A/B measurements).
+ * --------------------------------------------------------------------------------------------- */
+int ls_spmv(const int32_t* rowptr, const int32_t* col, const float* val, int64_t V, int64_t nnz,
+            const float* x, float* y, int k, int variant, int device, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Jacobi-preconditioned conjugate gradient on M (SPD). One handle per matrix; owns its workspace
+ * (r, p, Ap, dinv, reduction scratch) sized for `kmax` right-hand-side columns (1..4).
+ * The CSR arrays are NOT copied: they must outlive the handle.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct ls_solver ls_solver;
+
+typedef struct ls_solve_info {
+    int32_t iterations;   /* iterations executed until every column met its threshold */
+    int32_t converged;    /* 1 if every column met its threshold */
+    double  rnorm[4];     /* final ||r||_2 per column (recursively updated residual) */
+    double  bnorm[4];     /* ||b||_2 per column */
+} ls_solve_info;
+
+int ls_solver_create(const int32_t* rowptr, const int32_t* col, const float* val, int64_t V,
+                     int64_t nnz, int kmax, int device, void* stream, ls_solver** h_out);
+int ls_solver_destroy(ls_solver* s);
+/* x0 may be NULL (cold start, x0 = 0). b, x, x0: (V,k) fp32 row-major contiguous; x may alias x0 but not b.
+ * A column is converged when ||r||_2 <= max(rtol*||b||_2, atol). SYNC (the host polls convergence).
+ * Returns LS_E_NOT_CONVERGED (info still filled) if max_iter is hit. */
+int ls_solver_solve(ls_solver* s, const float* b, const float* x0, float* x, int k, double rtol,
+                    double atol, int max_iter, ls_solve_info* h_info, void* stream);
+/* knobs for measurements: name in {"variant" (0 CSR+LDS, 1 CSR direct, 2 SELL-64), "check_every", "grid",
+ * "profile"}; unknown name -> LS_E_INVALID */
+int ls_solver_set(ls_solver* s, const char* name, int value);
+/* With "profile"=1 every solve brackets its three kernels per iteration with HIP events on the solve's
+ * stream; this returns the accumulated milliseconds of K1 (SpMV+dot), K2 (update), K3 (direction) over the
+ * h_iters iterations that really ran in the last solve. */
+int ls_solver_profile(const ls_solver* s, double* h_ms3, int* h_iters);
+/* bytes the handle allocated on the device */
+int ls_solver_workspace_bytes(const ls_solver* s, size_t* h_bytes);
+
+/* ------------------------------------------------------------------------------------------------
+ * AdamUniform step (optimize.py:18-41) on n contiguous fp32 elements, two kernels, no host sync:
+ *   g1 = b1 g1 + (1-b1) g ; g2 = b2 g2 + (1-b2) g^2 ; p -= lr * (g1/(1-b1^t)) / (1e-8 + max sqrt(g2/(1-b2^t)))
+ * scratch: at least 4096 bytes of device memory owned by the caller.
+ * --------------------------------------------------------------------------------------------- */
+int ls_adam_uniform_step(float* param, const float* grad, float* g1, float* g2, int64_t n, float lr,
+                         float beta1, float beta2, int step, void* scratch, int device, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LARGESTEPS_HIP_H */

@@ -1,0 +1,64 @@
+// adam.hip -- AdamUniform step (largesteps/optimize.py:18-41): Adam whose per-element sqrt(v_hat) is
+// replaced by one global max. Two kernels, no host sync: (1) moment update + per-workgroup max of
+// sqrt(g2/(1-b2^t)), (2) every workgroup reduces the <= 1024 partial maxima and applies the step.
+#include "common.h"
+#include <algorithm>
+#include <math.h>
+
+namespace ls {
+
+__global__ __launch_bounds__(BLOCK) void k_adam_moments(const float* __restrict__ grad, float* __restrict__ g1, float* __restrict__ g2,
+                                                        int64_t n, float b1, float b2, float inv_c2, float* __restrict__ pmax) {
+    __shared__ float s_max[BLOCK / WAVE];
+    float m = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        const float g = grad[i];
+        const float a = g1[i] * b1 + (1.0f - b1) * g;
+        const float v = g2[i] * b2 + (1.0f - b2) * (g * g);
+        g1[i] = a;
+        g2[i] = v;
+        m = fmaxf(m, sqrtf(v * inv_c2));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & (WAVE - 1)) == 0) s_max[threadIdx.x / WAVE] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int j = 1; j < BLOCK / WAVE; ++j) m = fmaxf(m, s_max[j]);
+        pmax[blockIdx.x] = m;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_adam_apply(float* __restrict__ param, const float* __restrict__ g1, int64_t n, float lr,
+                                                      float inv_c1, const float* __restrict__ pmax, int G) {
+    __shared__ float s_max[BLOCK / WAVE];
+    float m = 0.0f;
+    for (int g = threadIdx.x; g < G; g += BLOCK) m = fmaxf(m, pmax[g]);
+    m = wave_max(m);
+    if ((threadIdx.x & (WAVE - 1)) == 0) s_max[threadIdx.x / WAVE] = m;
+    __syncthreads();
+    m = s_max[0];
+    for (int j = 1; j < BLOCK / WAVE; ++j) m = fmaxf(m, s_max[j]);
+    const float denom = 1e-8f + m;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK)
+        param[i] = param[i] - lr * ((g1[i] * inv_c1) / denom);
+}
+
+}  // namespace ls
+
+using namespace ls;
+
+extern "C" int ls_adam_uniform_step(float* param, const float* grad, float* g1, float* g2, int64_t n, float lr, float beta1,
+                                    float beta2, int step, void* scratch, int device, void* stream) {
+    LS_REQUIRE(n >= 0 && (n == 0 || (param && grad && g1 && g2)) && scratch, LS_E_INVALID, "ls_adam_uniform_step: null pointer or negative size");
+    LS_REQUIRE(step >= 1, LS_E_INVALID, "ls_adam_uniform_step: step must be >= 1");
+    if (n == 0) return LS_OK;
+    DeviceGuard g(device);
+    LS_HIP(g.err);
+    const int G = (int)std::min<int64_t>(div_up(n, BLOCK), 1024);
+    const float inv_c1 = (float)(1.0 / (1.0 - pow((double)beta1, (double)step)));
+    const float inv_c2 = (float)(1.0 / (1.0 - pow((double)beta2, (double)step)));
+    hipLaunchKernelGGL(k_adam_moments, dim3(G), dim3(BLOCK), 0, (hipStream_t)stream, grad, g1, g2, n, beta1, beta2, inv_c2, (float*)scratch);
+    hipLaunchKernelGGL(k_adam_apply, dim3(G), dim3(BLOCK), 0, (hipStream_t)stream, param, g1, n, lr, inv_c1, (const float*)scratch, G);
+    LS_HIP(hipGetLastError());
+    return LS_OK;
+}

@@ -1,0 +1,459 @@
+// assemble.hip -- sort-free CSR assembly of M = a*I + b*L (uniform / cotangent Laplacian) on gfx950.
+//
+// Replaces largesteps/geometry.py:3-133 of the reference, which builds the same matrix through
+// torch.unique(dim=1) + sparse add + coalesce() (several device-wide radix sorts and host syncs).
+// Here:   count half-edges per vertex (atomics) -> scan -> scatter half-edges into per-row slots
+//         -> per-row sort + merge (rows are ~12 slots long) -> scan -> LDS-staged coalesced emit.
+// Semantics reproduced exactly:
+//   * uniform: every undirected edge once per direction (dedup), diag = #distinct neighbours,
+//     off-diag = fl(b*(-1)), diag = fl(a + fl(b*deg)); unreferenced vertices keep only the a*I entry.
+//   * cot: per face fp32 Heron area with the 1e-12 clamp, weights /4, contributions of the incident
+//     faces are scaled first (fl(b*(-w))) and then summed; diag = fl(a + fl(b * sum_w)).
+// The fp32 operation order of the cotangents is the one of oracle/laplacian.py (explicit fma chain
+// in the edge norm, everything else unfused): this file is compiled with -ffp-contract=off.
+#include "common.h"
+#include <algorithm>
+
+#pragma STDC FP_CONTRACT OFF
+
+namespace ls {
+
+// ------------------------------------------------------------------------------------------------
+// workspace layout (shared by ls_assemble_pattern and ls_assemble_fill; depends on V and F only)
+// ------------------------------------------------------------------------------------------------
+struct AsmLayout {
+    size_t cnt, slot_ptr, fill, ucnt, diag, flags, bsum, slot_col, slot_val, total;
+    int64_t nslots;
+    AsmLayout(int64_t V, int64_t F) {
+        auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
+        nslots = 6 * F;
+        size_t o = 0;
+        cnt = o;       o = al(o + 4 * (size_t)(V + 1));
+        slot_ptr = o;  o = al(o + 4 * (size_t)(V + 1));
+        fill = o;      o = al(o + 4 * (size_t)(V + 1));
+        ucnt = o;      o = al(o + 4 * (size_t)(V + 1));
+        diag = o;      o = al(o + 4 * (size_t)(V + 1));
+        flags = o;     o = al(o + 64);
+        bsum = o;      o = al(o + 4 * (size_t)((V + 1) / 2048 + 4));
+        slot_col = o;  o = al(o + 4 * (size_t)nslots);
+        slot_val = o;  o = al(o + 4 * (size_t)nslots);
+        total = o;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// exclusive scan of int32 (three kernels; the middle one is a single workgroup)
+// ------------------------------------------------------------------------------------------------
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_CHUNK = BLOCK * SCAN_ITEMS;   // 2048 elements per workgroup
+
+__device__ __forceinline__ int wave_inclusive_scan(int x) {
+    const int lane = threadIdx.x & (WAVE - 1);
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        int y = __shfl_up(x, off, WAVE);
+        if (lane >= off) x += y;
+    }
+    return x;
+}
+
+// exclusive scan of one value per thread across the block; returns exclusive prefix, *total = block sum
+__device__ __forceinline__ int block_exclusive_scan(int x, int* total, int* smem /* BLOCK/WAVE + 1 */) {
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    int inc = wave_inclusive_scan(x);
+    if (lane == WAVE - 1) smem[w] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int j = 0; j < BLOCK / WAVE; ++j) { int t = smem[j]; smem[j] = run; run += t; }
+        smem[BLOCK / WAVE] = run;
+    }
+    __syncthreads();
+    int res = inc - x + smem[w];
+    *total = smem[BLOCK / WAVE];
+    __syncthreads();
+    return res;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_scan_reduce(const int* __restrict__ in, int64_t n, int* __restrict__ bsum) {
+    __shared__ int smem[BLOCK / WAVE + 1];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) if (base + i < n) s += in[base + i];
+    int total;
+    block_exclusive_scan(s, &total, smem);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_scan_bsums(int* __restrict__ bsum, int nb) {   // <<<1, BLOCK>>>
+    __shared__ int smem[BLOCK / WAVE + 1];
+    int carry = 0;
+    for (int base = 0; base < nb; base += BLOCK) {
+        const int i = base + threadIdx.x;
+        int v = (i < nb) ? bsum[i] : 0;
+        int total;
+        int ex = block_exclusive_scan(v, &total, smem);
+        if (i < nb) bsum[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) bsum[nb] = carry;   // grand total
+}
+
+__global__ __launch_bounds__(BLOCK) void k_scan_final(const int* __restrict__ in, int64_t n, const int* __restrict__ bsum,
+                                                      int* __restrict__ out /* n + 1 entries */) {
+    __shared__ int smem[BLOCK / WAVE + 1];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) { v[i] = (base + i < n) ? in[base + i] : 0; s += v[i]; }
+    int total;
+    int run = block_exclusive_scan(s, &total, smem) + bsum[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        if (base + i < n) out[base + i] = run;
+        run += v[i];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = bsum[gridDim.x];
+}
+
+// out[0..n] = exclusive scan of in[0..n); out[n] = total. `in` and `out` may not alias.
+static int exclusive_scan(const int* in, int64_t n, int* out, int* bsum, hipStream_t st) {
+    const int nb = div_up(n, SCAN_CHUNK);
+    hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(BLOCK), 0, st, in, n, bsum);
+    hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(BLOCK), 0, st, bsum, nb);
+    hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(BLOCK), 0, st, in, n, bsum, out);
+    LS_HIP(hipGetLastError());
+    return LS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1. count half-edges per row, validate indices
+// ------------------------------------------------------------------------------------------------
+template <typename IdxT>
+__global__ __launch_bounds__(BLOCK) void k_count(const IdxT* __restrict__ faces, int64_t F, int64_t V,
+                                                 int* __restrict__ cnt, int* __restrict__ flags) {
+    for (int64_t f = (int64_t)blockIdx.x * BLOCK + threadIdx.x; f < F; f += (int64_t)gridDim.x * BLOCK) {
+        const int64_t i0 = (int64_t)faces[3 * f + 0], i1 = (int64_t)faces[3 * f + 1], i2 = (int64_t)faces[3 * f + 2];
+        if (i0 < 0 || i1 < 0 || i2 < 0 || i0 >= V || i1 >= V || i2 >= V) { flags[0] = 1; continue; }
+        // each of the 3 edges puts one slot into the rows of both of its end points
+        atomicAdd(&cnt[i0], 2);
+        atomicAdd(&cnt[i1], 2);
+        atomicAdd(&cnt[i2], 2);
+    }
+}
+
+// fp32 cotangents of one face in the reference's operation order (geometry.py:20-41, oracle/laplacian.py)
+__device__ __forceinline__ float edge_norm(float ax, float ay, float az, float bx, float by, float bz) {
+    const float x = ax - bx, y = ay - by, z = az - bz;
+    return sqrtf(fmaf(z, z, fmaf(y, y, x * x)));
+}
+
+__device__ __forceinline__ void face_cot(const float* __restrict__ verts, int64_t i0, int64_t i1, int64_t i2,
+                                         float& cota, float& cotb, float& cotc) {
+    const float x0 = verts[3 * i0], y0 = verts[3 * i0 + 1], z0 = verts[3 * i0 + 2];
+    const float x1 = verts[3 * i1], y1 = verts[3 * i1 + 1], z1 = verts[3 * i1 + 2];
+    const float x2 = verts[3 * i2], y2 = verts[3 * i2 + 1], z2 = verts[3 * i2 + 2];
+    const float A = edge_norm(x1, y1, z1, x2, y2, z2);   // opposite v0
+    const float B = edge_norm(x0, y0, z0, x2, y2, z2);   // opposite v1
+    const float C = edge_norm(x0, y0, z0, x1, y1, z1);   // opposite v2
+    const float s = 0.5f * ((A + B) + C);
+    float prod = ((s * (s - A)) * (s - B)) * (s - C);
+    prod = prod < 1e-12f ? 1e-12f : prod;                // clamp_(min=1e-12); NaN passes through like torch
+    const float area = sqrtf(prod);
+    const float A2 = A * A, B2 = B * B, C2 = C * C;
+    cota = (((B2 + C2) - A2) / area) / 4.0f;
+    cotb = (((A2 + C2) - B2) / area) / 4.0f;
+    cotc = (((A2 + B2) - C2) / area) / 4.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2. scatter half-edges into the slots of their rows
+// ------------------------------------------------------------------------------------------------
+template <typename IdxT, bool COT>
+__global__ __launch_bounds__(BLOCK) void k_scatter(const IdxT* __restrict__ faces, int64_t F, int64_t V,
+                                                   const float* __restrict__ verts, const int* __restrict__ slot_ptr,
+                                                   int* __restrict__ fill, int* __restrict__ slot_col,
+                                                   float* __restrict__ slot_val) {
+    for (int64_t f = (int64_t)blockIdx.x * BLOCK + threadIdx.x; f < F; f += (int64_t)gridDim.x * BLOCK) {
+        const int64_t i0 = (int64_t)faces[3 * f + 0], i1 = (int64_t)faces[3 * f + 1], i2 = (int64_t)faces[3 * f + 2];
+        if (i0 < 0 || i1 < 0 || i2 < 0 || i0 >= V || i1 >= V || i2 >= V) continue;
+        float wa = 1.0f, wb = 1.0f, wc = 1.0f;
+        if (COT) face_cot(verts, i0, i1, i2, wa, wb, wc);
+        // geometry.py:43-50: cota -> (f1,f2), cotb -> (f2,f0), cotc -> (f0,f1), then symmetrised
+        const int64_t ep[3] = {i1, i2, i0}, eq[3] = {i2, i0, i1};
+        const float ew[3] = {wa, wb, wc};
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            int s = slot_ptr[ep[e]] + atomicAdd(&fill[ep[e]], 1);
+            slot_col[s] = (int)eq[e];
+            slot_val[s] = ew[e];
+            s = slot_ptr[eq[e]] + atomicAdd(&fill[eq[e]], 1);
+            slot_col[s] = (int)ep[e];
+            slot_val[s] = ew[e];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3. per row: sort slots by (col, weight), merge duplicates, produce the off-diagonal M entries in
+//    place (front of the row's slot range) and the diagonal value. One thread per row.
+// ------------------------------------------------------------------------------------------------
+template <bool COT>
+__global__ __launch_bounds__(BLOCK) void k_row_merge(int64_t V, const int* __restrict__ slot_ptr, int* __restrict__ slot_col,
+                                                     float* __restrict__ slot_val, float a, float b,
+                                                     int* __restrict__ ucnt, float* __restrict__ diag) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= V) return;
+    const int s0 = slot_ptr[i], n = slot_ptr[i + 1] - s0;
+    int* c = slot_col + s0;
+    float* w = slot_val + s0;
+    // insertion sort (rows are short: ~2 x valence); ties on col are ordered by weight so that the
+    // summation order, hence the fp32 result, does not depend on the atomics' arrival order
+    for (int k = 1; k < n; ++k) {
+        const int ck = c[k];
+        const float wk = w[k];
+        int j = k - 1;
+        while (j >= 0 && (c[j] > ck || (c[j] == ck && w[j] > wk))) { c[j + 1] = c[j]; w[j + 1] = w[j]; --j; }
+        c[j + 1] = ck;
+        w[j + 1] = wk;
+    }
+    int nu = 0;          // distinct off-diagonal columns written so far
+    int ndistinct = 0;   // distinct columns including a self loop (uniform degree bookkeeping)
+    bool self = false;
+    float wsum = 0.0f;   // cot: sum of all slot weights of this row (= column sum of W, geometry.py:59)
+    float selfacc = 0.0f;
+    int k = 0;
+    while (k < n) {
+        const int ck = c[k];
+        float acc = 0.0f;
+        int k2 = k;
+        while (k2 < n && c[k2] == ck) {
+            if (COT) { wsum = wsum + w[k2]; acc = acc + b * (-w[k2]); }
+            ++k2;
+        }
+        ++ndistinct;
+        if (ck == (int)i) {
+            self = true;
+            selfacc = acc;
+        } else {
+            c[nu] = ck;                       // nu <= k: never overwrites unread slots
+            w[nu] = COT ? acc : b * -1.0f;
+            ++nu;
+        }
+        k = k2;
+    }
+    float d;
+    if (COT) {
+        float t = b * wsum;
+        if (self) t = t + selfacc;
+        d = a + t;
+    } else {
+        // L_ii = (#distinct adjacency entries, a self loop included) - (1 if self loop)   [geometry.py:86-94]
+        const float lii = (float)(ndistinct - (self ? 1 : 0));
+        d = a + b * lii;
+    }
+    diag[i] = d;
+    ucnt[i] = nu + 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 4. emit CSR (+ COO int64 indices, + 1/diag). Rows of a tile are staged in LDS in their final
+//    order so that the global stores of col/val/coo are fully coalesced.
+// ------------------------------------------------------------------------------------------------
+constexpr int EMIT_CAP = 6144;   // entries staged per tile (256 rows x 24); larger tiles store directly
+
+__global__ __launch_bounds__(BLOCK) void k_emit(int64_t V, const int* __restrict__ slot_ptr, const int* __restrict__ slot_col,
+                                                const float* __restrict__ slot_val, const float* __restrict__ diag,
+                                                const int* __restrict__ rowptr, int* __restrict__ col, float* __restrict__ val,
+                                                int64_t* __restrict__ coo_row, int64_t* __restrict__ coo_col,
+                                                float* __restrict__ dinv) {
+    __shared__ int s_col[EMIT_CAP];
+    __shared__ float s_val[EMIT_CAP];
+    __shared__ unsigned short s_row[EMIT_CAP];
+    const int64_t r0 = (int64_t)blockIdx.x * TILE_ROWS;
+    const int64_t r1 = min(r0 + (int64_t)TILE_ROWS, V);
+    const int base = rowptr[r0], total = rowptr[r1] - base;
+    const bool staged = total <= EMIT_CAP;
+    const int64_t i = r0 + threadIdx.x;
+    if (i < r1) {
+        const int n = rowptr[i + 1] - rowptr[i] - 1;   // off-diagonal entries
+        const int* c = slot_col + slot_ptr[i];
+        const float* w = slot_val + slot_ptr[i];
+        const float d = diag[i];
+        if (dinv) dinv[i] = 1.0f / d;
+        int o = rowptr[i] - base;
+        auto put = [&](int ck, float wk) {
+            if (staged) { s_col[o] = ck; s_val[o] = wk; s_row[o] = (unsigned short)threadIdx.x; }
+            else {
+                col[base + o] = ck; val[base + o] = wk;
+                if (coo_row) { coo_row[base + o] = i; coo_col[base + o] = ck; }
+            }
+            ++o;
+        };
+        int k = 0;
+        while (k < n && c[k] < (int)i) { put(c[k], w[k]); ++k; }   // the self column was merged into d
+        put((int)i, d);
+        while (k < n) { put(c[k], w[k]); ++k; }
+    }
+    if (!staged) return;
+    __syncthreads();
+    for (int t = threadIdx.x; t < total; t += BLOCK) {
+        const int ck = s_col[t];
+        col[base + t] = ck;
+        val[base + t] = s_val[t];
+        if (coo_row) { coo_row[base + t] = r0 + s_row[t]; coo_col[base + t] = ck; }
+    }
+}
+
+// foreign COO (coalesced) -> CSR
+__global__ __launch_bounds__(BLOCK) void k_coo_hist(const int64_t* __restrict__ rows, const int64_t* __restrict__ cols,
+                                                    const float* __restrict__ vals, int64_t nnz, int64_t V,
+                                                    int* __restrict__ cnt, int* __restrict__ col, float* __restrict__ diagv,
+                                                    int* __restrict__ flags) {
+    for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t < nnz; t += (int64_t)gridDim.x * BLOCK) {
+        const int64_t r = rows[t], c = cols[t];
+        if (r < 0 || r >= V || c < 0 || c >= V) { flags[0] = 1; continue; }
+        if (t > 0) {   // must be row-major sorted and duplicate free (torch coalesce order)
+            const int64_t pr = rows[t - 1], pc = cols[t - 1];
+            if (pr > r || (pr == r && pc >= c)) flags[1] = 1;
+        }
+        atomicAdd(&cnt[r], 1);
+        col[t] = (int)c;
+        if (r == c && diagv) diagv[r] = vals[t];
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_invert(float* __restrict__ d, int64_t V, int* __restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= V) return;
+    const float v = d[i];
+    if (!(v > 0.0f)) flags[2] = 1;    // Jacobi needs a positive diagonal (SPD matrix)
+    d[i] = 1.0f / v;
+}
+
+}  // namespace ls
+
+using namespace ls;
+
+extern "C" int ls_assemble_workspace_bytes(int64_t V, int64_t F, size_t* h_bytes) {
+    LS_REQUIRE(h_bytes && V >= 0 && F >= 0, LS_E_INVALID, "ls_assemble_workspace_bytes: bad argument");
+    LS_REQUIRE(V < (int64_t)2000000000 && 6 * F < (int64_t)2000000000, LS_E_OVERFLOW,
+               "mesh too large for the int32 index space (V=%lld F=%lld)", (long long)V, (long long)F);
+    *h_bytes = AsmLayout(V, F).total;
+    return LS_OK;
+}
+
+extern "C" int ls_assemble_pattern(const void* faces, int idx_bytes, int64_t F, int64_t V, const float* verts, int kind,
+                                   float a, float b, void* workspace, size_t workspace_bytes, int32_t* rowptr,
+                                   int64_t* h_nnz, int device, void* stream) {
+    LS_REQUIRE(V >= 0 && F >= 0 && (F == 0 || faces) && workspace && rowptr && h_nnz, LS_E_INVALID,
+               "ls_assemble_pattern: null pointer or negative size");
+    LS_REQUIRE(idx_bytes == 4 || idx_bytes == 8, LS_E_INVALID, "faces must be int32 or int64 (idx_bytes=%d)", idx_bytes);
+    LS_REQUIRE(kind == LS_LAPLACIAN_UNIFORM || kind == LS_LAPLACIAN_COT, LS_E_INVALID, "unknown Laplacian kind %d", kind);
+    LS_REQUIRE(kind == LS_LAPLACIAN_UNIFORM || verts || F == 0, LS_E_INVALID, "cotangent Laplacian needs vertex positions");
+    LS_REQUIRE(V < (int64_t)2000000000 && 6 * F < (int64_t)2000000000, LS_E_OVERFLOW, "mesh too large for int32 indices");
+    const AsmLayout L(V, F);
+    LS_REQUIRE(workspace_bytes >= L.total, LS_E_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, L.total);
+    DeviceGuard g(device);
+    LS_HIP(g.err);
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    int* cnt = (int*)(ws + L.cnt);
+    int* slot_ptr = (int*)(ws + L.slot_ptr);
+    int* fill = (int*)(ws + L.fill);
+    int* ucnt = (int*)(ws + L.ucnt);
+    float* diag = (float*)(ws + L.diag);
+    int* flags = (int*)(ws + L.flags);
+    int* bsum = (int*)(ws + L.bsum);
+    int* slot_col = (int*)(ws + L.slot_col);
+    float* slot_val = (float*)(ws + L.slot_val);
+
+    // cnt, slot_ptr, fill, ucnt, diag, flags are contiguous: one memset
+    LS_HIP(hipMemsetAsync(ws, 0, L.bsum, st));
+    if (V == 0) { LS_HIP(hipMemsetAsync(rowptr, 0, 4, st)); *h_nnz = 0; LS_HIP(hipStreamSynchronize(st)); return LS_OK; }
+    const int fgrid = F ? (int)std::min<int64_t>(div_up(F, BLOCK), 8192) : 1;
+    if (F) {
+        if (idx_bytes == 4) hipLaunchKernelGGL(k_count<int32_t>, dim3(fgrid), dim3(BLOCK), 0, st, (const int32_t*)faces, F, V, cnt, flags);
+        else hipLaunchKernelGGL(k_count<int64_t>, dim3(fgrid), dim3(BLOCK), 0, st, (const int64_t*)faces, F, V, cnt, flags);
+    }
+    int rc = exclusive_scan(cnt, V, slot_ptr, bsum, st);
+    if (rc) return rc;
+    if (F) {
+        const bool cot = kind == LS_LAPLACIAN_COT;
+        if (idx_bytes == 4) {
+            if (cot) hipLaunchKernelGGL((k_scatter<int32_t, true>), dim3(fgrid), dim3(BLOCK), 0, st, (const int32_t*)faces, F, V, verts, slot_ptr, fill, slot_col, slot_val);
+            else hipLaunchKernelGGL((k_scatter<int32_t, false>), dim3(fgrid), dim3(BLOCK), 0, st, (const int32_t*)faces, F, V, verts, slot_ptr, fill, slot_col, slot_val);
+        } else {
+            if (cot) hipLaunchKernelGGL((k_scatter<int64_t, true>), dim3(fgrid), dim3(BLOCK), 0, st, (const int64_t*)faces, F, V, verts, slot_ptr, fill, slot_col, slot_val);
+            else hipLaunchKernelGGL((k_scatter<int64_t, false>), dim3(fgrid), dim3(BLOCK), 0, st, (const int64_t*)faces, F, V, verts, slot_ptr, fill, slot_col, slot_val);
+        }
+    }
+    const int vgrid = div_up(V, BLOCK);
+    if (kind == LS_LAPLACIAN_COT) hipLaunchKernelGGL(k_row_merge<true>, dim3(vgrid), dim3(BLOCK), 0, st, V, slot_ptr, slot_col, slot_val, a, b, ucnt, diag);
+    else hipLaunchKernelGGL(k_row_merge<false>, dim3(vgrid), dim3(BLOCK), 0, st, V, slot_ptr, slot_col, slot_val, a, b, ucnt, diag);
+    rc = exclusive_scan(ucnt, V, rowptr, bsum, st);
+    if (rc) return rc;
+    LS_HIP(hipGetLastError());
+    int h[2] = {0, 0};
+    LS_HIP(hipMemcpyAsync(&h[0], rowptr + V, 4, hipMemcpyDeviceToHost, st));
+    LS_HIP(hipMemcpyAsync(&h[1], flags, 4, hipMemcpyDeviceToHost, st));
+    LS_HIP(hipStreamSynchronize(st));
+    LS_REQUIRE(h[1] == 0, LS_E_INDEX, "a face index is outside [0, %lld)", (long long)V);
+    *h_nnz = h[0];
+    return LS_OK;
+}
+
+extern "C" int ls_assemble_fill(const void* workspace, size_t workspace_bytes, int64_t V, int64_t F, const int32_t* rowptr,
+                                int32_t* col, float* val, int64_t* coo_idx, int64_t nnz, float* dinv, int device,
+                                void* stream) {
+    LS_REQUIRE(workspace && rowptr && V >= 0 && F >= 0 && nnz >= 0 && (nnz == 0 || (col && val)), LS_E_INVALID,
+               "ls_assemble_fill: null pointer or negative size");
+    const AsmLayout L(V, F);
+    LS_REQUIRE(workspace_bytes >= L.total, LS_E_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, L.total);
+    if (V == 0) return LS_OK;
+    DeviceGuard g(device);
+    LS_HIP(g.err);
+    const char* ws = (const char*)workspace;
+    hipLaunchKernelGGL(k_emit, dim3(div_up(V, TILE_ROWS)), dim3(BLOCK), 0, (hipStream_t)stream, V,
+                       (const int*)(ws + L.slot_ptr), (const int*)(ws + L.slot_col), (const float*)(ws + L.slot_val),
+                       (const float*)(ws + L.diag), rowptr, col, val, coo_idx, coo_idx ? coo_idx + nnz : nullptr, dinv);
+    LS_HIP(hipGetLastError());
+    return LS_OK;
+}
+
+extern "C" int ls_csr_from_coo(const int64_t* coo_rows, const int64_t* coo_cols, const float* vals, int64_t nnz, int64_t V,
+                               int32_t* rowptr, int32_t* col, float* dinv, void* scratch, size_t scratch_bytes, int device,
+                               void* stream) {
+    LS_REQUIRE(V >= 0 && nnz >= 0 && rowptr && scratch && (nnz == 0 || (coo_rows && coo_cols && col)), LS_E_INVALID,
+               "ls_csr_from_coo: null pointer or negative size");
+    LS_REQUIRE(V < (int64_t)2000000000 && nnz < (int64_t)2000000000, LS_E_OVERFLOW, "matrix too large for int32 indices");
+    const size_t need = 4 * (size_t)(V + 1) + 4 * (size_t)((V + 1) / 2048 + 4) + 64 + 512;
+    LS_REQUIRE(scratch_bytes >= need, LS_E_WORKSPACE, "scratch too small: %zu < %zu", scratch_bytes, need);
+    LS_REQUIRE(!dinv || vals, LS_E_INVALID, "dinv requested without values");
+    DeviceGuard g(device);
+    LS_HIP(g.err);
+    hipStream_t st = (hipStream_t)stream;
+    auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
+    char* ws = (char*)scratch;
+    int* cnt = (int*)ws;
+    int* flags = (int*)(ws + al(4 * (size_t)(V + 1)));
+    int* bsum = flags + 16;
+    LS_HIP(hipMemsetAsync(ws, 0, al(4 * (size_t)(V + 1)) + 64, st));
+    if (dinv && V) LS_HIP(hipMemsetAsync(dinv, 0, 4 * (size_t)V, st));
+    if (nnz) hipLaunchKernelGGL(k_coo_hist, dim3((int)std::min<int64_t>(div_up(nnz, BLOCK), 8192)), dim3(BLOCK), 0, st,
+                                coo_rows, coo_cols, vals, nnz, V, cnt, col, dinv, flags);
+    if (V == 0) { LS_HIP(hipMemsetAsync(rowptr, 0, 4, st)); return LS_OK; }
+    int rc = exclusive_scan(cnt, V, rowptr, bsum, st);
+    if (rc) return rc;
+    if (dinv) hipLaunchKernelGGL(k_invert, dim3(div_up(V, BLOCK)), dim3(BLOCK), 0, st, dinv, V, flags);
+    LS_HIP(hipGetLastError());
+    int h[3];
+    LS_HIP(hipMemcpyAsync(h, flags, 12, hipMemcpyDeviceToHost, st));
+    LS_HIP(hipStreamSynchronize(st));
+    LS_REQUIRE(h[0] == 0, LS_E_INDEX, "COO index outside [0, %lld)", (long long)V);
+    LS_REQUIRE(h[1] == 0, LS_E_INVALID, "COO matrix is not coalesced (row-major sorted, unique): call .coalesce() first");
+    LS_REQUIRE(!dinv || h[2] == 0, LS_E_INVALID, "matrix has a missing or non-positive diagonal entry: not SPD");
+    return LS_OK;
+}

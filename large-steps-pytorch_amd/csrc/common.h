@@ -1,0 +1,125 @@
+// common.h -- shared host/device helpers for liblargesteps_hip.so (gfx950 only, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/largesteps_hip.h"
+
+namespace ls {
+
+constexpr int WAVE = 64;           // gfx950 wavefront
+constexpr int BLOCK = 256;         // 4 waves, one per SIMD
+constexpr int TILE_ROWS = 256;     // rows handled by one block pass (one row per thread)
+constexpr int MAX_GRID = 2048;     // upper bound of reduction partials per kernel (8 blocks per CU on 256 CUs)
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define LS_HIP(expr)                                                        \
+    do {                                                                    \
+        hipError_t _e = (expr);                                             \
+        if (_e != hipSuccess) return ::ls::hip_fail(_e, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+#define LS_REQUIRE(cond, code, ...)                                         \
+    do {                                                                    \
+        if (!(cond)) { ::ls::set_error(__VA_ARGS__); return (code); }       \
+    } while (0)
+
+struct DeviceGuard {  // every entry point pins the device itself: no thread-local state is assumed
+    int prev = -1;
+    hipError_t err;
+    explicit DeviceGuard(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) err = hipSetDevice(device);
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+inline int div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- device side ---------------------------------------------------------------------------------
+#ifdef __HIPCC__
+
+template <int K> struct Vec { float v[K]; };   // K interleaved right-hand-side columns of one vertex (4-byte aligned)
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T x) {
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) x += __shfl_down(x, off, WAVE);
+    return x;   // valid in lane 0
+}
+
+__device__ __forceinline__ float wave_max(float x) {
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) x = fmaxf(x, __shfl_down(x, off, WAVE));
+    return x;
+}
+
+// Block sum of N doubles per thread. Result valid in thread 0. `smem` holds (BLOCK/WAVE)*N doubles.
+template <int N>
+__device__ __forceinline__ void block_sum(double (&x)[N], double* smem) {
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        x[i] = wave_sum(x[i]);
+        if (lane == 0) smem[w * N + i] = x[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double s = 0.0;
+            for (int j = 0; j < BLOCK / WAVE; ++j) s += smem[j * N + i];
+            x[i] = s;
+        }
+    }
+    __syncthreads();
+}
+
+// Deterministic reduction of a partial array part[n*G + g], g < G (written by the G blocks of the
+// previous kernel) into out[n], n < N, broadcast to every thread of the block through smem.
+// smem: N + (BLOCK/WAVE)*N doubles.
+template <int N>
+__device__ __forceinline__ void reduce_partials(const double* __restrict__ part, int G, double (&out)[N], double* smem) {
+    double acc[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double s = 0.0;
+        for (int g = threadIdx.x; g < G; g += BLOCK) s += part[(size_t)i * MAX_GRID + g];
+        acc[i] = s;
+    }
+    block_sum<N>(acc, smem + N);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) smem[i] = acc[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = smem[i];
+    __syncthreads();
+}
+
+// XCD-aware tile schedule. Workgroup b runs on XCD b % 8 (observed placement, used for L2 locality
+// only, never for correctness). The T row tiles are cut into 8 contiguous ranges, one per XCD, and
+// the G/8 workgroups of an XCD stride through their range, so neighbouring rows (and the vector
+// entries they gather) stay in one XCD's L2 and the same rows meet the same L2 in every kernel.
+struct TileSched {
+    int first, step, end;
+    __device__ __forceinline__ TileSched(int T, int G) {
+        if (G >= 8 && (G & 7) == 0) {
+            const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, per = (T + 7) >> 3;
+            const int lo = xcd * per;
+            end = min(T, lo + per);
+            first = lo + local;
+            step = G >> 3;
+        } else {
+            first = blockIdx.x; step = G; end = T;
+        }
+    }
+};
+
+#endif  // __HIPCC__
+
+}  // namespace ls

@@ -1,0 +1,573 @@
+// pcg.hip -- Jacobi-preconditioned conjugate gradient for M x = b, K interleaved right-hand sides.
+//
+// Replaces the per-step solve of the reference: largesteps/solvers.py:26-39 (CholeskySolver ->
+// cholespy/CHOLMOD triangular solves) and :41-126 (ConjugateGradientSolver: per column, ~10 torch
+// kernels and one host sync per iteration).
+//
+// One iteration = three kernels, all scalars stay on the device, every column has its own alpha/beta:
+//   K1  Ap = M p                      ; partial  p.Ap
+//   K2  x += a p ; r -= a Ap          ; partial  r.D^-1 r , r.r        (a  = rz / pAp)
+//   K3  p = D^-1 r + b p              ; publishes rz, ||r||^2, the column mask and the stop flag  (b = rz'/rz)
+// Dot products: fp32 products accumulated in fp64 per thread, wave shuffle + LDS block reduction,
+// one partial per workgroup; the NEXT kernel reduces the <= 1024 partials in a fixed order in every
+// workgroup (deterministic, no atomics, no extra launch).
+// The host enqueues iterations in chunks and polls a stop flag one chunk behind the GPU; kernels of
+// iterations past the stop point return immediately.
+#include "spmv_kernels.h"
+#include <algorithm>
+#include <limits.h>
+#include <string.h>
+#include <new>
+#include <vector>
+
+namespace ls {
+
+constexpr int KMAX = 4;
+constexpr int PROF_MAX_ITERS = 512;
+constexpr int PART_PAP = 0, PART_RZ = 1, PART_RR = 2, PART_BB = 3, PART_SLOTS = 4;
+
+struct Scal {
+    double rz[2][KMAX];      // r.z, ring indexed by iteration parity
+    double thr2[KMAX];       // squared stop threshold per column
+    double bb[KMAX];         // ||b||^2
+    double rr[KMAX];         // latest ||r||^2
+    int mask[2];             // active-column bit mask, ring indexed by iteration parity
+    int stop_iter;           // kernels of iteration n run iff n < stop_iter
+    int bad;                 // 1: non-finite residual, 2: p.Ap <= 0 (matrix not SPD)
+};
+
+__device__ __forceinline__ double* part_ptr(double* part, int slot) { return part + (size_t)slot * KMAX * MAX_GRID; }
+
+template <int K>
+__device__ __forceinline__ Vec<K> ldv(const float* __restrict__ a, int64_t i) { return reinterpret_cast<const Vec<K>*>(a)[i]; }
+template <int K>
+__device__ __forceinline__ void stv(float* __restrict__ a, int64_t i, const Vec<K>& v) { reinterpret_cast<Vec<K>*>(a)[i] = v; }
+
+template <int N>
+__device__ __forceinline__ void write_partials(double (&acc)[N], double* __restrict__ part, int slot0, int per_slot, double* smem) {
+    block_sum<N>(acc, smem);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            const int slot = slot0 + n / per_slot, c = n % per_slot;
+            part_ptr(part, slot)[(size_t)c * MAX_GRID + blockIdx.x] = acc[n];
+        }
+    }
+}
+
+// matrix access variants: 0 = CSR staged through LDS, 1 = CSR direct, 2 = SELL-64
+template <int K, int VARIANT>
+__device__ __forceinline__ void mat_row(const CsrView& A, const SellView& S, const float* __restrict__ x, int64_t r0, int64_t r1,
+                                        int64_t V, int2* s_cv, float (&acc)[K]) {
+    const int64_t i = r0 + threadIdx.x;
+    if (VARIANT == 0) row_csr_lds<K>(A, x, r0, r1, s_cv, acc);
+    else if (VARIANT == 1) { if (i < r1) row_csr_direct<K>(A, x, i, acc); }
+    else { if ((i & ~(int64_t)(WAVE - 1)) < V) row_sell<K>(S, x, i, acc); }
+}
+
+// ---- setup of one solve ----------------------------------------------------------------------------
+template <int K, int VARIANT, bool WARM>
+__global__ __launch_bounds__(BLOCK) void k_init(CsrView A, SellView S, const float* __restrict__ dinv, const float* __restrict__ b,
+                                                const float* __restrict__ x0, float* __restrict__ x, float* __restrict__ r,
+                                                float* __restrict__ p, double* __restrict__ part, int64_t V, int T, int G) {
+    __shared__ int2 s_cv[(VARIANT == 0 && WARM) ? LDS_CAP : 1];
+    __shared__ double s_red[5 * 3 * K];
+    double acc[3 * K];
+#pragma unroll
+    for (int n = 0; n < 3 * K; ++n) acc[n] = 0.0;
+    const TileSched sch(T, G);
+    for (int tile = sch.first; tile < sch.end; tile += sch.step) {
+        const int64_t r0 = (int64_t)tile * TILE_ROWS, r1 = min(r0 + (int64_t)TILE_ROWS, V);
+        const int64_t i = r0 + threadIdx.x;
+        float ax[K];
+#pragma unroll
+        for (int q = 0; q < K; ++q) ax[q] = 0.0f;
+        if (WARM) mat_row<K, VARIANT>(A, S, x0, r0, r1, V, s_cv, ax);
+        if (i < r1) {
+            const Vec<K> bv = ldv<K>(b, i);
+            const float di = dinv[i];
+            Vec<K> xv, rv, pv;
+            if (WARM) xv = ldv<K>(x0, i);
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                if (!WARM) xv.v[q] = 0.0f;
+                rv.v[q] = bv.v[q] - ax[q];
+                pv.v[q] = di * rv.v[q];
+                acc[q] += (double)rv.v[q] * (double)pv.v[q];            // r.z
+                acc[K + q] += (double)rv.v[q] * (double)rv.v[q];        // r.r
+                acc[2 * K + q] += (double)bv.v[q] * (double)bv.v[q];    // b.b
+            }
+            stv<K>(x, i, xv);
+            stv<K>(r, i, rv);
+            stv<K>(p, i, pv);
+        }
+    }
+    write_partials<3 * K>(acc, part, PART_RZ, K, s_red);   // slots RZ, RR, BB
+}
+
+template <int K>
+__global__ __launch_bounds__(BLOCK) void k_init_scal(double* __restrict__ part, Scal* __restrict__ sc, int G, double rtol2, double atol2) {
+    __shared__ double s_red[5 * 3 * K];
+    double v[3 * K];
+    // the three partial arrays are contiguous slots: reduce them as one [3K][MAX_GRID] array
+    {
+        double acc[3 * K];
+#pragma unroll
+        for (int n = 0; n < 3 * K; ++n) {
+            const double* pp = part_ptr(part, PART_RZ + n / K) + (size_t)(n % K) * MAX_GRID;
+            double s = 0.0;
+            for (int g = threadIdx.x; g < G; g += BLOCK) s += pp[g];
+            acc[n] = s;
+        }
+        block_sum<3 * K>(acc, s_red);
+#pragma unroll
+        for (int n = 0; n < 3 * K; ++n) v[n] = acc[n];
+    }
+    if (threadIdx.x == 0) {
+        int mask = 0, bad = 0;
+        for (int q = 0; q < K; ++q) {
+            const double rz = v[q], rr = v[K + q], bb = v[2 * K + q];
+            const double thr2 = fmax(rtol2 * bb, atol2);
+            sc->rz[0][q] = rz;
+            sc->rz[1][q] = rz;
+            sc->rr[q] = rr;
+            sc->bb[q] = bb;
+            sc->thr2[q] = thr2;
+            if (!(rr == rr) || !(bb == bb) || rr > 1e300 || bb > 1e300) bad = 1;
+            else if (rr > thr2) mask |= 1 << q;
+        }
+        sc->mask[0] = mask;
+        sc->mask[1] = mask;
+        sc->bad = bad;
+        sc->stop_iter = (mask == 0 || bad) ? 0 : INT_MAX;
+    }
+}
+
+// ---- K1: Ap = M p, partial p.Ap ----------------------------------------------------------------------
+template <int K, int VARIANT>
+__global__ __launch_bounds__(BLOCK) void k_spmv_dot(CsrView A, SellView S, const float* __restrict__ p, float* __restrict__ Ap,
+                                                    double* __restrict__ part, const Scal* __restrict__ sc, int it, int64_t V,
+                                                    int T, int G) {
+    __shared__ int2 s_cv[VARIANT == 0 ? LDS_CAP : 1];
+    __shared__ double s_red[5 * K];
+    if (it >= sc->stop_iter) return;
+    double acc[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) acc[q] = 0.0;
+    const TileSched sch(T, G);
+    for (int tile = sch.first; tile < sch.end; tile += sch.step) {
+        const int64_t r0 = (int64_t)tile * TILE_ROWS, r1 = min(r0 + (int64_t)TILE_ROWS, V);
+        const int64_t i = r0 + threadIdx.x;
+        float ap[K];
+#pragma unroll
+        for (int q = 0; q < K; ++q) ap[q] = 0.0f;
+        mat_row<K, VARIANT>(A, S, p, r0, r1, V, s_cv, ap);
+        if (i < r1) {
+            const Vec<K> pv = ldv<K>(p, i);
+            Vec<K> o;
+#pragma unroll
+            for (int q = 0; q < K; ++q) { o.v[q] = ap[q]; acc[q] += (double)pv.v[q] * (double)ap[q]; }
+            stv<K>(Ap, i, o);
+        }
+    }
+    write_partials<K>(acc, part, PART_PAP, K, s_red);
+}
+
+// ---- K2: x += alpha p ; r -= alpha Ap ; partial r.D^-1 r and r.r --------------------------------------
+template <int K>
+__global__ __launch_bounds__(BLOCK) void k_update(const float* __restrict__ dinv, const float* __restrict__ p,
+                                                  const float* __restrict__ Ap, float* __restrict__ x, float* __restrict__ r,
+                                                  double* __restrict__ part, Scal* __restrict__ sc, int it, int64_t V, int T, int G) {
+    __shared__ double s_red[5 * 2 * K];
+    if (it >= sc->stop_iter) return;
+    double pAp[K];
+    reduce_partials<K>(part_ptr(part, PART_PAP), G, pAp, s_red);
+    const int mask = sc->mask[it & 1];
+    float alpha[K];
+    int bad = 0;
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+        const bool on = (mask >> q) & 1;
+        if (on && !(pAp[q] > 0.0)) bad = 2;
+        alpha[q] = (on && pAp[q] > 0.0) ? (float)(sc->rz[it & 1][q] / pAp[q]) : 0.0f;
+    }
+    if (bad && blockIdx.x == 0 && threadIdx.x == 0) sc->bad = bad;
+    double acc[2 * K];
+#pragma unroll
+    for (int n = 0; n < 2 * K; ++n) acc[n] = 0.0;
+    const TileSched sch(T, G);
+    for (int tile = sch.first; tile < sch.end; tile += sch.step) {
+        const int64_t i = (int64_t)tile * TILE_ROWS + threadIdx.x;
+        if (i < V) {
+            const Vec<K> pv = ldv<K>(p, i), av = ldv<K>(Ap, i);
+            Vec<K> xv = ldv<K>(x, i), rv = ldv<K>(r, i);
+            const float di = dinv[i];
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                xv.v[q] = fmaf(alpha[q], pv.v[q], xv.v[q]);
+                rv.v[q] = fmaf(-alpha[q], av.v[q], rv.v[q]);
+                const double rq = (double)rv.v[q];
+                acc[q] += rq * (double)(di * rv.v[q]);
+                acc[K + q] += rq * rq;
+            }
+            stv<K>(x, i, xv);
+            stv<K>(r, i, rv);
+        }
+    }
+    write_partials<2 * K>(acc, part, PART_RZ, K, s_red);   // slots RZ, RR
+}
+
+// ---- K3: p = D^-1 r + beta p ; publish scalars for the next iteration --------------------------------
+template <int K>
+__global__ __launch_bounds__(BLOCK) void k_direction(const float* __restrict__ dinv, const float* __restrict__ r, float* __restrict__ p,
+                                                     const double* __restrict__ part, Scal* __restrict__ sc, int it, int64_t V,
+                                                     int T, int G) {
+    __shared__ double s_red[5 * 2 * K];
+    if (it >= sc->stop_iter) return;
+    double red[2 * K];
+    {
+        double acc[2 * K];
+#pragma unroll
+        for (int n = 0; n < 2 * K; ++n) {
+            const double* pp = part + (size_t)(PART_RZ + n / K) * KMAX * MAX_GRID + (size_t)(n % K) * MAX_GRID;
+            double s = 0.0;
+            for (int g = threadIdx.x; g < G; g += BLOCK) s += pp[g];
+            acc[n] = s;
+        }
+        block_sum<2 * K>(acc, s_red + 2 * K);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int n = 0; n < 2 * K; ++n) s_red[n] = acc[n];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < 2 * K; ++n) red[n] = s_red[n];
+    }
+    const int mask = sc->mask[it & 1];
+    float beta[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+        const double rz_old = sc->rz[it & 1][q];
+        beta[q] = (((mask >> q) & 1) && rz_old > 0.0) ? (float)(red[q] / rz_old) : 0.0f;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int nmask = 0, bad = 0;
+        for (int q = 0; q < K; ++q) {
+            const double rr = red[K + q];
+            if ((mask >> q) & 1) {
+                sc->rz[(it + 1) & 1][q] = red[q];
+                sc->rr[q] = rr;
+                if (!(rr == rr) || rr > 1e300) bad = 1;
+                else if (rr > sc->thr2[q]) nmask |= 1 << q;
+            } else {
+                sc->rz[(it + 1) & 1][q] = sc->rz[it & 1][q];
+            }
+        }
+        sc->mask[(it + 1) & 1] = nmask;
+        if (bad) sc->bad = bad;
+        if (nmask == 0 || bad || sc->bad) sc->stop_iter = it + 1;
+    }
+    const TileSched sch(T, G);
+    for (int tile = sch.first; tile < sch.end; tile += sch.step) {
+        const int64_t i = (int64_t)tile * TILE_ROWS + threadIdx.x;
+        if (i < V) {
+            const Vec<K> rv = ldv<K>(r, i);
+            Vec<K> pv = ldv<K>(p, i);
+            const float di = dinv[i];
+#pragma unroll
+            for (int q = 0; q < K; ++q) pv.v[q] = fmaf(beta[q], pv.v[q], di * rv.v[q]);
+            stv<K>(p, i, pv);
+        }
+    }
+}
+
+// ---- CSR -> SELL-64 ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_sell_widths(const int* __restrict__ rowptr, int64_t V, int S, int* __restrict__ width64) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    int len = (i < V) ? rowptr[i + 1] - rowptr[i] : 0;
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) len = max(len, __shfl_down(len, off, WAVE));
+    const int64_t slice = i >> 6;
+    if ((threadIdx.x & (WAVE - 1)) == 0 && slice < S) width64[slice] = len * WAVE;
+}
+
+__global__ void k_sell_scan(const int* __restrict__ width64, int S, int* __restrict__ slice_ptr) {   // <<<1,1>>>: S <= V/64, one-off
+    long long run = 0;
+    for (int s = 0; s < S; ++s) { slice_ptr[s] = (int)run; run += width64[s]; }
+    slice_ptr[S] = run > (long long)INT_MAX ? -1 : (int)run;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_sell_fill(CsrView A, int64_t V, const int* __restrict__ slice_ptr, int2* __restrict__ cv) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int64_t slice = i >> 6;
+    if ((i & ~(int64_t)(WAVE - 1)) >= V) return;
+    const int off = slice_ptr[slice], width = (slice_ptr[slice + 1] - off) >> 6;
+    int s = 0, len = 0;
+    if (i < V) { s = A.rowptr[i]; len = A.rowptr[i + 1] - s; }
+    const int own = (int)min(i, V - 1);
+    for (int t = 0; t < width; ++t) {
+        int2 e = make_int2(own, 0);                       // padding: val = 0, a valid (own) column
+        if (t < len) e = make_int2(A.col[s + t], __float_as_int(A.val[s + t]));
+        cv[(size_t)off + (size_t)t * WAVE + lane] = e;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_diag_inv(CsrView A, int64_t V, float* __restrict__ dinv, int* __restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= V) return;
+    float d = 0.0f;
+    for (int j = A.rowptr[i]; j < A.rowptr[i + 1]; ++j) if (A.col[j] == (int)i) d = A.val[j];
+    if (!(d > 0.0f)) *flag = 1;
+    dinv[i] = 1.0f / d;
+}
+
+}  // namespace ls
+
+using namespace ls;
+
+struct ls_solver {
+    int device = 0;
+    int64_t V = 0, nnz = 0;
+    int kmax = 0;
+    CsrView csr{};
+    SellView sell{};
+    int* slice_ptr = nullptr;
+    int2* sell_cv = nullptr;
+    int64_t sell_entries = 0;
+    float *dinv = nullptr, *r = nullptr, *p = nullptr, *Ap = nullptr;
+    double* part = nullptr;
+    Scal* scal = nullptr;
+    Scal* h_scal = nullptr;       // pinned, 2 polling slots + 1 final
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int variant = 2, check_every = 16, grid = 0, last_iters = 0;
+    size_t bytes = 0;
+    // optional per-kernel timing with HIP events on the solve's own stream (ls_solver_set("profile", 1))
+    int profile = 0;
+    std::vector<hipEvent_t> pev;
+    double prof_ms[3] = {0, 0, 0};   // accumulated K1, K2, K3 time of the last profiled solve
+    int prof_iters = 0;
+};
+
+template <typename T>
+static int dev_alloc(ls_solver* s, T** out, size_t n) {
+    void* p = nullptr;
+    const size_t b = std::max<size_t>(n * sizeof(T), 256);
+    LS_HIP(hipMalloc(&p, b));
+    s->bytes += b;
+    *out = (T*)p;
+    return LS_OK;
+}
+
+static void free_solver(ls_solver* s) {
+    if (!s) return;
+    (void)hipFree(s->slice_ptr); (void)hipFree(s->sell_cv); (void)hipFree(s->dinv); (void)hipFree(s->r);
+    (void)hipFree(s->p); (void)hipFree(s->Ap); (void)hipFree(s->part); (void)hipFree(s->scal);
+    if (s->h_scal) (void)hipHostFree(s->h_scal);
+    for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : s->pev) if (e) (void)hipEventDestroy(e);
+    delete s;
+}
+
+static int create_impl(ls_solver* s, hipStream_t st) {
+    const int64_t V = s->V;
+    const size_t vk = (size_t)std::max<int64_t>(V, 1) * s->kmax;
+    int rc;
+    if ((rc = dev_alloc(s, &s->dinv, (size_t)std::max<int64_t>(V, 1)))) return rc;
+    if ((rc = dev_alloc(s, &s->r, vk))) return rc;
+    if ((rc = dev_alloc(s, &s->p, vk))) return rc;
+    if ((rc = dev_alloc(s, &s->Ap, vk))) return rc;
+    if ((rc = dev_alloc(s, &s->part, (size_t)PART_SLOTS * KMAX * MAX_GRID))) return rc;
+    if ((rc = dev_alloc(s, &s->scal, 1))) return rc;
+    LS_HIP(hipHostMalloc((void**)&s->h_scal, 3 * sizeof(Scal), hipHostMallocDefault));
+    for (auto& e : s->ev) LS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    LS_HIP(hipMemsetAsync(s->part, 0, sizeof(double) * PART_SLOTS * KMAX * MAX_GRID, st));
+    LS_HIP(hipMemsetAsync(s->scal, 0, sizeof(Scal), st));
+    if (V == 0) return LS_OK;
+    // Jacobi preconditioner
+    int* flag = (int*)s->scal;   // scal is re-initialised by every solve; borrow its first word
+    hipLaunchKernelGGL(k_diag_inv, dim3(div_up(V, BLOCK)), dim3(BLOCK), 0, st, s->csr, V, s->dinv, flag);
+    // SELL-64 copy of the matrix
+    const int S = div_up(V, WAVE);
+    int* width64 = nullptr;
+    if ((rc = dev_alloc(s, &s->slice_ptr, (size_t)S + 1))) return rc;
+    LS_HIP(hipMalloc((void**)&width64, sizeof(int) * (size_t)S));
+    hipLaunchKernelGGL(k_sell_widths, dim3(div_up((int64_t)S * WAVE, BLOCK)), dim3(BLOCK), 0, st, s->csr.rowptr, V, S, width64);
+    hipLaunchKernelGGL(k_sell_scan, dim3(1), dim3(1), 0, st, width64, S, s->slice_ptr);
+    int h[2] = {0, 0};
+    LS_HIP(hipMemcpyAsync(&h[0], s->slice_ptr + S, sizeof(int), hipMemcpyDeviceToHost, st));
+    LS_HIP(hipMemcpyAsync(&h[1], flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    LS_HIP(hipStreamSynchronize(st));
+    (void)hipFree(width64);
+    LS_REQUIRE(h[1] == 0, LS_E_INVALID, "matrix has a missing or non-positive diagonal entry: not SPD, Jacobi-PCG refused");
+    LS_REQUIRE(h[0] >= 0, LS_E_OVERFLOW, "SELL copy of the matrix overflows int32 entry offsets");
+    s->sell_entries = h[0];
+    if ((rc = dev_alloc(s, &s->sell_cv, (size_t)std::max(h[0], 1)))) return rc;
+    hipLaunchKernelGGL(k_sell_fill, dim3(div_up((int64_t)S * WAVE, BLOCK)), dim3(BLOCK), 0, st, s->csr, V, s->slice_ptr, s->sell_cv);
+    LS_HIP(hipMemsetAsync(s->scal, 0, sizeof(Scal), st));
+    LS_HIP(hipGetLastError());
+    s->sell = SellView{s->slice_ptr, s->sell_cv};
+    return LS_OK;
+}
+
+extern "C" int ls_solver_create(const int32_t* rowptr, const int32_t* col, const float* val, int64_t V, int64_t nnz, int kmax,
+                                int device, void* stream, ls_solver** h_out) {
+    LS_REQUIRE(h_out, LS_E_INVALID, "ls_solver_create: h_out is null");
+    *h_out = nullptr;
+    LS_REQUIRE(V >= 0 && nnz >= 0 && rowptr && (nnz == 0 || (col && val)), LS_E_INVALID, "ls_solver_create: null pointer or negative size");
+    LS_REQUIRE(kmax >= 1 && kmax <= KMAX, LS_E_INVALID, "ls_solver_create: kmax=%d outside [1,%d]", kmax, KMAX);
+    LS_REQUIRE(V < (int64_t)2000000000 && nnz < (int64_t)2000000000, LS_E_OVERFLOW, "matrix too large for int32 indices");
+    DeviceGuard g(device);
+    LS_HIP(g.err);
+    ls_solver* s = new (std::nothrow) ls_solver();
+    LS_REQUIRE(s, LS_E_INVALID, "out of host memory");
+    s->device = device; s->V = V; s->nnz = nnz; s->kmax = kmax;
+    s->csr = CsrView{rowptr, col, val};
+    const int rc = create_impl(s, (hipStream_t)stream);
+    if (rc) { free_solver(s); return rc; }
+    *h_out = s;
+    return LS_OK;
+}
+
+extern "C" int ls_solver_destroy(ls_solver* s) {
+    if (!s) return LS_OK;
+    DeviceGuard g(s->device);
+    free_solver(s);
+    return LS_OK;
+}
+
+extern "C" int ls_solver_set(ls_solver* s, const char* name, int value) {
+    LS_REQUIRE(s && name, LS_E_INVALID, "ls_solver_set: null argument");
+    if (!strcmp(name, "variant")) { LS_REQUIRE(value >= 0 && value <= 2, LS_E_INVALID, "variant must be 0 (CSR+LDS), 1 (CSR direct) or 2 (SELL-64)"); s->variant = value; }
+    else if (!strcmp(name, "check_every")) { LS_REQUIRE(value >= 1 && value <= 4096, LS_E_INVALID, "check_every outside [1,4096]"); s->check_every = value; }
+    else if (!strcmp(name, "profile")) { s->profile = value ? 1 : 0; }
+    else if (!strcmp(name, "grid")) { LS_REQUIRE(value >= 0 && value <= MAX_GRID, LS_E_INVALID, "grid outside [0,%d]", MAX_GRID); s->grid = value; }
+    else { set_error("ls_solver_set: unknown knob '%s'", name); return LS_E_INVALID; }
+    return LS_OK;
+}
+
+extern "C" int ls_solver_profile(const ls_solver* s, double* h_ms3, int* h_iters) {
+    LS_REQUIRE(s && h_ms3 && h_iters, LS_E_INVALID, "ls_solver_profile: null argument");
+    for (int i = 0; i < 3; ++i) h_ms3[i] = s->prof_ms[i];
+    *h_iters = s->prof_iters;
+    return LS_OK;
+}
+
+extern "C" int ls_solver_workspace_bytes(const ls_solver* s, size_t* h_bytes) {
+    LS_REQUIRE(s && h_bytes, LS_E_INVALID, "ls_solver_workspace_bytes: null argument");
+    *h_bytes = s->bytes;
+    return LS_OK;
+}
+
+namespace {
+
+template <int K, int VARIANT>
+int solve_impl(ls_solver* s, const float* b, const float* x0, float* x, double rtol, double atol, int max_iter,
+               ls_solve_info* info, hipStream_t st) {
+    const int64_t V = s->V;
+    const int T = div_up(V, TILE_ROWS);
+    int G = s->grid > 0 ? s->grid : 1024;
+    G = T < 8 ? T : std::min(T & ~7, G & ~7);
+    if (G < 1) G = 1;
+    const dim3 grid(G), block(BLOCK);
+    if (x0) hipLaunchKernelGGL((k_init<K, VARIANT, true>), grid, block, 0, st, s->csr, s->sell, s->dinv, b, x0, x, s->r, s->p, s->part, V, T, G);
+    else hipLaunchKernelGGL((k_init<K, VARIANT, false>), grid, block, 0, st, s->csr, s->sell, s->dinv, b, x0, x, s->r, s->p, s->part, V, T, G);
+    hipLaunchKernelGGL(k_init_scal<K>, dim3(1), block, 0, st, s->part, s->scal, G, rtol * rtol, atol * atol);
+
+    if (s->profile && s->pev.empty()) {
+        s->pev.assign(4 * PROF_MAX_ITERS, nullptr);
+        for (auto& e : s->pev) LS_HIP(hipEventCreate(&e));
+    }
+    int n = 0, chunk_id = 0;
+    bool stopped = false;
+    // first chunk: as long as the previous solve on this matrix needed (iteration counts are stable)
+    int chunk = std::max(s->check_every, std::min(s->last_iters, max_iter));
+    while (n < max_iter && !stopped) {
+        const int todo = std::min(chunk, max_iter - n);
+        for (int j = 0; j < todo; ++j, ++n) {
+            const bool prof = s->profile && n < PROF_MAX_ITERS;
+            if (prof) LS_HIP(hipEventRecord(s->pev[4 * n + 0], st));
+            hipLaunchKernelGGL((k_spmv_dot<K, VARIANT>), grid, block, 0, st, s->csr, s->sell, s->p, s->Ap, s->part, s->scal, n, V, T, G);
+            if (prof) LS_HIP(hipEventRecord(s->pev[4 * n + 1], st));
+            hipLaunchKernelGGL(k_update<K>, grid, block, 0, st, s->dinv, s->p, s->Ap, x, s->r, s->part, s->scal, n, V, T, G);
+            if (prof) LS_HIP(hipEventRecord(s->pev[4 * n + 2], st));
+            hipLaunchKernelGGL(k_direction<K>, grid, block, 0, st, s->dinv, s->r, s->p, s->part, s->scal, n, V, T, G);
+            if (prof) LS_HIP(hipEventRecord(s->pev[4 * n + 3], st));
+        }
+        LS_HIP(hipGetLastError());
+        const int slot = chunk_id & 1;
+        LS_HIP(hipMemcpyAsync(&s->h_scal[slot], s->scal, sizeof(Scal), hipMemcpyDeviceToHost, st));
+        LS_HIP(hipEventRecord(s->ev[slot], st));
+        if (chunk_id >= 1) {   // look at the chunk before the one just enqueued: the GPU never idles
+            const int prev = (chunk_id - 1) & 1;
+            LS_HIP(hipEventSynchronize(s->ev[prev]));
+            if (s->h_scal[prev].stop_iter != INT_MAX) stopped = true;
+        }
+        ++chunk_id;
+        chunk = s->check_every;
+    }
+    LS_HIP(hipMemcpyAsync(&s->h_scal[2], s->scal, sizeof(Scal), hipMemcpyDeviceToHost, st));
+    LS_HIP(hipStreamSynchronize(st));
+    const Scal& f = s->h_scal[2];
+    const bool conv = f.stop_iter != INT_MAX && f.bad == 0;
+    const int iters = f.stop_iter != INT_MAX ? f.stop_iter : n;
+    if (conv) s->last_iters = iters;
+    if (s->profile) {   // only iterations that really ran (kernels past the stop point return at once)
+        s->prof_iters = std::min(iters, PROF_MAX_ITERS);
+        for (double& m : s->prof_ms) m = 0.0;
+        for (int i = 0; i < s->prof_iters; ++i)
+            for (int kk = 0; kk < 3; ++kk) {
+                float ms = 0.f;
+                LS_HIP(hipEventElapsedTime(&ms, s->pev[4 * i + kk], s->pev[4 * i + kk + 1]));
+                s->prof_ms[kk] += ms;
+            }
+    }
+    if (info) {
+        info->iterations = iters;
+        info->converged = conv ? 1 : 0;
+        for (int q = 0; q < 4; ++q) {
+            info->rnorm[q] = q < K ? sqrt(f.rr[q]) : 0.0;
+            info->bnorm[q] = q < K ? sqrt(f.bb[q]) : 0.0;
+        }
+    }
+    if (!conv) {
+        if (f.bad == 1) set_error("PCG: non-finite residual after %d iterations", iters);
+        else if (f.bad == 2) set_error("PCG: p.Ap <= 0 after %d iterations: matrix is not positive definite", iters);
+        else set_error("PCG: not converged after %d iterations (max_iter=%d)", iters, max_iter);
+        return LS_E_NOT_CONVERGED;
+    }
+    return LS_OK;
+}
+
+template <int K>
+int solve_variant(ls_solver* s, const float* b, const float* x0, float* x, double rtol, double atol, int max_iter,
+                  ls_solve_info* info, hipStream_t st) {
+    switch (s->variant) {
+        case 0: return solve_impl<K, 0>(s, b, x0, x, rtol, atol, max_iter, info, st);
+        case 1: return solve_impl<K, 1>(s, b, x0, x, rtol, atol, max_iter, info, st);
+        default: return solve_impl<K, 2>(s, b, x0, x, rtol, atol, max_iter, info, st);
+    }
+}
+
+}  // namespace
+
+extern "C" int ls_solver_solve(ls_solver* s, const float* b, const float* x0, float* x, int k, double rtol, double atol,
+                               int max_iter, ls_solve_info* h_info, void* stream) {
+    LS_REQUIRE(s, LS_E_INVALID, "ls_solver_solve: null handle");
+    LS_REQUIRE(k >= 1 && k <= s->kmax, LS_E_INVALID, "ls_solver_solve: k=%d outside [1,%d]", k, s->kmax);
+    LS_REQUIRE(s->V == 0 || (b && x), LS_E_INVALID, "ls_solver_solve: null pointer");
+    LS_REQUIRE(x != b, LS_E_INVALID, "ls_solver_solve: x must not alias b");
+    LS_REQUIRE(rtol >= 0.0 && atol >= 0.0 && (rtol > 0.0 || atol > 0.0) && max_iter >= 0, LS_E_INVALID,
+               "ls_solver_solve: need rtol, atol >= 0 (one of them > 0) and max_iter >= 0");
+    if (h_info) memset(h_info, 0, sizeof(*h_info));
+    if (s->V == 0) { if (h_info) h_info->converged = 1; return LS_OK; }
+    DeviceGuard g(s->device);
+    LS_HIP(g.err);
+    hipStream_t st = (hipStream_t)stream;
+    switch (k) {
+        case 1: return solve_variant<1>(s, b, x0, x, rtol, atol, max_iter, h_info, st);
+        case 2: return solve_variant<2>(s, b, x0, x, rtol, atol, max_iter, h_info, st);
+        case 3: return solve_variant<3>(s, b, x0, x, rtol, atol, max_iter, h_info, st);
+        default: return solve_variant<4>(s, b, x0, x, rtol, atol, max_iter, h_info, st);
+    }
+}

@@ -1,0 +1,203 @@
+"""
+ctypes binding of liblargesteps_hip.so (C ABI: include/largesteps_hip.h).
+
+This is the only module that touches the native library. There is NO fallback: if the shared library is
+missing, or a tensor is not on a HIP device, the call fails loudly.
+
+Tensors cross the boundary as raw device pointers + sizes + (device ordinal, hipStream_t). The stream is
+always torch's current stream of the tensor's device *on the calling thread* -- autograd runs backward()
+on its own worker thread (reference: largesteps/solvers.py:139-145), so nothing is cached per thread.
+"""
+import ctypes
+import os
+import threading
+import weakref
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.environ.get("LARGESTEPS_HIP_LIB", os.path.join(_HERE, "..", "lib", "liblargesteps_hip.so"))
+
+LS_E_INVALID, LS_E_INDEX, LS_E_WORKSPACE, LS_E_OVERFLOW, LS_E_STATE, LS_E_NOT_CONVERGED = -1, -2, -3, -4, -5, -6
+
+_lib = None
+_lib_lock = threading.Lock()
+
+c_void_p, c_int, c_i64, c_float, c_double, c_size_t = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float,
+                                                        ctypes.c_double, ctypes.c_size_t)
+
+
+class SolveInfo(ctypes.Structure):
+    _fields_ = [("iterations", ctypes.c_int32), ("converged", ctypes.c_int32),
+                ("rnorm", ctypes.c_double * 4), ("bnorm", ctypes.c_double * 4)]
+
+
+_SIGNATURES = {
+    "ls_version": (c_int, []),
+    "ls_last_error": (ctypes.c_char_p, []),
+    "ls_assemble_workspace_bytes": (c_int, [c_i64, c_i64, ctypes.POINTER(c_size_t)]),
+    "ls_assemble_pattern": (c_int, [c_void_p, c_int, c_i64, c_i64, c_void_p, c_int, c_float, c_float, c_void_p, c_size_t,
+                                    c_void_p, ctypes.POINTER(c_i64), c_int, c_void_p]),
+    "ls_assemble_fill": (c_int, [c_void_p, c_size_t, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p,
+                                 c_int, c_void_p]),
+    "ls_csr_from_coo": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                c_int, c_void_p]),
+    "ls_spmv": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ls_solver_create": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_int, c_int, c_void_p, ctypes.POINTER(c_void_p)]),
+    "ls_solver_destroy": (c_int, [c_void_p]),
+    "ls_solver_solve": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double, c_double, c_int,
+                                ctypes.POINTER(SolveInfo), c_void_p]),
+    "ls_solver_set": (c_int, [c_void_p, ctypes.c_char_p, c_int]),
+    "ls_solver_profile": (c_int, [c_void_p, ctypes.POINTER(c_double * 3), ctypes.POINTER(c_int)]),
+    "ls_solver_workspace_bytes": (c_int, [c_void_p, ctypes.POINTER(c_size_t)]),
+    "ls_adam_uniform_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_float, c_float, c_float, c_int,
+                                     c_void_p, c_int, c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def lib_path():
+    return os.path.abspath(_LIB_PATH)
+
+
+def lib():
+    """Load liblargesteps_hip.so once. Raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        with _lib_lock:
+            if _lib is None:
+                path = lib_path()
+                if not os.path.exists(path):
+                    raise RuntimeError(
+                        f"largesteps: native library not found at {path}. Build it with "
+                        f"`make -C {os.path.join(_HERE, '..', 'csrc')}` (hipcc, gfx950) or `python -c "
+                        f"'import __graft_entry__ as g; g.build()'` from the repository root. There is no CPU/PyTorch fallback.")
+                handle = ctypes.CDLL(path)
+                for name, (res, args) in _SIGNATURES.items():
+                    fn = getattr(handle, name)   # AttributeError if the ABI drifted
+                    fn.restype = res
+                    fn.argtypes = args
+                _lib = handle
+    return _lib
+
+
+class NotConverged(RuntimeError):
+    pass
+
+
+def last_error():
+    msg = lib().ls_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc):
+    """Map a C-ABI status to the Python exception the reference's code path would raise."""
+    if rc == 0:
+        return
+    msg = last_error()
+    if rc == LS_E_INVALID:
+        raise ValueError(msg)
+    if rc == LS_E_INDEX:
+        raise IndexError(msg)
+    if rc == LS_E_OVERFLOW:
+        raise OverflowError(msg)
+    if rc == LS_E_NOT_CONVERGED:
+        raise NotConverged(msg)
+    raise RuntimeError(f"largesteps native error {rc}: {msg}")
+
+
+def require_device(t, what):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{what} must be a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(f"largesteps (MI355X build): {what} must live on a HIP device ('cuda'), got device '{t.device}'. "
+                           "There is no CPU path in this package.")
+    return t
+
+
+def stream_of(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    """Raw device pointer of a tensor (NULL for None / empty tensors)."""
+    return ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# CSR side car of a torch sparse COO matrix
+# ---------------------------------------------------------------------------------------------------
+class CsrMatrix:
+    """int32 CSR (rowptr, col) + fp32 val of a (V,V) matrix on one HIP device. `val` is the very tensor
+    that backs M.values() (same order: row-major sorted COO == CSR order), so no value copy exists."""
+    __slots__ = ("V", "nnz", "rowptr", "col", "val", "device", "symmetric", "__weakref__")
+
+    def __init__(self, V, rowptr, col, val, symmetric):
+        self.V, self.nnz = int(V), int(col.shape[0])
+        self.rowptr, self.col, self.val = rowptr, col, val
+        self.device = val.device
+        self.symmetric = symmetric
+
+
+# (id(M)) -> (CsrMatrix, weakref(M)). Mirrors the reference's solver cache (parameterize.py:5-17): keyed by
+# object identity, dropped by a weakref callback when M is garbage collected, never holds M itself.
+_csr_cache = {}
+_csr_lock = threading.Lock()
+
+
+def register_csr(M, csr):
+    key = id(M)
+
+    def _drop(_wr, key=key):
+        with _csr_lock:
+            _csr_cache.pop(key, None)
+
+    with _csr_lock:
+        _csr_cache[key] = (csr, weakref.ref(M, _drop))
+
+
+def csr_of(M):
+    """CSR side car of M: the one built by compute_matrix, or (foreign matrix) converted on first use."""
+    key = id(M)
+    with _csr_lock:
+        hit = _csr_cache.get(key)
+    if hit is not None and hit[1]() is M:
+        return hit[0]
+    csr = csr_from_coo(M)
+    register_csr(M, csr)
+    return csr
+
+
+def csr_from_coo(M):
+    if not isinstance(M, torch.Tensor) or M.layout != torch.sparse_coo:
+        raise TypeError("expected a torch sparse COO matrix (as returned by largesteps.geometry.compute_matrix)")
+    require_device(M, "the system matrix")
+    if M.dim() != 2 or M.shape[0] != M.shape[1]:
+        raise ValueError(f"expected a square sparse matrix, got shape {tuple(M.shape)}")
+    if M.dtype != torch.float32:
+        raise TypeError(f"expected a float32 matrix, got {M.dtype}")
+    if not M.is_coalesced():
+        raise ValueError("the system matrix must be coalesced (call .coalesce(); the reference's solvers need it too)")
+    V = M.shape[0]
+    idx = M.indices()
+    rows, cols = idx[0].contiguous(), idx[1].contiguous()
+    val = M.values().contiguous()
+    nnz = val.shape[0]
+    dev = M.device
+    rowptr = torch.empty(V + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(nnz, dtype=torch.int32, device=dev)
+    scratch = torch.empty(4 * (V + 1) + 4 * ((V + 1) // 2048 + 4) + 1024, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().ls_csr_from_coo(ptr(rows), ptr(cols), ptr(val), nnz, V, ptr(rowptr), ptr(col), None, ptr(scratch),
+                                    scratch.numel(), dev.index, stream_of(dev)))
+    return CsrMatrix(V, rowptr, col, val, symmetric=None)
+
+
+def spmv(csr, x, variant=0):
+    """y = M x for x of shape (V,k), float32, contiguous."""
+    y = torch.empty_like(x)
+    dev = csr.device
+    check(lib().ls_spmv(ptr(csr.rowptr), ptr(csr.col), ptr(csr.val), csr.V, csr.nnz, ptr(x), ptr(y), x.shape[1], variant,
+                        dev.index, stream_of(dev)))
+    return y

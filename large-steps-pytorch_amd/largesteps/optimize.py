@@ -1,0 +1,60 @@
+"""
+AdamUniform (reference: largesteps/optimize.py:3-41): Adam whose per-element second-moment scaling is replaced
+by one global max. Same constructor, state keys ("step", "g1", "g2") and update rule; the step itself runs as
+two fused HIP kernels (csrc/adam.hip) instead of ~10 torch kernels and stays on the device.
+"""
+import torch
+
+from . import _native
+
+_scratch = {}
+
+
+def _scratch_for(dev):
+    s = _scratch.get(dev)
+    if s is None:
+        s = torch.empty(4096, dtype=torch.uint8, device=dev)
+        _scratch[dev] = s
+    return s
+
+
+class AdamUniform(torch.optim.Optimizer):
+    """
+    Variant of Adam with uniform scaling by the second moment.
+
+    Instead of dividing each component by the square root of its second moment,
+    we divide all of them by the max.
+    """
+    def __init__(self, params, lr=0.1, betas=(0.9, 0.999)):
+        defaults = dict(lr=lr, betas=betas)
+        super(AdamUniform, self).__init__(params, defaults)
+
+    def __setstate__(self, state):
+        super(AdamUniform, self).__setstate__(state)
+
+    @torch.no_grad()
+    def step(self):
+        lib = _native.lib()
+        for group in self.param_groups:
+            lr = group['lr']
+            b1, b2 = group['betas']
+            for p in group["params"]:
+                state = self.state[p]
+                # Lazy initialization
+                if len(state) == 0:
+                    state["step"] = 0
+                    state["g1"] = torch.zeros_like(p.data, memory_format=torch.contiguous_format)
+                    state["g2"] = torch.zeros_like(p.data, memory_format=torch.contiguous_format)
+                state["step"] += 1
+                _native.require_device(p.data, "AdamUniform parameter")
+                if p.dtype != torch.float32:
+                    raise TypeError(f"AdamUniform parameters must be float32, got {p.dtype}")
+                if not p.data.is_contiguous():
+                    raise ValueError("AdamUniform parameters must be contiguous")
+                grad = p.grad.data.contiguous()
+                dev = p.device
+                with torch.cuda.device(dev):
+                    _native.check(lib.ls_adam_uniform_step(_native.ptr(p.data), _native.ptr(grad), _native.ptr(state["g1"]),
+                                                           _native.ptr(state["g2"]), p.numel(), float(lr), float(b1), float(b2),
+                                                           int(state["step"]), _native.ptr(_scratch_for(dev)), dev.index,
+                                                           _native.stream_of(dev)))

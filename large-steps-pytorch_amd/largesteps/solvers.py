@@ -1,0 +1,197 @@
+"""
+Sparse SPD solvers of the parameterization path (reference: largesteps/solvers.py).
+
+Same classes and protocol as the reference (Solver :6, CholeskySolver :26, ConjugateGradientSolver :41,
+DifferentiableSolve :128, solve :148). Both concrete solvers run the hand-written HIP Jacobi-PCG
+(csrc/pcg.hip) through one native handle per matrix; neither cholespy/CHOLMOD nor torch sparse ops are used.
+"""
+import ctypes
+import warnings
+
+import torch
+from torch.autograd import Function
+
+from . import _native
+
+_KMAX = 4   # right-hand-side columns one native solve handles; wider b is solved in column groups
+
+
+class Solver:
+    """
+    Sparse linear system solver base class.
+    """
+    def __init__(self, M):
+        pass
+
+    def solve(self, b, backward=False):
+        """
+        Solve the linear system.
+
+        Parameters
+        ----------
+        b : torch.Tensor
+            The right hand side of the system Lx=b
+        backward : bool (optional)
+            Whether this is the backward or forward solve
+        """
+        raise NotImplementedError()
+
+
+class PCGSolver(Solver):
+    """
+    Jacobi-preconditioned conjugate gradients on the MI355X (one native handle per matrix).
+
+    Parameters
+    ----------
+    M : torch.sparse_coo_tensor
+        SPD system matrix (coalesced, fp32, on a HIP device), normally from `compute_matrix`.
+    rtol, atol : float
+        A column is converged when ||r||_2 <= max(rtol * ||b||_2, atol).
+    max_iter : int
+        Iteration cap (the reference's CG has none and can spin forever).
+    warm_start : bool
+        Start from the previous solution of the same pass (forward / backward kept apart, like
+        solvers.py:102-124) instead of zero.
+    """
+
+    def __init__(self, M, rtol=1e-6, atol=0.0, max_iter=10000, warm_start=False):
+        csr = _native.csr_of(M)
+        self._csr = csr                 # keeps rowptr/col/val alive; never M itself (cache eviction relies on it)
+        self.rtol, self.atol, self.max_iter, self.warm_start = float(rtol), float(atol), int(max_iter), bool(warm_start)
+        self.guess_fwd = None
+        self.guess_bwd = None
+        self.last_info = None
+        self._handle = ctypes.c_void_p(None)
+        dev = csr.device
+        with torch.cuda.device(dev):
+            _native.check(_native.lib().ls_solver_create(_native.ptr(csr.rowptr), _native.ptr(csr.col), _native.ptr(csr.val),
+                                                         csr.V, csr.nnz, _KMAX, dev.index, _native.stream_of(dev),
+                                                         ctypes.byref(self._handle)))
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value:
+            try:
+                _native.lib().ls_solver_destroy(h)
+            finally:
+                self._handle = ctypes.c_void_p(None)
+
+    def set_option(self, name, value):
+        """Measurement knobs of the native solver: 'variant' (0 CSR+LDS, 1 CSR direct, 2 SELL-64), 'check_every', 'grid', 'profile'."""
+        _native.check(_native.lib().ls_solver_set(self._handle, name.encode(), int(value)))
+
+    def kernel_profile(self):
+        """(ms_K1, ms_K2, ms_K3, iterations) of the last solve run with set_option('profile', 1)."""
+        ms = (ctypes.c_double * 3)()
+        it = ctypes.c_int(0)
+        _native.check(_native.lib().ls_solver_profile(self._handle, ctypes.byref(ms), ctypes.byref(it)))
+        return ms[0], ms[1], ms[2], it.value
+
+    def _solve_block(self, b, x0):
+        csr = self._csr
+        dev = csr.device
+        x = torch.empty_like(b)
+        info = _native.SolveInfo()
+        with torch.cuda.device(dev):
+            rc = _native.lib().ls_solver_solve(self._handle, _native.ptr(b), _native.ptr(x0) if x0 is not None else None,
+                                               _native.ptr(x), b.shape[1], self.rtol, self.atol, self.max_iter,
+                                               ctypes.byref(info), _native.stream_of(dev))
+        self.last_info = dict(iterations=info.iterations, converged=bool(info.converged),
+                              rnorm=list(info.rnorm)[:b.shape[1]], bnorm=list(info.bnorm)[:b.shape[1]])
+        if rc == _native.LS_E_NOT_CONVERGED:
+            msg = _native.last_error()
+            if "not converged" in msg:
+                warnings.warn(f"largesteps: {msg}; returning the last iterate", RuntimeWarning, stacklevel=3)
+            else:
+                raise RuntimeError(f"largesteps: {msg}")
+        else:
+            _native.check(rc)
+        return x
+
+    def solve(self, b, backward=False):
+        _native.require_device(b, "b")
+        csr = self._csr
+        if b.device != csr.device:
+            raise RuntimeError(f"matrix ({csr.device}) and b ({b.device}) must be on the same device")
+        if b.dtype != torch.float32:
+            raise TypeError(f"b must be float32, got {b.dtype}")
+        if b.dim() not in (1, 2) or b.shape[0] != csr.V:
+            raise ValueError(f"Invalid array shape {b.shape} for solve: expected ({csr.V}, k)")
+        squeeze = b.dim() == 1
+        b2 = (b.detach().unsqueeze(1) if squeeze else b.detach()).contiguous()
+        k = b2.shape[1]
+        x0 = None
+        if self.warm_start:
+            g = self.guess_bwd if backward else self.guess_fwd
+            if g is not None and g.shape == b2.shape:
+                x0 = g
+        if k <= _KMAX:
+            x = self._solve_block(b2, x0)
+        else:
+            x = torch.empty_like(b2)
+            for c0 in range(0, k, _KMAX):
+                c1 = min(c0 + _KMAX, k)
+                g0 = x0[:, c0:c1].contiguous() if x0 is not None else None
+                x[:, c0:c1] = self._solve_block(b2[:, c0:c1].contiguous(), g0)
+        if self.warm_start:
+            # like the reference (solvers.py:120-124) the guess aliases the returned tensor
+            if backward:
+                self.guess_bwd = x
+            else:
+                self.guess_fwd = x
+        return x.squeeze(1) if squeeze else x
+
+
+class CholeskySolver(PCGSolver):
+    """
+    Drop-in for the reference's default solver (solvers.py:26-39: cholespy / CHOLMOD factor + triangular solves).
+
+    No factorisation exists in this package: every solve is a cold-started HIP Jacobi-PCG run to a relative
+    residual of 1e-6, i.e. the result is a function of b only, like a direct solve, within the fp32 accuracy
+    class of the reference's single-precision Cholesky solve (tolerances: DESIGN.md).
+    """
+
+    def __init__(self, M, rtol=1e-6, max_iter=10000):
+        super().__init__(M, rtol=rtol, atol=0.0, max_iter=max_iter, warm_start=False)
+
+
+class ConjugateGradientSolver(PCGSolver):
+    """
+    Conjugate gradients solver with the reference's stopping rule and warm start (solvers.py:41-126):
+    every column iterates until ||r||_2 <= 1e-5 (absolute), starting from the previous forward /
+    backward solution. Differences: Jacobi preconditioning, all columns share each matrix pass, an iteration
+    cap, and no strong reference to M.
+    """
+
+    def __init__(self, M, atol=1e-5, max_iter=10000):
+        super().__init__(M, rtol=0.0, atol=atol, max_iter=max_iter, warm_start=True)
+
+    def solve(self, b, backward=False):
+        if len(b.shape) != 2:
+            raise ValueError(f"Invalid array shape {b.shape} for ConjugateGradientSolver.solve: expected shape (a, b)")
+        return super().solve(b, backward=backward)
+
+
+class DifferentiableSolve(Function):
+    """
+    Differentiable function to solve the linear system.
+
+    This simply calls the solve methods implemented by the Solver classes; the backward pass is the same
+    solve applied to the incoming gradient (M is symmetric). Reference: solvers.py:128-145.
+    """
+    @staticmethod
+    def forward(ctx, solver, b):
+        ctx.solver = solver
+        return solver.solve(b, backward=False)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        solver_grad = None  # We have to return a gradient per input argument in forward
+        b_grad = None
+        if ctx.needs_input_grad[1]:
+            b_grad = ctx.solver.solve(grad_output.contiguous(), backward=True)
+        return (solver_grad, b_grad)
+
+
+# Alias for DifferentiableSolve function
+solve = DifferentiableSolve.apply

@@ -1,0 +1,140 @@
+"""
+CPU-only checks of the boundary: the C-ABI library builds/loads and exports every symbol that
+include/largesteps_hip.h declares, the ctypes table matches the header, and the host-side logic that
+needs no device (argument validation, error strings, cache keys) behaves like the reference.
+No kernel is launched here.
+"""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "largesteps_hip.h")
+
+
+@pytest.fixture(scope="module")
+def native():
+    from largesteps import _native
+    if not os.path.exists(_native.lib_path()):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _native
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ls_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported_and_bound(native):
+    decl = _declared()
+    assert len(decl) >= 12
+    out = subprocess.run(["nm", "-D", "--defined-only", native.lib_path()], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    missing = [s for s in decl if s not in exported]
+    assert not missing, f"declared in the header but not exported: {missing}"
+    assert sorted(native.EXPORTED_SYMBOLS) == decl, "ctypes table and header drifted apart"
+    lib = native.lib()
+    assert lib.ls_version() == 100
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: the header must compile as C with no torch / HIP types."""
+    c = tmp_path / "t.c"
+    c.write_text('#include "largesteps_hip.h"\nint main(void){ls_solve_info i; i.iterations=0; return i.iterations + (LS_VERSION>0?0:1);}\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(c), "-o", str(tmp_path / "t.o")],
+                   check=True)
+
+
+def test_host_only_entry_points(native):
+    lib = native.lib()
+    n = ctypes.c_size_t(0)
+    assert lib.ls_assemble_workspace_bytes(1000000, 1996002, ctypes.byref(n)) == 0
+    # 5 int arrays of V+1, flags, scan sums, 2 x 6F slots
+    assert 5 * 4 * 1000001 + 2 * 4 * 6 * 1996002 <= n.value <= 5 * 4 * 1000001 + 2 * 4 * 6 * 1996002 + 64 * 1024
+    assert lib.ls_assemble_workspace_bytes(-1, 0, ctypes.byref(n)) == native.LS_E_INVALID
+    assert lib.ls_assemble_workspace_bytes(3 * 10 ** 9, 0, ctypes.byref(n)) == native.LS_E_OVERFLOW
+    assert "too large" in native.last_error()
+    assert lib.ls_solver_set(None, b"variant", 1) == native.LS_E_INVALID
+    with pytest.raises(ValueError):
+        native.check(native.LS_E_INVALID)
+    with pytest.raises(IndexError):
+        native.check(native.LS_E_INDEX)
+    assert lib.ls_solver_destroy(None) == 0
+
+
+def test_reference_error_strings_without_device(golden):
+    from largesteps.geometry import compute_matrix
+    from largesteps.parameterize import from_differential
+    from largesteps.solvers import Solver
+    e = golden.errors()
+    v = torch.from_numpy(golden["quad/verts"])
+    f = torch.from_numpy(golden["quad/faces"])
+    for a in (1.0, -0.1, 1.5):
+        with pytest.raises(ValueError) as ei:
+            compute_matrix(v, f, 1.0, alpha=a)
+        assert str(ei.value) == e[f"alpha={a}"]
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        compute_matrix(v, f, 1.0)
+    M = torch.sparse_coo_tensor(torch.tensor([[0, 1], [0, 1]]), torch.ones(2), (2, 2)).coalesce()
+    with pytest.raises(ValueError) as ei:
+        from_differential(M, v, "LU")
+    assert str(ei.value) == e["method"]
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        from_differential(M, torch.ones(2, 3), "Cholesky")
+    with pytest.raises(NotImplementedError):
+        Solver(M).solve(v)
+
+
+def test_api_surface_matches_reference():
+    import inspect
+    import largesteps
+    from largesteps import geometry, parameterize, solvers, optimize
+    assert largesteps.__version__.startswith("0.2.2")
+    assert list(inspect.signature(geometry.compute_matrix).parameters) == ["verts", "faces", "lambda_", "alpha", "cotan"]
+    assert inspect.signature(geometry.compute_matrix).parameters["alpha"].default is None
+    assert inspect.signature(geometry.compute_matrix).parameters["cotan"].default is False
+    assert list(inspect.signature(geometry.laplacian_uniform).parameters) == ["verts", "faces"]
+    assert list(inspect.signature(geometry.laplacian_cot).parameters) == ["verts", "faces"]
+    assert list(inspect.signature(parameterize.to_differential).parameters) == ["L", "v"]
+    sig = inspect.signature(parameterize.from_differential)
+    assert list(sig.parameters) == ["L", "u", "method"] and sig.parameters["method"].default == "Cholesky"
+    for name in ("Solver", "CholeskySolver", "ConjugateGradientSolver", "DifferentiableSolve", "solve"):
+        assert hasattr(solvers, name)
+    assert list(inspect.signature(solvers.Solver.solve).parameters) == ["self", "b", "backward"]
+    sig = inspect.signature(optimize.AdamUniform.__init__)
+    assert sig.parameters["lr"].default == 0.1 and sig.parameters["betas"].default == (0.9, 0.999)
+    assert hasattr(parameterize, "_cache") and hasattr(parameterize, "cache_put")
+
+
+def test_product_does_not_import_oracle():
+    """The shipped package must not route through the oracle (or any CPU fallback)."""
+    pkg = os.path.join(ROOT, "large-steps-pytorch_amd")
+    for d, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(d, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f"{fn} imports the oracle"
+                assert "scipy" not in src, f"{fn} uses scipy"
+
+
+def test_synthetic_meshes():
+    from largesteps import synthetic
+    v, f = synthetic.plane(1000)
+    assert v.shape == (1000000, 3) and f.shape == (1996002, 3) and v.dtype == np.float32 and f.dtype == np.int64
+    assert np.array_equal(f[0], [0, 1, 1001]) and np.array_equal(f[1], [0, 1001, 1000])
+    for n in (1, 2, 16):
+        v, f = synthetic.icosphere(n)
+        assert v.shape[0] == 10 * n * n + 2 and f.shape[0] == 20 * n * n
+        e = np.sort(np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]), axis=1)
+        _, cnt = np.unique(e, axis=0, return_counts=True)
+        assert (cnt == 2).all() and cnt.shape[0] == 30 * n * n
+    a = synthetic.config_mesh("cfg2_bunny70k")
+    b = synthetic.config_mesh("cfg2_bunny70k")
+    assert a[0].shape[0] == 70562 and np.array_equal(a[0], b[0])

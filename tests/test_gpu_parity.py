@@ -1,0 +1,392 @@
+"""
+GPU parity tests (-m gpu): the HIP path, called through the C ABI (largesteps._native -> liblargesteps_hip.so),
+against the CPU oracle and the reference-generated golden fixtures. Tolerances are stated at each assert.
+"""
+import gc
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import laplacian as ol
+from oracle import solve as osv
+
+pytestmark = pytest.mark.gpu
+
+ALL_MESHES = ["octahedron", "tetra", "quad", "collinear", "unreferenced", "nonmanifold", "dupface", "ico3", "plane12", "ico6"]
+CASES = ["uni_l10", "uni_l0p3", "uni_a0p95", "cot_l2", "cot_a0p9"]
+MANIFOLD = ("ico3", "plane12", "ico6", "octahedron", "tetra", "quad", "unreferenced")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from largesteps import _native
+    _native.lib()          # fail loudly if the extension is missing
+    return torch.device("cuda:0")
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+# ---------------------------------------------------------------------------------------------------
+# assembly
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("name", ALL_MESHES)
+def test_compute_matrix_vs_reference_and_oracle(golden, dev, name, case):
+    from largesteps.geometry import compute_matrix
+    v, f = golden[f"{name}/verts"], golden[f"{name}/faces"]
+    kw = golden.params[case]
+    M = compute_matrix(_t(v, dev), _t(f, dev), **kw)
+    assert M.is_coalesced() and M.dtype == torch.float32 and M.indices().dtype == torch.int64
+    idx = M.indices().cpu().numpy()
+    val = M.values().cpu().numpy()
+    ref_idx, ref_val = golden[f"{name}/{case}/idx"], golden[f"{name}/{case}/val"]
+    assert np.array_equal(idx, ref_idx), "index list must equal torch's coalesce order exactly"
+    r, c, oval = ol.compute_matrix(v, f, **kw)
+    if not kw["cotan"]:
+        assert np.array_equal(val, ref_val), "uniform M is bit exact vs the reference"
+    else:
+        off = idx[0] != idx[1]
+        scale = max(np.abs(ref_val).max(), abs(kw["alpha"] or kw["lambda_"]) * np.abs(ol.face_cotangents(v, f)).max())
+        if name in MANIFOLD:
+            # same fp32 operation order as the oracle -> bit exact off-diagonals (<= 2 terms per entry)
+            assert np.array_equal(val[off], oval[off])
+            # vs reference: torch-CPU's vectorised sqrt is 1 ulp off for ~0.6% of inputs -> 2 ulp
+            np.testing.assert_allclose(val[off], ref_val[off], rtol=2.5e-7, atol=0)
+        # diagonal / non-manifold sums: accumulation order is implementation defined in the reference
+        np.testing.assert_allclose(val, oval, rtol=0, atol=4e-6 * scale)
+        np.testing.assert_allclose(val, ref_val, rtol=0, atol=4e-6 * scale)
+    # int32 faces give the identical matrix (the reference accepts int32 for the uniform Laplacian only)
+    M32 = compute_matrix(_t(v, dev), _t(f.astype(np.int32), dev), **kw)
+    assert torch.equal(M32.indices(), M.indices())
+    assert np.array_equal(M32.values().cpu().numpy(), val)
+
+
+@pytest.mark.parametrize("name", ALL_MESHES)
+def test_laplacians(golden, dev, name):
+    from largesteps.geometry import laplacian_uniform, laplacian_cot
+    v, f = golden[f"{name}/verts"], golden[f"{name}/faces"]
+    L = laplacian_uniform(_t(v, dev), _t(f, dev))
+    assert np.array_equal(L.indices().cpu().numpy(), golden[f"{name}/Luni_idx"])
+    assert np.array_equal(L.values().cpu().numpy(), golden[f"{name}/Luni_val"])
+    Lc = laplacian_cot(_t(v, dev), _t(f, dev)).coalesce()
+    ref = golden[f"{name}/Lcot_val"]
+    assert np.array_equal(Lc.indices().cpu().numpy(), golden[f"{name}/Lcot_idx"])
+    scale = max(np.abs(ref).max(), np.abs(ol.face_cotangents(v, f)).max())
+    np.testing.assert_allclose(Lc.values().cpu().numpy(), ref, rtol=0, atol=4e-6 * scale)
+
+
+def test_face_permutation_and_large_mesh_pattern(dev):
+    """Assembly is independent of the face order (atomics arrival order) and exact at 250k vertices."""
+    from largesteps.geometry import compute_matrix
+    from largesteps import synthetic
+    v, f, _ = synthetic.config_mesh("cfg3_dragon250k")
+    perm = np.random.default_rng(0).permutation(f.shape[0])
+    A = compute_matrix(_t(v, dev), _t(f, dev), 0.0, alpha=0.95, cotan=True)
+    B = compute_matrix(_t(v, dev), _t(f[perm], dev), 0.0, alpha=0.95, cotan=True)
+    assert torch.equal(A.indices(), B.indices())
+    assert torch.equal(A.values(), B.values()), "row-local sort makes the fp32 sums order independent"
+    r, c, val = ol.compute_matrix(v, f, 0.0, alpha=0.95, cotan=True)
+    assert np.array_equal(A.indices().cpu().numpy(), np.stack([r, c]))
+    got = A.values().cpu().numpy()
+    off = r != c
+    assert np.array_equal(got[off], val[off])
+    np.testing.assert_allclose(got, val, rtol=0, atol=4e-6 * np.abs(val).max())
+    U = compute_matrix(_t(v, dev), _t(f, dev), 19.0)
+    r, c, val = ol.compute_matrix(v, f, 19.0)
+    assert np.array_equal(U.indices().cpu().numpy(), np.stack([r, c]))
+    assert np.array_equal(U.values().cpu().numpy(), val)
+
+
+def test_assembly_errors(golden, dev):
+    from largesteps.geometry import compute_matrix
+    e = golden.errors()
+    v, f = golden["quad/verts"], golden["quad/faces"]
+    for a in (1.0, -0.1, 1.5):
+        with pytest.raises(ValueError) as ei:
+            compute_matrix(_t(v, dev), _t(f, dev), 1.0, alpha=a)
+        assert str(ei.value) == e[f"alpha={a}"]
+    bad = f.copy()
+    bad[0, 0] = 99
+    with pytest.raises(IndexError):
+        compute_matrix(_t(v, dev), _t(bad, dev), 1.0)
+    with pytest.raises(RuntimeError):
+        compute_matrix(torch.from_numpy(v), torch.from_numpy(f), 1.0)      # CPU tensors: no CPU path
+    M = compute_matrix(_t(v, dev), _t(np.zeros((0, 3), np.int64), dev), 2.0)   # no faces -> identity
+    assert np.array_equal(M.values().cpu().numpy(), np.ones(4, np.float32))
+
+
+# ---------------------------------------------------------------------------------------------------
+# to_differential
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("name", ["octahedron", "tetra", "quad", "unreferenced", "ico3", "plane12", "ico6"])
+def test_to_differential(golden, dev, name, case):
+    from largesteps.geometry import compute_matrix
+    from largesteps.parameterize import to_differential
+    from largesteps import _native
+    v, f = golden[f"{name}/verts"], golden[f"{name}/faces"]
+    M = compute_matrix(_t(v, dev), _t(f, dev), **golden.params[case])
+    idx, val = M.indices().cpu().numpy(), M.values().cpu().numpy()
+    u64 = osv.to_differential(idx[0], idx[1], val, v)
+    # fp32 SpMV of ~7 terms: |err| <= ~8 ulp of ||M||_inf ||v||_inf
+    bound = 1e-6 * np.abs(val).max() * max(np.abs(v).max(), 1.0) * 8
+    u = to_differential(M, _t(v, dev))
+    assert np.abs(u.cpu().numpy() - u64).max() <= bound
+    assert np.abs(u.cpu().numpy() - golden[f"{name}/{case}/u"]).max() <= 2 * bound
+    csr = _native.csr_of(M)
+    for variant in (0, 1):
+        uv = _native.spmv(csr, _t(v, dev), variant)
+        assert np.abs(uv.cpu().numpy() - u64).max() <= bound
+    # 1-D and wide inputs
+    u1 = to_differential(M, _t(v[:, 0].copy(), dev))
+    assert u1.shape == (v.shape[0],) and np.abs(u1.cpu().numpy() - u64[:, 0]).max() <= bound
+    wide = np.random.default_rng(0).standard_normal((v.shape[0], 7)).astype(np.float32)
+    uw = to_differential(M, _t(wide, dev))
+    assert np.abs(uw.cpu().numpy() - osv.to_differential(idx[0], idx[1], val, wide)).max() <= bound * 4 * max(np.abs(wide).max(), 1)
+
+
+def test_to_differential_autograd(golden, dev):
+    from largesteps.geometry import compute_matrix
+    from largesteps.parameterize import to_differential
+    v, f = golden["ico6/verts"], golden["ico6/faces"]
+    M = compute_matrix(_t(v, dev), _t(f, dev), 5.0)
+    tv = _t(v, dev).requires_grad_(True)
+    w = torch.randn(v.shape, device=dev)
+    (to_differential(M, tv) * w).sum().backward()
+    ref = torch.sparse.mm(M.t(), w)
+    assert (tv.grad - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
+# ---------------------------------------------------------------------------------------------------
+# from_differential
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["uni_l10", "cot_a0p9"])
+@pytest.mark.parametrize("name", ["octahedron", "tetra", "ico3", "plane12", "ico6"])
+def test_from_differential_vs_reference(golden, dev, name, case):
+    from largesteps.geometry import compute_matrix
+    from largesteps.parameterize import from_differential
+    v, f = golden[f"{name}/verts"], golden[f"{name}/faces"]
+    M = compute_matrix(_t(v, dev), _t(f, dev), **golden.params[case])
+    idx, val = M.indices().cpu().numpy(), M.values().cpu().numpy()
+    u_np = golden[f"{name}/{case}/u"]
+    x64 = osv.from_differential(idx[0], idx[1], val, u_np)
+    scale = max(np.abs(x64).max(), 1.0)
+    g64 = osv.from_differential(idx[0], idx[1], val, golden[f"{name}/{case}/cg_w"])
+    for method in ("Cholesky", "CG"):
+        u = _t(u_np, dev).requires_grad_(True)
+        x = from_differential(M, u, method)
+        assert x.shape == u.shape and x.dtype == torch.float32 and x.data_ptr() != u.data_ptr()
+        # stated fp32 tolerance of the path: 1e-4 relative (max-abs) vs the fp64 direct solve; on these
+        # small well-conditioned systems the error is two orders of magnitude below that
+        assert np.abs(x.detach().cpu().numpy() - x64).max() <= 2e-5 * scale
+        assert np.abs(x.detach().cpu().numpy() - golden[f"{name}/{case}/cg_x"]).max() <= 4e-5 * scale
+        (x * _t(golden[f"{name}/{case}/cg_w"], dev)).sum().backward()
+        assert np.abs(u.grad.cpu().numpy() - g64).max() <= 2e-5 * max(np.abs(g64).max(), 1.0)
+        assert np.abs(u.grad.cpu().numpy() - golden[f"{name}/{case}/cg_grad_u"]).max() <= 4e-5 * max(np.abs(g64).max(), 1.0)
+    # warm-started second call of the reference-compatible CG (solvers.py:102-124)
+    x2 = from_differential(M, _t(u_np * np.float32(1.01), dev), "CG")
+    assert np.abs(x2.cpu().numpy() - golden[f"{name}/{case}/cg_x_warm"]).max() <= 4e-5 * scale
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 6])
+def test_solver_variants_and_widths(dev, variant, k):
+    from largesteps.geometry import compute_matrix
+    from largesteps.solvers import PCGSolver
+    from largesteps import synthetic
+    v, f = synthetic.icosphere(20)          # 4002 vertices: 16 tiles, ragged last tile and last SELL slice
+    v = synthetic.perturb(v, radial=0.05, seed=2)
+    M = compute_matrix(_t(v, dev), _t(f, dev), 0.0, alpha=0.9, cotan=True)
+    idx, val = M.indices().cpu().numpy(), M.values().cpu().numpy()
+    b = np.random.default_rng(k).standard_normal((v.shape[0], k)).astype(np.float32)
+    x64 = osv.from_differential(idx[0], idx[1], val, b)
+    s = PCGSolver(M, rtol=1e-6)
+    s.set_option("variant", variant)
+    x = s.solve(_t(b, dev))
+    assert s.last_info["converged"] and 5 < s.last_info["iterations"] < 500
+    assert np.abs(x.cpu().numpy() - x64).max() <= 1e-4 * np.abs(x64).max()
+    # warm start from the solution: converged at once, solution unchanged
+    s.warm_start = True
+    s.guess_fwd = x.clone()
+    x_again = s.solve(_t(b, dev))
+    assert s.last_info["iterations"] <= 10
+    assert np.abs(x_again.cpu().numpy() - x64).max() <= 1e-4 * np.abs(x64).max()
+    # zero right-hand side
+    z = s.solve(torch.zeros_like(x))
+    assert float(z.abs().max()) == 0.0
+
+
+def test_determinism_and_fresh_output(dev):
+    from largesteps.geometry import compute_matrix
+    from largesteps.parameterize import from_differential, to_differential
+    from largesteps import synthetic
+    v, f = synthetic.plane(200)
+    tv, tf = _t(v, dev), _t(f, dev)
+    M = compute_matrix(tv, tf, 50.0)
+    u = to_differential(M, tv)
+    u_copy = u.clone()
+    a = from_differential(M, u, "Cholesky")
+    b = from_differential(M, u, "Cholesky")
+    assert torch.equal(u, u_copy), "from_differential must not modify u (solvers.py:37-39)"
+    assert a.data_ptr() != b.data_ptr()
+    assert torch.equal(a, b), "fixed-order reductions: bitwise reproducible solves"
+
+
+@pytest.mark.parametrize("cfg", ["cfg2_bunny70k", "cfg3_dragon250k"])
+def test_configs_vs_oracle(dev, cfg):
+    """BASELINE.json configs 2 and 3 at full size against the fp64 direct solve (seconds on the CPU)."""
+    from largesteps.geometry import compute_matrix
+    from largesteps.parameterize import from_differential, to_differential
+    from largesteps import synthetic
+    v, f, c = synthetic.config_mesh(cfg)
+    tv, tf = _t(v, dev), _t(f, dev)
+    M = compute_matrix(tv, tf, c["lambda_"] if c["lambda_"] is not None else 0.0, alpha=c["alpha"], cotan=c["cotan"])
+    idx, val = M.indices().cpu().numpy(), M.values().cpu().numpy()
+    u = to_differential(M, tv)
+    u64 = osv.to_differential(idx[0], idx[1], val, v)
+    assert np.abs(u.cpu().numpy() - u64).max() <= 1e-6 * np.abs(val).max() * 8 * max(np.abs(v).max(), 1.0)
+    direct = osv.DirectSolver(idx[0], idx[1], val, v.shape[0])
+    rhs = np.random.default_rng(1).standard_normal(v.shape).astype(np.float32)       # white, worst case
+    for b_np in (u.cpu().numpy(), rhs):
+        x64 = direct.solve(b_np)
+        for method in ("Cholesky", "CG"):
+            x = from_differential(M, _t(b_np, dev), method).cpu().numpy()
+            # stated fp32 tolerance: ||x - x*||_inf <= 1e-4 ||x*||_inf vs the fp64 direct solve
+            assert np.abs(x - x64).max() <= 1e-4 * np.abs(x64).max(), (cfg, method)
+
+
+def test_one_million_vertices_properties(dev):
+    """Config 4 at full size (1000 x 1000 plane, lambda = 50): size independent properties only."""
+    from largesteps.geometry import compute_matrix
+    from largesteps.parameterize import from_differential, to_differential
+    from largesteps import synthetic, _native
+    from largesteps import parameterize
+    v, f, c = synthetic.config_mesh("cfg4_plane1m")
+    tv, tf = _t(v, dev), _t(f, dev)
+    M = compute_matrix(tv, tf, c["lambda_"])
+    assert M._nnz() == 6992002                                   # SURVEY.md §8 table [probe]
+    vals = M.values()
+    idx = M.indices()
+    # rows of L sum to zero -> M 1 = 1 ; M symmetric -> 1^T M = 1^T
+    ones = torch.ones(v.shape[0], 1, device=dev)
+    assert float((to_differential(M, ones) - 1).abs().max()) <= 1e-3     # 301 - 6*50 in fp32
+    assert torch.equal(idx[0], torch.sort(idx[0], stable=True)[0])
+    key = idx[0] * v.shape[0] + idx[1]
+    assert bool((key[1:] > key[:-1]).all()), "row-major sorted and unique"
+    assert float(vals.min()) == -50.0 and float(vals.max()) == 301.0
+    # round trip: from_differential(to_differential(v)) == v    
+    u = to_differential(M, tv)
+    x = from_differential(M, u, "Cholesky")
+    info = parameterize._cache[(id(M), "Cholesky")][0].last_info
+    assert info["converged"] and 50 < info["iterations"] < 400
+    assert float((x - tv).abs().max()) <= 1e-4
+    # true residual of the returned solution, recomputed with an independent SpMV
+    r = to_differential(M, x) - u
+    assert float((r.norm(dim=0) / u.norm(dim=0)).max()) <= 5e-6
+    # linearity of the solve
+    w = torch.randn_like(u)
+    xw = from_differential(M, w, "Cholesky")
+    xs = from_differential(M, u + 2 * w, "Cholesky")
+    assert float((xs - (x + 2 * xw)).abs().max()) <= 2e-4 * float(xs.abs().max())
+    csr = _native.csr_of(M)
+    assert csr.nnz == 6992002 and csr.rowptr.dtype == torch.int32
+
+
+# ---------------------------------------------------------------------------------------------------
+# boundary behaviour
+# ---------------------------------------------------------------------------------------------------
+def test_errors_and_protocol(golden, dev):
+    from largesteps.geometry import compute_matrix
+    from largesteps.parameterize import from_differential
+    from largesteps.solvers import Solver, ConjugateGradientSolver, solve
+    e = golden.errors()
+    v, f = golden["quad/verts"], golden["quad/faces"]
+    tv = _t(v, dev)
+    M = compute_matrix(tv, _t(f, dev), 1.0)
+    with pytest.raises(ValueError) as ei:
+        from_differential(M, tv, "LU")
+    assert str(ei.value) == e["method"]
+    with pytest.raises(ValueError) as ei:
+        ConjugateGradientSolver(M).solve(tv[:, 0])
+    assert str(ei.value) == e["cg_shape"]
+    with pytest.raises(NotImplementedError):
+        Solver(M).solve(tv)
+
+    class Twice(Solver):                      # any object with .solve(b, backward) plugs into solve()
+        def solve(self, b, backward=False):
+            return 2 * b
+
+    u = tv.clone().requires_grad_(True)
+    solve(Twice(M), u).sum().backward()
+    assert torch.equal(u.grad, torch.full_like(u, 2.0))
+
+
+def test_cache_lifetime(golden, dev):
+    from largesteps.geometry import compute_matrix
+    from largesteps.parameterize import from_differential
+    from largesteps import parameterize, _native
+    v, f = golden["ico6/verts"], golden["ico6/faces"]
+    tv = _t(v, dev)
+    n_solver, n_csr = len(parameterize._cache), len(_native._csr_cache)
+    M = compute_matrix(tv, _t(f, dev), 3.0)
+    x1 = from_differential(M, tv, "CG")
+    x2 = from_differential(M, tv, "CG")
+    assert (id(M), "CG") in parameterize._cache and len(parameterize._cache) == n_solver + 1
+    assert float((x1 - x2).abs().max()) <= 1e-5
+    from_differential(M, tv, "Cholesky")
+    assert len(parameterize._cache) == n_solver + 2
+    del M
+    gc.collect()
+    assert len(parameterize._cache) == n_solver, "solvers (CG included) die with the matrix"
+    assert len(_native._csr_cache) == n_csr
+
+
+def test_foreign_matrix(golden, dev):
+    """A matrix assembled by stock torch ops (what the reference's geometry.py returns) is accepted."""
+    from largesteps.parameterize import from_differential, to_differential
+    v = golden["ico6/verts"]
+    idx, val = golden["ico6/cot_a0p9/idx"], golden["ico6/cot_a0p9/val"]
+    M = torch.sparse_coo_tensor(_t(idx, dev), _t(val, dev), (v.shape[0],) * 2).coalesce()
+    u = to_differential(M, _t(v, dev))
+    assert np.abs(u.cpu().numpy() - golden["ico6/cot_a0p9/u"]).max() <= 1e-5
+    x = from_differential(M, u, "Cholesky")
+    assert np.abs(x.cpu().numpy() - v).max() <= 2e-5
+    with pytest.raises(ValueError):
+        to_differential(torch.sparse_coo_tensor(_t(idx[:, ::-1].copy(), dev), _t(val, dev), (v.shape[0],) * 2), _t(v, dev))
+
+
+def test_backward_on_autograd_thread_and_side_stream(golden, dev):
+    from largesteps.geometry import compute_matrix
+    from largesteps.parameterize import from_differential, to_differential
+    v, f = golden["ico6/verts"], golden["ico6/faces"]
+    tv, tf = _t(v, dev), _t(f, dev)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        M = compute_matrix(tv, tf, 10.0)
+        u = to_differential(M, tv).requires_grad_(True)
+        x = from_differential(M, u, "Cholesky")
+        loss = ((x - tv) ** 2).sum() + x.sum()
+        loss.backward()
+    side.synchronize()
+    idx, val = M.indices().cpu().numpy(), M.values().cpu().numpy()
+    g64 = osv.from_differential(idx[0], idx[1], val, np.ones_like(v))
+    assert np.abs(u.grad.cpu().numpy() - g64).max() <= 5e-5
+
+
+def test_adam_uniform(golden, dev):
+    from largesteps.optimize import AdamUniform
+    p = torch.nn.Parameter(_t(golden["adam/p0"], dev))
+    tgt = _t(golden["adam/target"], dev)
+    opt = AdamUniform([p], lr=0.05, betas=(0.9, 0.999))
+    for step in range(5):
+        opt.zero_grad()
+        ((p - tgt) ** 2).sum().backward()
+        opt.step()
+        # fp32 elementwise update: 2e-6 relative (bias-correction reciprocal rounding differs from torch)
+        np.testing.assert_allclose(p.detach().cpu().numpy(), golden["adam/traj"][step], rtol=2e-6, atol=2e-7)
+    assert set(opt.state[p].keys()) == {"step", "g1", "g2"}

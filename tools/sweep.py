@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""A/B sweep of the PCG knobs on one GPU: matrix access variant x grid size, per-kernel HIP-event times.
+Usage: python tools/sweep.py [workload ...]   (default: cfg4_plane1m cfg2_bunny70k cfg3_dragon250k)"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "large-steps-pytorch_amd")]
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from largesteps.geometry import compute_matrix  # noqa: E402
+from largesteps.parameterize import to_differential  # noqa: E402
+from largesteps.solvers import PCGSolver  # noqa: E402
+from largesteps import synthetic, _native  # noqa: E402
+
+
+def timeit(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+def main():
+    dev = torch.device("cuda:0")
+    names = sys.argv[1:] or ["cfg4_plane1m", "cfg2_bunny70k", "cfg3_dragon250k"]
+    for name in names:
+        v, f, c = synthetic.config_mesh(name)
+        tv, tf = torch.from_numpy(v).to(dev), torch.from_numpy(f).to(dev)
+        t_asm = timeit(lambda: compute_matrix(tv, tf, c["lambda_"] or 0.0, alpha=c["alpha"], cotan=c["cotan"]), 3)
+        M = compute_matrix(tv, tf, c["lambda_"] or 0.0, alpha=c["alpha"], cotan=c["cotan"])
+        u = to_differential(M, tv)
+        csr = _native.csr_of(M)
+        V, nnz = csr.V, csr.nnz
+        print(f"== {name}: V={V} nnz={nnz} assemble={t_asm:.2f} ms")
+        for variant in (0, 1):
+            t = timeit(lambda: _native.spmv(csr, tv, variant), 20)
+            print(f"   to_differential variant {variant}: {t * 1e3:8.1f} us  {(8 * nnz + 28 * V) / t / 1e6:8.1f} GB/s")
+        s = PCGSolver(M, rtol=1e-6)
+        for variant in (2, 0, 1):
+            for grid in (512, 1024, 2048):
+                for ce in (16,):
+                    s.set_option("variant", variant); s.set_option("grid", grid); s.set_option("check_every", ce)
+                    ms = timeit(lambda: s.solve(u), 5)
+                    it = s.last_info["iterations"]
+                    s.set_option("profile", 1)
+                    s.solve(u)
+                    k1, k2, k3, pit = s.kernel_profile()
+                    s.set_option("profile", 0)
+                    b1 = 8 * nnz + 4 * (V + 1) + 24 * V
+                    print(f"   variant {variant} grid {grid:5d} check {ce:3d}: {ms:8.3f} ms/solve  iters {it:4d}  {ms * 1e3 / it:7.2f} us/iter | "
+                          f"K1 {k1 / pit * 1e3:6.2f} us ({b1 / (k1 / pit) / 1e6:6.0f} GB/s)  K2 {k2 / pit * 1e3:6.2f} us ({76 * V / (k2 / pit) / 1e6:6.0f} GB/s)  "
+                          f"K3 {k3 / pit * 1e3:6.2f} us ({40 * V / (k3 / pit) / 1e6:6.0f} GB/s)", flush=True)
+        x = s.solve(u)
+        print(f"   max|x - v| = {float((x - tv).abs().max()):.2e}  rel residual {[r / b for r, b in zip(s.last_info['rnorm'], s.last_info['bnorm'])]}")
+        for ce in (4, 8, 32, 64):
+            s.set_option("variant", 2); s.set_option("grid", 1024); s.set_option("check_every", ce)
+            print(f"   check_every {ce:3d}: {timeit(lambda: s.solve(u), 5):8.3f} ms/solve")
+        # warm start from a slightly perturbed right-hand side (the optimisation loop's situation)
+        s.set_option("check_every", 16)
+        s.warm_start = True
+        s.solve(u)
+        ms = timeit(lambda: s.solve(u * 1.001), 5)
+        print(f"   warm start (u*1.001): {ms:8.3f} ms/solve iters {s.last_info['iterations']}")
+        del s, M
+
+
+if __name__ == "__main__":
+    main()
