@@ -3,12 +3,12 @@
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-( timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 2>&1 | tail -60 ) > gpurun_out/pytest.log 2>&1
+( timeout 700 python -m pytest tests -m gpu -q --timeout 300 2>&1 | tail -60 ) > gpurun_out/pytest.log 2>&1
 echo "pytest exit: $?" >> gpurun_out/pytest.log
-( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" ) > gpurun_out/smoke.log 2>&1
-( timeout 600 python bench.py --steps 20 --warmup 3 ) > gpurun_out/bench.json 2> gpurun_out/bench.err
-( timeout 900 python tools/sweep.py ) > gpurun_out/sweep.txt 2>&1
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline ) > gpurun_out/rocprof.log 2>&1
+( timeout 200 python -c "import __graft_entry__ as g; g.smoke()" ) > gpurun_out/smoke.log 2>&1
+( timeout 400 python bench.py --steps 20 --warmup 3 ) > gpurun_out/bench.json 2> gpurun_out/bench.err
+( timeout 500 python tools/sweep.py ) > gpurun_out/sweep.txt 2>&1
+( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline ) > gpurun_out/rocprof.log 2>&1
 ls -R gpurun_out | head -50
 tail -5 gpurun_out/pytest.log
 cat gpurun_out/smoke.log | tail -3
