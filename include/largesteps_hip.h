@@ -22,6 +22,7 @@
  *   ls_solver_*          largesteps/solvers.py:26-39 (CholeskySolver.__init__/solve -> cholespy) and
  *                        :41-126 (ConjugateGradientSolver); one handle == one cached solver object of
  *                        largesteps/parameterize.py:48-59
+ *   ls_solver_phase/...  no reference counterpart: the reference is single process / single GPU
  *   ls_adam_uniform_step largesteps/optimize.py:18-41
  */
 #ifndef LARGESTEPS_HIP_H
@@ -86,14 +87,14 @@ int ls_spmv(const int32_t* rowptr, const int32_t* col, const float* val, int64_t
             const float* x, float* y, int k, int variant, int device, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Jacobi-preconditioned conjugate gradient on M (SPD). One handle per matrix; owns its workspace
- * (r, p, Ap, dinv, reduction scratch) sized for `kmax` right-hand-side columns (1..4).
- * The CSR arrays are NOT copied: they must outlive the handle.
+ * Jacobi-preconditioned conjugate gradient on M (SPD). One handle per matrix; owns a SELL-64 copy of the
+ * matrix and its workspace (dinv, r, p, Ap, reduction scratch) sized for `kmax` right-hand-side columns
+ * (1..4). The CSR arrays are only read during creation. SYNC (once, to size the SELL copy).
  * --------------------------------------------------------------------------------------------- */
 typedef struct ls_solver ls_solver;
 
 typedef struct ls_solve_info {
-    int32_t iterations;   /* iterations executed until every column met its threshold */
+    int32_t iterations;   /* iterations executed until every column met its threshold (-1: still running, ls_solver_poll) */
     int32_t converged;    /* 1 if every column met its threshold */
     double  rnorm[4];     /* final ||r||_2 per column (recursively updated residual) */
     double  bnorm[4];     /* ||b||_2 per column */
@@ -107,8 +108,8 @@ int ls_solver_destroy(ls_solver* s);
  * Returns LS_E_NOT_CONVERGED (info still filled) if max_iter is hit. */
 int ls_solver_solve(ls_solver* s, const float* b, const float* x0, float* x, int k, double rtol,
                     double atol, int max_iter, ls_solve_info* h_info, void* stream);
-/* knobs for measurements: name in {"variant" (0 CSR+LDS, 1 CSR direct, 2 SELL-64), "check_every", "grid",
- * "profile"}; unknown name -> LS_E_INVALID */
+/* knobs for measurements: name in {"check_every", "grid" (workgroups per kernel, 0 = auto), "block" (0 = auto,
+ * 256 or 1024 threads per workgroup), "profile"}; unknown name -> LS_E_INVALID */
 int ls_solver_set(ls_solver* s, const char* name, int value);
 /* With "profile"=1 every solve brackets its three kernels per iteration with HIP events on the solve's
  * stream; this returns the accumulated milliseconds of K1 (SpMV+dot), K2 (update), K3 (direction) over the
@@ -116,6 +117,33 @@ int ls_solver_set(ls_solver* s, const char* name, int value);
 int ls_solver_profile(const ls_solver* s, double* h_ms3, int* h_iters);
 /* bytes the handle allocated on the device */
 int ls_solver_workspace_bytes(const ls_solver* s, size_t* h_bytes);
+
+/* ------------------------------------------------------------------------------------------------
+ * Vertex-block shard of the same solver (one process per GPU, largesteps/distributed.py). The shard owns
+ * rows [0, n_rows) of its block; columns are local ids: [0, n_rows) owned, [n_rows, n_cols) halo. The host
+ * driver launches one kernel at a time and, between them, exchanges the halo rows of p and sums the
+ * reduction partials across ranks (RCCL):
+ *   phase 0  r = b, p = D^-1 r, x = 0 ; partials r.z, r.r, b.b      -> all-reduce partials [1..3]
+ *   phase 1  thresholds / column mask from the summed partials
+ *   phase 2  K1: Ap = M p_ext ; partial p.Ap  (needs the halo of p)   -> all-reduce partials [0]
+ *   phase 3  K2: x += a p ; r -= a Ap ; partials r.z, r.r             -> all-reduce partials [1..2]
+ *   phase 4  K3: p = D^-1 r + b p ; publishes the stop flag            -> halo exchange of p
+ * ls_solver_buffers exposes p ((n_cols,k) fp32; the halo rows start at p + n_rows*k) and the partial array
+ * (4 slots x 4 columns x h_part_stride doubles; slot s, column c, workgroup g at ((s*4+c)*stride + g)); every
+ * rank must use the same "grid" so that the partial arrays line up.
+ * --------------------------------------------------------------------------------------------- */
+int ls_solver_create_ext(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
+                         int64_t n_cols, int64_t nnz, int kmax, int device, void* stream, ls_solver** h_out);
+int ls_solver_phase(ls_solver* s, int phase, const float* b, float* x, int k, double rtol, double atol,
+                    int it, void* stream);
+int ls_solver_buffers(ls_solver* s, float** h_p, double** h_part, int* h_grid, int* h_part_stride);
+/* Replace the handle's p ((n_cols*kmax) floats) and partial array (4*4*stride doubles, zero-initialised by the
+ * caller) by caller-owned device buffers, so that the host driver can hand them to its communication library. */
+int ls_solver_bind(ls_solver* s, float* p_ext, double* part);
+/* SYNC: copies the device scalars; h_info->iterations = -1 while no stop was published. */
+int ls_solver_poll(ls_solver* s, int k, int n_enqueued, ls_solve_info* h_info, void* stream);
+/* dst[t,:] = src[idx[t],:] for t < n (halo send buffer packing), k in 1..4 */
+int ls_gather_rows(const float* src, const int32_t* idx, int64_t n, int k, float* dst, int device, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * AdamUniform step (optimize.py:18-41) on n contiguous fp32 elements, two kernels, no host sync:

@@ -5,14 +5,22 @@
 // kernels and one host sync per iteration).
 //
 // One iteration = three kernels, all scalars stay on the device, every column has its own alpha/beta:
-//   K1  Ap = M p                      ; partial  p.Ap
+//   K1  Ap = M p                      ; partial  p.Ap                          (matrix in SELL-64)
 //   K2  x += a p ; r -= a Ap          ; partial  r.D^-1 r , r.r        (a  = rz / pAp)
 //   K3  p = D^-1 r + b p              ; publishes rz, ||r||^2, the column mask and the stop flag  (b = rz'/rz)
 // Dot products: fp32 products accumulated in fp64 per thread, wave shuffle + LDS block reduction,
 // one partial per workgroup; the NEXT kernel reduces the <= 1024 partials in a fixed order in every
-// workgroup (deterministic, no atomics, no extra launch).
+// workgroup (deterministic, no atomics, no extra launch). The loads of a workgroup's first row tile are
+// issued BEFORE that reduction so that the scalar hand-off hides under HBM latency.
+// Geometry: 1024-thread workgroups, two per CU (32 waves/CU) for large systems; 256-thread
+// workgroups for small ones. Row tiles are dealt to workgroups XCD-aware (common.h TileSched).
 // The host enqueues iterations in chunks and polls a stop flag one chunk behind the GPU; kernels of
 // iterations past the stop point return immediately.
+//
+// The same kernels serve the vertex-block sharded solver (largesteps/distributed.py): the matrix of a
+// shard is rectangular (n_rows owned rows, n_cols = owned + halo columns), p carries the halo entries,
+// and the partial arrays are summed across ranks (RCCL all-reduce) between the kernels, which is why
+// the kernels can also be launched one at a time (ls_solver_phase).
 #include "spmv_kernels.h"
 #include <algorithm>
 #include <limits.h>
@@ -23,8 +31,9 @@
 namespace ls {
 
 constexpr int KMAX = 4;
+constexpr int MAXG = 1024;            // capacity of one partial array (>= grid size of any PCG kernel)
 constexpr int PROF_MAX_ITERS = 512;
-constexpr int PART_PAP = 0, PART_RZ = 1, PART_RR = 2, PART_BB = 3, PART_SLOTS = 4;
+constexpr int PART_PAP = 0, PART_RZ = 1, PART_SLOTS = 4;   // slots: 0 p.Ap | 1 r.z | 2 r.r | 3 b.b
 
 struct Scal {
     double rz[2][KMAX];      // r.z, ring indexed by iteration parity
@@ -36,54 +45,112 @@ struct Scal {
     int bad;                 // 1: non-finite residual, 2: p.Ap <= 0 (matrix not SPD)
 };
 
-__device__ __forceinline__ double* part_ptr(double* part, int slot) { return part + (size_t)slot * KMAX * MAX_GRID; }
+// partial array n (0 <= n < N) of a group that starts at slot0 and holds K columns per slot
+__device__ __forceinline__ size_t part_off(int slot0, int K, int n) { return (size_t)((slot0 + n / K) * KMAX + n % K) * MAXG; }
 
 template <int K>
 __device__ __forceinline__ Vec<K> ldv(const float* __restrict__ a, int64_t i) { return reinterpret_cast<const Vec<K>*>(a)[i]; }
 template <int K>
 __device__ __forceinline__ void stv(float* __restrict__ a, int64_t i, const Vec<K>& v) { reinterpret_cast<Vec<K>*>(a)[i] = v; }
 
-template <int N>
-__device__ __forceinline__ void write_partials(double (&acc)[N], double* __restrict__ part, int slot0, int per_slot, double* smem) {
-    block_sum<N>(acc, smem);
+// Sum of N doubles per thread over a BS-thread workgroup; result valid in thread 0. smem: (BS/64)*N doubles.
+template <int N, int BS>
+__device__ __forceinline__ void wg_sum(double (&x)[N], double* smem) {
+    constexpr int NW = BS / WAVE;
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        x[i] = wave_sum(x[i]);
+        if (lane == 0) smem[w * N + i] = x[i];
+    }
+    __syncthreads();
+    if (w == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double v = lane < NW ? smem[lane * N + i] : 0.0;
+            x[i] = wave_sum(v);
+        }
+    }
+    __syncthreads();
+}
+
+// Deterministic reduction of N partial arrays (written by the G workgroups of the previous kernel, possibly
+// summed across ranks) to N scalars, broadcast to every thread. All loads are issued before the first add.
+// smem: N + (BS/64)*N doubles.
+template <int N, int K, int BS>
+__device__ __forceinline__ void reduce_partials(const double* __restrict__ part, int slot0, int G, double (&out)[N], double* smem) {
+    constexpr int J = (MAXG + BS - 1) / BS;
+    double v[N][J];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const double* __restrict__ pp = part + part_off(slot0, K, n);
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int g = threadIdx.x + j * BS;
+            v[n][j] = g < G ? pp[g] : 0.0;
+        }
+    }
+    double acc[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        double s = v[n][0];
+#pragma unroll
+        for (int j = 1; j < J; ++j) s += v[n][j];
+        acc[n] = s;
+    }
+    wg_sum<N, BS>(acc, smem + N);
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int n = 0; n < N; ++n) {
-            const int slot = slot0 + n / per_slot, c = n % per_slot;
-            part_ptr(part, slot)[(size_t)c * MAX_GRID + blockIdx.x] = acc[n];
-        }
+        for (int n = 0; n < N; ++n) smem[n] = acc[n];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < N; ++n) out[n] = smem[n];
+    __syncthreads();
+}
+
+template <int N, int K, int BS>
+__device__ __forceinline__ void write_partials(double (&acc)[N], double* __restrict__ part, int slot0, double* smem) {
+    wg_sum<N, BS>(acc, smem);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int n = 0; n < N; ++n) part[part_off(slot0, K, n) + blockIdx.x] = acc[n];
     }
 }
 
-// matrix access variants: 0 = CSR staged through LDS, 1 = CSR direct, 2 = SELL-64
-template <int K, int VARIANT>
-__device__ __forceinline__ void mat_row(const CsrView& A, const SellView& S, const float* __restrict__ x, int64_t r0, int64_t r1,
-                                        int64_t V, int2* s_cv, float (&acc)[K]) {
-    const int64_t i = r0 + threadIdx.x;
-    if (VARIANT == 0) row_csr_lds<K>(A, x, r0, r1, s_cv, acc);
-    else if (VARIANT == 1) { if (i < r1) row_csr_direct<K>(A, x, i, acc); }
-    else { if ((i & ~(int64_t)(WAVE - 1)) < V) row_sell<K>(S, x, i, acc); }
-}
+// tile schedule with BS-row tiles (see common.h TileSched for the XCD reasoning)
+struct Sched {
+    int first, step, end;
+    __device__ __forceinline__ Sched(int T, int G) {
+        if (G >= 8 && (G & 7) == 0) {
+            const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, per = (T + 7) >> 3;
+            const int lo = xcd * per;
+            end = min(T, lo + per);
+            first = lo + local;
+            step = G >> 3;
+        } else {
+            first = blockIdx.x; step = G; end = T;
+        }
+    }
+};
 
 // ---- setup of one solve ----------------------------------------------------------------------------
-template <int K, int VARIANT, bool WARM>
-__global__ __launch_bounds__(BLOCK) void k_init(CsrView A, SellView S, const float* __restrict__ dinv, const float* __restrict__ b,
-                                                const float* __restrict__ x0, float* __restrict__ x, float* __restrict__ r,
-                                                float* __restrict__ p, double* __restrict__ part, int64_t V, int T, int G) {
-    __shared__ int2 s_cv[(VARIANT == 0 && WARM) ? LDS_CAP : 1];
-    __shared__ double s_red[5 * 3 * K];
+template <int K, int BS, bool WARM>
+__global__ __launch_bounds__(BS) void k_init(SellView S, const float* __restrict__ dinv, const float* __restrict__ b,
+                                             const float* __restrict__ x0, float* __restrict__ x, float* __restrict__ r,
+                                             float* __restrict__ p, double* __restrict__ part, int64_t V, int T, int G) {
+    __shared__ double s_red[(BS / WAVE) * 3 * K];
     double acc[3 * K];
 #pragma unroll
     for (int n = 0; n < 3 * K; ++n) acc[n] = 0.0;
-    const TileSched sch(T, G);
+    const Sched sch(T, G);
     for (int tile = sch.first; tile < sch.end; tile += sch.step) {
-        const int64_t r0 = (int64_t)tile * TILE_ROWS, r1 = min(r0 + (int64_t)TILE_ROWS, V);
-        const int64_t i = r0 + threadIdx.x;
+        const int64_t i = (int64_t)tile * BS + threadIdx.x;
         float ax[K];
 #pragma unroll
         for (int q = 0; q < K; ++q) ax[q] = 0.0f;
-        if (WARM) mat_row<K, VARIANT>(A, S, x0, r0, r1, V, s_cv, ax);
-        if (i < r1) {
+        if (WARM && (i & ~(int64_t)(WAVE - 1)) < V) row_sell<K>(S, x0, i, ax);
+        if (i < V) {
             const Vec<K> bv = ldv<K>(b, i);
             const float di = dinv[i];
             Vec<K> xv, rv, pv;
@@ -102,27 +169,14 @@ __global__ __launch_bounds__(BLOCK) void k_init(CsrView A, SellView S, const flo
             stv<K>(p, i, pv);
         }
     }
-    write_partials<3 * K>(acc, part, PART_RZ, K, s_red);   // slots RZ, RR, BB
+    write_partials<3 * K, K, BS>(acc, part, PART_RZ, s_red);   // slots r.z, r.r, b.b
 }
 
 template <int K>
-__global__ __launch_bounds__(BLOCK) void k_init_scal(double* __restrict__ part, Scal* __restrict__ sc, int G, double rtol2, double atol2) {
-    __shared__ double s_red[5 * 3 * K];
+__global__ __launch_bounds__(1024) void k_init_scal(const double* __restrict__ part, Scal* __restrict__ sc, int G, double rtol2, double atol2) {
+    __shared__ double s_red[3 * K * 17];
     double v[3 * K];
-    // the three partial arrays are contiguous slots: reduce them as one [3K][MAX_GRID] array
-    {
-        double acc[3 * K];
-#pragma unroll
-        for (int n = 0; n < 3 * K; ++n) {
-            const double* pp = part_ptr(part, PART_RZ + n / K) + (size_t)(n % K) * MAX_GRID;
-            double s = 0.0;
-            for (int g = threadIdx.x; g < G; g += BLOCK) s += pp[g];
-            acc[n] = s;
-        }
-        block_sum<3 * K>(acc, s_red);
-#pragma unroll
-        for (int n = 0; n < 3 * K; ++n) v[n] = acc[n];
-    }
+    reduce_partials<3 * K, K, 1024>(part, PART_RZ, G, v, s_red);
     if (threadIdx.x == 0) {
         int mask = 0, bad = 0;
         for (int q = 0; q < K; ++q) {
@@ -144,25 +198,22 @@ __global__ __launch_bounds__(BLOCK) void k_init_scal(double* __restrict__ part, 
 }
 
 // ---- K1: Ap = M p, partial p.Ap ----------------------------------------------------------------------
-template <int K, int VARIANT>
-__global__ __launch_bounds__(BLOCK) void k_spmv_dot(CsrView A, SellView S, const float* __restrict__ p, float* __restrict__ Ap,
-                                                    double* __restrict__ part, const Scal* __restrict__ sc, int it, int64_t V,
-                                                    int T, int G) {
-    __shared__ int2 s_cv[VARIANT == 0 ? LDS_CAP : 1];
-    __shared__ double s_red[5 * K];
+template <int K, int BS>
+__global__ __launch_bounds__(BS) void k_spmv_dot(SellView S, const float* __restrict__ p, float* __restrict__ Ap,
+                                                 double* __restrict__ part, const Scal* __restrict__ sc, int it, int64_t V, int T, int G) {
+    __shared__ double s_red[(BS / WAVE) * K];
     if (it >= sc->stop_iter) return;
     double acc[K];
 #pragma unroll
     for (int q = 0; q < K; ++q) acc[q] = 0.0;
-    const TileSched sch(T, G);
+    const Sched sch(T, G);
     for (int tile = sch.first; tile < sch.end; tile += sch.step) {
-        const int64_t r0 = (int64_t)tile * TILE_ROWS, r1 = min(r0 + (int64_t)TILE_ROWS, V);
-        const int64_t i = r0 + threadIdx.x;
+        const int64_t i = (int64_t)tile * BS + threadIdx.x;
         float ap[K];
 #pragma unroll
         for (int q = 0; q < K; ++q) ap[q] = 0.0f;
-        mat_row<K, VARIANT>(A, S, p, r0, r1, V, s_cv, ap);
-        if (i < r1) {
+        if ((i & ~(int64_t)(WAVE - 1)) < V) row_sell<K>(S, p, i, ap);
+        if (i < V) {
             const Vec<K> pv = ldv<K>(p, i);
             Vec<K> o;
 #pragma unroll
@@ -170,18 +221,30 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_dot(CsrView A, SellView S, const
             stv<K>(Ap, i, o);
         }
     }
-    write_partials<K>(acc, part, PART_PAP, K, s_red);
+    write_partials<K, K, BS>(acc, part, PART_PAP, s_red);
 }
 
 // ---- K2: x += alpha p ; r -= alpha Ap ; partial r.D^-1 r and r.r --------------------------------------
-template <int K>
-__global__ __launch_bounds__(BLOCK) void k_update(const float* __restrict__ dinv, const float* __restrict__ p,
-                                                  const float* __restrict__ Ap, float* __restrict__ x, float* __restrict__ r,
-                                                  double* __restrict__ part, Scal* __restrict__ sc, int it, int64_t V, int T, int G) {
-    __shared__ double s_red[5 * 2 * K];
+template <int K, int BS>
+__global__ __launch_bounds__(BS) void k_update(const float* __restrict__ dinv, const float* __restrict__ p,
+                                               const float* __restrict__ Ap, float* __restrict__ x, float* __restrict__ r,
+                                               double* __restrict__ part, Scal* __restrict__ sc, int it, int64_t V, int T, int G) {
+    __shared__ double s_red[(BS / WAVE + 1) * 2 * K];
     if (it >= sc->stop_iter) return;
+    const Sched sch(T, G);
+    int tile = sch.first;
+    int64_t i = 0;
+    bool valid = false;
+    Vec<K> pv, av, xv, rv;
+    float di = 0.0f;
+    auto load = [&](int t) {
+        i = (int64_t)t * BS + threadIdx.x;
+        valid = t < sch.end && i < V;
+        if (valid) { pv = ldv<K>(p, i); av = ldv<K>(Ap, i); xv = ldv<K>(x, i); rv = ldv<K>(r, i); di = dinv[i]; }
+    };
+    load(tile);                                   // in flight while the scalars are reduced
     double pAp[K];
-    reduce_partials<K>(part_ptr(part, PART_PAP), G, pAp, s_red);
+    reduce_partials<K, K, BS>(part, PART_PAP, G, pAp, s_red);
     const int mask = sc->mask[it & 1];
     float alpha[K];
     int bad = 0;
@@ -195,13 +258,8 @@ __global__ __launch_bounds__(BLOCK) void k_update(const float* __restrict__ dinv
     double acc[2 * K];
 #pragma unroll
     for (int n = 0; n < 2 * K; ++n) acc[n] = 0.0;
-    const TileSched sch(T, G);
-    for (int tile = sch.first; tile < sch.end; tile += sch.step) {
-        const int64_t i = (int64_t)tile * TILE_ROWS + threadIdx.x;
-        if (i < V) {
-            const Vec<K> pv = ldv<K>(p, i), av = ldv<K>(Ap, i);
-            Vec<K> xv = ldv<K>(x, i), rv = ldv<K>(r, i);
-            const float di = dinv[i];
+    while (tile < sch.end) {
+        if (valid) {
 #pragma unroll
             for (int q = 0; q < K; ++q) {
                 xv.v[q] = fmaf(alpha[q], pv.v[q], xv.v[q]);
@@ -213,36 +271,32 @@ __global__ __launch_bounds__(BLOCK) void k_update(const float* __restrict__ dinv
             stv<K>(x, i, xv);
             stv<K>(r, i, rv);
         }
+        tile += sch.step;
+        load(tile);
     }
-    write_partials<2 * K>(acc, part, PART_RZ, K, s_red);   // slots RZ, RR
+    write_partials<2 * K, K, BS>(acc, part, PART_RZ, s_red);   // slots r.z, r.r
 }
 
 // ---- K3: p = D^-1 r + beta p ; publish scalars for the next iteration --------------------------------
-template <int K>
-__global__ __launch_bounds__(BLOCK) void k_direction(const float* __restrict__ dinv, const float* __restrict__ r, float* __restrict__ p,
-                                                     const double* __restrict__ part, Scal* __restrict__ sc, int it, int64_t V,
-                                                     int T, int G) {
-    __shared__ double s_red[5 * 2 * K];
+template <int K, int BS>
+__global__ __launch_bounds__(BS) void k_direction(const float* __restrict__ dinv, const float* __restrict__ r, float* __restrict__ p,
+                                                  const double* __restrict__ part, Scal* __restrict__ sc, int it, int64_t V, int T, int G) {
+    __shared__ double s_red[(BS / WAVE + 1) * 2 * K];
     if (it >= sc->stop_iter) return;
+    const Sched sch(T, G);
+    int tile = sch.first;
+    int64_t i = 0;
+    bool valid = false;
+    Vec<K> rv, pv;
+    float di = 0.0f;
+    auto load = [&](int t) {
+        i = (int64_t)t * BS + threadIdx.x;
+        valid = t < sch.end && i < V;
+        if (valid) { rv = ldv<K>(r, i); pv = ldv<K>(p, i); di = dinv[i]; }
+    };
+    load(tile);
     double red[2 * K];
-    {
-        double acc[2 * K];
-#pragma unroll
-        for (int n = 0; n < 2 * K; ++n) {
-            const double* pp = part + (size_t)(PART_RZ + n / K) * KMAX * MAX_GRID + (size_t)(n % K) * MAX_GRID;
-            double s = 0.0;
-            for (int g = threadIdx.x; g < G; g += BLOCK) s += pp[g];
-            acc[n] = s;
-        }
-        block_sum<2 * K>(acc, s_red + 2 * K);
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int n = 0; n < 2 * K; ++n) s_red[n] = acc[n];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int n = 0; n < 2 * K; ++n) red[n] = s_red[n];
-    }
+    reduce_partials<2 * K, K, BS>(part, PART_RZ, G, red, s_red);
     const int mask = sc->mask[it & 1];
     float beta[K];
 #pragma unroll
@@ -267,17 +321,14 @@ __global__ __launch_bounds__(BLOCK) void k_direction(const float* __restrict__ d
         if (bad) sc->bad = bad;
         if (nmask == 0 || bad || sc->bad) sc->stop_iter = it + 1;
     }
-    const TileSched sch(T, G);
-    for (int tile = sch.first; tile < sch.end; tile += sch.step) {
-        const int64_t i = (int64_t)tile * TILE_ROWS + threadIdx.x;
-        if (i < V) {
-            const Vec<K> rv = ldv<K>(r, i);
-            Vec<K> pv = ldv<K>(p, i);
-            const float di = dinv[i];
+    while (tile < sch.end) {
+        if (valid) {
 #pragma unroll
             for (int q = 0; q < K; ++q) pv.v[q] = fmaf(beta[q], pv.v[q], di * rv.v[q]);
             stv<K>(p, i, pv);
         }
+        tile += sch.step;
+        load(tile);
     }
 }
 
@@ -291,10 +342,27 @@ __global__ __launch_bounds__(BLOCK) void k_sell_widths(const int* __restrict__ r
     if ((threadIdx.x & (WAVE - 1)) == 0 && slice < S) width64[slice] = len * WAVE;
 }
 
-__global__ void k_sell_scan(const int* __restrict__ width64, int S, int* __restrict__ slice_ptr) {   // <<<1,1>>>: S <= V/64, one-off
-    long long run = 0;
-    for (int s = 0; s < S; ++s) { slice_ptr[s] = (int)run; run += width64[s]; }
-    slice_ptr[S] = run > (long long)INT_MAX ? -1 : (int)run;
+// exclusive scan of the slice sizes by one 1024-thread workgroup (S <= V/64; one-off per matrix)
+__global__ __launch_bounds__(1024) void k_sell_scan(const int* __restrict__ width64, int S, int* __restrict__ slice_ptr) {
+    __shared__ long long s_w[17];
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    long long carry = 0;
+    for (int base = 0; base < S; base += 1024) {
+        const int s = base + threadIdx.x;
+        const long long v = s < S ? width64[s] : 0;
+        long long inc = v;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) { long long y = __shfl_up(inc, off, WAVE); if (lane >= off) inc += y; }
+        if (lane == WAVE - 1) s_w[w] = inc;
+        __syncthreads();
+        if (threadIdx.x == 0) { long long run = 0; for (int j = 0; j < 16; ++j) { long long t = s_w[j]; s_w[j] = run; run += t; } s_w[16] = run; }
+        __syncthreads();
+        const long long ex = carry + s_w[w] + inc - v;
+        if (s < S) slice_ptr[s] = ex > (long long)INT_MAX ? -1 : (int)ex;
+        carry += s_w[16];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) slice_ptr[S] = carry > (long long)INT_MAX ? -1 : (int)carry;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_sell_fill(CsrView A, int64_t V, const int* __restrict__ slice_ptr, int2* __restrict__ cv) {
@@ -322,13 +390,19 @@ __global__ __launch_bounds__(BLOCK) void k_diag_inv(CsrView A, int64_t V, float*
     dinv[i] = 1.0f / d;
 }
 
+template <int K>
+__global__ __launch_bounds__(BLOCK) void k_gather_rows(const float* __restrict__ src, const int* __restrict__ idx, int64_t n, float* __restrict__ dst) {
+    const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t < n) stv<K>(dst, t, ldv<K>(src, idx[t]));
+}
+
 }  // namespace ls
 
 using namespace ls;
 
 struct ls_solver {
     int device = 0;
-    int64_t V = 0, nnz = 0;
+    int64_t V = 0, ncols = 0, nnz = 0;
     int kmax = 0;
     CsrView csr{};
     SellView sell{};
@@ -340,7 +414,8 @@ struct ls_solver {
     Scal* scal = nullptr;
     Scal* h_scal = nullptr;       // pinned, 2 polling slots + 1 final
     hipEvent_t ev[2] = {nullptr, nullptr};
-    int variant = 2, check_every = 16, grid = 0, last_iters = 0;
+    int check_every = 16, grid = 0, block = 0, last_iters = 0;
+    bool own_p = true, own_part = true;   // false after ls_solver_bind: the caller owns those buffers
     size_t bytes = 0;
     // optional per-kernel timing with HIP events on the solve's own stream (ls_solver_set("profile", 1))
     int profile = 0;
@@ -349,8 +424,25 @@ struct ls_solver {
     int prof_iters = 0;
 };
 
+namespace {
+
+struct Geometry { int bs, T, G; };
+
+Geometry geometry(const ls_solver* s) {
+    Geometry g;
+    g.bs = s->block ? s->block : (s->V >= 400000 ? 1024 : 256);
+    g.T = div_up(s->V, g.bs);
+    if (s->grid > 0) {
+        g.G = std::min(s->grid, MAXG);            // explicit: exactly this many workgroups (shards must agree on it)
+    } else {
+        const int cap = g.bs == 1024 ? 512 : 1024;   // 2 x 1024 or 4 x 256 threads per CU
+        g.G = g.T < 8 ? std::max(g.T, 1) : std::min(g.T & ~7, cap);
+    }
+    return g;
+}
+
 template <typename T>
-static int dev_alloc(ls_solver* s, T** out, size_t n) {
+int dev_alloc(ls_solver* s, T** out, size_t n) {
     void* p = nullptr;
     const size_t b = std::max<size_t>(n * sizeof(T), 256);
     LS_HIP(hipMalloc(&p, b));
@@ -359,29 +451,33 @@ static int dev_alloc(ls_solver* s, T** out, size_t n) {
     return LS_OK;
 }
 
-static void free_solver(ls_solver* s) {
+void free_solver(ls_solver* s) {
     if (!s) return;
     (void)hipFree(s->slice_ptr); (void)hipFree(s->sell_cv); (void)hipFree(s->dinv); (void)hipFree(s->r);
-    (void)hipFree(s->p); (void)hipFree(s->Ap); (void)hipFree(s->part); (void)hipFree(s->scal);
+    if (s->own_p) (void)hipFree(s->p);
+    if (s->own_part) (void)hipFree(s->part);
+    (void)hipFree(s->Ap); (void)hipFree(s->scal);
     if (s->h_scal) (void)hipHostFree(s->h_scal);
     for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : s->pev) if (e) (void)hipEventDestroy(e);
     delete s;
 }
 
-static int create_impl(ls_solver* s, hipStream_t st) {
+int create_impl(ls_solver* s, hipStream_t st) {
     const int64_t V = s->V;
     const size_t vk = (size_t)std::max<int64_t>(V, 1) * s->kmax;
+    const size_t pk = (size_t)std::max<int64_t>(s->ncols, 1) * s->kmax;
     int rc;
     if ((rc = dev_alloc(s, &s->dinv, (size_t)std::max<int64_t>(V, 1)))) return rc;
     if ((rc = dev_alloc(s, &s->r, vk))) return rc;
-    if ((rc = dev_alloc(s, &s->p, vk))) return rc;
+    if ((rc = dev_alloc(s, &s->p, pk))) return rc;
     if ((rc = dev_alloc(s, &s->Ap, vk))) return rc;
-    if ((rc = dev_alloc(s, &s->part, (size_t)PART_SLOTS * KMAX * MAX_GRID))) return rc;
+    if ((rc = dev_alloc(s, &s->part, (size_t)PART_SLOTS * KMAX * MAXG))) return rc;
     if ((rc = dev_alloc(s, &s->scal, 1))) return rc;
     LS_HIP(hipHostMalloc((void**)&s->h_scal, 3 * sizeof(Scal), hipHostMallocDefault));
     for (auto& e : s->ev) LS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    LS_HIP(hipMemsetAsync(s->part, 0, sizeof(double) * PART_SLOTS * KMAX * MAX_GRID, st));
+    LS_HIP(hipMemsetAsync(s->part, 0, sizeof(double) * PART_SLOTS * KMAX * MAXG, st));
+    LS_HIP(hipMemsetAsync(s->p, 0, sizeof(float) * pk, st));
     LS_HIP(hipMemsetAsync(s->scal, 0, sizeof(Scal), st));
     if (V == 0) return LS_OK;
     // Jacobi preconditioner
@@ -393,7 +489,7 @@ static int create_impl(ls_solver* s, hipStream_t st) {
     if ((rc = dev_alloc(s, &s->slice_ptr, (size_t)S + 1))) return rc;
     LS_HIP(hipMalloc((void**)&width64, sizeof(int) * (size_t)S));
     hipLaunchKernelGGL(k_sell_widths, dim3(div_up((int64_t)S * WAVE, BLOCK)), dim3(BLOCK), 0, st, s->csr.rowptr, V, S, width64);
-    hipLaunchKernelGGL(k_sell_scan, dim3(1), dim3(1), 0, st, width64, S, s->slice_ptr);
+    hipLaunchKernelGGL(k_sell_scan, dim3(1), dim3(1024), 0, st, width64, S, s->slice_ptr);
     int h[2] = {0, 0};
     LS_HIP(hipMemcpyAsync(&h[0], s->slice_ptr + S, sizeof(int), hipMemcpyDeviceToHost, st));
     LS_HIP(hipMemcpyAsync(&h[1], flag, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -410,70 +506,63 @@ static int create_impl(ls_solver* s, hipStream_t st) {
     return LS_OK;
 }
 
-extern "C" int ls_solver_create(const int32_t* rowptr, const int32_t* col, const float* val, int64_t V, int64_t nnz, int kmax,
-                                int device, void* stream, ls_solver** h_out) {
-    LS_REQUIRE(h_out, LS_E_INVALID, "ls_solver_create: h_out is null");
-    *h_out = nullptr;
-    LS_REQUIRE(V >= 0 && nnz >= 0 && rowptr && (nnz == 0 || (col && val)), LS_E_INVALID, "ls_solver_create: null pointer or negative size");
-    LS_REQUIRE(kmax >= 1 && kmax <= KMAX, LS_E_INVALID, "ls_solver_create: kmax=%d outside [1,%d]", kmax, KMAX);
-    LS_REQUIRE(V < (int64_t)2000000000 && nnz < (int64_t)2000000000, LS_E_OVERFLOW, "matrix too large for int32 indices");
-    DeviceGuard g(device);
-    LS_HIP(g.err);
-    ls_solver* s = new (std::nothrow) ls_solver();
-    LS_REQUIRE(s, LS_E_INVALID, "out of host memory");
-    s->device = device; s->V = V; s->nnz = nnz; s->kmax = kmax;
-    s->csr = CsrView{rowptr, col, val};
-    const int rc = create_impl(s, (hipStream_t)stream);
-    if (rc) { free_solver(s); return rc; }
-    *h_out = s;
-    return LS_OK;
+// ---- kernel launchers (one per phase; also used one at a time by the sharded driver) -----------------
+// phase: 0 init, 1 init_scal, 2 K1, 3 K2, 4 K3
+template <int K, int BS>
+void launch_phase(ls_solver* s, int phase, const float* b, const float* x0, float* x, double rtol, double atol, int it,
+                  const Geometry& g, hipStream_t st) {
+    const dim3 grid(g.G), block(BS);
+    switch (phase) {
+        case 0:
+            if (x0) hipLaunchKernelGGL((k_init<K, BS, true>), grid, block, 0, st, s->sell, s->dinv, b, x0, x, s->r, s->p, s->part, s->V, g.T, g.G);
+            else hipLaunchKernelGGL((k_init<K, BS, false>), grid, block, 0, st, s->sell, s->dinv, b, x0, x, s->r, s->p, s->part, s->V, g.T, g.G);
+            break;
+        case 1:
+            hipLaunchKernelGGL(k_init_scal<K>, dim3(1), dim3(1024), 0, st, s->part, s->scal, g.G, rtol * rtol, atol * atol);
+            break;
+        case 2:
+            hipLaunchKernelGGL((k_spmv_dot<K, BS>), grid, block, 0, st, s->sell, s->p, s->Ap, s->part, s->scal, it, s->V, g.T, g.G);
+            break;
+        case 3:
+            hipLaunchKernelGGL((k_update<K, BS>), grid, block, 0, st, s->dinv, s->p, s->Ap, x, s->r, s->part, s->scal, it, s->V, g.T, g.G);
+            break;
+        default:
+            hipLaunchKernelGGL((k_direction<K, BS>), grid, block, 0, st, s->dinv, s->r, s->p, s->part, s->scal, it, s->V, g.T, g.G);
+            break;
+    }
 }
 
-extern "C" int ls_solver_destroy(ls_solver* s) {
-    if (!s) return LS_OK;
-    DeviceGuard g(s->device);
-    free_solver(s);
-    return LS_OK;
+void dispatch_phase(ls_solver* s, int k, int phase, const float* b, const float* x0, float* x, double rtol, double atol, int it,
+                    const Geometry& g, hipStream_t st) {
+#define LS_CASE(KK)                                                                                          \
+    case KK:                                                                                                 \
+        if (g.bs == 1024) launch_phase<KK, 1024>(s, phase, b, x0, x, rtol, atol, it, g, st);                 \
+        else launch_phase<KK, 256>(s, phase, b, x0, x, rtol, atol, it, g, st);                               \
+        break;
+    switch (k) { LS_CASE(1) LS_CASE(2) LS_CASE(3) LS_CASE(4) default: break; }
+#undef LS_CASE
 }
 
-extern "C" int ls_solver_set(ls_solver* s, const char* name, int value) {
-    LS_REQUIRE(s && name, LS_E_INVALID, "ls_solver_set: null argument");
-    if (!strcmp(name, "variant")) { LS_REQUIRE(value >= 0 && value <= 2, LS_E_INVALID, "variant must be 0 (CSR+LDS), 1 (CSR direct) or 2 (SELL-64)"); s->variant = value; }
-    else if (!strcmp(name, "check_every")) { LS_REQUIRE(value >= 1 && value <= 4096, LS_E_INVALID, "check_every outside [1,4096]"); s->check_every = value; }
-    else if (!strcmp(name, "profile")) { s->profile = value ? 1 : 0; }
-    else if (!strcmp(name, "grid")) { LS_REQUIRE(value >= 0 && value <= MAX_GRID, LS_E_INVALID, "grid outside [0,%d]", MAX_GRID); s->grid = value; }
-    else { set_error("ls_solver_set: unknown knob '%s'", name); return LS_E_INVALID; }
-    return LS_OK;
+void fill_info(const Scal& f, int k, int n_enqueued, ls_solve_info* info, bool* conv_out, int* iters_out) {
+    const bool conv = f.stop_iter != INT_MAX && f.bad == 0;
+    const int iters = f.stop_iter != INT_MAX ? f.stop_iter : n_enqueued;
+    if (info) {
+        info->iterations = iters;
+        info->converged = conv ? 1 : 0;
+        for (int q = 0; q < 4; ++q) {
+            info->rnorm[q] = q < k ? sqrt(f.rr[q]) : 0.0;
+            info->bnorm[q] = q < k ? sqrt(f.bb[q]) : 0.0;
+        }
+    }
+    *conv_out = conv;
+    *iters_out = iters;
 }
 
-extern "C" int ls_solver_profile(const ls_solver* s, double* h_ms3, int* h_iters) {
-    LS_REQUIRE(s && h_ms3 && h_iters, LS_E_INVALID, "ls_solver_profile: null argument");
-    for (int i = 0; i < 3; ++i) h_ms3[i] = s->prof_ms[i];
-    *h_iters = s->prof_iters;
-    return LS_OK;
-}
-
-extern "C" int ls_solver_workspace_bytes(const ls_solver* s, size_t* h_bytes) {
-    LS_REQUIRE(s && h_bytes, LS_E_INVALID, "ls_solver_workspace_bytes: null argument");
-    *h_bytes = s->bytes;
-    return LS_OK;
-}
-
-namespace {
-
-template <int K, int VARIANT>
-int solve_impl(ls_solver* s, const float* b, const float* x0, float* x, double rtol, double atol, int max_iter,
+int solve_impl(ls_solver* s, const float* b, const float* x0, float* x, int k, double rtol, double atol, int max_iter,
                ls_solve_info* info, hipStream_t st) {
-    const int64_t V = s->V;
-    const int T = div_up(V, TILE_ROWS);
-    int G = s->grid > 0 ? s->grid : 1024;
-    G = T < 8 ? T : std::min(T & ~7, G & ~7);
-    if (G < 1) G = 1;
-    const dim3 grid(G), block(BLOCK);
-    if (x0) hipLaunchKernelGGL((k_init<K, VARIANT, true>), grid, block, 0, st, s->csr, s->sell, s->dinv, b, x0, x, s->r, s->p, s->part, V, T, G);
-    else hipLaunchKernelGGL((k_init<K, VARIANT, false>), grid, block, 0, st, s->csr, s->sell, s->dinv, b, x0, x, s->r, s->p, s->part, V, T, G);
-    hipLaunchKernelGGL(k_init_scal<K>, dim3(1), block, 0, st, s->part, s->scal, G, rtol * rtol, atol * atol);
-
+    const Geometry g = geometry(s);
+    dispatch_phase(s, k, 0, b, x0, x, rtol, atol, 0, g, st);
+    dispatch_phase(s, k, 1, b, x0, x, rtol, atol, 0, g, st);
     if (s->profile && s->pev.empty()) {
         s->pev.assign(4 * PROF_MAX_ITERS, nullptr);
         for (auto& e : s->pev) LS_HIP(hipEventCreate(&e));
@@ -487,11 +576,11 @@ int solve_impl(ls_solver* s, const float* b, const float* x0, float* x, double r
         for (int j = 0; j < todo; ++j, ++n) {
             const bool prof = s->profile && n < PROF_MAX_ITERS;
             if (prof) LS_HIP(hipEventRecord(s->pev[4 * n + 0], st));
-            hipLaunchKernelGGL((k_spmv_dot<K, VARIANT>), grid, block, 0, st, s->csr, s->sell, s->p, s->Ap, s->part, s->scal, n, V, T, G);
+            dispatch_phase(s, k, 2, b, x0, x, rtol, atol, n, g, st);
             if (prof) LS_HIP(hipEventRecord(s->pev[4 * n + 1], st));
-            hipLaunchKernelGGL(k_update<K>, grid, block, 0, st, s->dinv, s->p, s->Ap, x, s->r, s->part, s->scal, n, V, T, G);
+            dispatch_phase(s, k, 3, b, x0, x, rtol, atol, n, g, st);
             if (prof) LS_HIP(hipEventRecord(s->pev[4 * n + 2], st));
-            hipLaunchKernelGGL(k_direction<K>, grid, block, 0, st, s->dinv, s->r, s->p, s->part, s->scal, n, V, T, G);
+            dispatch_phase(s, k, 4, b, x0, x, rtol, atol, n, g, st);
             if (prof) LS_HIP(hipEventRecord(s->pev[4 * n + 3], st));
         }
         LS_HIP(hipGetLastError());
@@ -509,8 +598,9 @@ int solve_impl(ls_solver* s, const float* b, const float* x0, float* x, double r
     LS_HIP(hipMemcpyAsync(&s->h_scal[2], s->scal, sizeof(Scal), hipMemcpyDeviceToHost, st));
     LS_HIP(hipStreamSynchronize(st));
     const Scal& f = s->h_scal[2];
-    const bool conv = f.stop_iter != INT_MAX && f.bad == 0;
-    const int iters = f.stop_iter != INT_MAX ? f.stop_iter : n;
+    bool conv;
+    int iters;
+    fill_info(f, k, n, info, &conv, &iters);
     if (conv) s->last_iters = iters;
     if (s->profile) {   // only iterations that really ran (kernels past the stop point return at once)
         s->prof_iters = std::min(iters, PROF_MAX_ITERS);
@@ -522,14 +612,6 @@ int solve_impl(ls_solver* s, const float* b, const float* x0, float* x, double r
                 s->prof_ms[kk] += ms;
             }
     }
-    if (info) {
-        info->iterations = iters;
-        info->converged = conv ? 1 : 0;
-        for (int q = 0; q < 4; ++q) {
-            info->rnorm[q] = q < K ? sqrt(f.rr[q]) : 0.0;
-            info->bnorm[q] = q < K ? sqrt(f.bb[q]) : 0.0;
-        }
-    }
     if (!conv) {
         if (f.bad == 1) set_error("PCG: non-finite residual after %d iterations", iters);
         else if (f.bad == 2) set_error("PCG: p.Ap <= 0 after %d iterations: matrix is not positive definite", iters);
@@ -539,17 +621,62 @@ int solve_impl(ls_solver* s, const float* b, const float* x0, float* x, double r
     return LS_OK;
 }
 
-template <int K>
-int solve_variant(ls_solver* s, const float* b, const float* x0, float* x, double rtol, double atol, int max_iter,
-                  ls_solve_info* info, hipStream_t st) {
-    switch (s->variant) {
-        case 0: return solve_impl<K, 0>(s, b, x0, x, rtol, atol, max_iter, info, st);
-        case 1: return solve_impl<K, 1>(s, b, x0, x, rtol, atol, max_iter, info, st);
-        default: return solve_impl<K, 2>(s, b, x0, x, rtol, atol, max_iter, info, st);
-    }
+}  // namespace
+
+extern "C" int ls_solver_create_ext(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n_rows, int64_t n_cols,
+                                    int64_t nnz, int kmax, int device, void* stream, ls_solver** h_out) {
+    LS_REQUIRE(h_out, LS_E_INVALID, "ls_solver_create: h_out is null");
+    *h_out = nullptr;
+    LS_REQUIRE(n_rows >= 0 && n_cols >= n_rows && nnz >= 0 && rowptr && (nnz == 0 || (col && val)), LS_E_INVALID,
+               "ls_solver_create: null pointer, negative size or n_cols < n_rows");
+    LS_REQUIRE(kmax >= 1 && kmax <= KMAX, LS_E_INVALID, "ls_solver_create: kmax=%d outside [1,%d]", kmax, KMAX);
+    LS_REQUIRE(n_cols < (int64_t)2000000000 && nnz < (int64_t)2000000000, LS_E_OVERFLOW, "matrix too large for int32 indices");
+    DeviceGuard g(device);
+    LS_HIP(g.err);
+    ls_solver* s = new (std::nothrow) ls_solver();
+    LS_REQUIRE(s, LS_E_INVALID, "out of host memory");
+    s->device = device; s->V = n_rows; s->ncols = n_cols; s->nnz = nnz; s->kmax = kmax;
+    s->csr = CsrView{rowptr, col, val};
+    const int rc = create_impl(s, (hipStream_t)stream);
+    if (rc) { free_solver(s); return rc; }
+    *h_out = s;
+    return LS_OK;
 }
 
-}  // namespace
+extern "C" int ls_solver_create(const int32_t* rowptr, const int32_t* col, const float* val, int64_t V, int64_t nnz, int kmax,
+                                int device, void* stream, ls_solver** h_out) {
+    return ls_solver_create_ext(rowptr, col, val, V, V, nnz, kmax, device, stream, h_out);
+}
+
+extern "C" int ls_solver_destroy(ls_solver* s) {
+    if (!s) return LS_OK;
+    DeviceGuard g(s->device);
+    free_solver(s);
+    return LS_OK;
+}
+
+extern "C" int ls_solver_set(ls_solver* s, const char* name, int value) {
+    LS_REQUIRE(s && name, LS_E_INVALID, "ls_solver_set: null argument");
+    if (!strcmp(name, "check_every")) { LS_REQUIRE(value >= 1 && value <= 4096, LS_E_INVALID, "check_every outside [1,4096]"); s->check_every = value; }
+    else if (!strcmp(name, "profile")) { s->profile = value ? 1 : 0; }
+    else if (!strcmp(name, "grid")) { LS_REQUIRE(value >= 0 && value <= MAXG, LS_E_INVALID, "grid outside [0,%d]", MAXG); s->grid = value; }
+    else if (!strcmp(name, "block")) { LS_REQUIRE(value == 0 || value == 256 || value == 1024, LS_E_INVALID, "block must be 0 (auto), 256 or 1024"); s->block = value; }
+    else { set_error("ls_solver_set: unknown knob '%s'", name); return LS_E_INVALID; }
+    return LS_OK;
+}
+
+extern "C" int ls_solver_profile(const ls_solver* s, double* h_ms3, int* h_iters) {
+    LS_REQUIRE(s && h_ms3 && h_iters, LS_E_INVALID, "ls_solver_profile: null argument");
+    for (int i = 0; i < 3; ++i) h_ms3[i] = s->prof_ms[i];
+    *h_iters = s->prof_iters;
+    return LS_OK;
+}
+
+extern "C" int ls_solver_workspace_bytes(const ls_solver* s, size_t* h_bytes) {
+    LS_REQUIRE(s && h_bytes, LS_E_INVALID, "ls_solver_workspace_bytes: null argument");
+    *h_bytes = s->bytes;
+    return LS_OK;
+}
 
 extern "C" int ls_solver_solve(ls_solver* s, const float* b, const float* x0, float* x, int k, double rtol, double atol,
                                int max_iter, ls_solve_info* h_info, void* stream) {
@@ -557,17 +684,81 @@ extern "C" int ls_solver_solve(ls_solver* s, const float* b, const float* x0, fl
     LS_REQUIRE(k >= 1 && k <= s->kmax, LS_E_INVALID, "ls_solver_solve: k=%d outside [1,%d]", k, s->kmax);
     LS_REQUIRE(s->V == 0 || (b && x), LS_E_INVALID, "ls_solver_solve: null pointer");
     LS_REQUIRE(x != b, LS_E_INVALID, "ls_solver_solve: x must not alias b");
+    LS_REQUIRE(s->ncols == s->V, LS_E_STATE, "ls_solver_solve: handle is a shard (n_cols > n_rows): drive it with ls_solver_phase");
     LS_REQUIRE(rtol >= 0.0 && atol >= 0.0 && (rtol > 0.0 || atol > 0.0) && max_iter >= 0, LS_E_INVALID,
                "ls_solver_solve: need rtol, atol >= 0 (one of them > 0) and max_iter >= 0");
     if (h_info) memset(h_info, 0, sizeof(*h_info));
     if (s->V == 0) { if (h_info) h_info->converged = 1; return LS_OK; }
     DeviceGuard g(s->device);
     LS_HIP(g.err);
+    return solve_impl(s, b, x0, x, k, rtol, atol, max_iter, h_info, (hipStream_t)stream);
+}
+
+// ---- one kernel at a time (sharded driver) ----------------------------------------------------------
+extern "C" int ls_solver_phase(ls_solver* s, int phase, const float* b, float* x, int k, double rtol, double atol, int it,
+                               void* stream) {
+    LS_REQUIRE(s, LS_E_INVALID, "ls_solver_phase: null handle");
+    LS_REQUIRE(phase >= 0 && phase <= 4, LS_E_INVALID, "ls_solver_phase: phase %d outside [0,4]", phase);
+    LS_REQUIRE(k >= 1 && k <= s->kmax, LS_E_INVALID, "ls_solver_phase: k=%d outside [1,%d]", k, s->kmax);
+    LS_REQUIRE((phase != 0 || (b && x)) && (phase != 3 || x), LS_E_INVALID, "ls_solver_phase: null pointer");
+    if (s->V == 0) return LS_OK;
+    DeviceGuard g(s->device);
+    LS_HIP(g.err);
+    dispatch_phase(s, k, phase, b, nullptr, x, rtol, atol, it, geometry(s), (hipStream_t)stream);
+    LS_HIP(hipGetLastError());
+    return LS_OK;
+}
+
+extern "C" int ls_solver_buffers(ls_solver* s, float** h_p, double** h_part, int* h_grid, int* h_part_stride) {
+    LS_REQUIRE(s && h_p && h_part && h_grid && h_part_stride, LS_E_INVALID, "ls_solver_buffers: null argument");
+    *h_p = s->p;
+    *h_part = s->part;
+    *h_grid = geometry(s).G;
+    *h_part_stride = MAXG;
+    return LS_OK;
+}
+
+extern "C" int ls_solver_bind(ls_solver* s, float* p_ext, double* part) {
+    LS_REQUIRE(s && p_ext && part, LS_E_INVALID, "ls_solver_bind: null argument");
+    DeviceGuard g(s->device);
+    LS_HIP(g.err);
+    if (s->own_p) (void)hipFree(s->p);
+    if (s->own_part) (void)hipFree(s->part);
+    s->p = p_ext; s->part = part;
+    s->own_p = s->own_part = false;
+    return LS_OK;
+}
+
+extern "C" int ls_solver_poll(ls_solver* s, int k, int n_enqueued, ls_solve_info* h_info, void* stream) {
+    LS_REQUIRE(s && h_info, LS_E_INVALID, "ls_solver_poll: null argument");
+    memset(h_info, 0, sizeof(*h_info));
+    DeviceGuard g(s->device);
+    LS_HIP(g.err);
+    hipStream_t st = (hipStream_t)stream;
+    LS_HIP(hipMemcpyAsync(&s->h_scal[2], s->scal, sizeof(Scal), hipMemcpyDeviceToHost, st));
+    LS_HIP(hipStreamSynchronize(st));
+    bool conv;
+    int iters;
+    fill_info(s->h_scal[2], k, n_enqueued, h_info, &conv, &iters);
+    if (s->h_scal[2].stop_iter == INT_MAX) h_info->iterations = -1;   // still running
+    if (s->h_scal[2].bad) { set_error("PCG: breakdown (code %d) after %d iterations", s->h_scal[2].bad, iters); return LS_E_NOT_CONVERGED; }
+    return LS_OK;
+}
+
+extern "C" int ls_gather_rows(const float* src, const int32_t* idx, int64_t n, int k, float* dst, int device, void* stream) {
+    LS_REQUIRE(n >= 0 && (n == 0 || (src && idx && dst)), LS_E_INVALID, "ls_gather_rows: null pointer or negative size");
+    LS_REQUIRE(k >= 1 && k <= KMAX, LS_E_INVALID, "ls_gather_rows: k=%d outside [1,%d]", k, KMAX);
+    if (n == 0) return LS_OK;
+    DeviceGuard g(device);
+    LS_HIP(g.err);
+    const dim3 grid(div_up(n, BLOCK)), block(BLOCK);
     hipStream_t st = (hipStream_t)stream;
     switch (k) {
-        case 1: return solve_variant<1>(s, b, x0, x, rtol, atol, max_iter, h_info, st);
-        case 2: return solve_variant<2>(s, b, x0, x, rtol, atol, max_iter, h_info, st);
-        case 3: return solve_variant<3>(s, b, x0, x, rtol, atol, max_iter, h_info, st);
-        default: return solve_variant<4>(s, b, x0, x, rtol, atol, max_iter, h_info, st);
+        case 1: hipLaunchKernelGGL(k_gather_rows<1>, grid, block, 0, st, src, idx, n, dst); break;
+        case 2: hipLaunchKernelGGL(k_gather_rows<2>, grid, block, 0, st, src, idx, n, dst); break;
+        case 3: hipLaunchKernelGGL(k_gather_rows<3>, grid, block, 0, st, src, idx, n, dst); break;
+        default: hipLaunchKernelGGL(k_gather_rows<4>, grid, block, 0, st, src, idx, n, dst); break;
     }
+    LS_HIP(hipGetLastError());
+    return LS_OK;
 }

@@ -74,6 +74,22 @@ __device__ __forceinline__ void row_sell(const SellView& A, const float* __restr
     const int off = __builtin_amdgcn_readfirstlane(A.slice_ptr[slice]);
     const int width = (__builtin_amdgcn_readfirstlane(A.slice_ptr[slice + 1]) - off) >> 6;
     const int2* __restrict__ p = A.cv + off + lane;
+    if (width <= 8) {
+        // the usual case (valence <= 7): every matrix load of the row, then every gather, is issued before
+        // the first use -- up to 8 + 8 independent loads in flight per lane. `width` is wave uniform.
+        int2 c[8];
+        Vec<K> xv[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) if (t < width) c[t] = p[(size_t)t * WAVE];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) if (t < width) xv[t] = reinterpret_cast<const Vec<K>*>(x)[c[t].x];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) if (t < width) {
+#pragma unroll
+            for (int q = 0; q < K; ++q) acc[q] = fmaf(__int_as_float(c[t].y), xv[t].v[q], acc[q]);
+        }
+        return;
+    }
     int t = 0;
     for (; t + 4 <= width; t += 4) {   // 4 matrix loads, then 4 gathers in flight per lane
         const int2 c0 = p[(size_t)(t + 0) * WAVE], c1 = p[(size_t)(t + 1) * WAVE];

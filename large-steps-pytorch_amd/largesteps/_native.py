@@ -44,6 +44,14 @@ _SIGNATURES = {
                                 c_int, c_void_p]),
     "ls_spmv": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ls_solver_create": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_int, c_int, c_void_p, ctypes.POINTER(c_void_p)]),
+    "ls_solver_create_ext": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_int, c_void_p,
+                                     ctypes.POINTER(c_void_p)]),
+    "ls_solver_phase": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_double, c_double, c_int, c_void_p]),
+    "ls_solver_buffers": (c_int, [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_int),
+                                  ctypes.POINTER(c_int)]),
+    "ls_solver_bind": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "ls_solver_poll": (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(SolveInfo), c_void_p]),
+    "ls_gather_rows": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_int, c_void_p]),
     "ls_solver_destroy": (c_int, [c_void_p]),
     "ls_solver_solve": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double, c_double, c_int,
                                 ctypes.POINTER(SolveInfo), c_void_p]),

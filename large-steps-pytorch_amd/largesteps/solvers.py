@@ -77,7 +77,7 @@ class PCGSolver(Solver):
                 self._handle = ctypes.c_void_p(None)
 
     def set_option(self, name, value):
-        """Measurement knobs of the native solver: 'variant' (0 CSR+LDS, 1 CSR direct, 2 SELL-64), 'check_every', 'grid', 'profile'."""
+        """Measurement knobs of the native solver: 'check_every', 'grid', 'block' (256 / 1024 threads), 'profile'."""
         _native.check(_native.lib().ls_solver_set(self._handle, name.encode(), int(value)))
 
     def kernel_profile(self):

@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""
+Worker of the multi-process tests of largesteps.distributed (one process per rank).
+
+    python tests/dist_worker.py --rank R --world P --port PORT --out DIR --mesh plane40 --backend gloo --ops numpy|hip
+
+--ops numpy : CPU tensors + gloo; the local kernels are the numpy statement below (TEST code: it restates
+              csrc/pcg.hip's three kernels so that the collectives / halo logic of ShardedPCG can run without a GPU).
+--ops hip   : the real HipShardOps on cuda:0 (all ranks share the one GPU of the test box; gloo moves the
+              device tensors), used by the -m gpu tests.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "large-steps-pytorch_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import scipy.sparse as sp  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from largesteps import synthetic  # noqa: E402
+from largesteps.distributed import ShardPlan, ShardedPCG  # noqa: E402
+from oracle import laplacian as ol  # noqa: E402
+
+INF = 2 ** 31 - 1
+
+
+class NumpyShardOps:
+    """Numpy statement of phases 0-4 of csrc/pcg.hip on one shard (same scalar semantics: per-column
+    alpha/beta, frozen converged columns, parity rings, stop flag). One partial per slot/column (grid 1)."""
+
+    def __init__(self, plan):
+        self.plan = plan
+        self.A = sp.csr_matrix((plan.val.astype(np.float64), plan.col, plan.rowptr), shape=(plan.n_own, plan.n_cols))
+        self.dinv = 1.0 / self.A.diagonal()
+        self.part = torch.zeros((4, 4, 1), dtype=torch.float64)
+        self._p = torch.zeros(max(plan.n_cols, 1) * 4, dtype=torch.float32)
+        self.send_idx = [(q, torch.from_numpy(idx)) for q, idx in plan.send]
+        self.r = self.Ap = None
+        self.rz = np.zeros((2, 4))
+        self.mask = np.zeros((2, 4), bool)
+        self.thr2 = np.zeros(4)
+        self.rr = np.zeros(4)
+        self.bb = np.zeros(4)
+        self.stop = INF
+
+    def new_vector(self, k):
+        return torch.empty((self.plan.n_own, k), dtype=torch.float32)
+
+    def p_ext(self, k):
+        return self._p[: self.plan.n_cols * k].view(self.plan.n_cols, k)
+
+    def _set(self, slot, k, vals):
+        self.part[slot, :k, 0] = torch.from_numpy(np.asarray(vals, dtype=np.float64))
+
+    def phase(self, ph, b, x, k, rtol, atol, it):
+        n = self.plan.n_own
+        p = self.p_ext(k).numpy()
+        if ph == 0:
+            self.r = b.numpy().astype(np.float32).copy()
+            x.zero_()
+            z = (self.dinv[:, None] * self.r).astype(np.float32)
+            p[:n] = z
+            self._set(1, k, (self.r.astype(np.float64) * z).sum(0))
+            self._set(2, k, (self.r.astype(np.float64) ** 2).sum(0))
+            self._set(3, k, (b.numpy().astype(np.float64) ** 2).sum(0))
+        elif ph == 1:
+            rz, rr, bb = (self.part[s, :k, 0].numpy().copy() for s in (1, 2, 3))
+            self.thr2[:k] = np.maximum(rtol * rtol * bb, atol * atol)
+            self.rz[:, :k] = rz
+            self.rr[:k], self.bb[:k] = rr, bb
+            self.mask[:, :k] = rr > self.thr2[:k]
+            self.stop = 0 if not self.mask[0, :k].any() else INF
+        elif it >= self.stop:
+            return
+        elif ph == 2:
+            self.Ap = (self.A @ p.astype(np.float64)).astype(np.float32)
+            self._set(0, k, (p[:n].astype(np.float64) * self.Ap).sum(0))
+        elif ph == 3:
+            pAp = self.part[0, :k, 0].numpy()
+            on = self.mask[it & 1, :k] & (pAp > 0)
+            alpha = np.where(on, self.rz[it & 1, :k] / np.where(pAp > 0, pAp, 1), 0).astype(np.float32)
+            x += torch.from_numpy(alpha * p[:n])
+            self.r = (self.r - alpha * self.Ap).astype(np.float32)
+            z = (self.dinv[:, None] * self.r).astype(np.float32)
+            self._set(1, k, (self.r.astype(np.float64) * z).sum(0))
+            self._set(2, k, (self.r.astype(np.float64) ** 2).sum(0))
+        elif ph == 4:
+            rz_new, rr = self.part[1, :k, 0].numpy().copy(), self.part[2, :k, 0].numpy().copy()
+            m = self.mask[it & 1, :k]
+            rz_old = self.rz[it & 1, :k]
+            beta = np.where(m & (rz_old > 0), rz_new / np.where(rz_old > 0, rz_old, 1), 0).astype(np.float32)
+            self.rz[(it + 1) & 1, :k] = np.where(m, rz_new, rz_old)
+            self.rr[:k] = np.where(m, rr, self.rr[:k])
+            nm = m & (rr > self.thr2[:k])
+            self.mask[(it + 1) & 1, :k] = nm
+            if not nm.any():
+                self.stop = it + 1
+            p[:n] = (self.dinv[:, None] * self.r + beta * p[:n]).astype(np.float32)
+
+    def pack(self, idx, k, out):
+        out.copy_(self.p_ext(k)[idx.long()])
+
+    def poll(self, k, n):
+        done = self.stop != INF
+        return dict(iterations=self.stop if done else -1, converged=done, rnorm=list(np.sqrt(self.rr[:k])),
+                    bnorm=list(np.sqrt(self.bb[:k])), breakdown=False)
+
+
+def test_matrix(name):
+    if name == "plane40":
+        v, f = synthetic.plane(40)
+        lam, alpha, cot = 30.0, None, False
+    elif name == "ico12cot":
+        v, f = synthetic.icosphere(12)
+        v = synthetic.perturb(v, radial=0.05, tangential=0.2, edge=0.1, seed=5)
+        lam, alpha, cot = 0.0, 0.9, True
+    else:
+        raise ValueError(name)
+    r, c, val = ol.compute_matrix(v, f, lam, alpha=alpha, cotan=cot)
+    V = v.shape[0]
+    rowptr = np.zeros(V + 1, np.int64)
+    np.add.at(rowptr, r + 1, 1)
+    return v, np.cumsum(rowptr), c, val
+
+
+test_matrix.__test__ = False   # a helper, not a pytest test
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rank", type=int, required=True)
+    ap.add_argument("--world", type=int, required=True)
+    ap.add_argument("--port", type=int, required=True)
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--mesh", default="plane40")
+    ap.add_argument("--backend", default="gloo")
+    ap.add_argument("--ops", default="numpy")
+    ap.add_argument("--k", type=int, default=3)
+    a = ap.parse_args()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(a.port)
+    dist.init_process_group(a.backend, rank=a.rank, world_size=a.world)
+    v, rowptr, col, val = test_matrix(a.mesh)
+    plan = ShardPlan.build(rowptr, col, val, v.shape[0], a.world, a.rank)
+    rng = np.random.default_rng(3)
+    b_full = (sp.csr_matrix((val.astype(np.float64), col, rowptr)) @ v.astype(np.float64)).astype(np.float32)
+    if a.k != 3:
+        b_full = rng.standard_normal((v.shape[0], a.k)).astype(np.float32)
+    b = torch.from_numpy(b_full[plan.lo:plan.hi].copy())
+    if a.ops == "numpy":
+        ops = NumpyShardOps(plan)
+    else:
+        from largesteps.distributed import HipShardOps
+        torch.cuda.set_device(0)
+        ops = HipShardOps(plan, torch.device("cuda:0"), grid=8, block=256)
+        b = b.cuda()
+    solver = ShardedPCG(plan, ops, rtol=1e-6, check_every=8)
+    x = solver.solve(b)
+    x2 = solver.solve(b)                                    # a second solve reuses every buffer
+    assert torch.equal(x, x2)
+    np.save(os.path.join(a.out, f"x_{a.rank}.npy"), x.cpu().numpy())
+    np.save(os.path.join(a.out, f"it_{a.rank}.npy"), np.array([solver.last_info["iterations"], int(solver.last_info["converged"])]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,46 @@
+"""
+The HIP kernels on vertex-block shards (-m gpu). The test box has ONE GPU, so the ranks are separate
+processes that share cuda:0 and talk through gloo (all-reduce of device tensors; halo rows staged through the
+host = the loopback transport of SURVEY.md §8e). What this covers that the CPU tests cannot: the rectangular
+shard matrices in SELL-64, halo packing (ls_gather_rows), ls_solver_phase / bind / poll, and that the sharded
+result equals the single-GPU one. RCCL itself only replaces the transport underneath torch.distributed.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from test_distributed_cpu import run_world, reference_solution  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("mesh,world,k", [("plane40", 1, 3), ("plane40", 2, 3), ("ico12cot", 2, 3), ("plane40", 4, 2)])
+def test_sharded_hip(tmp_path, mesh, world, k):
+    x64 = reference_solution(mesh, k)
+    x, its = run_world(tmp_path, world, mesh, k=k, ops="hip", timeout=600)
+    assert all(int(i[1]) == 1 for i in its)
+    assert len({int(i[0]) for i in its}) == 1
+    assert np.abs(x - x64).max() <= 1e-4 * np.abs(x64).max()
+
+
+def test_shard_from_matrix_single_rank():
+    """shard_from_matrix with no process group (P = 1) must reproduce from_differential bit for bit."""
+    import torch
+    from largesteps import synthetic
+    from largesteps.geometry import compute_matrix
+    from largesteps.parameterize import to_differential, from_differential
+    from largesteps.distributed import shard_from_matrix
+    dev = torch.device("cuda:0")
+    v, f = synthetic.plane(300)
+    tv, tf = torch.from_numpy(v).to(dev), torch.from_numpy(f).to(dev)
+    M = compute_matrix(tv, tf, 50.0)
+    u = to_differential(M, tv)
+    plan, solver = shard_from_matrix(M)
+    assert plan.n_own == v.shape[0] and plan.n_halo == 0
+    x = solver.solve(u)
+    ref = from_differential(M, u, "Cholesky")
+    assert solver.last_info["converged"]
+    assert torch.equal(x, ref), "same kernels, same grid, same reduction order"

@@ -192,20 +192,20 @@ def test_from_differential_vs_reference(golden, dev, name, case):
     assert np.abs(x2.cpu().numpy() - golden[f"{name}/{case}/cg_x_warm"]).max() <= 4e-5 * scale
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("block", [256, 1024])
 @pytest.mark.parametrize("k", [1, 2, 3, 4, 6])
-def test_solver_variants_and_widths(dev, variant, k):
+def test_solver_geometries_and_widths(dev, block, k):
     from largesteps.geometry import compute_matrix
     from largesteps.solvers import PCGSolver
     from largesteps import synthetic
-    v, f = synthetic.icosphere(20)          # 4002 vertices: 16 tiles, ragged last tile and last SELL slice
+    v, f = synthetic.icosphere(20)          # 4002 vertices: ragged last tile and last SELL slice, both geometries
     v = synthetic.perturb(v, radial=0.05, seed=2)
     M = compute_matrix(_t(v, dev), _t(f, dev), 0.0, alpha=0.9, cotan=True)
     idx, val = M.indices().cpu().numpy(), M.values().cpu().numpy()
     b = np.random.default_rng(k).standard_normal((v.shape[0], k)).astype(np.float32)
     x64 = osv.from_differential(idx[0], idx[1], val, b)
     s = PCGSolver(M, rtol=1e-6)
-    s.set_option("variant", variant)
+    s.set_option("block", block)
     x = s.solve(_t(b, dev))
     assert s.last_info["converged"] and 5 < s.last_info["iterations"] < 500
     assert np.abs(x.cpu().numpy() - x64).max() <= 1e-4 * np.abs(x64).max()
