@@ -115,6 +115,8 @@ int ls_solver_set(ls_solver* s, const char* name, int value);
  * stream; this returns the accumulated milliseconds of K1 (SpMV+dot), K2 (update), K3 (direction) over the
  * h_iters iterations that really ran in the last solve. */
 int ls_solver_profile(const ls_solver* s, double* h_ms3, int* h_iters);
+/* the handle's SELL-64 copy of the matrix: slice_ptr[V/64+1] (entry offsets), cv[entries] = {col, fp32 bits} */
+int ls_solver_sell(ls_solver* s, const int32_t** h_slice_ptr, const void** h_cv, int64_t* h_entries);
 /* bytes the handle allocated on the device */
 int ls_solver_workspace_bytes(const ls_solver* s, size_t* h_bytes);
 
@@ -152,6 +154,11 @@ int ls_gather_rows(const float* src, const int32_t* idx, int64_t n, int k, float
  * --------------------------------------------------------------------------------------------- */
 int ls_adam_uniform_step(float* param, const float* grad, float* g1, float* g2, int64_t n, float lr,
                          float beta1, float beta2, int step, void* scratch, int device, void* stream);
+
+/* A/B kernels used to choose the production kernels' structure (csrc/experiments.hip, tools/ubench.py); not
+ * part of the product path. */
+int ls_experiment(int which, int bs, int grid, int64_t V, const float* dinv, const float* r, float* p,
+                  const double* part, const int32_t* slice_ptr, const void* cv, void* stream);
 
 #ifdef __cplusplus
 }

@@ -44,6 +44,30 @@ inline int div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 template <int K> struct Vec { float v[K]; };   // K interleaved right-hand-side columns of one vertex (4-byte aligned)
 
+// ---- DPP wave reductions ---------------------------------------------------------------------------
+// __shfl_down lowers to ds_bpermute (an LDS-crossbar round trip, ~100+ cycles per dependent step); a
+// 6-step fp64 butterfly per value made the dot-product hand-off of the PCG kernels cost ~4 us per launch
+// (profiles/r01_ubench1_kernel_structure.txt). The DPP row operations below stay inside the VALU.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __hiloint2double(hi, lo);   // lanes without a source (masked rows) add +0.0
+}
+
+// Sum over the 64 lanes of a wave, returned in EVERY lane (wave-uniform).
+__device__ __forceinline__ double wave_sum_all(double v) {
+    v = dpp_add<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]   -> every lane: sum of its quad
+    v = dpp_add<0x141, 0xf>(v);   // row_half_mirror       -> sum of its 8 lanes
+    v = dpp_add<0x140, 0xf>(v);   // row_mirror            -> sum of its row of 16
+    v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1,3
+    v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2,3 -> lane 63 holds the wave total
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T x) {
 #pragma unroll

@@ -53,30 +53,31 @@ __device__ __forceinline__ Vec<K> ldv(const float* __restrict__ a, int64_t i) { 
 template <int K>
 __device__ __forceinline__ void stv(float* __restrict__ a, int64_t i, const Vec<K>& v) { reinterpret_cast<Vec<K>*>(a)[i] = v; }
 
-// Sum of N doubles per thread over a BS-thread workgroup; result valid in thread 0. smem: (BS/64)*N doubles.
+// Sum of N doubles per thread over a BS-thread workgroup, result in EVERY thread. One barrier (+ one trailing
+// barrier so that smem can be reused). smem: (BS/64)*N doubles.
 template <int N, int BS>
 __device__ __forceinline__ void wg_sum(double (&x)[N], double* smem) {
     constexpr int NW = BS / WAVE;
     const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-        x[i] = wave_sum(x[i]);
-        if (lane == 0) smem[w * N + i] = x[i];
+    for (int i = 0; i < N; ++i) x[i] = wave_sum_all(x[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) smem[w * N + i] = x[i];
     }
     __syncthreads();
-    if (w == 0) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            double v = lane < NW ? smem[lane * N + i] : 0.0;
-            x[i] = wave_sum(v);
-        }
+    for (int i = 0; i < N; ++i) {
+        double s = smem[i];
+#pragma unroll
+        for (int j = 1; j < NW; ++j) s += smem[j * N + i];   // same address in every lane: LDS broadcast
+        x[i] = s;
     }
     __syncthreads();
 }
 
 // Deterministic reduction of N partial arrays (written by the G workgroups of the previous kernel, possibly
-// summed across ranks) to N scalars, broadcast to every thread. All loads are issued before the first add.
-// smem: N + (BS/64)*N doubles.
+// summed across ranks) to N scalars in every thread. All loads are issued before the first add.
 template <int N, int K, int BS>
 __device__ __forceinline__ void reduce_partials(const double* __restrict__ part, int slot0, int G, double (&out)[N], double* smem) {
     constexpr int J = (MAXG + BS - 1) / BS;
@@ -90,23 +91,14 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ part,
             v[n][j] = g < G ? pp[g] : 0.0;
         }
     }
-    double acc[N];
 #pragma unroll
     for (int n = 0; n < N; ++n) {
         double s = v[n][0];
 #pragma unroll
         for (int j = 1; j < J; ++j) s += v[n][j];
-        acc[n] = s;
+        out[n] = s;
     }
-    wg_sum<N, BS>(acc, smem + N);
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int n = 0; n < N; ++n) smem[n] = acc[n];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int n = 0; n < N; ++n) out[n] = smem[n];
-    __syncthreads();
+    wg_sum<N, BS>(out, smem);
 }
 
 template <int N, int K, int BS>
@@ -430,7 +422,7 @@ struct Geometry { int bs, T, G; };
 
 Geometry geometry(const ls_solver* s) {
     Geometry g;
-    g.bs = s->block ? s->block : (s->V >= 400000 ? 1024 : 256);
+    g.bs = s->block ? s->block : 256;   // 1024-thread workgroups measured slower (profiles/r01_ubench1_kernel_structure.txt)
     g.T = div_up(s->V, g.bs);
     if (s->grid > 0) {
         g.G = std::min(s->grid, MAXG);            // explicit: exactly this many workgroups (shards must agree on it)
@@ -715,6 +707,12 @@ extern "C" int ls_solver_buffers(ls_solver* s, float** h_p, double** h_part, int
     *h_part = s->part;
     *h_grid = geometry(s).G;
     *h_part_stride = MAXG;
+    return LS_OK;
+}
+
+extern "C" int ls_solver_sell(ls_solver* s, const int32_t** h_slice_ptr, const void** h_cv, int64_t* h_entries) {
+    LS_REQUIRE(s && h_slice_ptr && h_cv && h_entries, LS_E_INVALID, "ls_solver_sell: null argument");
+    *h_slice_ptr = s->slice_ptr; *h_cv = s->sell_cv; *h_entries = s->sell_entries;
     return LS_OK;
 }
 

@@ -57,6 +57,8 @@ _SIGNATURES = {
                                 ctypes.POINTER(SolveInfo), c_void_p]),
     "ls_solver_set": (c_int, [c_void_p, ctypes.c_char_p, c_int]),
     "ls_solver_profile": (c_int, [c_void_p, ctypes.POINTER(c_double * 3), ctypes.POINTER(c_int)]),
+    "ls_solver_sell": (c_int, [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_i64)]),
+    "ls_experiment": (c_int, [c_int, c_int, c_int, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ls_solver_workspace_bytes": (c_int, [c_void_p, ctypes.POINTER(c_size_t)]),
     "ls_adam_uniform_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_float, c_float, c_float, c_int,
                                      c_void_p, c_int, c_void_p]),

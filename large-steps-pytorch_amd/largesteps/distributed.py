@@ -126,8 +126,11 @@ class HipShardOps:
     def __del__(self):
         h = getattr(self, "_handle", None)
         if h is not None and h.value:
-            _native.lib().ls_solver_destroy(h)
-            self._handle = ctypes.c_void_p(None)
+            try:
+                _native.lib().ls_solver_destroy(h)
+            except Exception:      # interpreter shutdown
+                pass
+            self._handle = None
 
     # -- LocalOps protocol ---------------------------------------------------------------------------
     def new_vector(self, k):
@@ -245,10 +248,9 @@ def shard_from_matrix(M, group=None, device=None, **solver_kw):
     dev = device if device is not None else csr.device
     # every rank must launch the same grid so that the partial arrays line up: size it on the largest block
     n_max = int(np.diff(block_bounds(csr.V, P)).max())
-    block = 1024 if n_max >= 400000 else 256
+    block = 256
     T = -(-n_max // block)
-    cap = 512 if block == 1024 else 1024
-    grid = max(T, 1) if T < 8 else min(T & ~7, cap)
+    grid = max(T, 1) if T < 8 else min(T & ~7, 1024)
     ops = HipShardOps(plan, dev, grid=grid, block=block)
     return plan, ShardedPCG(plan, ops, group=group, **solver_kw)
 

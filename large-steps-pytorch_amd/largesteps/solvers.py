@@ -73,8 +73,9 @@ class PCGSolver(Solver):
         if h is not None and h.value:
             try:
                 _native.lib().ls_solver_destroy(h)
-            finally:
-                self._handle = ctypes.c_void_p(None)
+            except Exception:      # interpreter shutdown: module globals may already be gone
+                pass
+            self._handle = None
 
     def set_option(self, name, value):
         """Measurement knobs of the native solver: 'check_every', 'grid', 'block' (256 / 1024 threads), 'profile'."""
