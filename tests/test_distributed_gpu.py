@@ -41,6 +41,10 @@ def test_shard_from_matrix_single_rank():
     plan, solver = shard_from_matrix(M)
     assert plan.n_own == v.shape[0] and plan.n_halo == 0
     x = solver.solve(u)
-    ref = from_differential(M, u, "Cholesky")
+    from largesteps.solvers import PCGSolver
+    ref_solver = PCGSolver(M, rtol=1e-6)
+    ref_solver.set_option("algo", 0)                 # the classic 3-kernel PCG is what the shards run
+    ref_solver.set_option("block", 256)
+    ref = ref_solver.solve(u)
     assert solver.last_info["converged"]
     assert torch.equal(x, ref), "same kernels, same grid, same reduction order"
