@@ -37,14 +37,22 @@ HBM_ACHIEVABLE_GBS = 6290.0
 WORKLOAD = "cfg4_plane1m"
 
 
-def algorithmic_bytes(V, nnz, k, iters, warm=False):
-    """CSR int32/fp32 contract format, k interleaved fp32 right-hand sides."""
-    b_spmv = 8 * nnz + 4 * (V + 1) + 2 * 4 * k * V              # K1: matrix + read p + write Ap
-    b_k2 = (4 * k + 1) * 4 * V + 2 * 4 * k * V                 # read x,p,Ap,r,dinv ; write x,r
-    b_k3 = (2 * k + 1) * 4 * V + 4 * k * V                     # read r,dinv,p ; write p
+def algorithmic_bytes(V, nnz, k, iters, method="pcg"):
+    """SURVEY.md §8(d) accounting: CSR-equivalent int32/fp32 matrix (8 B per stored entry + 4 B per row), k
+    interleaved fp32 right-hand sides, every array counted once per kernel that touches it.
+      pcg       K1 matrix + p + Ap | K2 x,p,Ap,r,1/diag -> x,r | K3 r,1/diag,p -> p        = 8 nnz + 4 V + (11k+2) 4V
+      chebyshev one kernel: matrix + x_k (gathered) + b + 1/diag + x_{k-1} -> x_{k+1}        = 8 nnz + 4 V + (4k+1) 4V
+    """
+    mat = 8 * nnz + 4 * (V + 1)
+    if method == "chebyshev":
+        b_iter = mat + (4 * k + 1) * 4 * V
+        # setup: zero x0 (write) ; final residual check: matrix + x + b
+        return dict(k1=b_iter, iter=b_iter, solve=4 * k * V + iters * b_iter + mat + 2 * 4 * k * V)
+    b_spmv = mat + 2 * 4 * k * V
+    b_k2 = (4 * k + 1) * 4 * V + 2 * 4 * k * V
+    b_k3 = (2 * k + 1) * 4 * V + 4 * k * V
     b_iter = b_spmv + b_k2 + b_k3
-    b_setup = (4 * k + 1) * 4 * V + (b_spmv if warm else 0)
-    return dict(k1=b_spmv, k2=b_k2, k3=b_k3, iter=b_iter, solve=b_setup + iters * b_iter)
+    return dict(k1=b_spmv, k2=b_k2, k3=b_k3, iter=b_iter, solve=(4 * k + 1) * 4 * V + iters * b_iter)
 
 
 def cpu_baseline(v, f, lam, u_np, seconds_cap=120.0):
@@ -86,15 +94,17 @@ def run_single(args):
     t_assemble = time.perf_counter() - t0
     u = to_differential(M, tv)
     V, nnz, k = v.shape[0], M._nnz(), 3
-    method = "Cholesky"                                   # cold start, rtol 1e-6 (the package default)
+    method_name = "CG" if args.pcg else "Cholesky"        # 'Cholesky': cold start, reduction 1e-6 (the package default)
 
     x = None
     for _ in range(args.warmup):
-        x = from_differential(M, u, method)
-    solver = parameterize._cache[(id(M), method)][0] if args.warmup else None
+        x = from_differential(M, u, method_name)
+    solver = parameterize._cache[(id(M), method_name)][0] if args.warmup else None
     if solver is None:
-        x = from_differential(M, u, method)
-        solver = parameterize._cache[(id(M), method)][0]
+        x = from_differential(M, u, method_name)
+        solver = parameterize._cache[(id(M), method_name)][0]
+    if args.pcg:                                          # A/B: the Jacobi-PCG at the same cold-start / 1e-6 setting
+        solver.rtol, solver.atol, solver.warm_start = 1e-6, 0.0, False
     if args.block is not None:
         solver.set_option("block", args.block)
     if args.grid:
@@ -102,45 +112,54 @@ def run_single(args):
     if args.check_every:
         solver.set_option("check_every", args.check_every)
     if args.block is not None or args.grid or args.check_every:
-        x = from_differential(M, u, method)
+        x = from_differential(M, u, method_name)
 
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        x = from_differential(M, u, method)
+        x = from_differential(M, u, method_name)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     info = dict(solver.last_info)
     ms = elapsed / args.steps * 1e3
+    method = info["method"]
 
-    # profiled pass: HIP events around every kernel on the solve's own stream
+    # profiled pass right after the timed region, same workload: HIP events on the solve's own stream
+    # (chebyshev: two events around the n back-to-back launches; pcg: events around every kernel)
     solver.set_option("profile", 1)
     prof = np.zeros(3)
     piters = 0
     for _ in range(max(1, min(args.steps, 5))):
-        from_differential(M, u, method)
+        from_differential(M, u, method_name)
         a, b, c, it = solver.kernel_profile()
         prof += (a, b, c)
         piters += it
     solver.set_option("profile", 0)
     k_ms = prof / max(piters, 1)
-    bts = algorithmic_bytes(V, nnz, k, info["iterations"])
+    bts = algorithmic_bytes(V, nnz, k, info["iterations"], method)
     k1_gbs = bts["k1"] / (k_ms[0] * 1e-3) / 1e9
     err = float((x - tv).abs().max())
+    if method == "chebyshev":
+        solver_desc = "HIP Chebyshev-accelerated Jacobi iteration (1 kernel/iteration, SELL-64, a-priori iteration count)"
+        kernel_desc = "k_cheb<3,%d> (x_{k+1} = x_k + c1 (x_k - x_{k-1}) + c2 D^-1 (b - M x_k), SELL-64)" % 512
+        kernel_us = dict(k_cheb=k_ms[0] * 1e3)
+    else:
+        solver_desc = "HIP Jacobi-PCG (3 kernels/iteration, SELL-64)"
+        kernel_desc = "k_spmv_dot<3> (K1: Ap = M p on SELL-64, partial p.Ap)"
+        kernel_us = dict(k1_spmv_dot=k_ms[0] * 1e3, k2_update=k_ms[1] * 1e3, k3_direction=k_ms[2] * 1e3)
     out = dict(
         metric="from_differential_solves_per_sec", value=1e3 / ms, unit="solves/s", n_gpus=1, steps=args.steps,
         warmup=args.warmup, ms_per_step=ms, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32",
         data="synthetic",
         config=dict(workload=f"{args.workload}: 1000x1000 plane, V={V}, nnz(M)={nnz}, M=I+{lam:g}*L_uniform, u=M v, k=3, "
-                             f"cold start, rtol=1e-6", solver="HIP Jacobi-PCG (3 kernels/iteration, SELL-64)",
+                             f"cold start, residual reduction 1e-6", solver=solver_desc, method=method,
                     iterations=info["iterations"], converged=info["converged"],
                     rel_residual=[float(r / b) for r, b in zip(info["rnorm"], info["bnorm"])],
                     max_abs_err_vs_v=err, assemble_ms=t_assemble * 1e3,
                     solve_bytes=bts["solve"], solve_gbs=bts["solve"] / (ms * 1e-3) / 1e9,
                     solve_frac_of_8tbs=bts["solve"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    kernel_us=dict(k1_spmv_dot=k_ms[0] * 1e3, k2_update=k_ms[1] * 1e3, k3_direction=k_ms[2] * 1e3),
-                    device=torch.cuda.get_device_name(0)),
-        roofline=dict(bound="hbm", kernel="k_spmv_dot<3,1024> (K1: Ap = M p on SELL-64, partial p.Ap)", achieved=k1_gbs,
+                    kernel_us=kernel_us, device=torch.cuda.get_device_name(0)),
+        roofline=dict(bound="hbm", kernel=kernel_desc, achieved=k1_gbs,
                       peak=HBM_PEAK_GBS, unit="GB/s", frac=k1_gbs / HBM_PEAK_GBS, frac_of_achievable=k1_gbs / HBM_ACHIEVABLE_GBS,
                       bytes_per_launch=bts["k1"], avg_launch_us=k_ms[0] * 1e3, launches_timed=int(piters), traffic=None),
     )
@@ -194,6 +213,7 @@ def main():
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--check-every", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pcg", action="store_true", help="time the Jacobi-PCG instead of the default (Chebyshev) solver")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")

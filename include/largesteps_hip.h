@@ -108,8 +108,21 @@ int ls_solver_destroy(ls_solver* s);
  * Returns LS_E_NOT_CONVERGED (info still filled) if max_iter is hit. */
 int ls_solver_solve(ls_solver* s, const float* b, const float* x0, float* x, int k, double rtol,
                     double atol, int max_iter, ls_solve_info* h_info, void* stream);
-/* knobs for measurements: name in {"algo" (1 = fused 2-kernel CG on the symmetrically scaled system, default for
- * square systems; 0 = classic 3-kernel Jacobi-PCG), "check_every", "grid" (workgroups per kernel, 0 = auto),
+/* Chebyshev-accelerated Jacobi iteration on the same handle: one kernel per iteration, no dot products. Needs
+ * ls_solver_set_spectrum(s, a_min) with a_min <= lambda_min(M) (M = a I + b L with L positive semi-definite: a);
+ * the upper end of spec(D^-1 M) is the handle's own Gershgorin bound. The iteration count is fixed a priori:
+ * ceil(log(2/t) / log((sqrt(kappa)+1)/(sqrt(kappa)-1))) for the requested residual reduction t (rtol, or
+ * max(rtol||b||, atol)/||r0|| after one residual evaluation when x0 or atol is given). h_info->rnorm is the TRUE
+ * fp32 residual of the returned x. SYNC once at the end. LS_E_STATE without a spectrum, LS_E_NOT_CONVERGED if the
+ * count exceeds max_iter or the final residual check fails (callers fall back to ls_solver_solve). */
+int ls_solver_set_spectrum(ls_solver* s, double a_min);
+int ls_solver_spectrum(const ls_solver* s, double* h_lmin, double* h_lmax);
+/* iterations the Chebyshev solver will run for a residual reduction `reduction` (e.g. rtol from a cold start) */
+int ls_solver_chebyshev_iterations(const ls_solver* s, double reduction, int* h_n);
+int ls_solver_solve_chebyshev(ls_solver* s, const float* b, const float* x0, float* x, int k, double rtol,
+                              double atol, int max_iter, ls_solve_info* h_info, void* stream);
+/* knobs for measurements: name in {"algo" (0 = classic 3-kernel Jacobi-PCG, default; 1 = fused 2-kernel CG on the
+ * symmetrically scaled system, square systems only), "check_every", "grid" (workgroups per kernel, 0 = auto),
  * "block" (0 = auto, 256, 512 or 1024 threads per workgroup), "profile"}; unknown name -> LS_E_INVALID */
 int ls_solver_set(ls_solver* s, const char* name, int value);
 /* With "profile"=1 every solve brackets its three kernels per iteration with HIP events on the solve's

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include "../../include/largesteps_hip.h"
 
 namespace ls {
@@ -31,6 +32,11 @@ struct DeviceGuard {  // every entry point pins the device itself: no thread-loc
     int prev = -1;
     hipError_t err;
     explicit DeviceGuard(int device) {
+        // The process is shared with PyTorch (and with this library's own fire-and-forget frees): drop any stale
+        // sticky error so that this entry point only reports failures of its own calls. LS_DEBUG=1 prints it.
+        const hipError_t stale = hipGetLastError();
+        if (stale != hipSuccess && getenv("LS_DEBUG"))
+            fprintf(stderr, "[largesteps] stale HIP error %d (%s) found on entry\n", (int)stale, hipGetErrorString(stale));
         err = hipGetDevice(&prev);
         if (err == hipSuccess && prev != device) err = hipSetDevice(device);
     }

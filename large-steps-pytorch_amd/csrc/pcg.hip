@@ -24,6 +24,7 @@
 #include "spmv_kernels.h"
 #include <algorithm>
 #include <limits.h>
+#include <math.h>
 #include <string.h>
 #include <new>
 #include <vector>
@@ -510,6 +511,90 @@ __global__ __launch_bounds__(BLOCK) void k_scale_rows(const float* __restrict__ 
     stv<K>(dst, i, v);
 }
 
+// ==== Chebyshev-accelerated Jacobi iteration: no dot products, ONE kernel per iteration =====================
+// x_{k+1} = x_k + c1_k (x_k - x_{k-1}) + c2_k D^-1 (b - M x_k), the coefficients being the Chebyshev recurrence
+// for the enclosure [lmin, lmax] of spec(D^-1 M) (Saad, Iterative Methods for Sparse Linear Systems, alg. 12.1
+// written in the 3-term form). lmax is Gershgorin's bound max_i sum_j |m_ij| / m_ii, lmin = a_min / max_i m_ii
+// with a_min <= lambda_min(M) supplied by the assembler (M = a I + b L, L positive semi-definite => a_min = a).
+// Per iteration and vertex: the matrix row, one gather of x_k, b, 1/diag, x_{k-1} read and x_{k+1} written in
+// place -- 8 nnz + 4 + 16k bytes, about half of a CG iteration, and no scalar hand-off between launches, so
+// nothing ever waits for a reduction (single GPU) or an all-reduce (sharded).  The residual b - M x_k is
+// recomputed, never recurred, so it is the TRUE fp32 residual.
+template <int K, int BS, bool FIRST>
+__global__ __launch_bounds__(BS) void k_cheb(SellView S, const float* __restrict__ dinv, const float* __restrict__ b,
+                                             const float* __restrict__ xc, float* __restrict__ xpn, float c1, float c2,
+                                             int64_t V, int T, int G) {
+    const Sched sch(T, G);
+    for (int tile = sch.first; tile < sch.end; tile += sch.step) {
+        const int64_t i = (int64_t)tile * BS + threadIdx.x;
+        float ax[K];
+#pragma unroll
+        for (int q = 0; q < K; ++q) ax[q] = 0.0f;
+        if ((i & ~(int64_t)(WAVE - 1)) < V) row_sell<K>(S, xc, i, ax);
+        if (i < V) {
+            const Vec<K> bv = ldv<K>(b, i), xv = ldv<K>(xc, i);
+            const float di = dinv[i];
+            Vec<K> xn;
+            if (FIRST) {
+#pragma unroll
+                for (int q = 0; q < K; ++q) xn.v[q] = fmaf(c2, di * (bv.v[q] - ax[q]), xv.v[q]);
+            } else {
+                const Vec<K> xp = ldv<K>(xpn, i);
+#pragma unroll
+                for (int q = 0; q < K; ++q) xn.v[q] = fmaf(c2, di * (bv.v[q] - ax[q]), fmaf(c1, xv.v[q] - xp.v[q], xv.v[q]));
+            }
+            stv<K>(xpn, i, xn);
+        }
+    }
+}
+
+// partials of ||b - M x||^2 (slots r.z and r.r, so that k_init_scal can be reused) and ||b||^2
+template <int K, int BS, bool ZERO_X>
+__global__ __launch_bounds__(BS) void k_resnorm(SellView S, const float* __restrict__ b, const float* __restrict__ x,
+                                                double* __restrict__ part, int64_t V, int T, int G) {
+    __shared__ double s_red[(BS / WAVE) * 3 * K];
+    double acc[3 * K];
+#pragma unroll
+    for (int n = 0; n < 3 * K; ++n) acc[n] = 0.0;
+    const Sched sch(T, G);
+    for (int tile = sch.first; tile < sch.end; tile += sch.step) {
+        const int64_t i = (int64_t)tile * BS + threadIdx.x;
+        float ax[K];
+#pragma unroll
+        for (int q = 0; q < K; ++q) ax[q] = 0.0f;
+        if (!ZERO_X && (i & ~(int64_t)(WAVE - 1)) < V) row_sell<K>(S, x, i, ax);
+        if (i < V) {
+            const Vec<K> bv = ldv<K>(b, i);
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                const double rq = (double)(bv.v[q] - ax[q]);
+                acc[q] += rq * rq;
+                acc[K + q] += rq * rq;
+                acc[2 * K + q] += (double)bv.v[q] * (double)bv.v[q];
+            }
+        }
+    }
+    write_partials<3 * K, K, BS>(acc, part, PART_RZ, s_red);
+}
+
+// Gershgorin bound of spec(D^-1 M) and max diagonal (one-off per matrix)
+__global__ __launch_bounds__(BLOCK) void k_gershgorin(CsrView A, int64_t V, const float* __restrict__ dinv, int* __restrict__ out /* [2] float bits */) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    float ratio = 0.0f, d = 0.0f;
+    if (i < V) {
+        float sum = 0.0f;
+        for (int j = A.rowptr[i]; j < A.rowptr[i + 1]; ++j) sum += fabsf(A.val[j]);
+        ratio = sum * dinv[i];
+        d = 1.0f / dinv[i];
+    }
+    ratio = wave_max(ratio);
+    d = wave_max(d);
+    if ((threadIdx.x & (WAVE - 1)) == 0) {     // positive floats order like their bit patterns
+        atomicMax(&out[0], __float_as_int(ratio));
+        atomicMax(&out[1], __float_as_int(d));
+    }
+}
+
 // ---- CSR -> SELL-64 ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_sell_widths(const int* __restrict__ rowptr, int64_t V, int S, int* __restrict__ width64) {
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -599,7 +684,9 @@ struct ls_solver {
     // fused variant (square systems only): scaled SELL copy, s = D^-1/2, d = diag, second p buffer, scaled x
     int2* sell_cv_scaled = nullptr;
     float *sv = nullptr, *dd = nullptr, *p1 = nullptr, *xh = nullptr;
-    int algo = 1;                 // 1 = fused 2-kernel CG on the scaled system, 0 = classic 3-kernel Jacobi PCG
+    int algo = 0;                 // 0 = classic 3-kernel Jacobi PCG (default), 1 = fused 2-kernel CG on the scaled system
+    double a_min = 0.0;           // caller-certified lower bound of lambda_min(M); 0 = unknown (Chebyshev refused)
+    double gersh = 0.0, dmax = 0.0;   // Gershgorin bound of spec(D^-1 M), max diagonal entry
     int last_G = -1;              // grid the partial arrays were last written with (tail must stay zero)
     double* part = nullptr;
     Scal* scal = nullptr;
@@ -689,11 +776,13 @@ int create_impl(ls_solver* s, hipStream_t st) {
     LS_HIP(hipMalloc((void**)&width64, sizeof(int) * (size_t)S));
     hipLaunchKernelGGL(k_sell_widths, dim3(div_up((int64_t)S * WAVE, BLOCK)), dim3(BLOCK), 0, st, s->csr.rowptr, V, S, width64);
     hipLaunchKernelGGL(k_sell_scan, dim3(1), dim3(1024), 0, st, width64, S, s->slice_ptr);
-    int h[2] = {0, 0};
+    hipLaunchKernelGGL(k_gershgorin, dim3(div_up(V, BLOCK)), dim3(BLOCK), 0, st, s->csr, V, s->dinv, flag + 2);
+    int h[5] = {0, 0, 0, 0, 0};   // SELL entries | diag flag, (unused), Gershgorin bits, max-diag bits
     LS_HIP(hipMemcpyAsync(&h[0], s->slice_ptr + S, sizeof(int), hipMemcpyDeviceToHost, st));
-    LS_HIP(hipMemcpyAsync(&h[1], flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    LS_HIP(hipMemcpyAsync(&h[1], flag, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
     LS_HIP(hipStreamSynchronize(st));
     (void)hipFree(width64);
+    { float f; memcpy(&f, &h[3], 4); s->gersh = f; memcpy(&f, &h[4], 4); s->dmax = f; }
     LS_REQUIRE(h[1] == 0, LS_E_INVALID, "matrix has a missing or non-positive diagonal entry: not SPD, Jacobi-PCG refused");
     LS_REQUIRE(h[0] >= 0, LS_E_OVERFLOW, "SELL copy of the matrix overflows int32 entry offsets");
     s->sell_entries = h[0];
@@ -749,15 +838,23 @@ void launch_phase(ls_solver* s, int phase, const float* b, const float* x0, floa
         case 7:
             hipLaunchKernelGGL((k_update<K, BS, true>), grid, block, 0, st, s->dd, p_new, s->Ap, s->xh, s->r, s->part, s->scal, it, s->V, g.T, g.G);
             break;
-        default:
+        case 8:
             hipLaunchKernelGGL((k_scale_rows<K, false>), dim3(div_up(s->V, BLOCK)), dim3(BLOCK), 0, st, s->sv, s->dd, s->xh, x, s->V);
+            break;
+        case 9:   // Chebyshev step: x0 = current iterate (gathered), x = x_{k-1} in / x_{k+1} out, rtol/atol carry c1/c2
+            if (it == 0) hipLaunchKernelGGL((k_cheb<K, BS, true>), grid, block, 0, st, s->sell, s->dinv, b, x0, x, (float)rtol, (float)atol, s->V, g.T, g.G);
+            else hipLaunchKernelGGL((k_cheb<K, BS, false>), grid, block, 0, st, s->sell, s->dinv, b, x0, x, (float)rtol, (float)atol, s->V, g.T, g.G);
+            break;
+        default:  // 10: residual / rhs norms of x0 (nullptr: x = 0)
+            if (x0) hipLaunchKernelGGL((k_resnorm<K, BS, false>), grid, block, 0, st, s->sell, b, x0, s->part, s->V, g.T, g.G);
+            else hipLaunchKernelGGL((k_resnorm<K, BS, true>), grid, block, 0, st, s->sell, b, x0, s->part, s->V, g.T, g.G);
             break;
     }
 }
 
 int dispatch_phase(ls_solver* s, int k, int phase, const float* b, const float* x0, float* x, double rtol, double atol, int it,
                    const Geometry& g, hipStream_t st) {
-    if ((phase == 0 || phase == 5) && g.G != s->last_G) {   // partial entries [G, MAXG) must read as zero
+    if ((phase == 0 || phase == 5 || phase == 10) && g.G != s->last_G) {   // partial entries [G, MAXG) must read as zero
         LS_HIP(hipMemsetAsync(s->part, 0, sizeof(double) * PART_SLOTS * KMAX * MAXG, st));
         s->last_G = g.G;
     }
@@ -853,6 +950,92 @@ int solve_impl(ls_solver* s, const float* b, const float* x0, float* x, int k, d
     return LS_OK;
 }
 
+// Chebyshev-Jacobi solve: the iteration count follows from the spectral enclosure and the requested reduction,
+// nothing is polled: n launches, one residual check, one sync.
+int solve_cheb(ls_solver* s, const float* b, const float* x0, float* x, int k, double rtol, double atol, int max_iter,
+               ls_solve_info* info, hipStream_t st) {
+    LS_REQUIRE(s->a_min > 0.0 && s->gersh > 0.0 && s->dmax > 0.0, LS_E_STATE,
+               "Chebyshev: no certified spectral enclosure for this matrix (ls_solver_set_spectrum)");
+    const Geometry g = geometry(s);
+    const double lmin = 0.98 * s->a_min / s->dmax, lmax = s->gersh * (1.0 + 1e-5);
+    const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma1 = theta / delta;
+    const double sk = sqrt(lmax / lmin), rate = (sk - 1.0) / (sk + 1.0);
+    int rc;
+    // requested residual reduction relative to the starting residual
+    double target = rtol;      // cold start without atol: ||r0|| = ||b||
+    double bb[4] = {0, 0, 0, 0};
+    if (x0 || atol > 0.0) {
+        if ((rc = dispatch_phase(s, k, 10, b, x0, x, rtol, atol, 0, g, st))) return rc;
+        dispatch_phase(s, k, 1, b, x0, x, rtol, atol, 0, g, st);
+        LS_HIP(hipMemcpyAsync(&s->h_scal[0], s->scal, sizeof(Scal), hipMemcpyDeviceToHost, st));
+        LS_HIP(hipStreamSynchronize(st));
+        target = 1.0;
+        for (int q = 0; q < k; ++q) {
+            const double r0 = sqrt(s->h_scal[0].rr[q]), thr = sqrt(s->h_scal[0].thr2[q]);
+            bb[q] = s->h_scal[0].bb[q];
+            if (r0 > thr) target = std::min(target, thr / r0);
+        }
+    }
+    int n = 0;
+    if (target < 1.0) n = (int)ceil(log(2.0 / std::max(target, 1e-30)) / -log(rate));
+    const bool capped = n > max_iter;
+    n = std::min(n, max_iter);
+    // iterate k reads buffer (k even ? Y : Z) and overwrites the other one; the final iterate must land in x
+    float* Y = (n & 1) ? s->xh : x;
+    float* Z = (n & 1) ? x : s->xh;
+    const size_t bytes = sizeof(float) * (size_t)s->V * k;
+    if (x0) { if (x0 != Y) LS_HIP(hipMemcpyAsync(Y, x0, bytes, hipMemcpyDeviceToDevice, st)); }
+    else LS_HIP(hipMemsetAsync(Y, 0, bytes, st));
+    if (s->profile && s->pev.empty()) {
+        s->pev.assign(4 * PROF_MAX_ITERS, nullptr);
+        for (auto& e : s->pev) LS_HIP(hipEventCreate(&e));
+    }
+    if (s->profile) LS_HIP(hipEventRecord(s->pev[0], st));
+    double rho = 1.0 / sigma1;
+    for (int it = 0; it < n; ++it) {
+        double c1 = 0.0, c2 = 1.0 / theta;
+        if (it > 0) {
+            const double rho_new = 1.0 / (2.0 * sigma1 - rho);
+            c1 = rho_new * rho;
+            c2 = 2.0 * rho_new / delta;
+            rho = rho_new;
+        }
+        dispatch_phase(s, k, 9, b, (it & 1) ? Z : Y, (it & 1) ? Y : Z, c1, c2, it, g, st);
+    }
+    if (s->profile) LS_HIP(hipEventRecord(s->pev[1], st));
+    LS_HIP(hipGetLastError());
+    // true residual of the returned iterate
+    if ((rc = dispatch_phase(s, k, 10, b, x, x, rtol, atol, 0, g, st))) return rc;
+    dispatch_phase(s, k, 1, b, x, x, rtol, atol, 0, g, st);
+    LS_HIP(hipMemcpyAsync(&s->h_scal[2], s->scal, sizeof(Scal), hipMemcpyDeviceToHost, st));
+    LS_HIP(hipStreamSynchronize(st));
+    const Scal& f = s->h_scal[2];
+    if (s->profile) {   // n back-to-back launches between two events: average includes the launch gaps
+        float ms = 0.f;
+        LS_HIP(hipEventElapsedTime(&ms, s->pev[0], s->pev[1]));
+        s->prof_ms[0] = ms; s->prof_ms[1] = s->prof_ms[2] = 0.0;
+        s->prof_iters = n;
+    }
+    bool ok = !capped && f.bad == 0;
+    if (info) {
+        info->iterations = n;
+        for (int q = 0; q < 4; ++q) { info->rnorm[q] = q < k ? sqrt(f.rr[q]) : 0.0; info->bnorm[q] = q < k ? sqrt(f.bb[q]) : 0.0; }
+    }
+    // sanity only: the true fp32 residual floors near eps32 ||M|| ||x||, far above a 1e-6 request, so the test is
+    // the a-priori count plus "finite and at least 1e-3 ||b|| (or the request, if looser)"
+    for (int q = 0; q < k; ++q) {
+        const double lim = std::max(f.thr2[q], 1e-6 * f.bb[q]);
+        if (!(f.rr[q] <= lim)) ok = false;
+    }
+    if (info) info->converged = ok ? 1 : 0;
+    if (!ok) {
+        set_error(capped ? "Chebyshev: %d iterations needed for the requested reduction exceed max_iter"
+                         : "Chebyshev: residual check failed after %d iterations (spectral enclosure violated?)", n);
+        return LS_E_NOT_CONVERGED;
+    }
+    return LS_OK;
+}
+
 }  // namespace
 
 extern "C" int ls_solver_create_ext(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n_rows, int64_t n_cols,
@@ -896,6 +1079,44 @@ extern "C" int ls_solver_set(ls_solver* s, const char* name, int value) {
     else if (!strcmp(name, "algo")) { LS_REQUIRE((value == 0 || value == 1) && (value == 0 || s->ncols == s->V), LS_E_INVALID, "algo must be 0 (classic) or 1 (fused; square systems only)"); s->algo = value; }
     else { set_error("ls_solver_set: unknown knob '%s'", name); return LS_E_INVALID; }
     return LS_OK;
+}
+
+extern "C" int ls_solver_set_spectrum(ls_solver* s, double a_min) {
+    LS_REQUIRE(s && a_min >= 0.0, LS_E_INVALID, "ls_solver_set_spectrum: need a handle and a_min >= 0");
+    s->a_min = a_min;
+    return LS_OK;
+}
+
+extern "C" int ls_solver_chebyshev_iterations(const ls_solver* s, double reduction, int* h_n) {
+    LS_REQUIRE(s && h_n && reduction > 0.0, LS_E_INVALID, "ls_solver_chebyshev_iterations: bad argument");
+    LS_REQUIRE(s->a_min > 0.0 && s->gersh > 0.0 && s->dmax > 0.0, LS_E_STATE, "Chebyshev: no certified spectral enclosure for this matrix");
+    const double lmin = 0.98 * s->a_min / s->dmax, lmax = s->gersh * (1.0 + 1e-5);
+    const double sk = sqrt(lmax / lmin), rate = (sk - 1.0) / (sk + 1.0);
+    *h_n = reduction >= 1.0 ? 0 : (int)std::min(2.0e9, ceil(log(2.0 / reduction) / -log(rate)));
+    return LS_OK;
+}
+
+extern "C" int ls_solver_spectrum(const ls_solver* s, double* h_lmin, double* h_lmax) {
+    LS_REQUIRE(s && h_lmin && h_lmax, LS_E_INVALID, "ls_solver_spectrum: null argument");
+    *h_lmin = s->dmax > 0.0 ? s->a_min / s->dmax : 0.0;
+    *h_lmax = s->gersh;
+    return LS_OK;
+}
+
+extern "C" int ls_solver_solve_chebyshev(ls_solver* s, const float* b, const float* x0, float* x, int k, double rtol, double atol,
+                                         int max_iter, ls_solve_info* h_info, void* stream) {
+    LS_REQUIRE(s, LS_E_INVALID, "ls_solver_solve_chebyshev: null handle");
+    LS_REQUIRE(k >= 1 && k <= s->kmax, LS_E_INVALID, "ls_solver_solve_chebyshev: k=%d outside [1,%d]", k, s->kmax);
+    LS_REQUIRE(s->V == 0 || (b && x), LS_E_INVALID, "ls_solver_solve_chebyshev: null pointer");
+    LS_REQUIRE(x != b, LS_E_INVALID, "ls_solver_solve_chebyshev: x must not alias b");
+    LS_REQUIRE(s->ncols == s->V, LS_E_STATE, "ls_solver_solve_chebyshev: square systems only");
+    LS_REQUIRE(rtol >= 0.0 && atol >= 0.0 && (rtol > 0.0 || atol > 0.0) && max_iter >= 0, LS_E_INVALID,
+               "ls_solver_solve_chebyshev: need rtol, atol >= 0 (one of them > 0) and max_iter >= 0");
+    if (h_info) memset(h_info, 0, sizeof(*h_info));
+    if (s->V == 0) { if (h_info) h_info->converged = 1; return LS_OK; }
+    DeviceGuard g(s->device);
+    LS_HIP(g.err);
+    return solve_cheb(s, b, x0, x, k, rtol, atol, max_iter, h_info, (hipStream_t)stream);
 }
 
 extern "C" int ls_solver_profile(const ls_solver* s, double* h_ms3, int* h_iters) {

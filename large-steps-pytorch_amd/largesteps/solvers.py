@@ -52,9 +52,16 @@ class PCGSolver(Solver):
     warm_start : bool
         Start from the previous solution of the same pass (forward / backward kept apart, like
         solvers.py:102-124) instead of zero.
+    chebyshev : bool
+        Use the Chebyshev-accelerated Jacobi iteration (one kernel per iteration, no dot products) when the
+        matrix comes with a certified spectral enclosure (matrices built by `compute_matrix`); falls back to
+        PCG otherwise, or if its final residual check fails. `rtol` is then the a-priori guaranteed reduction
+        of the residual; `last_info['rnorm']` is the true fp32 residual of the returned solution.
+    chebyshev_cap : int
+        Largest a-priori Chebyshev iteration count (cold start, at `rtol`) for which Chebyshev is preferred to PCG.
     """
 
-    def __init__(self, M, rtol=1e-6, atol=0.0, max_iter=10000, warm_start=False):
+    def __init__(self, M, rtol=1e-6, atol=0.0, max_iter=10000, warm_start=False, chebyshev=False, chebyshev_cap=400):
         csr = _native.csr_of(M)
         self._csr = csr                 # keeps rowptr/col/val alive; never M itself (cache eviction relies on it)
         self.rtol, self.atol, self.max_iter, self.warm_start = float(rtol), float(atol), int(max_iter), bool(warm_start)
@@ -67,6 +74,18 @@ class PCGSolver(Solver):
             _native.check(_native.lib().ls_solver_create(_native.ptr(csr.rowptr), _native.ptr(csr.col), _native.ptr(csr.val),
                                                          csr.V, csr.nnz, _KMAX, dev.index, _native.stream_of(dev),
                                                          ctypes.byref(self._handle)))
+        self.chebyshev = False
+        self.chebyshev_iterations = None
+        if csr.a_min is not None:
+            _native.check(_native.lib().ls_solver_set_spectrum(self._handle, float(csr.a_min)))
+            if chebyshev and self.rtol > 0.0:
+                # The count is known a priori from the enclosure. A Chebyshev step costs ~0.4 of a PCG iteration, but
+                # PCG adapts to the actual spectrum: with a loose enclosure (cotangent weights of sliver triangles, one
+                # vertex of very high valence) the bound explodes and PCG wins -- keep Chebyshev only below the cap.
+                n = ctypes.c_int(0)
+                _native.check(_native.lib().ls_solver_chebyshev_iterations(self._handle, self.rtol, ctypes.byref(n)))
+                self.chebyshev_iterations = n.value
+                self.chebyshev = n.value <= int(chebyshev_cap)
 
     def __del__(self):
         h = getattr(self, "_handle", None)
@@ -93,11 +112,22 @@ class PCGSolver(Solver):
         dev = csr.device
         x = torch.empty_like(b)
         info = _native.SolveInfo()
+        lib = _native.lib()
+        args = (self._handle, _native.ptr(b), _native.ptr(x0) if x0 is not None else None, _native.ptr(x), b.shape[1],
+                self.rtol, self.atol, self.max_iter, ctypes.byref(info), _native.stream_of(dev))
+        method = "pcg"
         with torch.cuda.device(dev):
-            rc = _native.lib().ls_solver_solve(self._handle, _native.ptr(b), _native.ptr(x0) if x0 is not None else None,
-                                               _native.ptr(x), b.shape[1], self.rtol, self.atol, self.max_iter,
-                                               ctypes.byref(info), _native.stream_of(dev))
-        self.last_info = dict(iterations=info.iterations, converged=bool(info.converged),
+            rc = None
+            if self.chebyshev:
+                rc = lib.ls_solver_solve_chebyshev(*args)
+                method = "chebyshev"
+                if rc in (_native.LS_E_NOT_CONVERGED, _native.LS_E_STATE):
+                    warnings.warn(f"largesteps: {_native.last_error()}; falling back to PCG", RuntimeWarning, stacklevel=3)
+                    rc = None
+            if rc is None:
+                rc = lib.ls_solver_solve(*args)
+                method = "pcg"
+        self.last_info = dict(iterations=info.iterations, converged=bool(info.converged), method=method,
                               rnorm=list(info.rnorm)[:b.shape[1]], bnorm=list(info.bnorm)[:b.shape[1]])
         if rc == _native.LS_E_NOT_CONVERGED:
             msg = _native.last_error()
@@ -147,13 +177,15 @@ class CholeskySolver(PCGSolver):
     """
     Drop-in for the reference's default solver (solvers.py:26-39: cholespy / CHOLMOD factor + triangular solves).
 
-    No factorisation exists in this package: every solve is a cold-started HIP Jacobi-PCG run to a relative
-    residual of 1e-6, i.e. the result is a function of b only, like a direct solve, within the fp32 accuracy
-    class of the reference's single-precision Cholesky solve (tolerances: DESIGN.md).
+    No factorisation exists in this package: every solve is a cold-started iteration run to a residual reduction
+    of 1e-6, i.e. the result is a function of b only, like a direct solve, within the fp32 accuracy class of the
+    reference's single-precision Cholesky solve (tolerances: DESIGN.md). For matrices from `compute_matrix`
+    (spectral enclosure known) the iteration is the Chebyshev-accelerated Jacobi method -- one HIP kernel per
+    iteration, no reductions; any other matrix is solved by the Jacobi-PCG.
     """
 
-    def __init__(self, M, rtol=1e-6, max_iter=10000):
-        super().__init__(M, rtol=rtol, atol=0.0, max_iter=max_iter, warm_start=False)
+    def __init__(self, M, rtol=1e-6, max_iter=10000, chebyshev=True):
+        super().__init__(M, rtol=rtol, atol=0.0, max_iter=max_iter, warm_start=False, chebyshev=chebyshev)
 
 
 class ConjugateGradientSolver(PCGSolver):
@@ -165,7 +197,7 @@ class ConjugateGradientSolver(PCGSolver):
     """
 
     def __init__(self, M, atol=1e-5, max_iter=10000):
-        super().__init__(M, rtol=0.0, atol=atol, max_iter=max_iter, warm_start=True)
+        super().__init__(M, rtol=0.0, atol=atol, max_iter=max_iter, warm_start=True, chebyshev=False)
 
     def solve(self, b, backward=False):
         if len(b.shape) != 2:

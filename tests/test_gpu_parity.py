@@ -223,6 +223,53 @@ def test_solver_geometries_and_widths(dev, algo, block, k):
     assert float(z.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("cot", [False, True])
+@pytest.mark.parametrize("k", [1, 3, 4])
+def test_chebyshev_solver(dev, cot, k):
+    """Chebyshev-Jacobi path (the 'Cholesky' default for compute_matrix matrices) vs the fp64 direct solve."""
+    from largesteps.geometry import compute_matrix
+    from largesteps.solvers import PCGSolver
+    from largesteps import synthetic
+    v, f = synthetic.icosphere(20)
+    v = synthetic.perturb(v, radial=0.05, tangential=0.15 if cot else 0.0, edge=0.06, seed=2)
+    kw = dict(lambda_=0.0, alpha=0.9, cotan=True) if cot else dict(lambda_=25.0)
+    M = compute_matrix(_t(v, dev), _t(f, dev), **kw)
+    idx, val = M.indices().cpu().numpy(), M.values().cpu().numpy()
+    b = np.random.default_rng(k).standard_normal((v.shape[0], k)).astype(np.float32)
+    x64 = osv.from_differential(idx[0], idx[1], val, b)
+    s = PCGSolver(M, rtol=1e-6, chebyshev=True)
+    assert s.chebyshev
+    x = s.solve(_t(b, dev))
+    assert s.last_info["method"] == "chebyshev" and s.last_info["converged"]
+    # stated tolerance of the path: 1e-4 relative max-abs error vs the fp64 direct solve
+    assert np.abs(x.cpu().numpy() - x64).max() <= 1e-4 * np.abs(x64).max()
+    n_cold = s.last_info["iterations"]
+    # the enclosure really contains the spectrum: lmin <= lambda(D^-1 M) <= lmax (dense check, 4002 vertices)
+    import ctypes
+    from largesteps import _native
+    lo, hi = ctypes.c_double(), ctypes.c_double()
+    _native.check(_native.lib().ls_solver_spectrum(s._handle, ctypes.byref(lo), ctypes.byref(hi)))
+    import scipy.sparse as sp
+    A = sp.csr_matrix((val.astype(np.float64), (idx[0], idx[1]))).toarray()
+    d = np.diag(A)
+    ev = np.linalg.eigvalsh(A / np.sqrt(np.outer(d, d)))
+    assert lo.value <= ev.min() * (1 + 1e-6) and ev.max() <= hi.value * (1 + 1e-6)
+    # warm start from the solution: the residual evaluation finds (almost) nothing left to do
+    s.warm_start = True
+    s.guess_fwd = x.clone()
+    x2 = s.solve(_t(b, dev))
+    assert s.last_info["iterations"] < n_cold // 2
+    assert np.abs(x2.cpu().numpy() - x64).max() <= 1e-4 * np.abs(x64).max()
+    # zero right-hand side, and a matrix without enclosure (foreign) falls back to PCG
+    s.warm_start = False
+    assert float(s.solve(torch.zeros_like(x)).abs().max()) == 0.0
+    Mf = torch.sparse_coo_tensor(M.indices(), M.values(), M.shape).coalesce()
+    sf = PCGSolver(Mf, rtol=1e-6, chebyshev=True)
+    assert not sf.chebyshev
+    xf = sf.solve(_t(b, dev))
+    assert sf.last_info["method"] == "pcg" and np.abs(xf.cpu().numpy() - x64).max() <= 1e-4 * np.abs(x64).max()
+
+
 def test_determinism_and_fresh_output(dev):
     from largesteps.geometry import compute_matrix
     from largesteps.parameterize import from_differential, to_differential

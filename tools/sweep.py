@@ -54,7 +54,26 @@ def main():
                     err = float((s.solve(u) - tv).abs().max())
                     print(f"   algo {algo} block {block:4d} grid {grid:5d}: {ms:8.3f} ms/solve  iters {it:4d}  {ms * 1e3 / it:7.2f} us/iter | "
                           f"K1 {k1 / pit * 1e3:6.2f} us  K2 {k2 / pit * 1e3:6.2f} us  K3 {k3 / pit * 1e3:6.2f} us (event-bracketed) | max|x-v| {err:.1e}", flush=True)
-        s.set_option("algo", 1)
+        s.set_option("algo", 0); s.set_option("block", 0); s.set_option("grid", 0)
+        sc = PCGSolver(M, rtol=1e-6, chebyshev=True)
+        for block, grids in ((256, (512, 1024)), (512, (512, 1024)), (1024, (256, 512))):
+            for grid in grids:
+                sc.set_option("block", block); sc.set_option("grid", grid)
+                ms = timeit(lambda: sc.solve(u), 5)
+                xs = sc.solve(u)
+                inf = sc.last_info
+                print(f"   chebyshev block {block:4d} grid {grid:5d}: {ms:8.3f} ms/solve  iters {inf['iterations']:4d} ({inf['method']})  {ms * 1e3 / max(inf['iterations'], 1):7.2f} us/iter | "
+                      f"max|x-v| {float((xs - tv).abs().max()):.1e}  true rel residual {[f'{r / b:.1e}' for r, b in zip(inf['rnorm'], inf['bnorm'])]}", flush=True)
+        for rt in (1e-4, 1e-5, 1e-7):
+            sc.rtol = rt
+            xs = sc.solve(u)
+            print(f"   chebyshev rtol {rt:g}: iters {sc.last_info['iterations']}  max|x-v| {float((xs - tv).abs().max()):.1e}")
+        sc.rtol = 1e-6
+        sc.warm_start = True
+        sc.solve(u)
+        ms = timeit(lambda: sc.solve(u * 1.001), 5)
+        print(f"   chebyshev warm start (u*1.001): {ms:8.3f} ms/solve iters {sc.last_info['iterations']}")
+        del sc
         s.set_option("block", 0); s.set_option("grid", 0)
         x = s.solve(u)
         print(f"   max|x - v| = {float((x - tv).abs().max()):.2e}  rel residual {[r / b for r, b in zip(s.last_info['rnorm'], s.last_info['bnorm'])]}")
