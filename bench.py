@@ -177,12 +177,20 @@ def run_distributed(args):
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     local = int(os.environ.get("LOCAL_RANK", rank))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # LS_DIST_LOOPBACK=1: functional smoke test on a 1-GPU box -- every rank uses cuda:0 and gloo moves the data
+    # (RCCL refuses two ranks on one device). The numbers of such a run mean nothing.
+    loopback = os.environ.get("LS_DIST_LOOPBACK") == "1"
+    if loopback:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist.init_process_group("nccl", device_id=dev)
+    if loopback:
+        dist.init_process_group("gloo")
+    else:
+        dist.init_process_group("nccl", device_id=dev)
     out = lsd.bench_sharded(args.workload, dev, steps=args.steps, warmup=args.warmup)
     if rank == 0:
-        bts = algorithmic_bytes(out["V"], out["nnz"], 3, out["iterations"])
+        bts = algorithmic_bytes(out["V"], out["nnz"], 3, out["iterations"], out["method"])
         ms = out["ms_per_step"]
         res = dict(
             metric="from_differential_solves_per_sec", value=1e3 / ms, unit="solves/s", n_gpus=world, steps=args.steps,
@@ -190,10 +198,11 @@ def run_distributed(args):
             data="synthetic",
             config=dict(workload=f"{args.workload}: V={out['V']}, nnz(M)={out['nnz']}, k=3, cold start, rtol=1e-6, "
                                  f"{world} contiguous vertex blocks", solver=out["solver"], iterations=out["iterations"],
-                        converged=out["converged"], max_abs_err_vs_v=out["err"], halo_vertices=out["halo"],
+                        converged=out["converged"], max_abs_err_vs_v=out["err"], halo_vertices=out["halo"], method=out["method"],
+                        halo_depth=out["depth"], rows_per_rank=out["rows_per_rank"],
                         solve_bytes=bts["solve"], solve_gbs=bts["solve"] / (ms * 1e-3) / 1e9),
             # N > 1: whole sharded solve (all kernels + collectives) against the aggregate HBM peak of the N GPUs
-            roofline=dict(bound="hbm", kernel="whole sharded solve (K1+K2+K3 on every shard + halo exchange + all-reduces)",
+            roofline=dict(bound="hbm", kernel="whole sharded solve (all kernels on every shard + halo exchanges)",
                           achieved=bts["solve"] / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS * world, unit="GB/s",
                           frac=bts["solve"] / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), traffic=None),
             cpu_baseline=None,

@@ -158,6 +158,15 @@ int ls_solver_buffers(ls_solver* s, float** h_p, double** h_part, int* h_grid, i
 /* Replace the handle's p ((n_cols*kmax) floats) and partial array (4*4*stride doubles, zero-initialised by the
  * caller) by caller-owned device buffers, so that the host driver can hand them to its communication library. */
 int ls_solver_bind(ls_solver* s, float* p_ext, double* part);
+/* Sharded Chebyshev (largesteps/distributed.py ShardedChebyshev): `nsteps` iterations it0..it0+nsteps-1 on the first
+ * n_rows rows of the shard (owned rows + redundantly computed ghost layers). xa / xb: (n_cols,k) ping-pong buffers,
+ * iteration `it` gathers from (it even ? xa : xb) and overwrites the other; h_c1/h_c2: HOST arrays of the nsteps
+ * Chebyshev coefficients (it = 0: x1 = x0 + c2 D^-1 (b - M x0)). No collective is needed between these launches. */
+int ls_shard_cheb_steps(ls_solver* s, const float* b, float* xa, float* xb, int k, int it0, int nsteps,
+                        const float* h_c1, const float* h_c2, int64_t n_rows, void* stream);
+/* partials of ||b - M x||^2 (slots 1 and 2) and ||b||^2 (slot 3) over the first n_rows rows -> all-reduce ->
+ * ls_solver_phase(1) -> ls_solver_poll gives the global norms */
+int ls_shard_resnorm(ls_solver* s, const float* b, const float* x, int k, int64_t n_rows, void* stream);
 /* SYNC: copies the device scalars; h_info->iterations = -1 while no stop was published. */
 int ls_solver_poll(ls_solver* s, int k, int n_enqueued, ls_solve_info* h_info, void* stream);
 /* dst[t,:] = src[idx[t],:] for t < n (halo send buffer packing), k in 1..4 */

@@ -1180,6 +1180,45 @@ extern "C" int ls_solver_sell(ls_solver* s, const int32_t** h_slice_ptr, const v
     return LS_OK;
 }
 
+// ---- sharded Chebyshev: `nsteps` iterations on the first n_rows rows of the shard (owned + computed ghost layers) ----
+extern "C" int ls_shard_cheb_steps(ls_solver* s, const float* b, float* xa, float* xb, int k, int it0, int nsteps,
+                                   const float* h_c1, const float* h_c2, int64_t n_rows, void* stream) {
+    LS_REQUIRE(s && b && xa && xb && h_c1 && h_c2, LS_E_INVALID, "ls_shard_cheb_steps: null argument");
+    LS_REQUIRE(k >= 1 && k <= s->kmax && it0 >= 0 && nsteps >= 0 && n_rows >= 0 && n_rows <= s->V, LS_E_INVALID,
+               "ls_shard_cheb_steps: k, it0, nsteps or n_rows out of range");
+    if (n_rows == 0 || nsteps == 0) return LS_OK;
+    DeviceGuard g(s->device);
+    LS_HIP(g.err);
+    Geometry geo = geometry(s);
+    geo.T = div_up(n_rows, geo.bs);
+    const int64_t V_saved = s->V;
+    s->V = n_rows;                                   // the launchers read the row count from the handle
+    for (int j = 0; j < nsteps; ++j) {
+        const int it = it0 + j;
+        dispatch_phase(s, k, 9, b, (it & 1) ? xb : xa, (it & 1) ? xa : xb, (double)h_c1[j], (double)h_c2[j], it, geo, (hipStream_t)stream);
+    }
+    s->V = V_saved;
+    LS_HIP(hipGetLastError());
+    return LS_OK;
+}
+
+// partials of ||b - M x||^2 (slots 1,2) and ||b||^2 (slot 3) over the first n_rows rows
+extern "C" int ls_shard_resnorm(ls_solver* s, const float* b, const float* x, int k, int64_t n_rows, void* stream) {
+    LS_REQUIRE(s && b && x, LS_E_INVALID, "ls_shard_resnorm: null argument");
+    LS_REQUIRE(k >= 1 && k <= s->kmax && n_rows >= 0 && n_rows <= s->V, LS_E_INVALID, "ls_shard_resnorm: k or n_rows out of range");
+    DeviceGuard g(s->device);
+    LS_HIP(g.err);
+    Geometry geo = geometry(s);
+    geo.T = div_up(n_rows, geo.bs);
+    const int64_t V_saved = s->V;
+    s->V = n_rows;
+    const int rc = dispatch_phase(s, k, 10, b, x, nullptr, 0.0, 0.0, 0, geo, (hipStream_t)stream);
+    s->V = V_saved;
+    if (rc) return rc;
+    LS_HIP(hipGetLastError());
+    return LS_OK;
+}
+
 extern "C" int ls_solver_bind(ls_solver* s, float* p_ext, double* part) {
     LS_REQUIRE(s && p_ext && part, LS_E_INVALID, "ls_solver_bind: null argument");
     DeviceGuard g(s->device);

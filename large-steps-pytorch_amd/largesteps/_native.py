@@ -49,6 +49,8 @@ _SIGNATURES = {
     "ls_solver_phase": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_double, c_double, c_int, c_void_p]),
     "ls_solver_buffers": (c_int, [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_int),
                                   ctypes.POINTER(c_int)]),
+    "ls_shard_cheb_steps": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_i64, c_void_p]),
+    "ls_shard_resnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_void_p]),
     "ls_solver_bind": (c_int, [c_void_p, c_void_p, c_void_p]),
     "ls_solver_poll": (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(SolveInfo), c_void_p]),
     "ls_gather_rows": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_int, c_void_p]),

@@ -39,27 +39,54 @@ def block_bounds(V, P):
 class ShardPlan:
     """Everything rank `rank` of `P` needs to know about its block of a V x V CSR matrix (host side, numpy).
 
-    rowptr/col/val : local CSR; columns are local ids -- [0, n_own) owned, [n_own, n_own + n_halo) halo
-    halo_global    : global vertex id of every halo column (sorted => grouped by owner rank)
-    recv           : [(src_rank, offset_in_halo, count)]
-    send           : [(dst_rank, local_row_ids int32)]  rows of p this rank must ship each iteration
+    depth = 1 (PCG): the shard computes its owned rows; columns are [owned | halo layer 1].
+    depth = s > 1 (Chebyshev, one halo exchange per s iterations): the shard ALSO computes the ghost layers
+    1..s-1 redundantly (layer j = vertices at graph distance j from the block) and reads layer s, so that s
+    iterations can run between two exchanges -- after j iterations the layers > s-j are stale, the owned rows never are.
+
+    Local ids: [owned (n_own) | ghost layers 1..s-1 (computed) | ghost layer s (read only)]; the first `n_rows`
+    local ids are the rows of the local matrix. Ghosts are ordered by (owner rank, global id) inside each of the
+    two ghost groups, so every (owner, group) pair is one contiguous range:
+    recv : [(src_rank, offset_in_ghost_region, count)]   in local order
+    send : [(dst_rank, local_row_ids int32)]             the matching owned rows, message for message
     """
 
-    def __init__(self, rank, P, lo, hi, rowptr, col, val, halo_global, recv, send):
-        self.rank, self.P, self.lo, self.hi = rank, P, int(lo), int(hi)
+    def __init__(self, rank, P, lo, hi, depth, rowptr, col, val, ghost_global, n_ghost_rows, recv, send):
+        self.rank, self.P, self.lo, self.hi, self.depth = rank, P, int(lo), int(hi), int(depth)
         self.n_own = int(hi - lo)
-        self.n_halo = int(halo_global.shape[0])
+        self.n_halo = int(ghost_global.shape[0])
+        self.n_rows = self.n_own + int(n_ghost_rows)          # rows of the local matrix (owned + computed ghosts)
         self.n_cols = self.n_own + self.n_halo
         self.rowptr, self.col, self.val = rowptr, col, val
-        self.halo_global, self.recv, self.send = halo_global, recv, send
+        self.halo_global, self.recv, self.send = ghost_global, recv, send
 
     @staticmethod
-    def _halo_of(rowptr, col, lo, hi):
-        c = col[rowptr[lo]:rowptr[hi]]
-        return np.unique(c[(c < lo) | (c >= hi)])
+    def _layers(A, lo, hi, depth):
+        """Ghost layers 1..depth of the block [lo, hi): BFS on the pattern of the (scipy CSR) matrix."""
+        V = A.shape[0]
+        seen = np.zeros(V, dtype=bool)
+        seen[lo:hi] = True
+        frontier = np.arange(lo, hi)
+        layers = []
+        for _ in range(depth):
+            nb = np.unique(A[frontier].indices) if frontier.size else np.empty(0, np.int64)
+            nb = nb[~seen[nb]]
+            seen[nb] = True
+            layers.append(nb.astype(np.int64))
+            frontier = nb
+        return layers
 
     @staticmethod
-    def build(rowptr, col, val, V, P, rank):
+    def _ghost_groups(A, bounds, q, depth):
+        """(computed ghosts, read-only ghosts) of rank q, each sorted by (owner, global id)."""
+        layers = ShardPlan._layers(A, bounds[q], bounds[q + 1], depth)
+        inner = np.sort(np.concatenate(layers[:-1])) if depth > 1 else np.empty(0, np.int64)
+        outer = np.sort(layers[-1])
+        return inner, outer      # contiguous blocks => sorting by id sorts by owner first
+
+    @staticmethod
+    def build(rowptr, col, val, V, P, rank, depth=1):
+        import scipy.sparse as sp
         rowptr = np.asarray(rowptr).astype(np.int64)
         col = np.asarray(col).astype(np.int64)
         val = np.asarray(val, dtype=np.float32)
@@ -67,29 +94,42 @@ class ShardPlan:
             raise ValueError(f"invalid rank {rank} of {P}")
         if P > max(V, 1):
             raise ValueError(f"cannot cut {V} vertices into {P} non-empty blocks")
+        if depth < 1:
+            raise ValueError("halo depth must be >= 1")
         bounds = block_bounds(V, P)
         lo, hi = bounds[rank], bounds[rank + 1]
-        s, e = rowptr[lo], rowptr[hi]
-        c = col[s:e]
-        own = (c >= lo) & (c < hi)
-        halo = np.unique(c[~own])
-        local = np.where(own, c - lo, (hi - lo) + np.searchsorted(halo, c))
-        owner = np.searchsorted(bounds, halo, side="right") - 1
+        A = sp.csr_matrix((val, col, rowptr), shape=(V, V))
+        inner, outer = ShardPlan._ghost_groups(A, bounds, rank, depth)
+        ghosts = np.concatenate([inner, outer])
+        glob = np.concatenate([np.arange(lo, hi), ghosts])
+        lut = np.full(V, -1, dtype=np.int64)
+        lut[glob] = np.arange(glob.shape[0])
+        rows_global = glob[: (hi - lo) + inner.shape[0]]
+        Aloc = A[rows_global]                                  # rows in local order, columns still global
+        local_col = lut[Aloc.indices]
+        assert (local_col >= 0).all(), "a computed row references a column outside the halo"
+        # per-owner contiguous ranges of the two ghost groups
         recv = []
-        for q in np.unique(owner):
-            idx = np.nonzero(owner == q)[0]
-            assert idx[-1] - idx[0] + 1 == idx.shape[0]          # contiguous: halo sorted, blocks contiguous
-            recv.append((int(q), int(idx[0]), int(idx.shape[0])))
+        for group, base in ((inner, 0), (outer, inner.shape[0])):
+            owner = np.searchsorted(bounds, group, side="right") - 1
+            for q in np.unique(owner):
+                idx = np.nonzero(owner == q)[0]
+                assert idx[-1] - idx[0] + 1 == idx.shape[0]
+                recv.append((int(q), int(base + idx[0]), int(idx.shape[0])))
+        # what the others need from me, in THEIR order (group by group, ids ascending)
         send = []
-        for q in range(P):
-            if q == rank:
-                continue
-            hq = ShardPlan._halo_of(rowptr, col, bounds[q], bounds[q + 1])
-            mine = hq[(hq >= lo) & (hq < hi)]
-            if mine.shape[0]:
-                send.append((q, (mine - lo).astype(np.int32)))
-        return ShardPlan(rank, P, lo, hi, (rowptr[lo:hi + 1] - s).astype(np.int32), local.astype(np.int32),
-                         val[s:e].copy(), halo, recv, send)
+        groups_of = {q: ShardPlan._ghost_groups(A, bounds, q, depth) for q in range(P) if q != rank}
+        for gi in (0, 1):
+            for q in range(P):
+                if q == rank:
+                    continue
+                g = groups_of[q][gi]
+                mine = g[(g >= lo) & (g < hi)]
+                if mine.shape[0]:
+                    send.append((q, (mine - lo).astype(np.int32)))
+        # the receiver walks its recv list group by group and, inside a group, owner by owner: same order here
+        return ShardPlan(rank, P, lo, hi, depth, Aloc.indptr.astype(np.int32), local_col.astype(np.int32),
+                         Aloc.data.astype(np.float32), ghosts, inner.shape[0], recv, send)
 
 
 class HipShardOps:
@@ -106,7 +146,7 @@ class HipShardOps:
         lib = _native.lib()
         with torch.cuda.device(dev):
             _native.check(lib.ls_solver_create_ext(_native.ptr(self.rowptr), _native.ptr(self.col), _native.ptr(self.val),
-                                                   plan.n_own, plan.n_cols, plan.col.shape[0], _KMAX, dev.index,
+                                                   plan.n_rows, plan.n_cols, plan.col.shape[0], _KMAX, dev.index,
                                                    _native.stream_of(dev), ctypes.byref(self._handle)))
         if block is not None:
             _native.check(lib.ls_solver_set(self._handle, b"block", int(block)))
@@ -144,9 +184,33 @@ class HipShardOps:
         _native.check(_native.lib().ls_solver_phase(self._handle, phase, _native.ptr(b), _native.ptr(x), k, rtol, atol, it,
                                                     _native.stream_of(self.device)))
 
-    def pack(self, idx, k, out):
-        _native.check(_native.lib().ls_gather_rows(_native.ptr(self._p_flat), _native.ptr(idx), idx.shape[0], k,
+    def pack(self, src, idx, k, out):
+        """out[t,:] = src[idx[t],:] (send-buffer packing)."""
+        _native.check(_native.lib().ls_gather_rows(_native.ptr(src), _native.ptr(idx), idx.shape[0], k,
                                                    _native.ptr(out), self.device.index, _native.stream_of(self.device)))
+
+    def new_ext(self, k):
+        """zero (n_cols, k) vector: owned rows, then the ghost layers."""
+        return torch.zeros((self.plan.n_cols, k), dtype=torch.float32, device=self.device)
+
+    def local_spectrum(self):
+        """(Gershgorin bound of spec(D^-1 M), max diagonal) over this shard's rows."""
+        lo, hi = ctypes.c_double(), ctypes.c_double()
+        lib = _native.lib()
+        _native.check(lib.ls_solver_set_spectrum(self._handle, 1.0))
+        _native.check(lib.ls_solver_spectrum(self._handle, ctypes.byref(lo), ctypes.byref(hi)))
+        return hi.value, (1.0 / lo.value if lo.value > 0 else 0.0)
+
+    def cheb_steps(self, b, xa, xb, k, it0, c1, c2, n_rows):
+        n = len(c1)
+        a1 = (ctypes.c_float * n)(*c1)
+        a2 = (ctypes.c_float * n)(*c2)
+        _native.check(_native.lib().ls_shard_cheb_steps(self._handle, _native.ptr(b), _native.ptr(xa), _native.ptr(xb), k, it0, n,
+                                                        a1, a2, n_rows, _native.stream_of(self.device)))
+
+    def resnorm(self, b, x, k, n_rows):
+        _native.check(_native.lib().ls_shard_resnorm(self._handle, _native.ptr(b), _native.ptr(x), k, n_rows,
+                                                     _native.stream_of(self.device)))
 
     def poll(self, k, n):
         info = _native.SolveInfo()
@@ -173,28 +237,34 @@ class ShardedPCG:
             dist.all_reduce(self.ops.part[slot0:slot0 + nslots], op=dist.ReduceOp.SUM, group=self.group)
 
     def _exchange_halo(self, k):
+        self._exchange(self.ops.p_ext(k))
+
+    def _exchange(self, *fulls):
+        """Refresh the ghost rows of every `full` ((n_cols, k): owned rows first) from their owners, all tensors in
+        ONE batch of neighbour-only isend/irecv (one RCCL group launch)."""
         plan, ops = self.plan, self.ops
         if plan.P == 1 or (not plan.recv and not plan.send):
             return
-        p = ops.p_ext(k)
         # Loopback transport for single-GPU test boxes (SURVEY.md §8e): gloo cannot isend/irecv device tensors,
         # so with backend gloo + device tensors the halo rows are staged through host memory. RCCL ("nccl")
         # moves the device buffers directly.
-        stage = p.is_cuda and dist.get_backend(self.group) == "gloo"
+        stage = fulls[0].is_cuda and dist.get_backend(self.group) == "gloo"
         reqs, landed = [], []
-        for q, idx in ops.send_idx:
-            buf = self._sendbuf.get((q, k))
-            if buf is None:
-                buf = self._sendbuf[(q, k)] = torch.empty((idx.shape[0], k), dtype=torch.float32, device=p.device)
-            ops.pack(idx, k, buf)
-            reqs.append(dist.P2POp(dist.isend, buf.cpu() if stage else buf, self._peer(q), group=self.group))
-        for q, off, cnt in plan.recv:
-            dst = p[plan.n_own + off: plan.n_own + off + cnt]
-            if stage:
-                host = torch.empty(dst.shape, dtype=dst.dtype)
-                landed.append((dst, host))
-                dst = host
-            reqs.append(dist.P2POp(dist.irecv, dst, self._peer(q), group=self.group))
+        for t, full in enumerate(fulls):
+            k = full.shape[1]
+            for n, (q, idx) in enumerate(ops.send_idx):
+                buf = self._sendbuf.get((t, n, k))
+                if buf is None:
+                    buf = self._sendbuf[(t, n, k)] = torch.empty((idx.shape[0], k), dtype=torch.float32, device=full.device)
+                ops.pack(full, idx, k, buf)
+                reqs.append(dist.P2POp(dist.isend, buf.cpu() if stage else buf, self._peer(q), group=self.group))
+            for q, off, cnt in plan.recv:
+                dst = full[plan.n_own + off: plan.n_own + off + cnt]
+                if stage:
+                    host = torch.empty(dst.shape, dtype=dst.dtype)
+                    landed.append((dst, host))
+                    dst = host
+                reqs.append(dist.P2POp(dist.irecv, dst, self._peer(q), group=self.group))
         for w in dist.batch_isend_irecv(reqs):
             w.wait()
         for dst, host in landed:
@@ -238,19 +308,136 @@ class ShardedPCG:
         return x
 
 
-def shard_from_matrix(M, group=None, device=None, **solver_kw):
+class ShardedChebyshev(ShardedPCG):
+    """Vertex-block sharded Chebyshev-accelerated Jacobi iteration (the single-GPU default of csrc/pcg.hip, k_cheb).
+
+    No dot products => no all-reduce inside the iteration; the only exchange is the ghost rows of the two
+    iterates, and with a depth-s ShardPlan (ghost layers 1..s-1 recomputed redundantly) only once per s
+    iterations: n/s neighbour exchanges per solve instead of 2n all-reduces + n halo exchanges for PCG. The
+    iteration count n and the coefficients follow from the global spectral enclosure (one MAX all-reduce at
+    construction), so every rank runs the same schedule without talking.
+    """
+
+    def __init__(self, plan, ops, a_min, group=None, rtol=1e-6, max_iter=10000):
+        super().__init__(plan, ops, group=group, rtol=rtol, atol=0.0, max_iter=max_iter)
+        gersh, dmax = ops.local_spectrum()
+        t = torch.tensor([gersh, dmax], dtype=torch.float64)
+        if plan.P > 1:
+            dev_t = t.to(ops.new_ext(1).device) if dist.get_backend(group) == "nccl" else t
+            dist.all_reduce(dev_t, op=dist.ReduceOp.MAX, group=group)
+            t = dev_t.cpu()
+        self.lmax = float(t[0]) * (1.0 + 1e-5)
+        self.lmin = 0.98 * float(a_min) / float(t[1])
+
+    def schedule(self, reduction):
+        """(n, c1[], c2[]) of the Chebyshev recurrence for a residual reduction `reduction` (same on every rank)."""
+        import math
+        theta, delta = 0.5 * (self.lmax + self.lmin), 0.5 * (self.lmax - self.lmin)
+        sigma1 = theta / delta
+        sk = math.sqrt(self.lmax / self.lmin)
+        rate = (sk - 1.0) / (sk + 1.0)
+        n = 0 if reduction >= 1.0 else int(math.ceil(math.log(2.0 / reduction) / -math.log(rate)))
+        n = min(n, self.max_iter)
+        c1, c2, rho = [], [], 1.0 / sigma1
+        for it in range(n):
+            if it == 0:
+                c1.append(0.0)
+                c2.append(1.0 / theta)
+            else:
+                rho_new = 1.0 / (2.0 * sigma1 - rho)
+                c1.append(rho_new * rho)
+                c2.append(2.0 * rho_new / delta)
+                rho = rho_new
+        return n, c1, c2
+
+    def solve(self, b):
+        plan, ops = self.plan, self.ops
+        if b.dim() != 2 or b.shape[0] != plan.n_own or not (1 <= b.shape[1] <= _KMAX):
+            raise ValueError(f"expected a ({plan.n_own}, k<=4) block of the right-hand side, got {tuple(b.shape)}")
+        k = b.shape[1]
+        n, c1, c2 = self.schedule(self.rtol)                   # cold start: ||r0|| = ||b||
+        b_ext = ops.new_ext(k)
+        b_ext[: plan.n_own] = b.detach()
+        self._exchange(b_ext)                                   # the computed ghost rows need their b
+        xa, xb = ops.new_ext(k), ops.new_ext(k)
+        s = plan.depth
+        for it0 in range(0, n, s):
+            if it0 > 0:                                         # all ghost layers of both iterates are refreshed
+                self._exchange(xa, xb)
+            steps = min(s, n - it0)
+            ops.cheb_steps(b_ext, xa, xb, k, it0, c1[it0:it0 + steps], c2[it0:it0 + steps], plan.n_rows)
+        x_ext = xa if n % 2 == 0 else xb
+        # true residual of the result over the owned rows (needs ghost layer 1 of x), summed over ranks
+        self._exchange(x_ext)
+        ops.resnorm(b_ext, x_ext, k, plan.n_own)
+        self._allreduce(1, 3)
+        ops.phase(1, b_ext, x_ext, k, self.rtol, 0.0, 0)
+        info = ops.poll(k, n)
+        rr, bb = info["rnorm"], info["bnorm"]
+        ok = all(r == r and r <= max(self.rtol, 1e-3) * bn for r, bn in zip(rr, bb))
+        self.last_info = dict(iterations=n, converged=ok, rnorm=rr, bnorm=bb, breakdown=False, method="chebyshev",
+                              exchanges=max(0, (n - 1) // s) + 2)
+        if not ok:
+            raise RuntimeError("largesteps: sharded Chebyshev failed its residual check (spectral enclosure violated?)")
+        return x_ext[: plan.n_own].clone()
+
+
+def pick_depth(rowptr, col, V, P, max_depth=32, max_overhead=0.25):
+    """Largest halo depth whose redundantly computed ghost rows stay below `max_overhead` of the owned rows on every
+    rank (banded orderings: a layer is one 'grid row'; badly ordered meshes fall back to depth 1)."""
+    import scipy.sparse as sp
+    if P == 1:
+        return 1
+    A = sp.csr_matrix((np.ones(len(col), np.float32), np.asarray(col), np.asarray(rowptr)), shape=(V, V))
+    bounds = block_bounds(V, P)
+    best = max_depth
+    for q in range(P):
+        layers = ShardPlan._layers(A, bounds[q], bounds[q + 1], max_depth)
+        own = bounds[q + 1] - bounds[q]
+        extra, d = 0, 1
+        for j, L in enumerate(layers[:-1]):                     # depth j+2 computes layers 1..j+1
+            extra += L.shape[0]
+            if extra > max_overhead * own:
+                break
+            d = j + 2
+        best = min(best, d)
+    return max(1, best)
+
+
+def _common_grid(n_max):
+    block = 256
+    T = -(-n_max // block)
+    return block, (max(T, 1) if T < 8 else min(T & ~7, 1024))
+
+
+def shard_from_matrix(M, group=None, device=None, method="auto", depth=None, **solver_kw):
     """Convenience: every rank holds the full matrix M (as compute_matrix returns it) on its GPU; build this
-    rank's plan + HIP ops + driver. Returns (plan, ShardedPCG)."""
+    rank's plan + HIP ops + driver. method: 'chebyshev' (needs the spectral enclosure compute_matrix attaches),
+    'pcg', or 'auto'. Returns (plan, solver)."""
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     P = dist.get_world_size(group) if dist.is_initialized() else 1
     csr = _native.csr_of(M)
-    plan = ShardPlan.build(csr.rowptr.cpu().numpy(), csr.col.cpu().numpy(), csr.val.cpu().numpy(), csr.V, P, rank)
+    rowptr, col, val = csr.rowptr.cpu().numpy(), csr.col.cpu().numpy(), csr.val.cpu().numpy()
     dev = device if device is not None else csr.device
-    # every rank must launch the same grid so that the partial arrays line up: size it on the largest block
-    n_max = int(np.diff(block_bounds(csr.V, P)).max())
-    block = 256
-    T = -(-n_max // block)
-    grid = max(T, 1) if T < 8 else min(T & ~7, 1024)
+    cheb = method == "chebyshev" or (method == "auto" and csr.a_min is not None)
+    if cheb and csr.a_min is None:
+        raise ValueError("the Chebyshev solver needs a matrix built by compute_matrix (spectral enclosure)")
+    if cheb:
+        d = depth if depth is not None else pick_depth(rowptr, col, csr.V, P)
+        plan = ShardPlan.build(rowptr, col, val, csr.V, P, rank, depth=d)
+        # every rank launches the same grid (sized on the largest extended block)
+        n_max = torch.tensor([plan.n_rows], dtype=torch.int64, device=dev if (P > 1 and dist.get_backend(group) == "nccl") else "cpu")
+        if P > 1:
+            dist.all_reduce(n_max, op=dist.ReduceOp.MAX, group=group)
+        block, grid = _common_grid(int(n_max.item()))
+        ops = HipShardOps(plan, dev, grid=grid, block=block)
+        solver = ShardedChebyshev(plan, ops, csr.a_min, group=group, **solver_kw)
+        if method == "auto" and solver.schedule(solver.rtol)[0] > 400:      # loose enclosure: PCG wins (see solvers.py)
+            cheb = False
+        else:
+            return plan, solver
+    plan = ShardPlan.build(rowptr, col, val, csr.V, P, rank, depth=1)
+    block, grid = _common_grid(int(np.diff(block_bounds(csr.V, P)).max()))
     ops = HipShardOps(plan, dev, grid=grid, block=block)
     return plan, ShardedPCG(plan, ops, group=group, **solver_kw)
 
@@ -285,7 +472,10 @@ def bench_sharded(workload, device, steps, warmup):
     halo = torch.tensor([plan.n_halo], dtype=torch.int64, device=device)
     dist.all_reduce(halo, op=dist.ReduceOp.MAX)
     info = solver.last_info
+    cheb = isinstance(solver, ShardedChebyshev)
+    desc = (f"HIP Chebyshev-Jacobi sharded over {world} vertex blocks, halo depth {plan.depth} "
+            f"({info.get('exchanges', 0)} neighbour exchanges per solve, no all-reduce in the iteration, RCCL)") if cheb else \
+           f"HIP Jacobi-PCG sharded over {world} vertex blocks (halo isend/irecv + 2 all-reduces per iteration, RCCL)"
     return dict(V=v.shape[0], nnz=int(M._nnz()), ms_per_step=float(elapsed.item()) / steps * 1e3, iterations=info["iterations"],
-                converged=info["converged"], err=float(err.item()), halo=int(halo.item()),
-                solver=f"HIP Jacobi-PCG sharded over {world} vertex blocks (halo isend/irecv + 2 all-reduces per iteration, RCCL)",
-                kernel="k_spmv_dot<3> (K1 on the shard's SELL-64 block)", k1_gbs=0.0)
+                converged=info["converged"], err=float(err.item()), halo=int(halo.item()), solver=desc,
+                method="chebyshev" if cheb else "pcg", depth=plan.depth, rows_per_rank=plan.n_rows)

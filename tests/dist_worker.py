@@ -37,7 +37,7 @@ class NumpyShardOps:
 
     def __init__(self, plan):
         self.plan = plan
-        self.A = sp.csr_matrix((plan.val.astype(np.float64), plan.col, plan.rowptr), shape=(plan.n_own, plan.n_cols))
+        self.A = sp.csr_matrix((plan.val.astype(np.float64), plan.col, plan.rowptr), shape=(plan.n_rows, plan.n_cols))
         self.dinv = 1.0 / self.A.diagonal()
         self.part = torch.zeros((4, 4, 1), dtype=torch.float64)
         self._p = torch.zeros(max(plan.n_cols, 1) * 4, dtype=torch.float32)
@@ -104,10 +104,36 @@ class NumpyShardOps:
                 self.stop = it + 1
             p[:n] = (self.dinv[:, None] * self.r + beta * p[:n]).astype(np.float32)
 
-    def pack(self, idx, k, out):
-        out.copy_(self.p_ext(k)[idx.long()])
+    def pack(self, src, idx, k, out):
+        out.copy_(src[idx.long()])
+
+    # ---- Chebyshev (numpy statement of k_cheb / k_resnorm / k_gershgorin) ----
+    def new_ext(self, k):
+        return torch.zeros((self.plan.n_cols, k), dtype=torch.float32)
+
+    def local_spectrum(self):
+        d = self.A.diagonal()
+        return float((abs(self.A).sum(axis=1).A1 / d).max()), float(d.max())
+
+    def cheb_steps(self, b, xa, xb, k, it0, c1, c2, n_rows):
+        A, dinv = self.A[:n_rows], self.dinv[:n_rows, None]
+        for j, (a1, a2) in enumerate(zip(c1, c2)):
+            it = it0 + j
+            cur, oth = (xb, xa) if it & 1 else (xa, xb)
+            xc = cur.numpy().astype(np.float64)
+            z = dinv * (b.numpy()[:n_rows].astype(np.float64) - A @ xc)
+            new = xc[:n_rows] + a2 * z if it == 0 else xc[:n_rows] + a1 * (xc[:n_rows] - oth.numpy()[:n_rows]) + a2 * z
+            oth[:n_rows] = torch.from_numpy(new.astype(np.float32))
+
+    def resnorm(self, b, x, k, n_rows):
+        r = b.numpy()[:n_rows].astype(np.float64) - self.A[:n_rows] @ x.numpy().astype(np.float64)
+        self._set(1, k, (r ** 2).sum(0))
+        self._set(2, k, (r ** 2).sum(0))
+        self._set(3, k, (b.numpy()[:n_rows].astype(np.float64) ** 2).sum(0))
 
     def poll(self, k, n):
+        if self.r is None:          # Chebyshev driver: only the norms published by phase 1 matter
+            return dict(iterations=n, converged=True, rnorm=list(np.sqrt(self.rr[:k])), bnorm=list(np.sqrt(self.bb[:k])), breakdown=False)
         done = self.stop != INF
         return dict(iterations=self.stop if done else -1, converged=done, rnorm=list(np.sqrt(self.rr[:k])),
                     bnorm=list(np.sqrt(self.bb[:k])), breakdown=False)
@@ -143,12 +169,14 @@ def main():
     ap.add_argument("--backend", default="gloo")
     ap.add_argument("--ops", default="numpy")
     ap.add_argument("--k", type=int, default=3)
+    ap.add_argument("--solver", default="pcg")
+    ap.add_argument("--depth", type=int, default=1)
     a = ap.parse_args()
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(a.port)
     dist.init_process_group(a.backend, rank=a.rank, world_size=a.world)
     v, rowptr, col, val = test_matrix(a.mesh)
-    plan = ShardPlan.build(rowptr, col, val, v.shape[0], a.world, a.rank)
+    plan = ShardPlan.build(rowptr, col, val, v.shape[0], a.world, a.rank, depth=a.depth)
     rng = np.random.default_rng(3)
     b_full = (sp.csr_matrix((val.astype(np.float64), col, rowptr)) @ v.astype(np.float64)).astype(np.float32)
     if a.k != 3:
@@ -161,7 +189,12 @@ def main():
         torch.cuda.set_device(0)
         ops = HipShardOps(plan, torch.device("cuda:0"), grid=8, block=256)
         b = b.cuda()
-    solver = ShardedPCG(plan, ops, rtol=1e-6, check_every=8)
+    if a.solver == "cheb":
+        from largesteps.distributed import ShardedChebyshev
+        a_min = 1.0 if a.mesh == "plane40" else float(np.float32(1.0 - 0.9))
+        solver = ShardedChebyshev(plan, ops, a_min, rtol=1e-6)
+    else:
+        solver = ShardedPCG(plan, ops, rtol=1e-6, check_every=8)
     x = solver.solve(b)
     x2 = solver.solve(b)                                    # a second solve reuses every buffer
     assert torch.equal(x, x2)

@@ -27,13 +27,14 @@ def free_port():
         return s.getsockname()[1]
 
 
+@pytest.mark.parametrize("depth", [1, 3])
 @pytest.mark.parametrize("mesh", ["plane40", "ico12cot"])
 @pytest.mark.parametrize("P", [1, 2, 3, 4, 8])
-def test_shard_plan(mesh, P):
+def test_shard_plan(mesh, P, depth):
     v, rowptr, col, val = dist_worker.test_matrix(mesh)
     V = v.shape[0]
     A = sp.csr_matrix((val.astype(np.float64), col, rowptr), shape=(V, V))
-    plans = [ShardPlan.build(rowptr, col, val, V, P, r) for r in range(P)]
+    plans = [ShardPlan.build(rowptr, col, val, V, P, r, depth=depth) for r in range(P)]
     bounds = block_bounds(V, P)
     assert bounds[0] == 0 and bounds[-1] == V and sum(p.n_own for p in plans) == V
     x = np.random.default_rng(0).standard_normal((V, 3))
@@ -41,21 +42,27 @@ def test_shard_plan(mesh, P):
     for p in plans:
         assert p.lo == bounds[p.rank] and p.hi == bounds[p.rank + 1]
         assert p.rowptr.dtype == np.int32 and p.col.dtype == np.int32 and p.col.max(initial=0) < p.n_cols
-        # local SpMV on [owned | halo] reproduces the global one
-        x_ext = np.concatenate([x[p.lo:p.hi], x[p.halo_global]])
-        A_loc = sp.csr_matrix((p.val.astype(np.float64), p.col, p.rowptr), shape=(p.n_own, p.n_cols))
-        np.testing.assert_allclose(A_loc @ x_ext, y[p.lo:p.hi], rtol=1e-12, atol=1e-12)
+        # local SpMV on [owned | ghosts] reproduces the global one on EVERY computed row (owned + layers < depth)
+        glob = np.concatenate([np.arange(p.lo, p.hi), p.halo_global])
+        assert np.unique(glob).shape[0] == glob.shape[0]
+        x_ext = x[glob]
+        A_loc = sp.csr_matrix((p.val.astype(np.float64), p.col, p.rowptr), shape=(p.n_rows, p.n_cols))
+        np.testing.assert_allclose(A_loc @ x_ext, y[glob[:p.n_rows]], rtol=1e-12, atol=1e-12)
         # the diagonal stays at local id == row
-        assert np.allclose(A_loc.diagonal(), A.diagonal()[p.lo:p.hi])
-        # halo is sorted, disjoint from the block, and the recv list tiles it by owner
-        assert (np.diff(p.halo_global) > 0).all() and not ((p.halo_global >= p.lo) & (p.halo_global < p.hi)).any()
+        assert np.allclose(A_loc.diagonal(), A.diagonal()[glob[:p.n_rows]])
+        assert p.n_rows == p.n_own if depth == 1 else p.n_rows >= p.n_own
+        # ghosts are disjoint from the block, and the recv list tiles them by (group, owner)
+        assert not ((p.halo_global >= p.lo) & (p.halo_global < p.hi)).any()
         assert sum(c for _, _, c in p.recv) == p.n_halo
+        msgs_from = {}
         for q, off, cnt in p.recv:
             seg = p.halo_global[off:off + cnt]
-            assert (seg >= bounds[q]).all() and (seg < bounds[q + 1]).all()
-            # what I receive from q is exactly what q sends to me, in the same order
-            sent = [idx for dst, idx in plans[q].send if dst == p.rank]
-            assert len(sent) == 1 and np.array_equal(sent[0].astype(np.int64) + plans[q].lo, seg)
+            assert (seg >= bounds[q]).all() and (seg < bounds[q + 1]).all() and (np.diff(seg) > 0).all()
+            msgs_from.setdefault(q, []).append(seg)
+        # what I receive from q is exactly what q sends to me, message by message, in the same order
+        for q, segs in msgs_from.items():
+            sent = [idx.astype(np.int64) + plans[q].lo for dst, idx in plans[q].send if dst == p.rank]
+            assert len(sent) == len(segs) and all(np.array_equal(a, b) for a, b in zip(sent, segs))
         for dst, idx in p.send:
             assert any(src == p.rank for src, _, _ in plans[dst].recv)
     if P == 1:
@@ -64,12 +71,12 @@ def test_shard_plan(mesh, P):
         ShardPlan.build(rowptr, col, val, V, P, P)
 
 
-def run_world(tmp_path, world, mesh, k=3, ops="numpy", backend="gloo", timeout=300):
+def run_world(tmp_path, world, mesh, k=3, ops="numpy", backend="gloo", timeout=300, solver="pcg", depth=1):
     port = free_port()
     env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), "--rank", str(r), "--world", str(world),
                                "--port", str(port), "--out", str(tmp_path), "--mesh", mesh, "--k", str(k), "--ops", ops,
-                               "--backend", backend], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                               "--backend", backend, "--solver", solver, "--depth", str(depth)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(world)]
     outs = []
     try:
@@ -110,3 +117,17 @@ def test_sharded_pcg_gloo(tmp_path, mesh, world):
     x1, its1 = run_world(single, 1, mesh)
     assert abs(int(its1[0][0]) - int(its[0][0])) <= 2
     assert np.abs(x - x1).max() <= 2e-5 * np.abs(x64).max()
+
+
+@pytest.mark.parametrize("mesh,world,depth", [("plane40", 2, 1), ("plane40", 2, 4), ("ico12cot", 2, 3), ("plane40", 3, 5)])
+def test_sharded_chebyshev_gloo(tmp_path, mesh, world, depth):
+    """Chebyshev shards: halo exchange only, once per `depth` iterations; same answer as the unsharded run."""
+    x64 = reference_solution(mesh)
+    x, its = run_world(tmp_path, world, mesh, solver="cheb", depth=depth)
+    assert all(int(i[1]) == 1 for i in its) and len({int(i[0]) for i in its}) == 1
+    assert np.abs(x - x64).max() <= 1e-4 * np.abs(x64).max()
+    single = tmp_path / "single"
+    single.mkdir()
+    x1, its1 = run_world(single, 1, mesh, solver="cheb", depth=1)
+    assert int(its1[0][0]) == int(its[0][0]), "the schedule depends on the global spectrum only"
+    assert np.abs(x - x1).max() <= 1e-5 * np.abs(x64).max()

@@ -26,6 +26,14 @@ def test_sharded_hip(tmp_path, mesh, world, k):
     assert np.abs(x - x64).max() <= 1e-4 * np.abs(x64).max()
 
 
+@pytest.mark.parametrize("mesh,world,depth", [("plane40", 1, 1), ("plane40", 2, 4), ("ico12cot", 2, 2), ("plane40", 4, 3)])
+def test_sharded_chebyshev_hip(tmp_path, mesh, world, depth):
+    x64 = reference_solution(mesh)
+    x, its = run_world(tmp_path, world, mesh, ops="hip", timeout=600, solver="cheb", depth=depth)
+    assert all(int(i[1]) == 1 for i in its) and len({int(i[0]) for i in its}) == 1
+    assert np.abs(x - x64).max() <= 1e-4 * np.abs(x64).max()
+
+
 def test_shard_from_matrix_single_rank():
     """shard_from_matrix with no process group (P = 1) must reproduce from_differential bit for bit."""
     import torch
@@ -38,7 +46,7 @@ def test_shard_from_matrix_single_rank():
     tv, tf = torch.from_numpy(v).to(dev), torch.from_numpy(f).to(dev)
     M = compute_matrix(tv, tf, 50.0)
     u = to_differential(M, tv)
-    plan, solver = shard_from_matrix(M)
+    plan, solver = shard_from_matrix(M, method="pcg")
     assert plan.n_own == v.shape[0] and plan.n_halo == 0
     x = solver.solve(u)
     from largesteps.solvers import PCGSolver
@@ -48,3 +56,9 @@ def test_shard_from_matrix_single_rank():
     ref = ref_solver.solve(u)
     assert solver.last_info["converged"]
     assert torch.equal(x, ref), "same kernels, same grid, same reduction order"
+    # and the Chebyshev shard driver (P = 1: no exchange) against the single-GPU Chebyshev path
+    plan_c, cheb = shard_from_matrix(M, method="auto")
+    xc = cheb.solve(u)
+    ref_c = from_differential(M, u, "Cholesky")
+    assert cheb.last_info["method"] == "chebyshev" and cheb.last_info["converged"]
+    assert float((xc - ref_c).abs().max()) <= 1e-6 * float(ref_c.abs().max())
