@@ -37,15 +37,17 @@ HBM_ACHIEVABLE_GBS = 6290.0
 WORKLOAD = "cfg4_plane1m"
 
 
-def algorithmic_bytes(V, nnz, k, iters, method="pcg"):
+def algorithmic_bytes(V, nnz, k, iters, method="pcg", implicit_values=False):
     """SURVEY.md §8(d) accounting: CSR-equivalent int32/fp32 matrix (8 B per stored entry + 4 B per row), k
     interleaved fp32 right-hand sides, every array counted once per kernel that touches it.
       pcg       K1 matrix + p + Ap | K2 x,p,Ap,r,1/diag -> x,r | K3 r,1/diag,p -> p        = 8 nnz + 4 V + (11k+2) 4V
-      chebyshev one kernel: matrix + x_k (gathered) + b + 1/diag + x_{k-1} -> x_{k+1}        = 8 nnz + 4 V + (4k+1) 4V
+      chebyshev one kernel: matrix + x_k (gathered) + b + diag + x_{k-1} -> x_{k+1}          = 8 nnz + 4 V + (4k+1) 4V
+                (uniform Laplacian, implicit values: 4 (nnz - V) + 4 V + (4k+1) 4V)
     """
     mat = 8 * nnz + 4 * (V + 1)
     if method == "chebyshev":
-        b_iter = mat + (4 * k + 1) * 4 * V
+        # uniform Laplacian: values implicit, the kernel reads the off-diagonal neighbour ids only (4 B each)
+        b_iter = (4 * (nnz - V) + 4 * (V + 1) if implicit_values else mat) + (4 * k + 1) * 4 * V
         # setup: zero x0 (write) ; final residual check: matrix + x + b
         return dict(k1=b_iter, iter=b_iter, solve=4 * k * V + iters * b_iter + mat + 2 * 4 * k * V)
     b_spmv = mat + 2 * 4 * k * V
@@ -136,12 +138,15 @@ def run_single(args):
         piters += it
     solver.set_option("profile", 0)
     k_ms = prof / max(piters, 1)
-    bts = algorithmic_bytes(V, nnz, k, info["iterations"], method)
+    implicit = bool(getattr(solver, "implicit_values", False)) and method == "chebyshev"
+    bts = algorithmic_bytes(V, nnz, k, info["iterations"], method, implicit)
     k1_gbs = bts["k1"] / (k_ms[0] * 1e-3) / 1e9
     err = float((x - tv).abs().max())
     if method == "chebyshev":
-        solver_desc = "HIP Chebyshev-accelerated Jacobi iteration (1 kernel/iteration, SELL-64, a-priori iteration count)"
-        kernel_desc = "k_cheb<3,%d> (x_{k+1} = x_k + c1 (x_k - x_{k-1}) + c2 D^-1 (b - M x_k), SELL-64)" % 512
+        solver_desc = "HIP Chebyshev-accelerated Jacobi iteration (1 kernel/iteration, SELL-64, a-priori iteration count" + \
+                      (", implicit uniform-Laplacian values)" if implicit else ")")
+        kernel_desc = ("k_cheb_uniform<3,512>" if implicit else "k_cheb<3,512>") + \
+                      " (x_{k+1} = x_k + c1 (x_k - x_{k-1}) + c2 D^-1 (b - M x_k), SELL-64)"
         kernel_us = dict(k_cheb=k_ms[0] * 1e3)
     else:
         solver_desc = "HIP Jacobi-PCG (3 kernels/iteration, SELL-64)"

@@ -116,6 +116,9 @@ int ls_solver_solve(ls_solver* s, const float* b, const float* x0, float* x, int
  * fp32 residual of the returned x. SYNC once at the end. LS_E_STATE without a spectrum, LS_E_NOT_CONVERGED if the
  * count exceeds max_iter or the final residual check fails (callers fall back to ls_solver_solve). */
 int ls_solver_set_spectrum(ls_solver* s, double a_min);
+/* Declare M = a I + b L_uniform (every off-diagonal entry equals -b): the Chebyshev solver then reads only the
+ * neighbour ids (4 B per entry instead of 8 B) -- values are implicit. SYNC once (sizes the column-only SELL copy). */
+int ls_solver_set_uniform(ls_solver* s, float a, float b, void* stream);
 int ls_solver_spectrum(const ls_solver* s, double* h_lmin, double* h_lmax);
 /* iterations the Chebyshev solver will run for a residual reduction `reduction` (e.g. rtol from a cold start) */
 int ls_solver_chebyshev_iterations(const ls_solver* s, double reduction, int* h_n);

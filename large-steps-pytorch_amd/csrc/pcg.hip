@@ -548,6 +548,82 @@ __global__ __launch_bounds__(BS) void k_cheb(SellView S, const float* __restrict
     }
 }
 
+// ---- uniform-Laplacian specialisation of the Chebyshev step: the matrix values are implicit -----------------
+// M = a I + b L_uniform  =>  (M x)_i = M_ii x_i - b * sum_{j in N(i)} x_j : only the neighbour ids are read
+// (SELL-64 of int32 columns without the diagonal, 4 B per entry instead of 8 B per {col,val} pair). Padding
+// entries point at row V of the iterate buffers, which the solver keeps at zero.
+template <int K, int BS, bool FIRST>
+__global__ __launch_bounds__(BS) void k_cheb_uniform(const int* __restrict__ slice_ptr, const int* __restrict__ cols,
+                                                     const float* __restrict__ dd, const float* __restrict__ b,
+                                                     const float* __restrict__ xc, float* __restrict__ xpn, float c1, float c2,
+                                                     float offdiag, int64_t V, int T, int G) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const Sched sch(T, G);
+    for (int tile = sch.first; tile < sch.end; tile += sch.step) {
+        const int64_t i = (int64_t)tile * BS + threadIdx.x;
+        float sum[K];
+#pragma unroll
+        for (int q = 0; q < K; ++q) sum[q] = 0.0f;
+        if ((i & ~(int64_t)(WAVE - 1)) < V) {
+            const int slice = __builtin_amdgcn_readfirstlane((int)(i >> 6));
+            const int off = __builtin_amdgcn_readfirstlane(slice_ptr[slice]);
+            const int width = (__builtin_amdgcn_readfirstlane(slice_ptr[slice + 1]) - off) >> 6;
+            const int* __restrict__ p = cols + off + lane;
+            if (width <= 8) {
+                int c[8];
+                Vec<K> xv[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) if (t < width) c[t] = p[(size_t)t * WAVE];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) if (t < width) xv[t] = ldv<K>(xc, c[t]);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) if (t < width) {
+#pragma unroll
+                    for (int q = 0; q < K; ++q) sum[q] += xv[t].v[q];
+                }
+            } else {
+                for (int t = 0; t < width; ++t) {
+                    const Vec<K> xv = ldv<K>(xc, p[(size_t)t * WAVE]);
+#pragma unroll
+                    for (int q = 0; q < K; ++q) sum[q] += xv.v[q];
+                }
+            }
+        }
+        if (i < V) {
+            const Vec<K> bv = ldv<K>(b, i), xv = ldv<K>(xc, i);
+            const float di = dd[i];
+            Vec<K> xn;
+            if (FIRST) {
+#pragma unroll
+                for (int q = 0; q < K; ++q) xn.v[q] = fmaf(c2, (bv.v[q] - fmaf(offdiag, sum[q], di * xv.v[q])) / di, xv.v[q]);
+            } else {
+                const Vec<K> xp = ldv<K>(xpn, i);
+#pragma unroll
+                for (int q = 0; q < K; ++q)
+                    xn.v[q] = fmaf(c2, (bv.v[q] - fmaf(offdiag, sum[q], di * xv.v[q])) / di, fmaf(c1, xv.v[q] - xp.v[q], xv.v[q]));
+            }
+            stv<K>(xpn, i, xn);
+        }
+    }
+}
+
+// off-diagonal column ids of the CSR rows as SELL-64 (padding -> row V, a zero row of the iterate buffers)
+__global__ __launch_bounds__(BLOCK) void k_sell_cols_fill(CsrView A, int64_t V, const int* __restrict__ slice_ptr, int* __restrict__ cols) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int64_t slice = i >> 6;
+    if ((i & ~(int64_t)(WAVE - 1)) >= V) return;
+    const int off = slice_ptr[slice], width = (slice_ptr[slice + 1] - off) >> 6;
+    int s = 0, e = 0;
+    if (i < V) { s = A.rowptr[i]; e = A.rowptr[i + 1]; }
+    int t = 0;
+    for (int j = s; j < e; ++j) {
+        const int cj = A.col[j];
+        if (cj != (int)i) { cols[(size_t)off + (size_t)t * WAVE + lane] = cj; ++t; }
+    }
+    for (; t < width; ++t) cols[(size_t)off + (size_t)t * WAVE + lane] = (int)V;
+}
+
 // partials of ||b - M x||^2 (slots r.z and r.r, so that k_init_scal can be reused) and ||b||^2
 template <int K, int BS, bool ZERO_X>
 __global__ __launch_bounds__(BS) void k_resnorm(SellView S, const float* __restrict__ b, const float* __restrict__ x,
@@ -596,9 +672,9 @@ __global__ __launch_bounds__(BLOCK) void k_gershgorin(CsrView A, int64_t V, cons
 }
 
 // ---- CSR -> SELL-64 ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_sell_widths(const int* __restrict__ rowptr, int64_t V, int S, int* __restrict__ width64) {
+__global__ __launch_bounds__(BLOCK) void k_sell_widths(const int* __restrict__ rowptr, int64_t V, int S, int* __restrict__ width64, int minus) {
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    int len = (i < V) ? rowptr[i + 1] - rowptr[i] : 0;
+    int len = (i < V) ? max(rowptr[i + 1] - rowptr[i] - minus, 0) : 0;
 #pragma unroll
     for (int off = WAVE / 2; off > 0; off >>= 1) len = max(len, __shfl_down(len, off, WAVE));
     const int64_t slice = i >> 6;
@@ -685,6 +761,12 @@ struct ls_solver {
     int2* sell_cv_scaled = nullptr;
     float *sv = nullptr, *dd = nullptr, *p1 = nullptr, *xh = nullptr;
     int algo = 0;                 // 0 = classic 3-kernel Jacobi PCG (default), 1 = fused 2-kernel CG on the scaled system
+    // uniform-Laplacian specialisation (ls_solver_set_uniform): column-only SELL, zero-padded iterate buffers
+    int* slice_ptr_u = nullptr;
+    int* cols_u = nullptr;
+    float *xu0 = nullptr, *xu1 = nullptr;
+    float uni_offdiag = 0.0f;
+    bool uni = false;
     double a_min = 0.0;           // caller-certified lower bound of lambda_min(M); 0 = unknown (Chebyshev refused)
     double gersh = 0.0, dmax = 0.0;   // Gershgorin bound of spec(D^-1 M), max diagonal entry
     int last_G = -1;              // grid the partial arrays were last written with (tail must stay zero)
@@ -732,6 +814,7 @@ int dev_alloc(ls_solver* s, T** out, size_t n) {
 void free_solver(ls_solver* s) {
     if (!s) return;
     (void)hipFree(s->slice_ptr); (void)hipFree(s->sell_cv); (void)hipFree(s->dinv); (void)hipFree(s->r);
+    (void)hipFree(s->slice_ptr_u); (void)hipFree(s->cols_u); (void)hipFree(s->xu0); (void)hipFree(s->xu1);
     (void)hipFree(s->sell_cv_scaled); (void)hipFree(s->sv); (void)hipFree(s->dd); (void)hipFree(s->p1); (void)hipFree(s->xh);
     if (s->own_p) (void)hipFree(s->p);
     if (s->own_part) (void)hipFree(s->part);
@@ -774,7 +857,7 @@ int create_impl(ls_solver* s, hipStream_t st) {
     int* width64 = nullptr;
     if ((rc = dev_alloc(s, &s->slice_ptr, (size_t)S + 1))) return rc;
     LS_HIP(hipMalloc((void**)&width64, sizeof(int) * (size_t)S));
-    hipLaunchKernelGGL(k_sell_widths, dim3(div_up((int64_t)S * WAVE, BLOCK)), dim3(BLOCK), 0, st, s->csr.rowptr, V, S, width64);
+    hipLaunchKernelGGL(k_sell_widths, dim3(div_up((int64_t)S * WAVE, BLOCK)), dim3(BLOCK), 0, st, s->csr.rowptr, V, S, width64, 0);
     hipLaunchKernelGGL(k_sell_scan, dim3(1), dim3(1024), 0, st, width64, S, s->slice_ptr);
     hipLaunchKernelGGL(k_gershgorin, dim3(div_up(V, BLOCK)), dim3(BLOCK), 0, st, s->csr, V, s->dinv, flag + 2);
     int h[5] = {0, 0, 0, 0, 0};   // SELL entries | diag flag, (unused), Gershgorin bits, max-diag bits
@@ -844,6 +927,10 @@ void launch_phase(ls_solver* s, int phase, const float* b, const float* x0, floa
         case 9:   // Chebyshev step: x0 = current iterate (gathered), x = x_{k-1} in / x_{k+1} out, rtol/atol carry c1/c2
             if (it == 0) hipLaunchKernelGGL((k_cheb<K, BS, true>), grid, block, 0, st, s->sell, s->dinv, b, x0, x, (float)rtol, (float)atol, s->V, g.T, g.G);
             else hipLaunchKernelGGL((k_cheb<K, BS, false>), grid, block, 0, st, s->sell, s->dinv, b, x0, x, (float)rtol, (float)atol, s->V, g.T, g.G);
+            break;
+        case 11:  // Chebyshev step, uniform-Laplacian specialisation (same argument convention as 9)
+            if (it == 0) hipLaunchKernelGGL((k_cheb_uniform<K, BS, true>), grid, block, 0, st, s->slice_ptr_u, s->cols_u, s->dd, b, x0, x, (float)rtol, (float)atol, s->uni_offdiag, s->V, g.T, g.G);
+            else hipLaunchKernelGGL((k_cheb_uniform<K, BS, false>), grid, block, 0, st, s->slice_ptr_u, s->cols_u, s->dd, b, x0, x, (float)rtol, (float)atol, s->uni_offdiag, s->V, g.T, g.G);
             break;
         default:  // 10: residual / rhs norms of x0 (nullptr: x = 0)
             if (x0) hipLaunchKernelGGL((k_resnorm<K, BS, false>), grid, block, 0, st, s->sell, b, x0, s->part, s->V, g.T, g.G);
@@ -981,9 +1068,14 @@ int solve_cheb(ls_solver* s, const float* b, const float* x0, float* x, int k, d
     const bool capped = n > max_iter;
     n = std::min(n, max_iter);
     // iterate k reads buffer (k even ? Y : Z) and overwrites the other one; the final iterate must land in x
-    float* Y = (n & 1) ? s->xh : x;
-    float* Z = (n & 1) ? x : s->xh;
+    const bool uni = s->uni && s->xu0;
+    float* Y = uni ? s->xu0 : ((n & 1) ? s->xh : x);
+    float* Z = uni ? s->xu1 : ((n & 1) ? x : s->xh);
     const size_t bytes = sizeof(float) * (size_t)s->V * k;
+    if (uni) {   // row V of both buffers is the zero row the padding entries point at (layout depends on k)
+        LS_HIP(hipMemsetAsync(s->xu0 + (size_t)s->V * k, 0, sizeof(float) * k, st));
+        LS_HIP(hipMemsetAsync(s->xu1 + (size_t)s->V * k, 0, sizeof(float) * k, st));
+    }
     if (x0) { if (x0 != Y) LS_HIP(hipMemcpyAsync(Y, x0, bytes, hipMemcpyDeviceToDevice, st)); }
     else LS_HIP(hipMemsetAsync(Y, 0, bytes, st));
     if (s->profile && s->pev.empty()) {
@@ -1000,8 +1092,9 @@ int solve_cheb(ls_solver* s, const float* b, const float* x0, float* x, int k, d
             c2 = 2.0 * rho_new / delta;
             rho = rho_new;
         }
-        dispatch_phase(s, k, 9, b, (it & 1) ? Z : Y, (it & 1) ? Y : Z, c1, c2, it, g, st);
+        dispatch_phase(s, k, uni ? 11 : 9, b, (it & 1) ? Z : Y, (it & 1) ? Y : Z, c1, c2, it, g, st);
     }
+    if (uni) LS_HIP(hipMemcpyAsync(x, (n & 1) ? Z : Y, bytes, hipMemcpyDeviceToDevice, st));
     if (s->profile) LS_HIP(hipEventRecord(s->pev[1], st));
     LS_HIP(hipGetLastError());
     // true residual of the returned iterate
@@ -1084,6 +1177,40 @@ extern "C" int ls_solver_set(ls_solver* s, const char* name, int value) {
 extern "C" int ls_solver_set_spectrum(ls_solver* s, double a_min) {
     LS_REQUIRE(s && a_min >= 0.0, LS_E_INVALID, "ls_solver_set_spectrum: need a handle and a_min >= 0");
     s->a_min = a_min;
+    return LS_OK;
+}
+
+extern "C" int ls_solver_set_uniform(ls_solver* s, float a, float b, void* stream) {
+    LS_REQUIRE(s, LS_E_INVALID, "ls_solver_set_uniform: null handle");
+    LS_REQUIRE(s->ncols == s->V, LS_E_STATE, "ls_solver_set_uniform: square systems only");
+    if (s->uni || s->V == 0) return LS_OK;
+    DeviceGuard g(s->device);
+    LS_HIP(g.err);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t V = s->V;
+    const int S = div_up(V, WAVE);
+    int rc;
+    int* width64 = nullptr;
+    if ((rc = dev_alloc(s, &s->slice_ptr_u, (size_t)S + 1))) return rc;
+    LS_HIP(hipMalloc((void**)&width64, sizeof(int) * (size_t)S));
+    hipLaunchKernelGGL(k_sell_widths, dim3(div_up((int64_t)S * WAVE, BLOCK)), dim3(BLOCK), 0, st, s->csr.rowptr, V, S, width64, 1);
+    hipLaunchKernelGGL(k_sell_scan, dim3(1), dim3(1024), 0, st, width64, S, s->slice_ptr_u);
+    int total = 0;
+    LS_HIP(hipMemcpyAsync(&total, s->slice_ptr_u + S, sizeof(int), hipMemcpyDeviceToHost, st));
+    LS_HIP(hipStreamSynchronize(st));
+    (void)hipFree(width64);
+    LS_REQUIRE(total >= 0, LS_E_OVERFLOW, "SELL copy of the matrix overflows int32 entry offsets");
+    if ((rc = dev_alloc(s, &s->cols_u, (size_t)std::max(total, 1)))) return rc;
+    hipLaunchKernelGGL(k_sell_cols_fill, dim3(div_up((int64_t)S * WAVE, BLOCK)), dim3(BLOCK), 0, st, s->csr, V, s->slice_ptr_u, s->cols_u);
+    const size_t n = (size_t)(V + 1) * s->kmax;
+    if ((rc = dev_alloc(s, &s->xu0, n))) return rc;
+    if ((rc = dev_alloc(s, &s->xu1, n))) return rc;
+    LS_HIP(hipMemsetAsync(s->xu0, 0, sizeof(float) * n, st));
+    LS_HIP(hipMemsetAsync(s->xu1, 0, sizeof(float) * n, st));
+    LS_HIP(hipGetLastError());
+    (void)a;
+    s->uni_offdiag = -b;            // M_ij = fl(b * -1) for every edge (geometry.py:86-94 + :128/:132)
+    s->uni = true;
     return LS_OK;
 }
 
@@ -1223,6 +1350,7 @@ extern "C" int ls_solver_bind(ls_solver* s, float* p_ext, double* part) {
     LS_REQUIRE(s && p_ext && part, LS_E_INVALID, "ls_solver_bind: null argument");
     DeviceGuard g(s->device);
     LS_HIP(g.err);
+    (void)hipFree(s->slice_ptr_u); (void)hipFree(s->cols_u); (void)hipFree(s->xu0); (void)hipFree(s->xu1);
     (void)hipFree(s->sell_cv_scaled); (void)hipFree(s->sv); (void)hipFree(s->dd); (void)hipFree(s->p1); (void)hipFree(s->xh);
     if (s->own_p) (void)hipFree(s->p);
     if (s->own_part) (void)hipFree(s->part);

@@ -61,15 +61,27 @@ class ShardPlan:
         self.halo_global, self.recv, self.send = ghost_global, recv, send
 
     @staticmethod
-    def _layers(A, lo, hi, depth):
-        """Ghost layers 1..depth of the block [lo, hi): BFS on the pattern of the (scipy CSR) matrix."""
-        V = A.shape[0]
+    def _entries(rowptr, rows):
+        """Flat positions (into col / val) of all entries of the CSR rows `rows`, row after row, + the row lengths."""
+        starts = rowptr[rows]
+        lens = rowptr[rows + 1] - starts
+        total = int(lens.sum())
+        if total == 0:
+            return np.empty(0, np.int64), lens
+        first = np.cumsum(lens) - lens                       # position of each row's first entry in the output
+        pos = np.arange(total, dtype=np.int64) - np.repeat(first, lens) + np.repeat(starts, lens)
+        return pos, lens
+
+    @staticmethod
+    def _layers(rowptr, col, V, lo, hi, depth):
+        """Ghost layers 1..depth of the block [lo, hi): breadth-first search on the matrix pattern."""
         seen = np.zeros(V, dtype=bool)
         seen[lo:hi] = True
-        frontier = np.arange(lo, hi)
+        frontier = np.arange(lo, hi, dtype=np.int64)
         layers = []
         for _ in range(depth):
-            nb = np.unique(A[frontier].indices) if frontier.size else np.empty(0, np.int64)
+            pos, _ = ShardPlan._entries(rowptr, frontier)
+            nb = np.unique(col[pos])
             nb = nb[~seen[nb]]
             seen[nb] = True
             layers.append(nb.astype(np.int64))
@@ -77,16 +89,15 @@ class ShardPlan:
         return layers
 
     @staticmethod
-    def _ghost_groups(A, bounds, q, depth):
+    def _ghost_groups(rowptr, col, V, bounds, q, depth):
         """(computed ghosts, read-only ghosts) of rank q, each sorted by (owner, global id)."""
-        layers = ShardPlan._layers(A, bounds[q], bounds[q + 1], depth)
+        layers = ShardPlan._layers(rowptr, col, V, bounds[q], bounds[q + 1], depth)
         inner = np.sort(np.concatenate(layers[:-1])) if depth > 1 else np.empty(0, np.int64)
         outer = np.sort(layers[-1])
         return inner, outer      # contiguous blocks => sorting by id sorts by owner first
 
     @staticmethod
     def build(rowptr, col, val, V, P, rank, depth=1):
-        import scipy.sparse as sp
         rowptr = np.asarray(rowptr).astype(np.int64)
         col = np.asarray(col).astype(np.int64)
         val = np.asarray(val, dtype=np.float32)
@@ -98,15 +109,15 @@ class ShardPlan:
             raise ValueError("halo depth must be >= 1")
         bounds = block_bounds(V, P)
         lo, hi = bounds[rank], bounds[rank + 1]
-        A = sp.csr_matrix((val, col, rowptr), shape=(V, V))
-        inner, outer = ShardPlan._ghost_groups(A, bounds, rank, depth)
+        inner, outer = ShardPlan._ghost_groups(rowptr, col, V, bounds, rank, depth)
         ghosts = np.concatenate([inner, outer])
         glob = np.concatenate([np.arange(lo, hi), ghosts])
         lut = np.full(V, -1, dtype=np.int64)
         lut[glob] = np.arange(glob.shape[0])
         rows_global = glob[: (hi - lo) + inner.shape[0]]
-        Aloc = A[rows_global]                                  # rows in local order, columns still global
-        local_col = lut[Aloc.indices]
+        pos, lens = ShardPlan._entries(rowptr, rows_global)    # rows in local order, columns still global
+        local_rowptr = np.concatenate([[0], np.cumsum(lens)])
+        local_col = lut[col[pos]]
         assert (local_col >= 0).all(), "a computed row references a column outside the halo"
         # per-owner contiguous ranges of the two ghost groups
         recv = []
@@ -118,7 +129,7 @@ class ShardPlan:
                 recv.append((int(q), int(base + idx[0]), int(idx.shape[0])))
         # what the others need from me, in THEIR order (group by group, ids ascending)
         send = []
-        groups_of = {q: ShardPlan._ghost_groups(A, bounds, q, depth) for q in range(P) if q != rank}
+        groups_of = {q: ShardPlan._ghost_groups(rowptr, col, V, bounds, q, depth) for q in range(P) if q != rank}
         for gi in (0, 1):
             for q in range(P):
                 if q == rank:
@@ -128,8 +139,8 @@ class ShardPlan:
                 if mine.shape[0]:
                     send.append((q, (mine - lo).astype(np.int32)))
         # the receiver walks its recv list group by group and, inside a group, owner by owner: same order here
-        return ShardPlan(rank, P, lo, hi, depth, Aloc.indptr.astype(np.int32), local_col.astype(np.int32),
-                         Aloc.data.astype(np.float32), ghosts, inner.shape[0], recv, send)
+        return ShardPlan(rank, P, lo, hi, depth, local_rowptr.astype(np.int32), local_col.astype(np.int32),
+                         val[pos].astype(np.float32), ghosts, inner.shape[0], recv, send)
 
 
 class HipShardOps:
@@ -385,14 +396,13 @@ class ShardedChebyshev(ShardedPCG):
 def pick_depth(rowptr, col, V, P, max_depth=32, max_overhead=0.25):
     """Largest halo depth whose redundantly computed ghost rows stay below `max_overhead` of the owned rows on every
     rank (banded orderings: a layer is one 'grid row'; badly ordered meshes fall back to depth 1)."""
-    import scipy.sparse as sp
     if P == 1:
         return 1
-    A = sp.csr_matrix((np.ones(len(col), np.float32), np.asarray(col), np.asarray(rowptr)), shape=(V, V))
+    rowptr, col = np.asarray(rowptr).astype(np.int64), np.asarray(col).astype(np.int64)
     bounds = block_bounds(V, P)
     best = max_depth
     for q in range(P):
-        layers = ShardPlan._layers(A, bounds[q], bounds[q + 1], max_depth)
+        layers = ShardPlan._layers(rowptr, col, V, bounds[q], bounds[q + 1], max_depth)
         own = bounds[q + 1] - bounds[q]
         extra, d = 0, 1
         for j, L in enumerate(layers[:-1]):                     # depth j+2 computes layers 1..j+1

@@ -6,6 +6,7 @@ DifferentiableSolve :128, solve :148). Both concrete solvers run the hand-writte
 (csrc/pcg.hip) through one native handle per matrix; neither cholespy/CHOLMOD nor torch sparse ops are used.
 """
 import ctypes
+import os
 import warnings
 
 import torch
@@ -76,6 +77,7 @@ class PCGSolver(Solver):
                                                          ctypes.byref(self._handle)))
         self.chebyshev = False
         self.chebyshev_iterations = None
+        self.implicit_values = False      # True: the Chebyshev kernel reads neighbour ids only (uniform Laplacian)
         if csr.a_min is not None:
             _native.check(_native.lib().ls_solver_set_spectrum(self._handle, float(csr.a_min)))
             if chebyshev and self.rtol > 0.0:
@@ -86,6 +88,12 @@ class PCGSolver(Solver):
                 _native.check(_native.lib().ls_solver_chebyshev_iterations(self._handle, self.rtol, ctypes.byref(n)))
                 self.chebyshev_iterations = n.value
                 self.chebyshev = n.value <= int(chebyshev_cap)
+                if self.chebyshev and csr.uniform is not None and not os.environ.get("LARGESTEPS_EXPLICIT_VALUES"):
+                    # uniform Laplacian: every off-diagonal entry is -b, the solver reads neighbour ids only
+                    with torch.cuda.device(dev):
+                        _native.check(_native.lib().ls_solver_set_uniform(self._handle, float(csr.uniform[0]), float(csr.uniform[1]),
+                                                                          _native.stream_of(dev)))
+                    self.implicit_values = True
 
     def __del__(self):
         h = getattr(self, "_handle", None)
