@@ -57,6 +57,23 @@ def algorithmic_bytes(V, nnz, k, iters, method="pcg", implicit_values=False):
     return dict(k1=b_spmv, k2=b_k2, k3=b_k3, iter=b_iter, solve=(4 * k + 1) * 4 * V + iters * b_iter)
 
 
+def pmc_traffic(kernel_prefix, workload):
+    """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/r01_pmc_traffic.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 correction applied), or None."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        if d.get("workload") != workload:
+            return None
+        for name, rec in d["kernels"].items():
+            if name.startswith(kernel_prefix):
+                return rec["traffic_bytes"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def cpu_baseline(v, f, lam, u_np, seconds_cap=120.0):
     """Oracle direct solver timed on the host: factor once (reported, not counted), then re-solves."""
     from oracle import laplacian as ol, solve as osv
@@ -166,7 +183,9 @@ def run_single(args):
                     kernel_us=kernel_us, device=torch.cuda.get_device_name(0)),
         roofline=dict(bound="hbm", kernel=kernel_desc, achieved=k1_gbs,
                       peak=HBM_PEAK_GBS, unit="GB/s", frac=k1_gbs / HBM_PEAK_GBS, frac_of_achievable=k1_gbs / HBM_ACHIEVABLE_GBS,
-                      bytes_per_launch=bts["k1"], avg_launch_us=k_ms[0] * 1e3, launches_timed=int(piters), traffic=None),
+                      bytes_per_launch=bts["k1"], avg_launch_us=k_ms[0] * 1e3, launches_timed=int(piters),
+                      traffic=pmc_traffic("ls::k_cheb_uniform<3, 512, false>" if implicit else
+                                          ("ls::k_cheb<3, 512, false>" if method == "chebyshev" else "ls::k_spmv_dot<3"), args.workload)),
     )
     if not args.no_cpu_baseline:
         base, _ = cpu_baseline(v, f, lam, u.cpu().numpy())
