@@ -114,7 +114,8 @@ int ls_solver_solve(ls_solver* s, const float* b, const float* x0, float* x, int
  * ceil(log(2/t) / log((sqrt(kappa)+1)/(sqrt(kappa)-1))) for the requested residual reduction t (rtol, or
  * max(rtol||b||, atol)/||r0|| after one residual evaluation when x0 or atol is given). h_info->rnorm is the TRUE
  * fp32 residual of the returned x. SYNC once at the end. LS_E_STATE without a spectrum, LS_E_NOT_CONVERGED if the
- * count exceeds max_iter or the final residual check fails (callers fall back to ls_solver_solve). */
+ * count exceeds max_iter or the final check fails: ||b - M x|| must be <= max(request, 8 eps32 ||M|| ||x||), the
+ * backward-stable fp32 level (callers fall back to ls_solver_solve). */
 int ls_solver_set_spectrum(ls_solver* s, double a_min);
 /* Declare M = a I + b L_uniform (every off-diagonal entry equals -b): the Chebyshev solver then reads only the
  * neighbour ids (4 B per entry instead of 8 B) -- values are implicit. SYNC once (sizes the column-only SELL copy). */
@@ -124,13 +125,12 @@ int ls_solver_spectrum(const ls_solver* s, double* h_lmin, double* h_lmax);
 int ls_solver_chebyshev_iterations(const ls_solver* s, double reduction, int* h_n);
 int ls_solver_solve_chebyshev(ls_solver* s, const float* b, const float* x0, float* x, int k, double rtol,
                               double atol, int max_iter, ls_solve_info* h_info, void* stream);
-/* knobs for measurements: name in {"algo" (0 = classic 3-kernel Jacobi-PCG, default; 1 = fused 2-kernel CG on the
- * symmetrically scaled system, square systems only), "check_every", "grid" (workgroups per kernel, 0 = auto),
- * "block" (0 = auto, 256, 512 or 1024 threads per workgroup), "profile"}; unknown name -> LS_E_INVALID */
+/* knobs for measurements: name in {"check_every", "grid" (workgroups per kernel, 0 = auto), "block" (0 = auto,
+ * 256, 512 or 1024 threads per workgroup), "profile"}; unknown name -> LS_E_INVALID */
 int ls_solver_set(ls_solver* s, const char* name, int value);
 /* With "profile"=1 every solve brackets its three kernels per iteration with HIP events on the solve's
- * stream; this returns the accumulated milliseconds of K1 (SpMV+dot; fused: direction+SpMV+dot), K2 (update),
- * K3 (direction; 0 for the fused variant) over the h_iters iterations that really ran in the last solve. */
+ * stream; this returns the accumulated milliseconds of K1 (SpMV+dot), K2 (update), K3 (direction) over the h_iters
+ * iterations that really ran in the last PCG solve; after a Chebyshev solve: [0] = total of the h_iters launches. */
 int ls_solver_profile(const ls_solver* s, double* h_ms3, int* h_iters);
 /* the handle's SELL-64 copy of the matrix: slice_ptr[V/64+1] (entry offsets), cv[entries] = {col, fp32 bits} */
 int ls_solver_sell(ls_solver* s, const int32_t** h_slice_ptr, const void** h_cv, int64_t* h_entries);
@@ -147,8 +147,6 @@ int ls_solver_workspace_bytes(const ls_solver* s, size_t* h_bytes);
  *   phase 2  K1: Ap = M p_ext ; partial p.Ap  (needs the halo of p)   -> all-reduce partials [0]
  *   phase 3  K2: x += a p ; r -= a Ap ; partials r.z, r.r             -> all-reduce partials [1..2]
  *   phase 4  K3: p = D^-1 r + b p ; publishes the stop flag            -> halo exchange of p
- * (phases 5..8 are the fused single-GPU variant -- init, direction+SpMV, update, unscale -- exposed for
- * measurements only; they need a square system)
  * ls_solver_buffers exposes p ((n_cols,k) fp32; the halo rows start at p + n_rows*k) and the partial array
  * (4 slots x 4 columns x h_part_stride doubles; slot s, column c, workgroup g at ((s*4+c)*stride + g)); every
  * rank must use the same "grid" so that the partial arrays line up.

@@ -337,8 +337,9 @@ class ShardedChebyshev(ShardedPCG):
             dev_t = t.to(ops.new_ext(1).device) if dist.get_backend(group) == "nccl" else t
             dist.all_reduce(dev_t, op=dist.ReduceOp.MAX, group=group)
             t = dev_t.cpu()
+        self.dmax = float(t[1])
         self.lmax = float(t[0]) * (1.0 + 1e-5)
-        self.lmin = 0.98 * float(a_min) / float(t[1])
+        self.lmin = 0.98 * float(a_min) / self.dmax
 
     def schedule(self, reduction):
         """(n, c1[], c2[]) of the Chebyshev recurrence for a residual reduction `reduction` (same on every rank)."""
@@ -378,24 +379,28 @@ class ShardedChebyshev(ShardedPCG):
             steps = min(s, n - it0)
             ops.cheb_steps(b_ext, xa, xb, k, it0, c1[it0:it0 + steps], c2[it0:it0 + steps], plan.n_rows)
         x_ext = xa if n % 2 == 0 else xb
-        # true residual of the result over the owned rows (needs ghost layer 1 of x), summed over ranks
+        # true residual of the result over the owned rows (needs ghost layer 1 of x), summed over ranks; accepted when
+        # it is at the requested level or at the fp32 backward-stable level 8 eps ||M|| ||x|| (as in csrc/pcg.hip)
         self._exchange(x_ext)
         ops.resnorm(b_ext, x_ext, k, plan.n_own)
         self._allreduce(1, 3)
-        ops.phase(1, b_ext, x_ext, k, self.rtol, 0.0, 0)
-        info = ops.poll(k, n)
-        rr, bb = info["rnorm"], info["bnorm"]
-        ok = all(r == r and r <= max(self.rtol, 1e-3) * bn for r, bn in zip(rr, bb))
-        self.last_info = dict(iterations=n, converged=ok, rnorm=rr, bnorm=bb, breakdown=False, method="chebyshev",
-                              exchanges=max(0, (n - 1) // s) + 2)
+        sums = ops.part[1:4, :k].sum(dim=2).cpu().numpy()      # rows: ||r||^2, ||x||^2, ||b||^2 per column
+        rr, xx, bb = sums[0], sums[1], sums[2]
+        mnorm = self.lmax * self.dmax
+        lim = np.maximum(self.rtol ** 2 * bb, 64.0 * 3.6e-15 * mnorm * mnorm * xx)
+        ok = bool(np.all(rr == rr) and np.all(rr <= lim))
+        self.last_info = dict(iterations=n, converged=ok, rnorm=list(np.sqrt(rr)), bnorm=list(np.sqrt(bb)), breakdown=False,
+                              method="chebyshev", exchanges=max(0, (n - 1) // s) + 2)
         if not ok:
             raise RuntimeError("largesteps: sharded Chebyshev failed its residual check (spectral enclosure violated?)")
         return x_ext[: plan.n_own].clone()
 
 
-def pick_depth(rowptr, col, V, P, max_depth=32, max_overhead=0.25):
+def pick_depth(rowptr, col, V, P, max_depth=64, max_overhead=1.0):
     """Largest halo depth whose redundantly computed ghost rows stay below `max_overhead` of the owned rows on every
-    rank (banded orderings: a layer is one 'grid row'; badly ordered meshes fall back to depth 1)."""
+    rank (banded orderings: a layer is one 'grid row'; badly ordered meshes fall back to depth 1). The default is
+    generous on purpose: at strong-scaling sizes a shard's kernels take microseconds while every exchange costs a
+    host-driven RCCL group launch, so recomputing ghost rows is far cheaper than talking more often."""
     if P == 1:
         return 1
     rowptr, col = np.asarray(rowptr).astype(np.int64), np.asarray(col).astype(np.int64)

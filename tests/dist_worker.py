@@ -128,7 +128,7 @@ class NumpyShardOps:
     def resnorm(self, b, x, k, n_rows):
         r = b.numpy()[:n_rows].astype(np.float64) - self.A[:n_rows] @ x.numpy().astype(np.float64)
         self._set(1, k, (r ** 2).sum(0))
-        self._set(2, k, (r ** 2).sum(0))
+        self._set(2, k, (x.numpy()[:n_rows].astype(np.float64) ** 2).sum(0))
         self._set(3, k, (b.numpy()[:n_rows].astype(np.float64) ** 2).sum(0))
 
     def poll(self, k, n):

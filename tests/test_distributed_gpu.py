@@ -51,7 +51,6 @@ def test_shard_from_matrix_single_rank():
     x = solver.solve(u)
     from largesteps.solvers import PCGSolver
     ref_solver = PCGSolver(M, rtol=1e-6)
-    ref_solver.set_option("algo", 0)                 # the classic 3-kernel PCG is what the shards run
     ref_solver.set_option("block", 256)
     ref = ref_solver.solve(u)
     assert solver.last_info["converged"]

@@ -41,10 +41,10 @@ def main():
             t = timeit(lambda: _native.spmv(csr, tv, variant), 20)
             print(f"   to_differential variant {variant}: {t * 1e3:8.1f} us  {(8 * nnz + 28 * V) / t / 1e6:8.1f} GB/s")
         s = PCGSolver(M, rtol=1e-6)
-        for algo in (1, 0):
+        for algo in (0,):
             for block, grids in ((512, (512, 1024)), (256, (512, 1024)), (1024, (256, 512))):
                 for grid in grids:
-                    s.set_option("algo", algo); s.set_option("block", block); s.set_option("grid", grid); s.set_option("check_every", 16)
+                    s.set_option("block", block); s.set_option("grid", grid); s.set_option("check_every", 16)
                     ms = timeit(lambda: s.solve(u), 5)
                     it = s.last_info["iterations"]
                     s.set_option("profile", 1)
@@ -54,7 +54,7 @@ def main():
                     err = float((s.solve(u) - tv).abs().max())
                     print(f"   algo {algo} block {block:4d} grid {grid:5d}: {ms:8.3f} ms/solve  iters {it:4d}  {ms * 1e3 / it:7.2f} us/iter | "
                           f"K1 {k1 / pit * 1e3:6.2f} us  K2 {k2 / pit * 1e3:6.2f} us  K3 {k3 / pit * 1e3:6.2f} us (event-bracketed) | max|x-v| {err:.1e}", flush=True)
-        s.set_option("algo", 0); s.set_option("block", 0); s.set_option("grid", 0)
+        s.set_option("block", 0); s.set_option("grid", 0)
         sc = PCGSolver(M, rtol=1e-6, chebyshev=True)
         for block, grids in ((256, (512, 1024)), (512, (512, 1024)), (1024, (256, 512))):
             for grid in grids:
