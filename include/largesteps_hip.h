@@ -126,7 +126,8 @@ int ls_solver_chebyshev_iterations(const ls_solver* s, double reduction, int* h_
 int ls_solver_solve_chebyshev(ls_solver* s, const float* b, const float* x0, float* x, int k, double rtol,
                               double atol, int max_iter, ls_solve_info* h_info, void* stream);
 /* knobs for measurements: name in {"check_every", "grid" (workgroups per kernel, 0 = auto), "block" (0 = auto,
- * 256, 512 or 1024 threads per workgroup), "profile"}; unknown name -> LS_E_INVALID */
+ * 256, 512 or 1024 threads per workgroup), "graph" (1 = replay the Chebyshev launches of a solve as one hipGraph,
+ * default; 0 = eager launches), "profile"}; unknown name -> LS_E_INVALID */
 int ls_solver_set(ls_solver* s, const char* name, int value);
 /* With "profile"=1 every solve brackets its three kernels per iteration with HIP events on the solve's
  * stream; this returns the accumulated milliseconds of K1 (SpMV+dot), K2 (update), K3 (direction) over the h_iters

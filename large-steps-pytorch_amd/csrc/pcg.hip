@@ -28,6 +28,7 @@
 #include <string.h>
 #include <new>
 #include <vector>
+#include <map>
 
 namespace ls {
 
@@ -582,13 +583,18 @@ struct ls_solver {
     int2* sell_cv = nullptr;
     int64_t sell_entries = 0;
     float *dinv = nullptr, *r = nullptr, *p = nullptr, *Ap = nullptr;
-    float *dd = nullptr, *xh = nullptr;   // square systems: diagonal, second iterate buffer of the Chebyshev solver
+    float* dd = nullptr;                  // square systems: the diagonal
     // uniform-Laplacian specialisation (ls_solver_set_uniform): column-only SELL, zero-padded iterate buffers
     int* slice_ptr_u = nullptr;
     int* cols_u = nullptr;
-    float *xu0 = nullptr, *xu1 = nullptr;
     float uni_offdiag = 0.0f;
     bool uni = false;
+    // Chebyshev work buffers (square systems): iterates with one extra (zero) row, staged right-hand side; the n
+    // launches of a solve are replayed as one hipGraph per (k, n, kernel flavour)
+    float *xu0 = nullptr, *xu1 = nullptr, *bh = nullptr;
+    hipStream_t cap = nullptr;
+    std::map<uint64_t, hipGraphExec_t> graphs;
+    int use_graph = 1;
     double a_min = 0.0;           // caller-certified lower bound of lambda_min(M); 0 = unknown (Chebyshev refused)
     double gersh = 0.0, dmax = 0.0;   // Gershgorin bound of spec(D^-1 M), max diagonal entry
     int last_G = -1;              // grid the partial arrays were last written with (tail must stay zero)
@@ -612,13 +618,15 @@ struct Geometry { int bs, T, G; };
 
 Geometry geometry(const ls_solver* s) {
     Geometry g;
-    g.bs = s->block ? s->block : 512;
+    // 512-thread workgroups once there are enough rows to give every CU several of them, 256 below that
+    g.bs = s->block ? s->block : (s->V >= 262144 ? 512 : 256);
     g.T = div_up(s->V, g.bs);
     if (s->grid > 0) {
         g.G = std::min(s->grid, MAXG);            // explicit: exactly this many workgroups (shards must agree on it)
     } else {
         const int cap = g.bs == 1024 ? 512 : 1024;   // 2 x 1024, 4 x 512 or 4 x 256 threads per CU
-        g.G = g.T < 8 ? std::max(g.T, 1) : std::min(g.T & ~7, cap);
+        // a multiple of 8 (XCD-aware schedule) that covers every tile in one pass whenever the cap allows it
+        g.G = g.T < 8 ? std::max(g.T, 1) : std::min((g.T + 7) & ~7, cap);
     }
     return g;
 }
@@ -637,13 +645,16 @@ void free_solver(ls_solver* s) {
     if (!s) return;
     (void)hipFree(s->slice_ptr); (void)hipFree(s->sell_cv); (void)hipFree(s->dinv); (void)hipFree(s->r);
     (void)hipFree(s->slice_ptr_u); (void)hipFree(s->cols_u); (void)hipFree(s->xu0); (void)hipFree(s->xu1);
-    (void)hipFree(s->dd); (void)hipFree(s->xh);
+    (void)hipFree(s->dd);
     if (s->own_p) (void)hipFree(s->p);
     if (s->own_part) (void)hipFree(s->part);
     (void)hipFree(s->Ap); (void)hipFree(s->scal);
     if (s->h_scal) (void)hipHostFree(s->h_scal);
     for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : s->pev) if (e) (void)hipEventDestroy(e);
+    for (auto& kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
+    if (s->cap) (void)hipStreamDestroy(s->cap);
+    (void)hipFree(s->bh);
     delete s;
 }
 
@@ -668,8 +679,14 @@ int create_impl(ls_solver* s, hipStream_t st) {
     int* flag = (int*)s->scal;   // scal is re-initialised by every solve; borrow its first word
     const bool square = s->ncols == s->V;
     if (square) {
-        if ((rc = dev_alloc(s, &s->dd, (size_t)V))) return rc;
-        if ((rc = dev_alloc(s, &s->xh, vk))) return rc;
+        const size_t n1 = (size_t)(V + 1) * s->kmax;
+        if ((rc = dev_alloc(s, &s->dd, (size_t)std::max<int64_t>(V, 1)))) return rc;
+        if ((rc = dev_alloc(s, &s->xu0, n1))) return rc;
+        if ((rc = dev_alloc(s, &s->xu1, n1))) return rc;
+        if ((rc = dev_alloc(s, &s->bh, vk))) return rc;
+        LS_HIP(hipMemsetAsync(s->xu0, 0, sizeof(float) * n1, st));
+        LS_HIP(hipMemsetAsync(s->xu1, 0, sizeof(float) * n1, st));
+        LS_HIP(hipStreamCreateWithFlags(&s->cap, hipStreamNonBlocking));
     }
     hipLaunchKernelGGL(k_diag_inv, dim3(div_up(V, BLOCK)), dim3(BLOCK), 0, st, s->csr, V, s->dinv, s->dd, flag);
     // SELL-64 copy of the matrix
@@ -861,34 +878,61 @@ int solve_cheb(ls_solver* s, const float* b, const float* x0, float* x, int k, d
     if (target < 1.0) n = (int)ceil(log(2.0 / std::max(target, 1e-30)) / -log(rate));
     const bool capped = n > max_iter;
     n = std::min(n, max_iter);
-    // iterate k reads buffer (k even ? Y : Z) and overwrites the other one; the final iterate must land in x
-    const bool uni = s->uni && s->xu0;
-    float* Y = uni ? s->xu0 : ((n & 1) ? s->xh : x);
-    float* Z = uni ? s->xu1 : ((n & 1) ? x : s->xh);
+    // iterate `it` gathers from (it even ? Y : Z) and overwrites the other buffer; both are handle-owned with one
+    // extra row (index V) kept at zero: the padding entries of the column-only SELL point at it
+    const bool uni = s->uni;
+    float *Y = s->xu0, *Z = s->xu1;
     const size_t bytes = sizeof(float) * (size_t)s->V * k;
-    if (uni) {   // row V of both buffers is the zero row the padding entries point at (layout depends on k)
-        LS_HIP(hipMemsetAsync(s->xu0 + (size_t)s->V * k, 0, sizeof(float) * k, st));
-        LS_HIP(hipMemsetAsync(s->xu1 + (size_t)s->V * k, 0, sizeof(float) * k, st));
-    }
-    if (x0) { if (x0 != Y) LS_HIP(hipMemcpyAsync(Y, x0, bytes, hipMemcpyDeviceToDevice, st)); }
+    LS_HIP(hipMemsetAsync(Y + (size_t)s->V * k, 0, sizeof(float) * k, st));   // the zero row moves with k
+    LS_HIP(hipMemsetAsync(Z + (size_t)s->V * k, 0, sizeof(float) * k, st));
+    if (x0) LS_HIP(hipMemcpyAsync(Y, x0, bytes, hipMemcpyDeviceToDevice, st));
     else LS_HIP(hipMemsetAsync(Y, 0, bytes, st));
     if (s->profile && s->pev.empty()) {
         s->pev.assign(4 * PROF_MAX_ITERS, nullptr);
         for (auto& e : s->pev) LS_HIP(hipEventCreate(&e));
     }
-    if (s->profile) LS_HIP(hipEventRecord(s->pev[0], st));
-    double rho = 1.0 / sigma1;
-    for (int it = 0; it < n; ++it) {
-        double c1 = 0.0, c2 = 1.0 / theta;
-        if (it > 0) {
-            const double rho_new = 1.0 / (2.0 * sigma1 - rho);
-            c1 = rho_new * rho;
-            c2 = 2.0 * rho_new / delta;
-            rho = rho_new;
+    auto enqueue = [&](const float* rhs, hipStream_t stream) {   // the n dependent launches of this solve
+        double rho = 1.0 / sigma1;
+        for (int it = 0; it < n; ++it) {
+            double c1 = 0.0, c2 = 1.0 / theta;
+            if (it > 0) {
+                const double rho_new = 1.0 / (2.0 * sigma1 - rho);
+                c1 = rho_new * rho;
+                c2 = 2.0 * rho_new / delta;
+                rho = rho_new;
+            }
+            dispatch_phase(s, k, uni ? 11 : 9, rhs, (it & 1) ? Z : Y, (it & 1) ? Y : Z, c1, c2, it, g, stream);
         }
-        dispatch_phase(s, k, uni ? 11 : 9, b, (it & 1) ? Z : Y, (it & 1) ? Y : Z, c1, c2, it, g, st);
+    };
+    if (s->profile) LS_HIP(hipEventRecord(s->pev[0], st));
+    if (s->use_graph && n > 0) {
+        // One hipGraph per (k, n, flavour, geometry): all pointers inside are handle-owned, so b is staged once
+        // (a 4kV-byte copy, <0.2 % of a solve). Replaying removes the per-kernel host launch cost that dominates
+        // small meshes (a 70k-vertex step is ~2 us of GPU time against ~4 us of eager launch).
+        const uint64_t key = ((uint64_t)n << 32) | ((uint64_t)g.G << 12) | ((uint64_t)(g.bs >> 8) << 8) | ((uint64_t)k << 4) | (uni ? 1u : 0u);
+        auto found = s->graphs.find(key);
+        if (found == s->graphs.end()) {
+            if (s->graphs.size() >= 16) {           // warm starts produce many different n: keep the cache bounded
+                for (auto& kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
+                s->graphs.clear();
+            }
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            LS_HIP(hipStreamBeginCapture(s->cap, hipStreamCaptureModeThreadLocal));
+            enqueue(s->bh, s->cap);
+            const hipError_t e_end = hipStreamEndCapture(s->cap, &graph);
+            if (e_end != hipSuccess || !graph) return hip_fail(e_end != hipSuccess ? e_end : hipErrorUnknown, "hipStreamEndCapture", __FILE__, __LINE__);
+            const hipError_t e_inst = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (e_inst != hipSuccess) return hip_fail(e_inst, "hipGraphInstantiate", __FILE__, __LINE__);
+            found = s->graphs.emplace(key, exec).first;
+        }
+        LS_HIP(hipMemcpyAsync(s->bh, b, bytes, hipMemcpyDeviceToDevice, st));
+        LS_HIP(hipGraphLaunch(found->second, st));
+    } else {
+        enqueue(b, st);
     }
-    if (uni) LS_HIP(hipMemcpyAsync(x, (n & 1) ? Z : Y, bytes, hipMemcpyDeviceToDevice, st));
+    LS_HIP(hipMemcpyAsync(x, (n & 1) ? Z : Y, bytes, hipMemcpyDeviceToDevice, st));
     if (s->profile) LS_HIP(hipEventRecord(s->pev[1], st));
     LS_HIP(hipGetLastError());
     // true residual of the returned iterate
@@ -965,6 +1009,7 @@ extern "C" int ls_solver_set(ls_solver* s, const char* name, int value) {
     LS_REQUIRE(s && name, LS_E_INVALID, "ls_solver_set: null argument");
     if (!strcmp(name, "check_every")) { LS_REQUIRE(value >= 1 && value <= 4096, LS_E_INVALID, "check_every outside [1,4096]"); s->check_every = value; }
     else if (!strcmp(name, "profile")) { s->profile = value ? 1 : 0; }
+    else if (!strcmp(name, "graph")) { s->use_graph = value ? 1 : 0; }
     else if (!strcmp(name, "grid")) { LS_REQUIRE(value >= 0 && value <= MAXG, LS_E_INVALID, "grid outside [0,%d]", MAXG); s->grid = value; }
     else if (!strcmp(name, "block")) { LS_REQUIRE(value == 0 || value == 256 || value == 512 || value == 1024, LS_E_INVALID, "block must be 0 (auto), 256, 512 or 1024"); s->block = value; }
     else { set_error("ls_solver_set: unknown knob '%s'", name); return LS_E_INVALID; }
@@ -999,11 +1044,6 @@ extern "C" int ls_solver_set_uniform(ls_solver* s, float a, float b, void* strea
     LS_REQUIRE(total >= 0, LS_E_OVERFLOW, "SELL copy of the matrix overflows int32 entry offsets");
     if ((rc = dev_alloc(s, &s->cols_u, (size_t)std::max(total, 1)))) return rc;
     hipLaunchKernelGGL(k_sell_cols_fill, dim3(div_up((int64_t)S * WAVE, BLOCK)), dim3(BLOCK), 0, st, s->csr, V, s->slice_ptr_u, s->cols_u);
-    const size_t n = (size_t)(V + 1) * s->kmax;
-    if ((rc = dev_alloc(s, &s->xu0, n))) return rc;
-    if ((rc = dev_alloc(s, &s->xu1, n))) return rc;
-    LS_HIP(hipMemsetAsync(s->xu0, 0, sizeof(float) * n, st));
-    LS_HIP(hipMemsetAsync(s->xu1, 0, sizeof(float) * n, st));
     LS_HIP(hipGetLastError());
     (void)a;
     s->uni_offdiag = -b;            // M_ij = fl(b * -1) for every edge (geometry.py:86-94 + :128/:132)
@@ -1146,8 +1186,6 @@ extern "C" int ls_solver_bind(ls_solver* s, float* p_ext, double* part) {
     LS_REQUIRE(s && p_ext && part, LS_E_INVALID, "ls_solver_bind: null argument");
     DeviceGuard g(s->device);
     LS_HIP(g.err);
-    (void)hipFree(s->slice_ptr_u); (void)hipFree(s->cols_u); (void)hipFree(s->xu0); (void)hipFree(s->xu1);
-    (void)hipFree(s->dd); (void)hipFree(s->xh);
     if (s->own_p) (void)hipFree(s->p);
     if (s->own_part) (void)hipFree(s->part);
     s->p = p_ext; s->part = part;

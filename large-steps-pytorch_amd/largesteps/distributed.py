@@ -422,7 +422,7 @@ def pick_depth(rowptr, col, V, P, max_depth=64, max_overhead=1.0):
 def _common_grid(n_max):
     block = 256
     T = -(-n_max // block)
-    return block, (max(T, 1) if T < 8 else min(T & ~7, 1024))
+    return block, (max(T, 1) if T < 8 else min((T + 7) & ~7, 1024))
 
 
 def shard_from_matrix(M, group=None, device=None, method="auto", depth=None, **solver_kw):

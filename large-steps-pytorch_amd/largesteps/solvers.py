@@ -105,7 +105,7 @@ class PCGSolver(Solver):
             self._handle = None
 
     def set_option(self, name, value):
-        """Measurement knobs of the native solver: 'check_every', 'grid', 'block' (256 / 512 / 1024), 'profile'."""
+        """Measurement knobs of the native solver: 'check_every', 'grid', 'block' (256 / 512 / 1024), 'graph', 'profile'."""
         _native.check(_native.lib().ls_solver_set(self._handle, name.encode(), int(value)))
 
     def kernel_profile(self):

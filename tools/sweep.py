@@ -64,6 +64,10 @@ def main():
                 inf = sc.last_info
                 print(f"   chebyshev block {block:4d} grid {grid:5d}: {ms:8.3f} ms/solve  iters {inf['iterations']:4d} ({inf['method']})  {ms * 1e3 / max(inf['iterations'], 1):7.2f} us/iter | "
                       f"max|x-v| {float((xs - tv).abs().max()):.1e}  true rel residual {[f'{r / b:.1e}' for r, b in zip(inf['rnorm'], inf['bnorm'])]}", flush=True)
+        sc.set_option("block", 0); sc.set_option("grid", 0)
+        for gr in (0, 1):
+            sc.set_option("graph", gr)
+            print(f"   chebyshev graph={gr}: {timeit(lambda: sc.solve(u), 10):8.3f} ms/solve")
         for rt in (1e-4, 1e-5, 1e-7):
             sc.rtol = rt
             xs = sc.solve(u)
