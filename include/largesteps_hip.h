@@ -121,13 +121,23 @@ int ls_solver_set_spectrum(ls_solver* s, double a_min);
  * neighbour ids (4 B per entry instead of 8 B) -- values are implicit. SYNC once (sizes the column-only SELL copy). */
 int ls_solver_set_uniform(ls_solver* s, float a, float b, void* stream);
 int ls_solver_spectrum(const ls_solver* s, double* h_lmin, double* h_lmax);
+/* Patch plan of the LDS-resident s-step Chebyshev kernel (host arrays, built by largesteps/patches.py; needs
+ * ls_solver_set_uniform first): the vertices are renumbered patch-major (h_perm[new] = old); patch p owns the new ids
+ * [table[8p], table[8p] + table[8p+1]); one workgroup keeps both iterates of the patch and of its ghost layers 1..depth
+ * in LDS and advances `depth` Chebyshev steps per launch, so HBM sees vectors and matrix once per `depth` iterations.
+ * table: 8 int32 per patch {own_start, n_own, n_rows, n_local, ell_width, off_gid, off_cols, off_diag}; h_ghost_gid:
+ * new global ids of the local vertices >= n_own; h_cols16: per patch (ell_width, n_rows) uint16 local neighbour ids
+ * (padding = n_local); h_diag: per patch the n_rows diagonal entries. SYNC (copies the arrays). */
+int ls_solver_set_patches(ls_solver* s, const int32_t* h_table, int n_patches, const int32_t* h_ghost_gid, int64_t n_gid,
+                          const uint16_t* h_cols16, int64_t n_cols, const float* h_diag, int64_t n_diag,
+                          const int32_t* h_perm, int depth, int max_local, int max_rows, void* stream);
 /* iterations the Chebyshev solver will run for a residual reduction `reduction` (e.g. rtol from a cold start) */
 int ls_solver_chebyshev_iterations(const ls_solver* s, double reduction, int* h_n);
 int ls_solver_solve_chebyshev(ls_solver* s, const float* b, const float* x0, float* x, int k, double rtol,
                               double atol, int max_iter, ls_solve_info* h_info, void* stream);
 /* knobs for measurements: name in {"check_every", "grid" (workgroups per kernel, 0 = auto), "block" (0 = auto,
  * 256, 512 or 1024 threads per workgroup), "graph" (1 = replay the Chebyshev launches of a solve as one hipGraph,
- * default; 0 = eager launches), "profile"}; unknown name -> LS_E_INVALID */
+ * default; 0 = eager launches), "patch" (1 = use the patch plan if one was set, default), "profile"}; unknown name -> LS_E_INVALID */
 int ls_solver_set(ls_solver* s, const char* name, int value);
 /* With "profile"=1 every solve brackets its three kernels per iteration with HIP events on the solve's
  * stream; this returns the accumulated milliseconds of K1 (SpMV+dot), K2 (update), K3 (direction) over the h_iters

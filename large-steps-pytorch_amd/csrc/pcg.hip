@@ -29,6 +29,7 @@
 #include <new>
 #include <vector>
 #include <map>
+#include <type_traits>
 
 namespace ls {
 
@@ -503,6 +504,152 @@ __global__ __launch_bounds__(BLOCK) void k_gershgorin(CsrView A, int64_t V, cons
     }
 }
 
+// ==== LDS-resident, s-step Chebyshev on mesh patches (temporal blocking; plan: largesteps/patches.py) ========
+// One workgroup owns a compact patch of ~2k vertices plus its ghost layers 1..s and keeps BOTH iterates of all those
+// vertices in LDS for s consecutive Chebyshev steps: the neighbour gathers of the sparse product become LDS reads and
+// HBM sees vectors and matrix once per s iterations. Ghost layers go stale one layer per step (they are recomputed
+// redundantly, layer s is read-only); the patch's own vertices never do. Uniform Laplacian only (implicit values):
+// the matrix is the ELL list of LOCAL neighbour ids (uint16), padding -> slot n_local which holds zeros.
+struct PatchCoef { float c1[8]; float c2[8]; int steps; };
+constexpr int PATCH_RPT = 8;     // rows per thread upper bound: a patch may compute at most 8 * PATCH_BS rows
+
+// LDS holds one K-float slot per local vertex. (Padding K = 3 to 16-byte slots for single ds_read_b128 gathers was
+// measured: no gain -- the step loop is latency bound, not LDS-issue bound -- and it shrinks the patches that fit.)
+template <int K> struct PatchSlot { static constexpr int KP = K; };
+template <int KP> struct LdsVec;
+template <> struct LdsVec<1> { typedef float T; };
+template <> struct LdsVec<2> { typedef float2 T; };
+template <> struct LdsVec<3> { struct T { float x, y, z; }; };
+template <> struct LdsVec<4> { typedef float4 T; };
+
+template <int K, int PATCH_BS>
+__global__ __launch_bounds__(PATCH_BS) void k_patch_cheb(const int* __restrict__ table, const int* __restrict__ ghost_gid,
+                                                         const unsigned short* __restrict__ cols16, const float* __restrict__ diag,
+                                                         const float* __restrict__ b, const float* __restrict__ in_cur,
+                                                         const float* __restrict__ in_prev, float* __restrict__ out_cur,
+                                                         float* __restrict__ out_prev, PatchCoef coef, float offdiag, int cap1) {
+    constexpr int KP = PatchSlot<K>::KP;
+    typedef typename LdsVec<KP>::T slot_t;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    slot_t* cur = reinterpret_cast<slot_t*>(smem);
+    slot_t* oth = cur + cap1;
+    const int* __restrict__ t = table + (size_t)blockIdx.x * 8;
+    const int own_start = t[0], n_own = t[1], n_rows = t[2], n_local = t[3], W = t[4], og = t[5], oc = t[6], od = t[7];
+    auto pack = [](const Vec<K>& v) { slot_t o; float* f = reinterpret_cast<float*>(&o);
+#pragma unroll
+        for (int q = 0; q < KP; ++q) f[q] = q < K ? v.v[q] : 0.0f;
+        return o; };
+    for (int l = threadIdx.x; l < n_local; l += PATCH_BS) {
+        const int g = l < n_own ? own_start + l : ghost_gid[og + l - n_own];
+        cur[l] = pack(ldv<K>(in_cur, g));
+        oth[l] = pack(ldv<K>(in_prev, g));
+    }
+    if (threadIdx.x == 0) { Vec<K> z; for (int q = 0; q < K; ++q) z.v[q] = 0.0f; cur[n_local] = pack(z); oth[n_local] = pack(z); }
+    // per-thread rows r = tid + j * BS: right-hand side, diagonal and the (<= 8) local neighbour ids stay in registers
+    // for all steps of this launch (two uint16 ids per register); wider rows re-read their ids from L2 every step
+    float bl[PATCH_RPT][K], dl[PATCH_RPT], dd_j[PATCH_RPT];
+    unsigned nb[PATCH_RPT][4];
+    const bool narrow = W <= 8;
+#pragma unroll
+    for (int j = 0; j < PATCH_RPT; ++j) {
+        const int r = threadIdx.x + j * PATCH_BS;
+        dl[j] = 1.0f;
+        dd_j[j] = 1.0f;
+#pragma unroll
+        for (int q = 0; q < K; ++q) bl[j][q] = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) nb[j][e] = (unsigned)n_local | ((unsigned)n_local << 16);   // zero slot
+        if (r < n_rows) {
+            const int g = r < n_own ? own_start + r : ghost_gid[og + r - n_own];
+            const Vec<K> bv = ldv<K>(b, g);
+#pragma unroll
+            for (int q = 0; q < K; ++q) bl[j][q] = bv.v[q];
+            dd_j[j] = diag[od + r];
+            dl[j] = 1.0f / dd_j[j];
+            if (narrow) {
+                const unsigned short* __restrict__ cr = cols16 + oc + r;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (e < W) {
+                        const unsigned c = cr[(size_t)e * n_rows];
+                        nb[j][e >> 1] = (e & 1) ? ((nb[j][e >> 1] & 0xffffu) | (c << 16)) : ((nb[j][e >> 1] & 0xffff0000u) | c);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // one Chebyshev step on this thread's rows; NW = number of neighbour slots actually read (patch-uniform ELL width)
+    auto step_rows = [&](auto nw_tag, float c1, float c2) {
+        constexpr int NW = decltype(nw_tag)::value;
+#pragma unroll
+        for (int j = 0; j < PATCH_RPT; ++j) {
+            const int r = threadIdx.x + j * PATCH_BS;
+            if (r < n_rows) {
+                float sum[K];
+#pragma unroll
+                for (int q = 0; q < K; ++q) sum[q] = 0.0f;
+                if (NW > 0) {
+                    slot_t g8[NW > 0 ? NW : 1];
+#pragma unroll
+                    for (int e = 0; e < NW; ++e)        // padding ids point at the zero slot: no branch needed
+                        g8[e] = cur[(e & 1) ? (nb[j][e >> 1] >> 16) : (nb[j][e >> 1] & 0xffffu)];
+#pragma unroll
+                    for (int e = 0; e < NW; ++e) {
+                        const float* f = reinterpret_cast<const float*>(&g8[e]);
+#pragma unroll
+                        for (int q = 0; q < K; ++q) sum[q] += f[q];
+                    }
+                } else {
+                    const unsigned short* __restrict__ cr = cols16 + oc + r;
+                    for (int e = 0; e < W; ++e) {
+                        const slot_t gv = cur[cr[(size_t)e * n_rows]];
+                        const float* f = reinterpret_cast<const float*>(&gv);
+#pragma unroll
+                        for (int q = 0; q < K; ++q) sum[q] += f[q];
+                    }
+                }
+                const slot_t xcv = cur[r];
+                slot_t xpv = oth[r];
+                const float* xc = reinterpret_cast<const float*>(&xcv);
+                float* xp = reinterpret_cast<float*>(&xpv);
+                const float w = c2 * dl[j];             // dl holds 1/diag: c2 D^-1 (b - M x) without a division
+#pragma unroll
+                for (int q = 0; q < K; ++q) {
+                    const float ax = fmaf(offdiag, sum[q], dd_j[j] * xc[q]);
+                    xp[q] = fmaf(w, bl[j][q] - ax, fmaf(c1, xc[q] - xp[q], xc[q]));
+                }
+                oth[r] = xpv;   // oth[r] is touched by this thread only during this step: update in place
+            }
+        }
+    };
+    for (int step = 0; step < coef.steps; ++step) {
+        const float c1 = coef.c1[step], c2 = coef.c2[step];
+        if (!narrow) step_rows(std::integral_constant<int, 0>(), c1, c2);
+        else if (W <= 6) step_rows(std::integral_constant<int, 6>(), c1, c2);
+        else if (W == 7) step_rows(std::integral_constant<int, 7>(), c1, c2);
+        else step_rows(std::integral_constant<int, 8>(), c1, c2);
+        __syncthreads();
+        slot_t* tmp = cur; cur = oth; oth = tmp;
+    }
+    for (int l = threadIdx.x; l < n_own; l += PATCH_BS) {
+        Vec<K> a, c;
+        const slot_t av = cur[l], cv = oth[l];
+        const float* fa = reinterpret_cast<const float*>(&av);
+        const float* fc = reinterpret_cast<const float*>(&cv);
+#pragma unroll
+        for (int q = 0; q < K; ++q) { a.v[q] = fa[q]; c.v[q] = fc[q]; }
+        stv<K>(out_cur, own_start + l, a);
+        stv<K>(out_prev, own_start + l, c);
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(BLOCK) void k_scatter_rows(const float* __restrict__ src, const int* __restrict__ idx, int64_t n, float* __restrict__ dst) {
+    const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t < n) stv<K>(dst, idx[t], ldv<K>(src, t));
+}
+
 // ---- CSR -> SELL-64 ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_sell_widths(const int* __restrict__ rowptr, int64_t V, int S, int* __restrict__ width64, int minus) {
     const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -595,6 +742,15 @@ struct ls_solver {
     hipStream_t cap = nullptr;
     std::map<uint64_t, hipGraphExec_t> graphs;
     int use_graph = 1;
+    // patch plan of the LDS-resident s-step kernel (ls_solver_set_patches)
+    struct {
+        int n = 0, depth = 0, cap1 = 0, bs = 512;
+        int *table = nullptr, *gid = nullptr, *perm = nullptr;
+        unsigned short* cols = nullptr;
+        float *diag = nullptr, *bn = nullptr, *it[4] = {nullptr, nullptr, nullptr, nullptr};
+    } patch;
+    int use_patch = 1;
+    int profile_eager = 0;        // 1: profile the one-step kernel even when a patch plan exists
     double a_min = 0.0;           // caller-certified lower bound of lambda_min(M); 0 = unknown (Chebyshev refused)
     double gersh = 0.0, dmax = 0.0;   // Gershgorin bound of spec(D^-1 M), max diagonal entry
     int last_G = -1;              // grid the partial arrays were last written with (tail must stay zero)
@@ -655,6 +811,9 @@ void free_solver(ls_solver* s) {
     for (auto& kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
     if (s->cap) (void)hipStreamDestroy(s->cap);
     (void)hipFree(s->bh);
+    (void)hipFree(s->patch.table); (void)hipFree(s->patch.gid); (void)hipFree(s->patch.perm); (void)hipFree(s->patch.cols);
+    (void)hipFree(s->patch.diag); (void)hipFree(s->patch.bn);
+    for (float* q : s->patch.it) (void)hipFree(q);
     delete s;
 }
 
@@ -848,6 +1007,57 @@ int solve_impl(ls_solver* s, const float* b, const float* x0, float* x, int k, d
     return LS_OK;
 }
 
+// n Chebyshev steps as ceil(n / depth) launches of the patch kernel (patch-major numbering inside)
+template <int K>
+void launch_patch(ls_solver* s, const float* in_cur, const float* in_prev, float* out_cur, float* out_prev, const PatchCoef& coef, hipStream_t st) {
+    const size_t lds = 2 * (size_t)s->patch.cap1 * PatchSlot<K>::KP * sizeof(float);
+    if (s->patch.bs == 1024)
+        hipLaunchKernelGGL((k_patch_cheb<K, 1024>), dim3(s->patch.n), dim3(1024), lds, st, s->patch.table, s->patch.gid, s->patch.cols,
+                           s->patch.diag, s->patch.bn, in_cur, in_prev, out_cur, out_prev, coef, s->uni_offdiag, s->patch.cap1);
+    else
+        hipLaunchKernelGGL((k_patch_cheb<K, 512>), dim3(s->patch.n), dim3(512), lds, st, s->patch.table, s->patch.gid, s->patch.cols,
+                           s->patch.diag, s->patch.bn, in_cur, in_prev, out_cur, out_prev, coef, s->uni_offdiag, s->patch.cap1);
+}
+
+int solve_cheb_patched(ls_solver* s, const float* b, const float* x0, float* x, int k, int n, double theta, double delta,
+                       double sigma1, hipStream_t st) {
+    const int64_t V = s->V;
+    const dim3 vg(div_up(V, BLOCK)), vb(BLOCK);
+    const size_t bytes = sizeof(float) * (size_t)V * k;
+    float** it = s->patch.it;      // pairs (it[0], it[1]) and (it[2], it[3]): (current, previous)
+#define LS_K(KK, ...) switch (KK) { case 1: { constexpr int K = 1; __VA_ARGS__; } break; case 2: { constexpr int K = 2; __VA_ARGS__; } break; \
+                                    case 3: { constexpr int K = 3; __VA_ARGS__; } break; default: { constexpr int K = 4; __VA_ARGS__; } break; }
+    LS_K(k, hipLaunchKernelGGL(k_gather_rows<K>, vg, vb, 0, st, b, s->patch.perm, V, s->patch.bn));
+    if (x0) { LS_K(k, hipLaunchKernelGGL(k_gather_rows<K>, vg, vb, 0, st, x0, s->patch.perm, V, it[0])); }
+    else LS_HIP(hipMemsetAsync(it[0], 0, bytes, st));
+    LS_HIP(hipMemsetAsync(it[1], 0, bytes, st));
+    if (s->profile) LS_HIP(hipEventRecord(s->pev[0], st));
+    double rho = 1.0 / sigma1;
+    int src = 0;
+    for (int it0 = 0; it0 < n; it0 += s->patch.depth) {
+        PatchCoef coef;
+        coef.steps = std::min(s->patch.depth, n - it0);
+        for (int j = 0; j < coef.steps; ++j) {
+            double c1 = 0.0, c2 = 1.0 / theta;
+            if (it0 + j > 0) {
+                const double rho_new = 1.0 / (2.0 * sigma1 - rho);
+                c1 = rho_new * rho;
+                c2 = 2.0 * rho_new / delta;
+                rho = rho_new;
+            }
+            coef.c1[j] = (float)c1;
+            coef.c2[j] = (float)c2;
+        }
+        LS_K(k, launch_patch<K>(s, it[src], it[src + 1], it[2 - src], it[3 - src], coef, st));
+        src = 2 - src;
+    }
+    if (s->profile) LS_HIP(hipEventRecord(s->pev[1], st));
+    LS_K(k, hipLaunchKernelGGL(k_scatter_rows<K>, vg, vb, 0, st, (const float*)it[src], (const int*)s->patch.perm, V, x));
+#undef LS_K
+    LS_HIP(hipGetLastError());
+    return LS_OK;
+}
+
 // Chebyshev-Jacobi solve: the iteration count follows from the spectral enclosure and the requested reduction,
 // nothing is polled: n launches, one residual check, one sync.
 int solve_cheb(ls_solver* s, const float* b, const float* x0, float* x, int k, double rtol, double atol, int max_iter,
@@ -874,10 +1084,17 @@ int solve_cheb(ls_solver* s, const float* b, const float* x0, float* x, int k, d
             if (r0 > thr) target = std::min(target, thr / r0);
         }
     }
+    if (s->profile && s->pev.empty()) {
+        s->pev.assign(4 * PROF_MAX_ITERS, nullptr);
+        for (auto& e : s->pev) LS_HIP(hipEventCreate(&e));
+    }
     int n = 0;
     if (target < 1.0) n = (int)ceil(log(2.0 / std::max(target, 1e-30)) / -log(rate));
     const bool capped = n > max_iter;
     n = std::min(n, max_iter);
+    if (s->patch.n > 0 && s->use_patch && s->uni && !s->profile_eager && 2 * (size_t)s->patch.cap1 * k * sizeof(float) <= 160 * 1024) {
+        if ((rc = solve_cheb_patched(s, b, x0, x, k, n, theta, delta, sigma1, st))) return rc;
+    } else {
     // iterate `it` gathers from (it even ? Y : Z) and overwrites the other buffer; both are handle-owned with one
     // extra row (index V) kept at zero: the padding entries of the column-only SELL point at it
     const bool uni = s->uni;
@@ -933,6 +1150,7 @@ int solve_cheb(ls_solver* s, const float* b, const float* x0, float* x, int k, d
         enqueue(b, st);
     }
     LS_HIP(hipMemcpyAsync(x, (n & 1) ? Z : Y, bytes, hipMemcpyDeviceToDevice, st));
+    }
     if (s->profile) LS_HIP(hipEventRecord(s->pev[1], st));
     LS_HIP(hipGetLastError());
     // true residual of the returned iterate
@@ -1010,6 +1228,7 @@ extern "C" int ls_solver_set(ls_solver* s, const char* name, int value) {
     if (!strcmp(name, "check_every")) { LS_REQUIRE(value >= 1 && value <= 4096, LS_E_INVALID, "check_every outside [1,4096]"); s->check_every = value; }
     else if (!strcmp(name, "profile")) { s->profile = value ? 1 : 0; }
     else if (!strcmp(name, "graph")) { s->use_graph = value ? 1 : 0; }
+    else if (!strcmp(name, "patch")) { s->use_patch = value ? 1 : 0; }
     else if (!strcmp(name, "grid")) { LS_REQUIRE(value >= 0 && value <= MAXG, LS_E_INVALID, "grid outside [0,%d]", MAXG); s->grid = value; }
     else if (!strcmp(name, "block")) { LS_REQUIRE(value == 0 || value == 256 || value == 512 || value == 1024, LS_E_INVALID, "block must be 0 (auto), 256, 512 or 1024"); s->block = value; }
     else { set_error("ls_solver_set: unknown knob '%s'", name); return LS_E_INVALID; }
@@ -1048,6 +1267,50 @@ extern "C" int ls_solver_set_uniform(ls_solver* s, float a, float b, void* strea
     (void)a;
     s->uni_offdiag = -b;            // M_ij = fl(b * -1) for every edge (geometry.py:86-94 + :128/:132)
     s->uni = true;
+    return LS_OK;
+}
+
+extern "C" int ls_solver_set_patches(ls_solver* s, const int32_t* h_table, int n_patches, const int32_t* h_ghost_gid, int64_t n_gid,
+                                     const uint16_t* h_cols16, int64_t n_cols, const float* h_diag, int64_t n_diag,
+                                     const int32_t* h_perm, int depth, int max_local, int max_rows, void* stream) {
+    LS_REQUIRE(s && h_table && h_perm && n_patches > 0 && depth >= 1 && depth <= 8, LS_E_INVALID, "ls_solver_set_patches: bad argument");
+    LS_REQUIRE(s->ncols == s->V && s->uni, LS_E_STATE, "ls_solver_set_patches: needs a square system declared uniform (ls_solver_set_uniform)");
+    LS_REQUIRE(max_rows <= 1024 * PATCH_RPT && max_local < 65535, LS_E_INVALID, "ls_solver_set_patches: patch too large (rows %d, local %d)", max_rows, max_local);
+    const size_t lds = 2 * (size_t)(max_local + 1) * sizeof(float);     // per right-hand-side column
+    LS_REQUIRE(lds <= 160 * 1024, LS_E_INVALID, "ls_solver_set_patches: %zu bytes of LDS per patch and column exceed 160 KiB", lds);
+    if (s->patch.n) return LS_OK;
+    DeviceGuard g(s->device);
+    LS_HIP(g.err);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    auto up = [&](auto** dst, const auto* src, size_t n) -> int {
+        if ((rc = dev_alloc(s, dst, std::max<size_t>(n, 1)))) return rc;
+        if (n) LS_HIP(hipMemcpyAsync(*dst, src, n * sizeof(**dst), hipMemcpyHostToDevice, st));
+        return LS_OK;
+    };
+    if ((rc = up(&s->patch.table, h_table, (size_t)n_patches * 8))) return rc;
+    if ((rc = up(&s->patch.gid, h_ghost_gid, (size_t)n_gid))) return rc;
+    if ((rc = up(&s->patch.cols, h_cols16, (size_t)n_cols))) return rc;
+    if ((rc = up(&s->patch.diag, h_diag, (size_t)n_diag))) return rc;
+    if ((rc = up(&s->patch.perm, h_perm, (size_t)s->V))) return rc;
+    const size_t vk = (size_t)s->V * s->kmax;
+    if ((rc = dev_alloc(s, &s->patch.bn, vk))) return rc;
+    for (auto& q : s->patch.it) if ((rc = dev_alloc(s, &q, vk))) return rc;
+    // kernels with more than 64 KiB of dynamic LDS need the opt-in
+    (void)hipFuncSetAttribute((const void*)k_patch_cheb<1, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_patch_cheb<1, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_patch_cheb<2, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_patch_cheb<2, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_patch_cheb<3, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_patch_cheb<3, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_patch_cheb<4, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_patch_cheb<4, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+    LS_HIP(hipStreamSynchronize(st));     // the host arrays may go away after return
+    s->patch.depth = depth;
+    s->patch.bs = max_rows > 512 * PATCH_RPT ? 1024 : 512;
+    s->patch.cap1 = max_local + 1;
+    s->patch.n = n_patches;
     return LS_OK;
 }
 

@@ -61,6 +61,8 @@ _SIGNATURES = {
     "ls_solver_set_spectrum": (c_int, [c_void_p, c_double]),
     "ls_solver_chebyshev_iterations": (c_int, [c_void_p, c_double, ctypes.POINTER(c_int)]),
     "ls_solver_set_uniform": (c_int, [c_void_p, c_float, c_float, c_void_p]),
+    "ls_solver_set_patches": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int,
+                                      c_int, c_int, c_void_p]),
     "ls_solver_spectrum": (c_int, [c_void_p, ctypes.POINTER(c_double), ctypes.POINTER(c_double)]),
     "ls_solver_solve_chebyshev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double, c_double, c_int,
                                           ctypes.POINTER(SolveInfo), c_void_p]),
@@ -149,9 +151,9 @@ def ptr(t):
 class CsrMatrix:
     """int32 CSR (rowptr, col) + fp32 val of a (V,V) matrix on one HIP device. `val` is the very tensor
     that backs M.values() (same order: row-major sorted COO == CSR order), so no value copy exists."""
-    __slots__ = ("V", "nnz", "rowptr", "col", "val", "device", "symmetric", "a_min", "uniform", "__weakref__")
+    __slots__ = ("V", "nnz", "rowptr", "col", "val", "device", "symmetric", "a_min", "uniform", "positions", "__weakref__")
 
-    def __init__(self, V, rowptr, col, val, symmetric, a_min=None, uniform=None):
+    def __init__(self, V, rowptr, col, val, symmetric, a_min=None, uniform=None, positions=None):
         self.V, self.nnz = int(V), int(col.shape[0])
         self.rowptr, self.col, self.val = rowptr, col, val
         self.device = val.device
@@ -160,6 +162,9 @@ class CsrMatrix:
         self.a_min = a_min
         # (a, b) if M = a I + b L_uniform (all off-diagonal values equal -b): lets the solver drop the value array
         self.uniform = uniform
+        # (V,3) vertex positions the matrix was assembled from (detached; only their spatial order is used, to cut
+        # the mesh into compact patches for the LDS-resident solver kernel)
+        self.positions = positions
 
 
 # (id(M)) -> (CsrMatrix, weakref(M)). Mirrors the reference's solver cache (parameterize.py:5-17): keyed by

@@ -57,9 +57,10 @@ def _assemble(verts, faces, kind, a, b):
     return V, rowptr, col, val, idx
 
 
-def _wrap(V, rowptr, col, val, idx, a_min=None, uniform=None):
+def _wrap(V, rowptr, col, val, idx, a_min=None, uniform=None, positions=None):
     M = torch.sparse_coo_tensor(idx, val, (V, V), is_coalesced=True)
-    _native.register_csr(M, _native.CsrMatrix(V, rowptr, col, M._values(), symmetric=True, a_min=a_min, uniform=uniform))
+    _native.register_csr(M, _native.CsrMatrix(V, rowptr, col, M._values(), symmetric=True, a_min=a_min, uniform=uniform,
+                                              positions=positions))
     return M
 
 
@@ -127,4 +128,5 @@ def compute_matrix(verts, faces, lambda_, alpha=None, cotan=False):
     # M = a I + b L with L positive semi-definite (graph Laplacian: always; cotangent stiffness matrix: as a
     # quadratic form) and b >= 0  =>  lambda_min(M) >= a: the enclosure the Chebyshev solver needs.
     a_min = a32 if (a32 > 0.0 and b32 >= 0.0) else None
-    return _wrap(*_assemble(verts, faces, kind, a32, b32), a_min=a_min, uniform=None if cotan else (a32, b32))
+    positions = verts.detach() if (verts.dim() == 2 and verts.shape[1] == 3) else None
+    return _wrap(*_assemble(verts, faces, kind, a32, b32), a_min=a_min, uniform=None if cotan else (a32, b32), positions=positions)

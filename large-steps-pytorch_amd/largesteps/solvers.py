@@ -9,6 +9,7 @@ import ctypes
 import os
 import warnings
 
+import numpy as np
 import torch
 from torch.autograd import Function
 
@@ -62,7 +63,8 @@ class PCGSolver(Solver):
         Largest a-priori Chebyshev iteration count (cold start, at `rtol`) for which Chebyshev is preferred to PCG.
     """
 
-    def __init__(self, M, rtol=1e-6, atol=0.0, max_iter=10000, warm_start=False, chebyshev=False, chebyshev_cap=400):
+    def __init__(self, M, rtol=1e-6, atol=0.0, max_iter=10000, warm_start=False, chebyshev=False, chebyshev_cap=400,
+                 patch_min_vertices=8192):
         csr = _native.csr_of(M)
         self._csr = csr                 # keeps rowptr/col/val alive; never M itself (cache eviction relies on it)
         self.rtol, self.atol, self.max_iter, self.warm_start = float(rtol), float(atol), int(max_iter), bool(warm_start)
@@ -78,6 +80,7 @@ class PCGSolver(Solver):
         self.chebyshev = False
         self.chebyshev_iterations = None
         self.implicit_values = False      # True: the Chebyshev kernel reads neighbour ids only (uniform Laplacian)
+        self.patch_plan = None            # PatchPlan of the LDS-resident s-step kernel, if one is in use
         if csr.a_min is not None:
             _native.check(_native.lib().ls_solver_set_spectrum(self._handle, float(csr.a_min)))
             if chebyshev and self.rtol > 0.0:
@@ -94,6 +97,34 @@ class PCGSolver(Solver):
                         _native.check(_native.lib().ls_solver_set_uniform(self._handle, float(csr.uniform[0]), float(csr.uniform[1]),
                                                                           _native.stream_of(dev)))
                     self.implicit_values = True
+                    if csr.positions is not None and csr.V >= patch_min_vertices and not os.environ.get("LARGESTEPS_NO_PATCHES"):
+                        self._set_patches(csr, dev)
+
+    def _set_patches(self, csr, dev):
+        """Host-side analysis for the patch kernel (csrc/pcg.hip k_patch_cheb): Morton-ordered patches + ghost layers.
+        A mesh whose patches do not fit LDS even at depth 2 simply keeps the one-step kernel."""
+        from .patches import PatchPlan
+        rowptr, col = csr.rowptr.cpu().numpy(), csr.col.cpu().numpy()
+        rows = torch.repeat_interleave(torch.arange(csr.V, device=dev), (csr.rowptr[1:] - csr.rowptr[:-1]).long())
+        diag = torch.zeros(csr.V, dtype=torch.float32, device=dev)
+        on = rows == csr.col.long()
+        diag[rows[on]] = csr.val[on]
+        # LDS budget: 2 buffers x (n_local+1) x 12 B (k = 3) <= 160 KiB -> n_local <= 6800.
+        # LARGESTEPS_PATCH="patch_size,depth,cap_local" overrides the defaults (tuning).
+        ps, depth, cap_local = (int(t) for t in os.environ.get("LARGESTEPS_PATCH", "4489,7,6800").split(","))
+        plan = PatchPlan.build(rowptr, col, diag.cpu().numpy(), csr.positions.cpu().numpy(), patch_size=ps, depth=depth,
+                               cap_local=cap_local)
+        if plan is None or plan.max_rows > 8192:
+            return
+        tab = np.ascontiguousarray(plan.table.reshape(-1))
+        perm32 = plan.perm.astype(np.int32)
+        as_p = lambda a: a.ctypes.data_as(ctypes.c_void_p)   # noqa: E731
+        with torch.cuda.device(dev):
+            _native.check(_native.lib().ls_solver_set_patches(self._handle, as_p(tab), plan.n_patches, as_p(plan.ghost_gid),
+                                                              plan.ghost_gid.shape[0], as_p(plan.cols16), plan.cols16.shape[0],
+                                                              as_p(plan.diag), plan.diag.shape[0], as_p(perm32), plan.depth,
+                                                              plan.max_local, plan.max_rows, _native.stream_of(dev)))
+        self.patch_plan = plan
 
     def __del__(self):
         h = getattr(self, "_handle", None)

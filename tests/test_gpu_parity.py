@@ -269,6 +269,37 @@ def test_chebyshev_solver(dev, cot, k):
     assert sf.last_info["method"] == "pcg" and np.abs(xf.cpu().numpy() - x64).max() <= 1e-4 * np.abs(x64).max()
 
 
+@pytest.mark.parametrize("k", [1, 3, 4])
+@pytest.mark.parametrize("patch_cfg", ["1500,4,6800", "3000,8,6800", "600,3,2000"])
+def test_patch_blocked_chebyshev(dev, monkeypatch, patch_cfg, k):
+    """LDS-resident s-step kernel (k_patch_cheb) == the one-step kernel == the fp64 oracle."""
+    from largesteps.geometry import compute_matrix
+    from largesteps.solvers import PCGSolver
+    from largesteps import synthetic
+    monkeypatch.setenv("LARGESTEPS_PATCH", patch_cfg)
+    v, f = synthetic.icosphere(40)                 # 16002 vertices: several patches, ragged sizes
+    v = synthetic.perturb(v, radial=0.05, seed=4)
+    M = compute_matrix(_t(v, dev), _t(f, dev), 30.0)
+    idx, val = M.indices().cpu().numpy(), M.values().cpu().numpy()
+    b = np.random.default_rng(k).standard_normal((v.shape[0], k)).astype(np.float32)
+    x64 = osv.from_differential(idx[0], idx[1], val, b)
+    s = PCGSolver(M, rtol=1e-6, chebyshev=True)
+    assert s.patch_plan is not None and s.patch_plan.n_patches >= 4
+    x = s.solve(_t(b, dev))
+    assert s.last_info["method"] == "chebyshev" and s.last_info["converged"]
+    assert np.abs(x.cpu().numpy() - x64).max() <= 1e-4 * np.abs(x64).max()
+    s.set_option("patch", 0)                       # same handle, one-step kernel
+    y = s.solve(_t(b, dev))
+    assert float((x - y).abs().max()) <= 2e-5 * float(y.abs().max())
+    s.set_option("patch", 1)
+    assert torch.equal(s.solve(_t(b, dev)), x), "deterministic"
+    # warm start through the patch path
+    s.warm_start = True
+    s.guess_fwd = x.clone()
+    x2 = s.solve(_t(b, dev))
+    assert np.abs(x2.cpu().numpy() - x64).max() <= 1e-4 * np.abs(x64).max()
+
+
 def test_determinism_and_fresh_output(dev):
     from largesteps.geometry import compute_matrix
     from largesteps.parameterize import from_differential, to_differential

@@ -67,7 +67,15 @@ def main():
         sc.set_option("block", 0); sc.set_option("grid", 0)
         for gr in (0, 1):
             sc.set_option("graph", gr)
-            print(f"   chebyshev graph={gr}: {timeit(lambda: sc.solve(u), 10):8.3f} ms/solve")
+            sc.set_option("patch", 0)
+            print(f"   chebyshev one-step kernel graph={gr}: {timeit(lambda: sc.solve(u), 10):8.3f} ms/solve")
+        sc.set_option("patch", 1)
+        if sc.patch_plan is not None:
+            pl = sc.patch_plan
+            ms = timeit(lambda: sc.solve(u), 10)
+            xs = sc.solve(u)
+            print(f"   chebyshev PATCH kernel ({pl.n_patches} patches, depth {pl.depth}, max_local {pl.max_local}, redundancy {pl.redundancy:.2f}): "
+                  f"{ms:8.3f} ms/solve  iters {sc.last_info['iterations']}  max|x-v| {float((xs - tv).abs().max()):.1e}")
         for rt in (1e-4, 1e-5, 1e-7):
             sc.rtol = rt
             xs = sc.solve(u)
