@@ -38,7 +38,7 @@ def _morton(q):
     return _spread3(q[:, 0]) | (_spread3(q[:, 1]) << np.uint64(1)) | (_spread3(q[:, 2]) << np.uint64(2))
 
 
-def cell_patches(positions, patch_size):
+def cell_patches(positions, patch_size, min_patches=256, min_patch_size=192):
     """Cut the vertices into 2^m spatially compact, equally sized patches by recursive coordinate bisection (median
     split along the longest axis of every box), m the smallest depth with ceil(V / 2^m) <= patch_size. Equal sizes keep
     the workgroups of the patch kernel balanced; 2^m >= 256 patches fill the 256 CUs evenly.
@@ -47,6 +47,9 @@ def cell_patches(positions, patch_size):
     V = p.shape[0]
     levels = 0
     while -(-V // (1 << levels)) > patch_size:
+        levels += 1
+    # at least one patch per CU (256) as long as the patches do not become tiny
+    while (1 << levels) < min_patches and V // (1 << (levels + 1)) >= min_patch_size:
         levels += 1
     boxes = [np.arange(V, dtype=np.int64)]
     for _ in range(levels):

@@ -61,10 +61,14 @@ class PCGSolver(Solver):
         of the residual; `last_info['rnorm']` is the true fp32 residual of the returned solution.
     chebyshev_cap : int
         Largest a-priori Chebyshev iteration count (cold start, at `rtol`) for which Chebyshev is preferred to PCG.
+    patch_min_vertices : int
+        From this mesh size on (and for uniform-Laplacian matrices whose vertex positions are known) the Chebyshev
+        steps run in the LDS-resident patch kernel, several iterations per launch (largesteps/patches.py); smaller
+        meshes cannot give every CU a patch worth keeping resident and stay with the one-step kernel.
     """
 
     def __init__(self, M, rtol=1e-6, atol=0.0, max_iter=10000, warm_start=False, chebyshev=False, chebyshev_cap=400,
-                 patch_min_vertices=8192):
+                 patch_min_vertices=400000):
         csr = _native.csr_of(M)
         self._csr = csr                 # keeps rowptr/col/val alive; never M itself (cache eviction relies on it)
         self.rtol, self.atol, self.max_iter, self.warm_start = float(rtol), float(atol), int(max_iter), bool(warm_start)
@@ -110,12 +114,12 @@ class PCGSolver(Solver):
         on = rows == csr.col.long()
         diag[rows[on]] = csr.val[on]
         # LDS budget: 2 buffers x (n_local+1) x 12 B (k = 3) <= 160 KiB -> n_local <= 6800.
-        # LARGESTEPS_PATCH="patch_size,depth,cap_local" overrides the defaults (tuning).
-        ps, depth, cap_local = (int(t) for t in os.environ.get("LARGESTEPS_PATCH", "4489,7,6800").split(","))
+        # LARGESTEPS_PATCH="patch_size,depth,cap_local,min_depth" overrides the defaults (tuning / tests).
+        ps, depth, cap_local, min_depth = (int(t) for t in (os.environ.get("LARGESTEPS_PATCH", "4096,8,6800,4") + ",4").split(",")[:4])
         plan = PatchPlan.build(rowptr, col, diag.cpu().numpy(), csr.positions.cpu().numpy(), patch_size=ps, depth=depth,
                                cap_local=cap_local)
-        if plan is None or plan.max_rows > 8192:
-            return
+        if plan is None or plan.max_rows > 8192 or plan.depth < min_depth:
+            return      # shallow plans (spread-out patches) are not worth the redundant work: keep the one-step kernel
         tab = np.ascontiguousarray(plan.table.reshape(-1))
         perm32 = plan.perm.astype(np.int32)
         as_p = lambda a: a.ctypes.data_as(ctypes.c_void_p)   # noqa: E731

@@ -270,7 +270,7 @@ def test_chebyshev_solver(dev, cot, k):
 
 
 @pytest.mark.parametrize("k", [1, 3, 4])
-@pytest.mark.parametrize("patch_cfg", ["1500,4,6800", "3000,8,6800", "600,3,2000"])
+@pytest.mark.parametrize("patch_cfg", ["1500,4,6800,2", "3000,8,6800,2", "600,3,2000,2"])
 def test_patch_blocked_chebyshev(dev, monkeypatch, patch_cfg, k):
     """LDS-resident s-step kernel (k_patch_cheb) == the one-step kernel == the fp64 oracle."""
     from largesteps.geometry import compute_matrix
@@ -283,7 +283,7 @@ def test_patch_blocked_chebyshev(dev, monkeypatch, patch_cfg, k):
     idx, val = M.indices().cpu().numpy(), M.values().cpu().numpy()
     b = np.random.default_rng(k).standard_normal((v.shape[0], k)).astype(np.float32)
     x64 = osv.from_differential(idx[0], idx[1], val, b)
-    s = PCGSolver(M, rtol=1e-6, chebyshev=True)
+    s = PCGSolver(M, rtol=1e-6, chebyshev=True, patch_min_vertices=1000)
     assert s.patch_plan is not None and s.patch_plan.n_patches >= 4
     x = s.solve(_t(b, dev))
     assert s.last_info["method"] == "chebyshev" and s.last_info["converged"]

@@ -95,5 +95,5 @@ def test_cell_patches_and_refusal():
     rp = np.cumsum(rp)
     d = np.ones(v.shape[0], np.float32)
     assert PatchPlan.build(rp, c, d, v, patch_size=500, depth=4, cap_local=100) is None, "patches that cannot fit are refused"
-    plan = PatchPlan.build(rp, c, d, v, patch_size=500, depth=8, cap_local=900)
-    assert plan is not None and 2 <= plan.depth < 8 and plan.max_local <= 900, "depth is reduced until the patches fit"
+    plan = PatchPlan.build(rp, c, d, v, patch_size=500, depth=8, cap_local=700)
+    assert plan is not None and 2 <= plan.depth < 8 and plan.max_local <= 700, "depth is reduced until the patches fit"
