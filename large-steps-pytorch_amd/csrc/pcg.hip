@@ -511,7 +511,7 @@ __global__ __launch_bounds__(BLOCK) void k_gershgorin(CsrView A, int64_t V, cons
 // redundantly, layer s is read-only); the patch's own vertices never do. Uniform Laplacian only (implicit values):
 // the matrix is the ELL list of LOCAL neighbour ids (uint16), padding -> slot n_local which holds zeros.
 struct PatchCoef { float c1[8]; float c2[8]; int steps; };
-constexpr int PATCH_RPT = 8;     // rows per thread upper bound: a patch may compute at most 8 * PATCH_BS rows
+constexpr int PATCH_RPT_MAX = 8;  // rows per thread upper bound: a patch may compute at most 8 * PATCH_BS rows
 
 // LDS holds one K-float slot per local vertex. (Padding K = 3 to 16-byte slots for single ds_read_b128 gathers was
 // measured: no gain -- the step loop is latency bound, not LDS-issue bound -- and it shrinks the patches that fit.)
@@ -522,7 +522,7 @@ template <> struct LdsVec<2> { typedef float2 T; };
 template <> struct LdsVec<3> { struct T { float x, y, z; }; };
 template <> struct LdsVec<4> { typedef float4 T; };
 
-template <int K, int PATCH_BS>
+template <int K, int PATCH_BS, int PATCH_RPT>
 __global__ __launch_bounds__(PATCH_BS) void k_patch_cheb(const int* __restrict__ table, const int* __restrict__ ghost_gid,
                                                          const unsigned short* __restrict__ cols16, const float* __restrict__ diag,
                                                          const float* __restrict__ b, const float* __restrict__ in_cur,
@@ -547,13 +547,12 @@ __global__ __launch_bounds__(PATCH_BS) void k_patch_cheb(const int* __restrict__
     if (threadIdx.x == 0) { Vec<K> z; for (int q = 0; q < K; ++q) z.v[q] = 0.0f; cur[n_local] = pack(z); oth[n_local] = pack(z); }
     // per-thread rows r = tid + j * BS: right-hand side, diagonal and the (<= 8) local neighbour ids stay in registers
     // for all steps of this launch (two uint16 ids per register); wider rows re-read their ids from L2 every step
-    float bl[PATCH_RPT][K], dl[PATCH_RPT], dd_j[PATCH_RPT];
+    float bl[PATCH_RPT][K], dd_j[PATCH_RPT];
     unsigned nb[PATCH_RPT][4];
     const bool narrow = W <= 8;
 #pragma unroll
     for (int j = 0; j < PATCH_RPT; ++j) {
         const int r = threadIdx.x + j * PATCH_BS;
-        dl[j] = 1.0f;
         dd_j[j] = 1.0f;
 #pragma unroll
         for (int q = 0; q < K; ++q) bl[j][q] = 0.0f;
@@ -565,7 +564,6 @@ __global__ __launch_bounds__(PATCH_BS) void k_patch_cheb(const int* __restrict__
 #pragma unroll
             for (int q = 0; q < K; ++q) bl[j][q] = bv.v[q];
             dd_j[j] = diag[od + r];
-            dl[j] = 1.0f / dd_j[j];
             if (narrow) {
                 const unsigned short* __restrict__ cr = cols16 + oc + r;
 #pragma unroll
@@ -613,7 +611,7 @@ __global__ __launch_bounds__(PATCH_BS) void k_patch_cheb(const int* __restrict__
                 slot_t xpv = oth[r];
                 const float* xc = reinterpret_cast<const float*>(&xcv);
                 float* xp = reinterpret_cast<float*>(&xpv);
-                const float w = c2 * dl[j];             // dl holds 1/diag: c2 D^-1 (b - M x) without a division
+                const float w = c2 / dd_j[j];           // one division per row and step: c2 D^-1 (b - M x)
 #pragma unroll
                 for (int q = 0; q < K; ++q) {
                     const float ax = fmaf(offdiag, sum[q], dd_j[j] * xc[q]);
@@ -744,7 +742,7 @@ struct ls_solver {
     int use_graph = 1;
     // patch plan of the LDS-resident s-step kernel (ls_solver_set_patches)
     struct {
-        int n = 0, depth = 0, cap1 = 0, bs = 512;
+        int n = 0, depth = 0, cap1 = 0, bs = 512, rpt = 8;
         int *table = nullptr, *gid = nullptr, *perm = nullptr;
         unsigned short* cols = nullptr;
         float *diag = nullptr, *bn = nullptr, *it[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1011,12 +1009,13 @@ int solve_impl(ls_solver* s, const float* b, const float* x0, float* x, int k, d
 template <int K>
 void launch_patch(ls_solver* s, const float* in_cur, const float* in_prev, float* out_cur, float* out_prev, const PatchCoef& coef, hipStream_t st) {
     const size_t lds = 2 * (size_t)s->patch.cap1 * PatchSlot<K>::KP * sizeof(float);
-    if (s->patch.bs == 1024)
-        hipLaunchKernelGGL((k_patch_cheb<K, 1024>), dim3(s->patch.n), dim3(1024), lds, st, s->patch.table, s->patch.gid, s->patch.cols,
-                           s->patch.diag, s->patch.bn, in_cur, in_prev, out_cur, out_prev, coef, s->uni_offdiag, s->patch.cap1);
-    else
-        hipLaunchKernelGGL((k_patch_cheb<K, 512>), dim3(s->patch.n), dim3(512), lds, st, s->patch.table, s->patch.gid, s->patch.cols,
-                           s->patch.diag, s->patch.bn, in_cur, in_prev, out_cur, out_prev, coef, s->uni_offdiag, s->patch.cap1);
+#define LS_PATCH_LAUNCH(BS, RPT)                                                                                        \
+    hipLaunchKernelGGL((k_patch_cheb<K, BS, RPT>), dim3(s->patch.n), dim3(BS), lds, st, s->patch.table, s->patch.gid,    \
+                       s->patch.cols, s->patch.diag, s->patch.bn, in_cur, in_prev, out_cur, out_prev, coef, s->uni_offdiag, \
+                       s->patch.cap1)
+    if (s->patch.bs == 1024) { if (s->patch.rpt <= 6) LS_PATCH_LAUNCH(1024, 6); else LS_PATCH_LAUNCH(1024, 8); }
+    else { if (s->patch.rpt <= 6) LS_PATCH_LAUNCH(512, 6); else LS_PATCH_LAUNCH(512, 8); }
+#undef LS_PATCH_LAUNCH
 }
 
 int solve_cheb_patched(ls_solver* s, const float* b, const float* x0, float* x, int k, int n, double theta, double delta,
@@ -1275,7 +1274,7 @@ extern "C" int ls_solver_set_patches(ls_solver* s, const int32_t* h_table, int n
                                      const int32_t* h_perm, int depth, int max_local, int max_rows, void* stream) {
     LS_REQUIRE(s && h_table && h_perm && n_patches > 0 && depth >= 1 && depth <= 8, LS_E_INVALID, "ls_solver_set_patches: bad argument");
     LS_REQUIRE(s->ncols == s->V && s->uni, LS_E_STATE, "ls_solver_set_patches: needs a square system declared uniform (ls_solver_set_uniform)");
-    LS_REQUIRE(max_rows <= 1024 * PATCH_RPT && max_local < 65535, LS_E_INVALID, "ls_solver_set_patches: patch too large (rows %d, local %d)", max_rows, max_local);
+    LS_REQUIRE(max_rows <= 1024 * PATCH_RPT_MAX && max_local < 65535, LS_E_INVALID, "ls_solver_set_patches: patch too large (rows %d, local %d)", max_rows, max_local);
     const size_t lds = 2 * (size_t)(max_local + 1) * sizeof(float);     // per right-hand-side column
     LS_REQUIRE(lds <= 160 * 1024, LS_E_INVALID, "ls_solver_set_patches: %zu bytes of LDS per patch and column exceed 160 KiB", lds);
     if (s->patch.n) return LS_OK;
@@ -1297,18 +1296,27 @@ extern "C" int ls_solver_set_patches(ls_solver* s, const int32_t* h_table, int n
     if ((rc = dev_alloc(s, &s->patch.bn, vk))) return rc;
     for (auto& q : s->patch.it) if ((rc = dev_alloc(s, &q, vk))) return rc;
     // kernels with more than 64 KiB of dynamic LDS need the opt-in
-    (void)hipFuncSetAttribute((const void*)k_patch_cheb<1, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_patch_cheb<1, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_patch_cheb<2, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_patch_cheb<2, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_patch_cheb<3, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_patch_cheb<3, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_patch_cheb<4, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_patch_cheb<4, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_patch_cheb<1, 512, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_patch_cheb<1, 512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_patch_cheb<1, 1024, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_patch_cheb<1, 1024, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_patch_cheb<2, 512, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_patch_cheb<2, 512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_patch_cheb<2, 1024, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_patch_cheb<2, 1024, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_patch_cheb<3, 512, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_patch_cheb<3, 512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_patch_cheb<3, 1024, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_patch_cheb<3, 1024, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_patch_cheb<4, 512, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_patch_cheb<4, 512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_patch_cheb<4, 1024, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_patch_cheb<4, 1024, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError();
     LS_HIP(hipStreamSynchronize(st));     // the host arrays may go away after return
     s->patch.depth = depth;
-    s->patch.bs = max_rows > 512 * PATCH_RPT ? 1024 : 512;
+    s->patch.bs = max_rows > 512 * PATCH_RPT_MAX ? 1024 : 512;
+    s->patch.rpt = div_up(max_rows, s->patch.bs);
     s->patch.cap1 = max_local + 1;
     s->patch.n = n_patches;
     return LS_OK;

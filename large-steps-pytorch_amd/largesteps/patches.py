@@ -42,7 +42,7 @@ def cell_patches(positions, patch_size, min_patches=256, min_patch_size=192):
     """Cut the vertices into 2^m spatially compact, equally sized patches by recursive coordinate bisection (median
     split along the longest axis of every box), m the smallest depth with ceil(V / 2^m) <= patch_size. Equal sizes keep
     the workgroups of the patch kernel balanced; 2^m >= 256 patches fill the 256 CUs evenly.
-    Returns (perm new->old: patch-major, Morton-sorted inside a patch; starts: first new id of every patch, + [V])."""
+    Returns (perm new->old: patch-major, scan-line order inside a patch; starts: first new id of every patch, + [V])."""
     p = np.asarray(positions, dtype=np.float64)
     V = p.shape[0]
     levels = 0
@@ -74,7 +74,15 @@ def cell_patches(positions, patch_size, min_patches=256, min_patch_size=192):
     order, starts = [], [0]
     for bi in np.argsort(ckey, kind="stable"):
         b = boxes[bi]
-        order.append(b[np.argsort(fine[b], kind="stable")])
+        # scan-line order inside the patch (rows along its longest axis, stacked along the second longest): the lanes
+        # of a wavefront then process consecutive vertices of one mesh row and their neighbours are consecutive local
+        # ids too -- stride-1 LDS gathers instead of the bank conflicts a space-filling curve produces
+        q = p[b]
+        e = q.max(axis=0) - q.min(axis=0)
+        a1, a2 = np.argsort(-e)[:2]
+        delta = max(float(np.sqrt(max(e[a1] * e[a2], 1e-300) / max(b.shape[0], 1))), 1e-30)
+        row = np.floor((q[:, a2] - q[:, a2].min()) / delta + 0.5).astype(np.int64)
+        order.append(b[np.lexsort((fine[b], q[:, a1], row))])
         starts.append(starts[-1] + b.shape[0])
     return np.concatenate(order).astype(np.int64), np.asarray(starts, dtype=np.int64)
 
