@@ -101,6 +101,30 @@ def test_face_permutation_and_large_mesh_pattern(dev):
     assert np.array_equal(U.values().cpu().numpy(), val)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_assembly_random_soup(dev, seed):
+    """Arbitrary triangle soups (non-manifold fans, duplicated faces, repeated vertices in a face, unreferenced
+    vertices, high valence): pattern exact, uniform values exact, cot values within the accumulation-order tolerance."""
+    from largesteps.geometry import compute_matrix
+    rng = np.random.default_rng(seed)
+    V = int(rng.integers(5, 400))
+    F = int(rng.integers(1, 4 * V))
+    f = rng.integers(0, max(2, int(V * 0.8)), size=(F, 3)).astype(np.int64)     # the last 20 % stay unreferenced
+    hub = int(rng.integers(0, V))
+    f[: F // 4, 0] = hub                                                        # one very high valence vertex
+    v = rng.standard_normal((V, 3)).astype(np.float32)
+    lam = float(rng.uniform(0.1, 60.0))
+    M = compute_matrix(_t(v, dev), _t(f, dev), lam)
+    r, c, val = ol.compute_matrix(v, f, lam)
+    assert np.array_equal(M.indices().cpu().numpy(), np.stack([r, c]))
+    assert np.array_equal(M.values().cpu().numpy(), val)
+    Mc = compute_matrix(_t(v, dev), _t(f.astype(np.int32), dev), lam, alpha=0.7, cotan=True)
+    r, c, val = ol.compute_matrix(v, f, lam, alpha=0.7, cotan=True)
+    assert np.array_equal(Mc.indices().cpu().numpy(), np.stack([r, c]))
+    scale = max(np.abs(val).max(), 0.7 * np.abs(ol.face_cotangents(v, f)).max())
+    np.testing.assert_allclose(Mc.values().cpu().numpy(), val, rtol=0, atol=2e-5 * scale)
+
+
 def test_assembly_errors(golden, dev):
     from largesteps.geometry import compute_matrix
     e = golden.errors()
