@@ -9,8 +9,11 @@ bench.py -- from_differential solves/sec on the 1M-vertex plane (BASELINE.json m
 One "step" = one from_differential solve  M x = u  (M = I + 50 L_uniform of the 1000x1000 plane, u = M v,
 k = 3 right-hand sides, cold start x0 = 0, stop at ||r|| <= 1e-6 ||b|| per column), inputs resident in HBM.
 N = 1: the public API path (largesteps.parameterize.from_differential -> C ABI -> HIP PCG).
-N > 1: the same mesh cut into N contiguous vertex blocks, one rank per GPU, halo exchange + fused dot-product
-all-reduce over RCCL (largesteps.distributed); strong scaling (total work fixed).
+N > 1 (one rank per GPU, RCCL; largesteps.distributed), strong scaling (total work fixed), two modes (--shard):
+  columns (default): the 3 right-hand-side columns are independent systems -> rank r solves column r on its GPU with
+                     the single-GPU kernels, one all-gather of the solution per solve, nothing per iteration;
+  vertex           : N contiguous vertex blocks, Chebyshev with depth-s ghost layers (a neighbour exchange every s
+                     iterations) -- the mode for meshes that do not fit one GPU; at 1M vertices it cannot beat 1 GPU.
 
 Prints ONE JSON line on rank 0 (contract: see the task description): metric/value/unit/... plus
   "roofline":     HBM roofline of the dominant kernel (K1: SpMV + p.Ap), timed with HIP events on the solve's
@@ -172,6 +175,11 @@ def run_single(args):
         bts["k1"] = bts["iter"] * plan.depth
         patch_note = dict(patches=plan.n_patches, depth=plan.depth, max_local_vertices=plan.max_local,
                           redundancy=plan.redundancy, bytes_moved_per_launch_model=patch_bytes,
+                          hbm_gbs_of_bytes_moved=patch_bytes / (float(k_ms[0]) * 1e-3) / 1e9,
+                          # what bounds the kernel instead: LDS. Per step and computed row: W neighbour slots + own
+                          # cur/prev read, one slot written, 4k bytes each; peak 128 B/clk/CU x 256 CUs x 2.4 GHz
+                          lds_gbs=float((T[:, 2] * (T[:, 4] + 3) * 4 * k).sum()) * plan.depth / (float(k_ms[0]) * 1e-3) / 1e9,
+                          lds_peak_gbs=128 * 256 * 2.4,
                           note="achieved = bytes a one-iteration-per-launch kernel needs for the `depth` iterations of one "
                                "launch / launch time: an EFFECTIVE rate, it can exceed the HBM peak because ghost-layer "
                                "recomputation in LDS replaces HBM traffic")
@@ -238,7 +246,7 @@ def run_distributed(args):
         dist.init_process_group("gloo")
     else:
         dist.init_process_group("nccl", device_id=dev)
-    out = lsd.bench_sharded(args.workload, dev, steps=args.steps, warmup=args.warmup)
+    out = lsd.bench_sharded(args.workload, dev, steps=args.steps, warmup=args.warmup, shard=args.shard)
     if rank == 0:
         bts = algorithmic_bytes(out["V"], out["nnz"], 3, out["iterations"], out["method"])
         ms = out["ms_per_step"]
@@ -247,7 +255,7 @@ def run_distributed(args):
             warmup=args.warmup, ms_per_step=ms, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32",
             data="synthetic",
             config=dict(workload=f"{args.workload}: V={out['V']}, nnz(M)={out['nnz']}, k=3, cold start, rtol=1e-6, "
-                                 f"{world} contiguous vertex blocks", solver=out["solver"], iterations=out["iterations"],
+                                 f"sharded by {out['shard']} over {world} ranks", solver=out["solver"], iterations=out["iterations"],
                         converged=out["converged"], max_abs_err_vs_v=out["err"], halo_vertices=out["halo"], method=out["method"],
                         halo_depth=out["depth"], rows_per_rank=out["rows_per_rank"],
                         solve_bytes=bts["solve"], solve_gbs=bts["solve"] / (ms * 1e-3) / 1e9),
@@ -273,6 +281,8 @@ def main():
     ap.add_argument("--check-every", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pcg", action="store_true", help="time the Jacobi-PCG instead of the default (Chebyshev) solver")
+    ap.add_argument("--shard", default="auto", choices=["auto", "columns", "vertex"],
+                    help="N > 1: right-hand-side columns across ranks (no per-iteration communication) or vertex blocks")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")

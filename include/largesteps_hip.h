@@ -123,9 +123,11 @@ int ls_solver_set_uniform(ls_solver* s, float a, float b, void* stream);
 int ls_solver_spectrum(const ls_solver* s, double* h_lmin, double* h_lmax);
 /* Patch plan of the LDS-resident s-step Chebyshev kernel (host arrays, built by largesteps/patches.py; needs
  * ls_solver_set_uniform first): the vertices are renumbered patch-major (h_perm[new] = old); patch p owns the new ids
- * [table[8p], table[8p] + table[8p+1]); one workgroup keeps both iterates of the patch and of its ghost layers 1..depth
+ * [table[16p], table[16p] + table[16p+1]); one workgroup keeps both iterates of the patch and of its ghost layers 1..depth
  * in LDS and advances `depth` Chebyshev steps per launch, so HBM sees vectors and matrix once per `depth` iterations.
- * table: 8 int32 per patch {own_start, n_own, n_rows, n_local, ell_width, off_gid, off_cols, off_diag}; h_ghost_gid:
+ * table: 16 int32 per patch {own_start, n_own, n_rows, n_local, ell_width, off_gid, off_cols, off_diag, lim[0..7]} with
+ * lim[m] = number of rows in layers <= m (lim[0] = n_own, lim[m >= depth-1] = n_rows): step j of an S-step launch only
+ * recomputes rows < lim[S-1-j], the outer layers are stale by then and never reach an own vertex; h_ghost_gid:
  * new global ids of the local vertices >= n_own; h_cols16: per patch (ell_width, n_rows) uint16 local neighbour ids
  * (padding = n_local); h_diag: per patch the n_rows diagonal entries. SYNC (copies the arrays). */
 int ls_solver_set_patches(ls_solver* s, const int32_t* h_table, int n_patches, const int32_t* h_ghost_gid, int64_t n_gid,

@@ -511,6 +511,7 @@ __global__ __launch_bounds__(BLOCK) void k_gershgorin(CsrView A, int64_t V, cons
 // redundantly, layer s is read-only); the patch's own vertices never do. Uniform Laplacian only (implicit values):
 // the matrix is the ELL list of LOCAL neighbour ids (uint16), padding -> slot n_local which holds zeros.
 struct PatchCoef { float c1[8]; float c2[8]; int steps; };
+constexpr int PATCH_TABLE_COLS = 16;   // 8 header ints + lim[0..7] (largesteps/patches.py)
 constexpr int PATCH_RPT_MAX = 8;  // rows per thread upper bound: a patch may compute at most 8 * PATCH_BS rows
 
 // LDS holds one K-float slot per local vertex. (Padding K = 3 to 16-byte slots for single ds_read_b128 gathers was
@@ -533,8 +534,9 @@ __global__ __launch_bounds__(PATCH_BS) void k_patch_cheb(const int* __restrict__
     extern __shared__ __attribute__((aligned(16))) float smem[];
     slot_t* cur = reinterpret_cast<slot_t*>(smem);
     slot_t* oth = cur + cap1;
-    const int* __restrict__ t = table + (size_t)blockIdx.x * 8;
+    const int* __restrict__ t = table + (size_t)blockIdx.x * PATCH_TABLE_COLS;
     const int own_start = t[0], n_own = t[1], n_rows = t[2], n_local = t[3], W = t[4], og = t[5], oc = t[6], od = t[7];
+    const int* __restrict__ lim = t + 8;   // lim[m] = rows of layers <= m: all that S-1-j remaining steps can still carry to an own vertex
     auto pack = [](const Vec<K>& v) { slot_t o; float* f = reinterpret_cast<float*>(&o);
 #pragma unroll
         for (int q = 0; q < KP; ++q) f[q] = q < K ? v.v[q] : 0.0f;
@@ -578,12 +580,12 @@ __global__ __launch_bounds__(PATCH_BS) void k_patch_cheb(const int* __restrict__
     }
     __syncthreads();
     // one Chebyshev step on this thread's rows; NW = number of neighbour slots actually read (patch-uniform ELL width)
-    auto step_rows = [&](auto nw_tag, float c1, float c2) {
+    auto step_rows = [&](auto nw_tag, float c1, float c2, int rows) {
         constexpr int NW = decltype(nw_tag)::value;
 #pragma unroll
         for (int j = 0; j < PATCH_RPT; ++j) {
             const int r = threadIdx.x + j * PATCH_BS;
-            if (r < n_rows) {
+            if (r < rows) {
                 float sum[K];
 #pragma unroll
                 for (int q = 0; q < K; ++q) sum[q] = 0.0f;
@@ -623,10 +625,11 @@ __global__ __launch_bounds__(PATCH_BS) void k_patch_cheb(const int* __restrict__
     };
     for (int step = 0; step < coef.steps; ++step) {
         const float c1 = coef.c1[step], c2 = coef.c2[step];
-        if (!narrow) step_rows(std::integral_constant<int, 0>(), c1, c2);
-        else if (W <= 6) step_rows(std::integral_constant<int, 6>(), c1, c2);
-        else if (W == 7) step_rows(std::integral_constant<int, 7>(), c1, c2);
-        else step_rows(std::integral_constant<int, 8>(), c1, c2);
+        const int rows = lim[coef.steps - 1 - step];   // shrinking steps: stale outer layers are not recomputed
+        if (!narrow) step_rows(std::integral_constant<int, 0>(), c1, c2, rows);
+        else if (W <= 6) step_rows(std::integral_constant<int, 6>(), c1, c2, rows);
+        else if (W == 7) step_rows(std::integral_constant<int, 7>(), c1, c2, rows);
+        else step_rows(std::integral_constant<int, 8>(), c1, c2, rows);
         __syncthreads();
         slot_t* tmp = cur; cur = oth; oth = tmp;
     }
@@ -1287,7 +1290,7 @@ extern "C" int ls_solver_set_patches(ls_solver* s, const int32_t* h_table, int n
         if (n) LS_HIP(hipMemcpyAsync(*dst, src, n * sizeof(**dst), hipMemcpyHostToDevice, st));
         return LS_OK;
     };
-    if ((rc = up(&s->patch.table, h_table, (size_t)n_patches * 8))) return rc;
+    if ((rc = up(&s->patch.table, h_table, (size_t)n_patches * PATCH_TABLE_COLS))) return rc;
     if ((rc = up(&s->patch.gid, h_ghost_gid, (size_t)n_gid))) return rc;
     if ((rc = up(&s->patch.cols, h_cols16, (size_t)n_cols))) return rc;
     if ((rc = up(&s->patch.diag, h_diag, (size_t)n_diag))) return rc;

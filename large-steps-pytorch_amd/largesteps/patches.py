@@ -17,10 +17,16 @@ Per patch p (all arrays concatenated, offsets in `table`):
     cols16         (W, n_rows) uint16, ELL by columns: local id of the t-th off-diagonal neighbour of row r
                    (padding -> n_local, a zero slot of the LDS buffers)
     diag           (n_rows,) fp32 diagonal entries
+
+Shrinking steps: after step j of a launch the values of layers > s-j are stale and never read again by anything that
+reaches an own vertex, so step j only recomputes rows of layers <= s-j (`lim` in the table): ~half of the ghost rows.
 """
 import numpy as np
 
-TABLE_COLS = 8   # own_start, n_own, n_rows, n_local, W, off_gid, off_cols, off_diag
+MAX_DEPTH = 8
+TABLE_COLS = 16  # own_start, n_own, n_rows, n_local, W, off_gid, off_cols, off_diag | lim[0..7]
+#                  lim[m] = rows of layers <= m (lim[0] = n_own, lim[depth-1] = n_rows): with S steps left in a launch only
+#                  the layers <= S-1 still influence the own vertices, so step j (0-based) of S computes rows < lim[S-1-j]
 
 
 def _spread3(x):
@@ -119,6 +125,8 @@ class PatchPlan:
         V = rowptr.shape[0] - 1
         if V == 0:
             return None
+        if not 1 <= depth <= MAX_DEPTH:
+            raise ValueError(f"patch depth must be in [1, {MAX_DEPTH}]")
         perm, starts = cell_patches(positions, patch_size)
         inv = np.empty(V, dtype=np.int64)
         inv[perm] = np.arange(V)
@@ -175,7 +183,9 @@ class PatchPlan:
             slot = np.arange(c.shape[0]) - np.repeat(np.cumsum(deg) - deg, deg)
             ell[slot, r_of] = lc
             lut[local] = -1
-            tables.append([s0, n_own, n_rows, local.shape[0], W, off_gid, off_cols, off_diag])
+            lims = np.cumsum([n_own] + [l.shape[0] for l in layers[:-1]]).tolist()
+            lims += [n_rows] * (MAX_DEPTH - len(lims))
+            tables.append([s0, n_own, n_rows, local.shape[0], W, off_gid, off_cols, off_diag] + lims)
             gids.append(local[n_own:].astype(np.int32))
             colss.append(ell.reshape(-1))
             diags.append(diag[rows])
@@ -194,17 +204,21 @@ class PatchPlan:
         """One launch: len(c1) <= depth Chebyshev steps on every patch from the global iterates (cur, prev) in the
         NEW numbering; returns the two newest iterates (newest, second newest) on the owned rows."""
         out_cur, out_prev = cur.copy(), prev.copy()
-        for own_start, n_own, n_rows, n_local, W, og, oc, od in self.table:
+        S = len(c1)
+        for row in self.table:
+            own_start, n_own, n_rows, n_local, W, og, oc, od = (int(t) for t in row[:8])
+            lim = row[8:]
             gid = np.concatenate([np.arange(own_start, own_start + n_own), self.ghost_gid[og:og + n_local - n_own]])
             A = np.vstack([cur[gid], np.zeros((1, cur.shape[1]), cur.dtype)])
             B = np.vstack([prev[gid], np.zeros((1, cur.shape[1]), cur.dtype)])
             ell = self.cols16[oc:oc + W * n_rows].reshape(W, n_rows).astype(np.int64)
             d = self.diag[od:od + n_rows][:, None]
             bl = b_new[gid[:n_rows]]
-            for a1, a2 in zip(c1, c2):
-                s = A[ell].sum(axis=0)                         # (n_rows, k) sum of the neighbours
-                ax = d * A[:n_rows] + offdiag * s
-                B[:n_rows] = A[:n_rows] + a1 * (A[:n_rows] - B[:n_rows]) + a2 * (bl - ax) / d
+            for j, (a1, a2) in enumerate(zip(c1, c2)):
+                m = int(lim[S - 1 - j])                        # rows still needed by the own vertices
+                s = A[ell[:, :m]].sum(axis=0)                  # (m, k) sum of the neighbours
+                ax = d[:m] * A[:m] + offdiag * s
+                B[:m] = A[:m] + a1 * (A[:m] - B[:m]) + a2 * (bl[:m] - ax) / d[:m]
                 A, B = B, A
             out_cur[own_start:own_start + n_own] = A[:n_own]
             out_prev[own_start:own_start + n_own] = B[:n_own]

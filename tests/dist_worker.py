@@ -189,6 +189,48 @@ def main():
         torch.cuda.set_device(0)
         ops = HipShardOps(plan, torch.device("cuda:0"), grid=8, block=256)
         b = b.cuda()
+    if a.solver == "cols":
+        # right-hand-side sharding: every rank holds the full b; the local solver is a numpy direct solve (test stand-in
+        # for the single-GPU HIP solver), the collective is the real all-gather
+        from largesteps.distributed import ColumnSharded
+        from oracle import solve as osv
+        V = v.shape[0]
+        direct = osv.DirectSolver(np.repeat(np.arange(V), np.diff(rowptr)), col, val, V)
+        calls = []
+
+        def local(bc):
+            calls.append(bc.shape[1])
+            return torch.from_numpy(direct.solve(bc.numpy().astype(np.float64)).astype(np.float32))
+
+        bt = torch.from_numpy(b_full)
+        if a.ops == "hip":                                   # the product's local solver on cuda:0 (all ranks share it)
+            from largesteps.solvers import CholeskySolver
+            torch.cuda.set_device(0)
+            rows = np.repeat(np.arange(V), np.diff(rowptr))
+            M = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, col])).cuda(), torch.from_numpy(val).cuda(), (V, V)).coalesce()
+            hip_solver = CholeskySolver(M)
+            bt = bt.cuda()
+
+            def local(bc):                                   # noqa: F811
+                calls.append(bc.shape[1])
+                return hip_solver.solve(bc)
+
+        cs = ColumnSharded(local, a.k)
+        x = cs.solve(bt)
+        assert torch.equal(x, cs.solve(bt))
+        x = x.cpu()
+        bt = None
+        assert calls == ([len(cs.columns)] * 2 if cs.columns else [])
+        try:
+            cs.solve(torch.from_numpy(b_full[:, :1].repeat(a.k + 1, axis=1)).to(x.device))
+            raise SystemExit("a wrong column count must raise")
+        except ValueError:
+            pass
+        np.save(os.path.join(a.out, f"x_{a.rank}.npy"), x.numpy())
+        np.save(os.path.join(a.out, f"it_{a.rank}.npy"), np.array(cs.columns + [-1], dtype=np.int64))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if a.solver == "cheb":
         from largesteps.distributed import ShardedChebyshev
         a_min = 1.0 if a.mesh == "plane40" else float(np.float32(1.0 - 0.9))

@@ -89,7 +89,8 @@ def run_world(tmp_path, world, mesh, k=3, ops="numpy", backend="gloo", timeout=3
                 p.kill()
     for r, p in enumerate(procs):
         assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-3000:]}"
-    x = np.concatenate([np.load(os.path.join(tmp_path, f"x_{r}.npy")) for r in range(world)])
+    xs = [np.load(os.path.join(tmp_path, f"x_{r}.npy")) for r in range(world)]
+    x = xs if solver == "cols" else np.concatenate(xs)
     its = [np.load(os.path.join(tmp_path, f"it_{r}.npy")) for r in range(world)]
     return x, its
 
@@ -131,3 +132,17 @@ def test_sharded_chebyshev_gloo(tmp_path, mesh, world, depth):
     x1, its1 = run_world(single, 1, mesh, solver="cheb", depth=1)
     assert int(its1[0][0]) == int(its[0][0]), "the schedule depends on the global spectrum only"
     assert np.abs(x - x1).max() <= 1e-5 * np.abs(x64).max()
+
+
+@pytest.mark.parametrize("world,k", [(2, 3), (3, 3), (4, 3), (2, 1), (3, 5)])
+def test_column_sharded_gloo(tmp_path, world, k):
+    """Right-hand-side sharding: rank r solves the columns c = r (mod min(P, k)), one all-gather returns the full
+    solution to every rank -- also when ranks idle (P > k) or hold several columns (k > P)."""
+    x64 = reference_solution("plane40", k)
+    xs, cols = run_world(tmp_path, world, "plane40", k=k, solver="cols")
+    owned = sorted(int(c) for cl in cols for c in cl[:-1])
+    assert owned == list(range(k)), "every column is solved exactly once"
+    assert sum(1 for cl in cols if len(cl) > 1) == min(world, k)
+    for x in xs:
+        assert x.shape == x64.shape and np.array_equal(x, xs[0])
+        assert np.abs(x - x64).max() <= 2e-6 * np.abs(x64).max()

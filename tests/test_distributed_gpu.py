@@ -34,6 +34,17 @@ def test_sharded_chebyshev_hip(tmp_path, mesh, world, depth):
     assert np.abs(x - x64).max() <= 1e-4 * np.abs(x64).max()
 
 
+@pytest.mark.parametrize("world,k", [(2, 3), (3, 3), (4, 2)])
+def test_column_sharded_hip(tmp_path, world, k):
+    """Right-hand-side sharding with the HIP solver as the local solver (loopback: gloo all-gather staged through the host)."""
+    x64 = reference_solution("plane40", k)
+    xs, cols = run_world(tmp_path, world, "plane40", k=k, ops="hip", timeout=600, solver="cols")
+    assert sorted(int(c) for cl in cols for c in cl[:-1]) == list(range(k))
+    for x in xs:
+        assert np.array_equal(x, xs[0])
+        assert np.abs(x - x64).max() <= 1e-4 * np.abs(x64).max()
+
+
 def test_shard_from_matrix_single_rank():
     """shard_from_matrix with no process group (P = 1) must reproduce from_differential bit for bit."""
     import torch
