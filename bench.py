@@ -178,7 +178,7 @@ def run_single(args):
                           hbm_gbs_of_bytes_moved=patch_bytes / (float(k_ms[0]) * 1e-3) / 1e9,
                           # what bounds the kernel instead: LDS. Per step and computed row: W neighbour slots + own
                           # cur/prev read, one slot written, 4k bytes each; peak 128 B/clk/CU x 256 CUs x 2.4 GHz
-                          lds_gbs=float((T[:, 2] * (T[:, 4] + 3) * 4 * k).sum()) * plan.depth / (float(k_ms[0]) * 1e-3) / 1e9,
+                          lds_gbs=float((T[:, 8:8 + plan.depth].sum(axis=1) * (T[:, 4] + 3) * 4 * k).sum()) / (float(k_ms[0]) * 1e-3) / 1e9,
                           lds_peak_gbs=128 * 256 * 2.4,
                           note="achieved = bytes a one-iteration-per-launch kernel needs for the `depth` iterations of one "
                                "launch / launch time: an EFFECTIVE rate, it can exceed the HBM peak because ghost-layer "

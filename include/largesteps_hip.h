@@ -123,9 +123,10 @@ int ls_solver_set_uniform(ls_solver* s, float a, float b, void* stream);
 int ls_solver_spectrum(const ls_solver* s, double* h_lmin, double* h_lmax);
 /* Patch plan of the LDS-resident s-step Chebyshev kernel (host arrays, built by largesteps/patches.py; needs
  * ls_solver_set_uniform first): the vertices are renumbered patch-major (h_perm[new] = old); patch p owns the new ids
- * [table[16p], table[16p] + table[16p+1]); one workgroup keeps both iterates of the patch and of its ghost layers 1..depth
+ * [table[20p], table[20p] + table[20p+1]); one workgroup keeps both iterates of the patch and of its ghost layers 1..depth
  * in LDS and advances `depth` Chebyshev steps per launch, so HBM sees vectors and matrix once per `depth` iterations.
- * table: 16 int32 per patch {own_start, n_own, n_rows, n_local, ell_width, off_gid, off_cols, off_diag, lim[0..7]} with
+ * table: 20 int32 per patch {own_start, n_own, n_rows, n_local, ell_width, off_gid, off_cols, off_diag, lim[0..11]}
+ * (depth <= 12) with
  * lim[m] = number of rows in layers <= m (lim[0] = n_own, lim[m >= depth-1] = n_rows): step j of an S-step launch only
  * recomputes rows < lim[S-1-j], the outer layers are stale by then and never reach an own vertex; h_ghost_gid:
  * new global ids of the local vertices >= n_own; h_cols16: per patch (ell_width, n_rows) uint16 local neighbour ids

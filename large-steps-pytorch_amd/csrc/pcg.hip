@@ -510,8 +510,9 @@ __global__ __launch_bounds__(BLOCK) void k_gershgorin(CsrView A, int64_t V, cons
 // HBM sees vectors and matrix once per s iterations. Ghost layers go stale one layer per step (they are recomputed
 // redundantly, layer s is read-only); the patch's own vertices never do. Uniform Laplacian only (implicit values):
 // the matrix is the ELL list of LOCAL neighbour ids (uint16), padding -> slot n_local which holds zeros.
-struct PatchCoef { float c1[8]; float c2[8]; int steps; };
-constexpr int PATCH_TABLE_COLS = 16;   // 8 header ints + lim[0..7] (largesteps/patches.py)
+constexpr int PATCH_MAX_DEPTH = 12;     // steps per launch upper bound (= MAX_DEPTH of largesteps/patches.py)
+struct PatchCoef { float c1[PATCH_MAX_DEPTH]; float c2[PATCH_MAX_DEPTH]; int steps; };
+constexpr int PATCH_TABLE_COLS = 8 + PATCH_MAX_DEPTH;   // 8 header ints + lim[] (largesteps/patches.py)
 constexpr int PATCH_RPT_MAX = 8;  // rows per thread upper bound: a patch may compute at most 8 * PATCH_BS rows
 
 // LDS holds one K-float slot per local vertex. (Padding K = 3 to 16-byte slots for single ds_read_b128 gathers was
@@ -1275,7 +1276,7 @@ extern "C" int ls_solver_set_uniform(ls_solver* s, float a, float b, void* strea
 extern "C" int ls_solver_set_patches(ls_solver* s, const int32_t* h_table, int n_patches, const int32_t* h_ghost_gid, int64_t n_gid,
                                      const uint16_t* h_cols16, int64_t n_cols, const float* h_diag, int64_t n_diag,
                                      const int32_t* h_perm, int depth, int max_local, int max_rows, void* stream) {
-    LS_REQUIRE(s && h_table && h_perm && n_patches > 0 && depth >= 1 && depth <= 8, LS_E_INVALID, "ls_solver_set_patches: bad argument");
+    LS_REQUIRE(s && h_table && h_perm && n_patches > 0 && depth >= 1 && depth <= PATCH_MAX_DEPTH, LS_E_INVALID, "ls_solver_set_patches: bad argument");
     LS_REQUIRE(s->ncols == s->V && s->uni, LS_E_STATE, "ls_solver_set_patches: needs a square system declared uniform (ls_solver_set_uniform)");
     LS_REQUIRE(max_rows <= 1024 * PATCH_RPT_MAX && max_local < 65535, LS_E_INVALID, "ls_solver_set_patches: patch too large (rows %d, local %d)", max_rows, max_local);
     const size_t lds = 2 * (size_t)(max_local + 1) * sizeof(float);     // per right-hand-side column

@@ -527,7 +527,8 @@ def bench_sharded(workload, device, steps, warmup, shard="auto"):
     if shard == "auto":
         shard = "columns" if k >= 2 else "vertex"
     if shard == "columns":
-        local = CholeskySolver(M)                                   # the single-GPU default path, on this rank's columns
+        # the single-GPU default path on this rank's columns; fewer columns per rank -> deeper patch plan
+        local = CholeskySolver(M, patch_columns=max(1, min(3, -(-k // min(world, k)))))
         solver = ColumnSharded(lambda bc: local.solve(bc), k)
         u, ref, plan = u_full, tv, None
         pick = lambda x: x                                          # noqa: E731

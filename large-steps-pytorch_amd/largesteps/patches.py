@@ -23,8 +23,8 @@ reaches an own vertex, so step j only recomputes rows of layers <= s-j (`lim` in
 """
 import numpy as np
 
-MAX_DEPTH = 8
-TABLE_COLS = 16  # own_start, n_own, n_rows, n_local, W, off_gid, off_cols, off_diag | lim[0..7]
+MAX_DEPTH = 12
+TABLE_COLS = 8 + MAX_DEPTH  # own_start, n_own, n_rows, n_local, W, off_gid, off_cols, off_diag | lim[0..MAX_DEPTH-1]
 #                  lim[m] = rows of layers <= m (lim[0] = n_own, lim[depth-1] = n_rows): with S steps left in a launch only
 #                  the layers <= S-1 still influence the own vertices, so step j (0-based) of S computes rows < lim[S-1-j]
 
@@ -116,10 +116,11 @@ class PatchPlan:
         return float(self.table[:, 2].sum()) / max(1, int(self.table[:, 1].sum()))
 
     @staticmethod
-    def build(rowptr, col, diag, positions, patch_size=4096, depth=8, cap_local=6500, min_depth=2):
+    def build(rowptr, col, diag, positions, patch_size=4096, depth=8, cap_local=6500, min_depth=2, cap_rows=8192):
         """rowptr/col: CSR pattern of M (diagonal included, old numbering); diag: (V,) diagonal of M; patch_size: upper
         bound of a patch's own vertices. Tries depth, depth-1, ... until every patch's local vertex count fits
-        `cap_local`; returns None if even `min_depth` does not fit (the caller keeps the one-step kernel)."""
+        `cap_local` (LDS) and its computed rows fit `cap_rows` (8 rows per thread of a 1024-thread workgroup); returns None
+        if even `min_depth` does not fit (the caller keeps the one-step kernel)."""
         rowptr = np.asarray(rowptr).astype(np.int64)
         col = np.asarray(col).astype(np.int64)
         V = rowptr.shape[0] - 1
@@ -135,13 +136,13 @@ class PatchPlan:
         ncol = inv[col[pos]]
         ndiag = np.asarray(diag, dtype=np.float32)[perm]
         for d in range(depth, min_depth - 1, -1):
-            plan = PatchPlan._try(V, perm, nrp, ncol, ndiag, starts, patch_size, d, cap_local)
+            plan = PatchPlan._try(V, perm, nrp, ncol, ndiag, starts, patch_size, d, cap_local, cap_rows)
             if plan is not None:
                 return plan
         return None
 
     @staticmethod
-    def _try(V, perm, rowptr, col, diag, starts, patch_size, depth, cap_local):
+    def _try(V, perm, rowptr, col, diag, starts, patch_size, depth, cap_local, cap_rows=8192):
         seen = np.zeros(V, dtype=bool)
         lut = np.full(V + 1, -1, dtype=np.int64)
         tables, gids, colss, diags = [], [], [], []
@@ -168,6 +169,8 @@ class PatchPlan:
             local = touched                                    # [own | L1 | ... | Ls]
             n_own = own.shape[0]
             n_rows = n_own + sum(l.shape[0] for l in layers[:-1])
+            if n_rows > cap_rows:
+                return None
             lut[local] = np.arange(local.shape[0])
             rows = local[:n_rows]
             p, lens = _entries(rowptr, rows)

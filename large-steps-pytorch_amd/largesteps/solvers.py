@@ -65,10 +65,16 @@ class PCGSolver(Solver):
         From this mesh size on (and for uniform-Laplacian matrices whose vertex positions are known) the Chebyshev
         steps run in the LDS-resident patch kernel, several iterations per launch (largesteps/patches.py); smaller
         meshes cannot give every CU a patch worth keeping resident and stay with the one-step kernel.
+    patch_columns : int
+        The largest number of right-hand-side columns the patch kernel has to serve (wider solves use the one-step
+        kernel): fewer columns leave LDS room for larger patches and deeper plans (12 instead of 8 steps per launch).
     """
 
     def __init__(self, M, rtol=1e-6, atol=0.0, max_iter=10000, warm_start=False, chebyshev=False, chebyshev_cap=400,
-                 patch_min_vertices=400000):
+                 patch_min_vertices=400000, patch_columns=3):
+        if not 1 <= int(patch_columns) <= _KMAX:
+            raise ValueError(f"patch_columns must be in [1, {_KMAX}]")
+        self.patch_columns = int(patch_columns)
         csr = _native.csr_of(M)
         self._csr = csr                 # keeps rowptr/col/val alive; never M itself (cache eviction relies on it)
         self.rtol, self.atol, self.max_iter, self.warm_start = float(rtol), float(atol), int(max_iter), bool(warm_start)
@@ -113,9 +119,12 @@ class PCGSolver(Solver):
         diag = torch.zeros(csr.V, dtype=torch.float32, device=dev)
         on = rows == csr.col.long()
         diag[rows[on]] = csr.val[on]
-        # LDS budget: 2 buffers x (n_local+1) x 12 B (k = 3) <= 160 KiB -> n_local <= 6800.
+        # LDS budget: 2 buffers x (n_local+1) x 4k B <= 160 KiB -> n_local <= 6800 for k = 3 columns; a solver that is
+        # only ever asked for k <= 2 columns (largesteps.distributed.ColumnSharded) fits larger patches -> deeper plans.
         # LARGESTEPS_PATCH="patch_size,depth,cap_local,min_depth" overrides the defaults (tuning / tests).
-        ps, depth, cap_local, min_depth = (int(t) for t in (os.environ.get("LARGESTEPS_PATCH", "4096,8,6800,4") + ",4").split(",")[:4])
+        kc = self.patch_columns
+        default = "4096,8,6800,4" if kc >= 3 else f"4096,12,{min(160 * 1024 // (8 * kc) - 16, 60000)},4"
+        ps, depth, cap_local, min_depth = (int(t) for t in (os.environ.get("LARGESTEPS_PATCH", default) + ",4").split(",")[:4])
         plan = PatchPlan.build(rowptr, col, diag.cpu().numpy(), csr.positions.cpu().numpy(), patch_size=ps, depth=depth,
                                cap_local=cap_local)
         if plan is None or plan.max_rows > 8192 or plan.depth < min_depth:
@@ -227,8 +236,9 @@ class CholeskySolver(PCGSolver):
     iteration, no reductions; any other matrix is solved by the Jacobi-PCG.
     """
 
-    def __init__(self, M, rtol=1e-6, max_iter=10000, chebyshev=True):
-        super().__init__(M, rtol=rtol, atol=0.0, max_iter=max_iter, warm_start=False, chebyshev=chebyshev)
+    def __init__(self, M, rtol=1e-6, max_iter=10000, chebyshev=True, patch_columns=3):
+        super().__init__(M, rtol=rtol, atol=0.0, max_iter=max_iter, warm_start=False, chebyshev=chebyshev,
+                         patch_columns=patch_columns)
 
 
 class ConjugateGradientSolver(PCGSolver):

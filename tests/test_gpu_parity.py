@@ -324,6 +324,29 @@ def test_patch_blocked_chebyshev(dev, monkeypatch, patch_cfg, k):
     assert np.abs(x2.cpu().numpy() - x64).max() <= 1e-4 * np.abs(x64).max()
 
 
+@pytest.mark.parametrize("pc", [1, 2])
+def test_patch_columns_deep_plan(dev, monkeypatch, pc):
+    """A solver that only has to serve <= pc columns plans larger patches / more steps per launch (depth up to 12,
+    shrinking steps); wider right-hand sides on the same handle take the one-step kernel."""
+    from largesteps.geometry import compute_matrix
+    from largesteps.solvers import PCGSolver
+    from largesteps import synthetic
+    monkeypatch.delenv("LARGESTEPS_PATCH", raising=False)
+    v, f = synthetic.plane(250)
+    M = compute_matrix(_t(v, dev), _t(f, dev), 40.0)
+    idx, val = M.indices().cpu().numpy(), M.values().cpu().numpy()
+    b = np.random.default_rng(pc).standard_normal((v.shape[0], 3)).astype(np.float32)
+    x64 = osv.from_differential(idx[0], idx[1], val, b)
+    s = PCGSolver(M, rtol=1e-6, chebyshev=True, patch_min_vertices=1000, patch_columns=pc)
+    assert s.patch_plan is not None and s.patch_plan.depth > 8
+    for k in (1, 2, 3):
+        x = s.solve(_t(b[:, :k].copy(), dev))
+        assert s.last_info["method"] == "chebyshev" and s.last_info["converged"]
+        assert np.abs(x.cpu().numpy() - x64[:, :k]).max() <= 1e-4 * np.abs(x64).max()
+    with pytest.raises(ValueError):
+        PCGSolver(M, patch_columns=0)
+
+
 def test_determinism_and_fresh_output(dev):
     from largesteps.geometry import compute_matrix
     from largesteps.parameterize import from_differential, to_differential
