@@ -145,6 +145,8 @@ def run_single(args):
     info = dict(solver.last_info)
     ms = elapsed / args.steps * 1e3
     method = info["method"]
+    if method == "nested-dissection":
+        return report_direct(args, solver, M, u, x, tv, v, f, lam, ms, t_assemble)
 
     # profiled pass right after the timed region, same workload: HIP events on the solve's own stream
     # (chebyshev: two events around the n back-to-back launches; pcg: events around every kernel)
@@ -229,6 +231,64 @@ def run_single(args):
     print(json.dumps(out), flush=True)
 
 
+def report_direct(args, solver, M, u, x, tv, v, f, lam, ms, t_assemble):
+    """JSON line for the factor-once / re-solve direct solver (largesteps.solvers.NestedDissectionSolver)."""
+    from largesteps.parameterize import to_differential
+    V, nnz, k = v.shape[0], M._nnz(), 3
+    plan = solver.plan
+    # profiled pass right after the timed region: HIP events around the up sweep and the down sweep (solve's stream)
+    solver.set_option("profile", 1)
+    n_prof = max(1, min(args.steps, 5))
+    up_ms = down_ms = 0.0
+    for _ in range(n_prof):
+        solver.solve(u)
+        inf = solver.info()
+        up_ms += inf["up_ms"] / n_prof
+        down_ms += inf["down_ms"] / n_prof
+    solver.set_option("profile", 0)
+    lv_s = [int(plan.s[plan.level_nodes(lv)].sum()) for lv in range(plan.D + 1)]
+    n_down = sum(1 for t in lv_s if t)
+    n_up = inf["launches"] - n_down
+    n_bnd = int(plan.b.sum())
+    # algorithmic bytes (fp32 factor: Finv once, W in both sweeps; vectors once per sweep)
+    up_bytes = 4 * plan.w_size + 4 * k * (2 * V + 3 * n_bnd) + 4 * V
+    down_bytes = 4 * (plan.w_size + plan.finv_size) + 4 * k * (2 * V + 3 * n_bnd) + 4 * V
+    solve_bytes = up_bytes + down_bytes
+    r = to_differential(M, x) - u
+    rel_res = [float(a / b) for a, b in zip(r.norm(dim=0).tolist(), u.norm(dim=0).tolist())]
+    down_gbs = down_bytes / (down_ms * 1e-3) / 1e9
+    out = dict(
+        metric="from_differential_solves_per_sec", value=1e3 / ms, unit="solves/s", n_gpus=1, steps=args.steps,
+        warmup=args.warmup, ms_per_step=ms, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32",
+        data="synthetic",
+        config=dict(workload=f"{args.workload}: 1000x1000 plane, V={V}, nnz(M)={nnz}, M=I+{lam:g}*L_uniform, u=M v, k=3, "
+                             f"factor once (not timed), re-solve timed",
+                    solver=(f"HIP nested-dissection multifrontal direct solver: {plan.D + 1} tree levels, fp64 factorisation on "
+                            f"the device (once), fp32 factor {plan.factor_entries / 1e6:.1f} M numbers; re-solve = "
+                            f"{inf['launches']} launches (one per level and sweep), no atomics"),
+                    method="nested-dissection", iterations=0, converged=True, rel_residual=rel_res,
+                    max_abs_err_vs_v=float((x - tv).abs().max()), assemble_ms=t_assemble * 1e3,
+                    factor_seconds=getattr(solver, "build_seconds", None),
+                    solve_bytes=solve_bytes, solve_gbs=solve_bytes / (ms * 1e-3) / 1e9,
+                    solve_frac_of_8tbs=solve_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    kernel_us=dict(up_sweep=up_ms * 1e3, down_sweep=down_ms * 1e3, up_launches=n_up, down_launches=n_down),
+                    device=torch.cuda.get_device_name(0)),
+        roofline=dict(bound="hbm", kernel=f"down sweep: k_nd_down_b<3> / k_nd_down<3>, {n_down} launches (x_s = Finv b'_s - W^T x_bnd per tree level)",
+                      achieved=down_gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=down_gbs / HBM_PEAK_GBS,
+                      frac_of_achievable=down_gbs / HBM_ACHIEVABLE_GBS, bytes_per_launch=down_bytes / n_down,
+                      avg_launch_us=down_ms * 1e3 / n_down, launches_timed=n_down * n_prof,
+                      traffic=pmc_traffic("ls::k_nd_down", args.workload),
+                      note="the sweeps are latency bound, not bandwidth bound: every tree level is one dependent launch "
+                           "(~8 us of launch + memory round trips), only the leaf levels stream enough bytes to matter"),
+    )
+    if not args.no_cpu_baseline:
+        base, _ = cpu_baseline(v, f, lam, u.cpu().numpy())
+        out["cpu_baseline"] = base
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out), flush=True)
+
+
 def run_distributed(args):
     import torch.distributed as dist
     from largesteps import distributed as lsd
@@ -281,9 +341,13 @@ def main():
     ap.add_argument("--check-every", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pcg", action="store_true", help="time the Jacobi-PCG instead of the default (Chebyshev) solver")
+    ap.add_argument("--iterative", action="store_true",
+                    help="'Cholesky' through the Chebyshev-Jacobi iteration instead of the nested-dissection direct solver (A/B)")
     ap.add_argument("--shard", default="auto", choices=["auto", "columns", "vertex"],
                     help="N > 1: right-hand-side columns across ranks (no per-iteration communication) or vertex blocks")
     args = ap.parse_args()
+    if args.iterative:
+        os.environ["LARGESTEPS_NO_DIRECT"] = "1"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
     if args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1:

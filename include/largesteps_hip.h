@@ -23,6 +23,8 @@
  *                        :41-126 (ConjugateGradientSolver); one handle == one cached solver object of
  *                        largesteps/parameterize.py:48-59
  *   ls_solver_phase/...  no reference counterpart: the reference is single process / single GPU
+ *   ls_direct_*          largesteps/solvers.py:36-39 (CholeskySolver.solve: the two triangular solves of the cholespy /
+ *                        CHOLMOD factorisation built at :34) -- re-solve phase of the nested-dissection direct solver
  *   ls_adam_uniform_step largesteps/optimize.py:18-41
  */
 #ifndef LARGESTEPS_HIP_H
@@ -192,6 +194,35 @@ int ls_gather_rows(const float* src, const int32_t* idx, int64_t n, int k, float
  *   g1 = b1 g1 + (1-b1) g ; g2 = b2 g2 + (1-b2) g^2 ; p -= lr * (g1/(1-b1^t)) / (1e-8 + max sqrt(g2/(1-b2^t)))
  * scratch: at least 4096 bytes of device memory owned by the caller.
  * --------------------------------------------------------------------------------------------- */
+/* ---- factor-once / re-solve direct solver (nested dissection, multifrontal; plan: largesteps/nested.py) ---------
+ * The elimination tree is a complete binary tree of `levels` levels in heap numbering (root 1, children 2i, 2i+1);
+ * the vertices are renumbered deepest level first (h_perm[new] = old), node i owns the new ids [own_start, own_start+s)
+ * and has b boundary vertices in its ancestors; h_ppos[bnd_off + i] = position of boundary vertex i in the PARENT's front
+ * [own | boundary] (n_bnd entries in all). Factor arrays (DEVICE, fp32, owned
+ * by the caller and kept alive for the handle's lifetime): d_finv[finv_off + t*s + j] = (F_ss^-1)[t][j];
+ * W = F_bs F_ss^-1 twice: d_wf[w_off + j*b + i] and d_wb[w_off + i*s + j] = W[i][j].
+ * h_nodes: (2^levels, 8) int64, row i = {s, b, own_start, bnd_off, front_off, finv_off, w_off, 0} (row 0 unused).
+ * h_map0 / h_map1: for every front position p of node i (h_map[front_off + p], p < s + b): index of that vertex in
+ * the boundary list of child 2i / 2i+1, or -1.
+ * One solve = one launch per level upwards
+ *     b'_s = b_s - (children's updates at own_i);   upd_i = W_i b'_s + (children's updates at bnd_i)
+ * (children push into two slots per parent front position), one launch per level downwards
+ *     x_s = F_ss^-1 b'_s - W_i^T x[bnd_i]          (parents push x into the children's boundary vectors);
+ * b is read and x written in the caller's numbering. No atomics: bitwise reproducible.
+ * ls_direct_create is SYNC (copies the host tables). */
+typedef struct ls_direct ls_direct;
+int ls_direct_create(int64_t V, int levels, const int64_t* h_nodes, const int32_t* h_perm, const int32_t* h_ppos,
+                     int64_t n_bnd, const int32_t* h_map0, const int32_t* h_map1, int64_t n_front, const float* d_finv,
+                     const float* d_wf, const float* d_wb, int device, void* stream, ls_direct** out);
+int ls_direct_destroy(ls_direct* d);
+/* x = M^-1 b for k <= 4 interleaved columns ((V, k) row-major, b != x) */
+int ls_direct_solve(ls_direct* d, const float* b, float* x, int k, void* stream);
+/* knobs: "profile" (1: the next solves time up sweep / down sweep / permutations with HIP events and synchronise) */
+int ls_direct_set(ls_direct* d, const char* name, int value);
+/* host-only: fp32 factor numbers one solve reads, kernel launches per solve, {up, down, permutations} ms of the last
+ * profiled solve (any pointer may be NULL) */
+int ls_direct_info(const ls_direct* d, int64_t* h_factor_entries, int* h_launches, double* h_ms3);
+
 int ls_adam_uniform_step(float* param, const float* grad, float* g1, float* g2, int64_t n, float lr,
                          float beta1, float beta2, int step, void* scratch, int device, void* stream);
 

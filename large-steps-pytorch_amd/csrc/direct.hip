@@ -1,0 +1,675 @@
+// direct.hip -- re-solve phase of the nested-dissection multifrontal direct solver (gfx950, wave64).
+//
+// Replaces the two sparse triangular solves of the reference's default method (largesteps/solvers.py:36-39,
+// cholespy/CHOLMOD `solver.solve(b, x)`). Plan and notation: largesteps/nested.py. The factor arrays (fp32) are
+// produced once per matrix by largesteps/direct.py and stay resident in HBM:
+//     Finv_i = F_ss^-1 (s x s, symmetric),  W_i = F_bs F_ss^-1 stored twice: wf[j*b + i] (up sweep, lanes = boundary
+//     rows i) and wb[i*s + j] (down sweep, lanes = own rows j) -- both sweeps read 512-byte coalesced wave rows.
+// One launch per tree level and sweep; a workgroup = 64 rows x NW waves that split the reduction range and meet in
+// LDS. The up sweep PULLS the children's updates through index maps (no atomics: bitwise reproducible).
+#include "common.h"
+#include <vector>
+#include <algorithm>
+#include <string.h>
+
+namespace ls {
+
+struct NodeDesc { int s, b, own_start, bnd_off, front_off, pad; long long finv_off, w_off; };
+
+// one workgroup's job: 64 rows (from row0) of one node; everything the kernels need in one 64-byte record
+struct alignas(64) Tile {
+    int node, row0, s, b, own_start, bnd_off, front_off;
+    int c0_off, c1_off;        // children's bnd_off, -1 = leaf
+    int pfront_off, parity;    // parent's front_off (-1 = root) and which child of it this node is
+    int forward;               // down sweep: 1 = rows are boundary rows that only hand x down to the children
+    long long finv_off, w_off;
+};
+
+constexpr int ND_UNROLL = 8;   // independent matrix loads in flight per lane
+
+// acc += sum_{u in [u0, u1)} col[u * stride] * sv[u * K + q]; the first ND_UNROLL values were prefetched
+template <int K>
+__device__ __forceinline__ void dot_strided(const float* __restrict__ col, size_t stride, int u0, int u1,
+                                            const float* __restrict__ sv, const float (&pre)[ND_UNROLL], float (&acc)[K]) {
+#pragma unroll
+    for (int e = 0; e < ND_UNROLL; ++e) {
+        if (u0 + e < u1) {
+#pragma unroll
+            for (int q = 0; q < K; ++q) acc[q] = fmaf(pre[e], sv[(u0 + e) * K + q], acc[q]);
+        }
+    }
+    int u = u0 + ND_UNROLL;
+    for (; u + ND_UNROLL <= u1; u += ND_UNROLL) {
+        float a[ND_UNROLL];
+#pragma unroll
+        for (int e = 0; e < ND_UNROLL; ++e) a[e] = col[(size_t)(u + e) * stride];
+#pragma unroll
+        for (int e = 0; e < ND_UNROLL; ++e) {
+#pragma unroll
+            for (int q = 0; q < K; ++q) acc[q] = fmaf(a[e], sv[(u + e) * K + q], acc[q]);
+        }
+    }
+    for (; u < u1; ++u) {
+        const float a = col[(size_t)u * stride];
+#pragma unroll
+        for (int q = 0; q < K; ++q) acc[q] = fmaf(a, sv[u * K + q], acc[q]);
+    }
+}
+
+__device__ __forceinline__ void prefetch_strided(const float* __restrict__ col, size_t stride, int u0, int u1, float (&pre)[ND_UNROLL]) {
+#pragma unroll
+    for (int e = 0; e < ND_UNROLL; ++e) pre[e] = (u0 + e < u1) ? col[(size_t)(u0 + e) * stride] : 0.0f;
+}
+
+// sum of acc over the NW waves of the workgroup, result in wave 0 (red: (NW-1) * 64 * K floats)
+template <int K>
+__device__ __forceinline__ void reduce_waves(float (&acc)[K], float* __restrict__ red) {
+    const int nw = blockDim.x >> 6, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (nw == 1) return;
+    if (w) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) red[((w - 1) * 64 + lane) * K + q] = acc[q];
+    }
+    __syncthreads();
+    if (w == 0) {
+        for (int o = 0; o < nw - 1; ++o) {
+#pragma unroll
+            for (int q = 0; q < K; ++q) acc[q] += red[(o * 64 + lane) * K + q];
+        }
+    }
+}
+
+// Up sweep, one tree level. Every front position p of a node has two input slots, slots[(front_off + p) * 2 + c],
+// into which child c PUSHED its update for that vertex (valid iff map_c[front_off + p] >= 0): the parent reads them
+// with one contiguous load -- no index indirection on the critical path, no atomics, no zero fill.
+//   b'_s = b_s - (slots at own_i)  [stored for the down sweep];   upd_i = W_i b'_s + (slots at bnd_i) -> parent's slots
+template <int K>
+__global__ __launch_bounds__(1024) void k_nd_up(const Tile* __restrict__ tiles, const int* __restrict__ perm,
+                                                const int* __restrict__ map0, const int* __restrict__ map1,
+                                                const int* __restrict__ ppos, const float* __restrict__ wf,
+                                                const float* __restrict__ b_in, float* __restrict__ bprime,
+                                                float* slots, int s_cap) {   // slots: own front read, parent's front written
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* sb = sm;
+    float* red = sm + (size_t)s_cap * K;
+    const Tile t = tiles[blockIdx.x];
+    const int nw = blockDim.x >> 6, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = t.row0 + lane, s = t.s, b = t.b;
+    const int chunk = (s + nw - 1) / nw, j0 = min(s, w * chunk), j1 = min(s, j0 + chunk);
+    const bool has_children = t.c0_off >= 0;
+    const bool row = i < b;
+    // everything that does not depend on this level's arithmetic is requested up front
+    const float* __restrict__ col = wf + t.w_off + (row ? i : 0);
+    float pre[ND_UNROLL];
+    prefetch_strided(col, (size_t)b, j0, row ? j1 : j0, pre);
+    int pp = 0;
+    float pass[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) pass[q] = 0.0f;
+    if (w == 0 && row) {
+        pp = ppos[t.bnd_off + i];
+        if (has_children) {
+            const size_t f = (size_t)(t.front_off + s + i);
+            const int m0 = map0[f], m1 = map1[f];
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                const float a0 = slots[(f * 2 + 0) * K + q], a1 = slots[(f * 2 + 1) * K + q];
+                pass[q] = (m0 >= 0 ? a0 : 0.0f) + (m1 >= 0 ? a1 : 0.0f);
+            }
+        }
+    }
+    for (int j = threadIdx.x; j < s; j += blockDim.x) {
+        float v[K];
+        const size_t g = (size_t)perm[t.own_start + j];
+#pragma unroll
+        for (int q = 0; q < K; ++q) v[q] = b_in[g * K + q];
+        if (has_children) {
+            const size_t f = (size_t)(t.front_off + j);
+            const int m0 = map0[f], m1 = map1[f];
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                const float a0 = slots[(f * 2 + 0) * K + q], a1 = slots[(f * 2 + 1) * K + q];
+                v[q] -= (m0 >= 0 ? a0 : 0.0f) + (m1 >= 0 ? a1 : 0.0f);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < K; ++q) sb[j * K + q] = v[q];
+        if (t.row0 == 0) {
+#pragma unroll
+            for (int q = 0; q < K; ++q) bprime[(size_t)(t.own_start + j) * K + q] = v[q];
+        }
+    }
+    __syncthreads();
+    float acc[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) acc[q] = 0.0f;
+    if (row) dot_strided<K>(col, (size_t)b, j0, j1, sb, pre, acc);
+    reduce_waves<K>(acc, red);
+    if (w == 0 && row) {
+        const size_t dst = ((size_t)(t.pfront_off + pp) * 2 + t.parity) * K;
+#pragma unroll
+        for (int q = 0; q < K; ++q) slots[dst + q] = acc[q] + pass[q];
+    }
+}
+
+// Down sweep, one tree level: x_s = Finv_i b'_s - W_i^T xb_i, where xb_i (x at the boundary vertices) was PUSHED by
+// the parent; every front position then hands its x to the children's xb (map0 / map1). Forward tiles only do that
+// for the boundary rows. x leaves in the caller's numbering.
+template <int K>
+__global__ __launch_bounds__(1024) void k_nd_down(const Tile* __restrict__ tiles, const int* __restrict__ perm,
+                                                  const int* __restrict__ map0, const int* __restrict__ map1,
+                                                  const float* __restrict__ finv, const float* __restrict__ wb,
+                                                  const float* __restrict__ bprime, float* xb, float* __restrict__ x_out,
+                                                  int s_cap, int b_cap) {   // xb: own rows read, children's rows written
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* sb = sm;
+    float* sx = sm + (size_t)s_cap * K;
+    float* red = sx + (size_t)b_cap * K;
+    const Tile t = tiles[blockIdx.x];
+    const int nw = blockDim.x >> 6, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int s = t.s, b = t.b, L = s + b;
+    const bool has_children = t.c0_off >= 0;
+    if (t.forward) {                       // boundary rows: xb_i -> children
+        const int i = t.row0 + threadIdx.x;
+        if (i < b) {
+            const size_t f = (size_t)(t.front_off + s + i);
+            const int m0 = map0[f], m1 = map1[f];
+            float v[K];
+#pragma unroll
+            for (int q = 0; q < K; ++q) v[q] = xb[(size_t)(t.bnd_off + i) * K + q];
+            if (m0 >= 0) {
+#pragma unroll
+                for (int q = 0; q < K; ++q) xb[(size_t)(t.c0_off + m0) * K + q] = v[q];
+            }
+            if (m1 >= 0) {
+#pragma unroll
+                for (int q = 0; q < K; ++q) xb[(size_t)(t.c1_off + m1) * K + q] = v[q];
+            }
+        }
+        return;
+    }
+    const int j = t.row0 + lane;
+    const bool row = j < s;
+    const int chunk = (L + nw - 1) / nw, t0 = min(L, w * chunk), t1 = min(L, t0 + chunk);
+    const float* __restrict__ fcol = finv + t.finv_off + (row ? j : 0);
+    const float* __restrict__ wcol = wb + t.w_off + (row ? j : 0);
+    const int f0 = min(t0, s), f1 = min(t1, s), g0 = max(t0, s) - s, g1 = max(t1, s) - s;   // Finv part, W part
+    float pre_f[ND_UNROLL], pre_w[ND_UNROLL];
+    prefetch_strided(fcol, (size_t)s, f0, row ? f1 : f0, pre_f);
+    prefetch_strided(wcol, (size_t)s, g0, row ? g1 : g0, pre_w);
+    int m0 = -1, m1 = -1;
+    size_t g = 0;
+    if (w == 0 && row) {
+        g = (size_t)perm[t.own_start + j];
+        if (has_children) { m0 = map0[t.front_off + j]; m1 = map1[t.front_off + j]; }
+    }
+    for (int u = threadIdx.x; u < s; u += blockDim.x) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) sb[u * K + q] = bprime[(size_t)(t.own_start + u) * K + q];
+    }
+    for (int i = threadIdx.x; i < b; i += blockDim.x) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) sx[i * K + q] = -xb[(size_t)(t.bnd_off + i) * K + q];
+    }
+    __syncthreads();
+    float acc[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) acc[q] = 0.0f;
+    if (row) {
+        dot_strided<K>(fcol, (size_t)s, f0, f1, sb, pre_f, acc);
+        dot_strided<K>(wcol, (size_t)s, g0, g1, sx, pre_w, acc);
+    }
+    reduce_waves<K>(acc, red);
+    if (w == 0 && row) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) x_out[g * K + q] = acc[q];
+        if (m0 >= 0) {
+#pragma unroll
+            for (int q = 0; q < K; ++q) xb[(size_t)(t.c0_off + m0) * K + q] = acc[q];
+        }
+        if (m1 >= 0) {
+#pragma unroll
+            for (int q = 0; q < K; ++q) xb[(size_t)(t.c1_off + m1) * K + q] = acc[q];
+        }
+    }
+}
+
+// ---- long reductions (the upper tree levels): lanes run ALONG the reduction, one wave per output row -----------
+// The row-per-lane kernels above walk the reduction sequentially (steps / ND_UNROLL dependent memory round trips per
+// wave); with a whole row spread over the 64 lanes every load of a row is independent and 256 B contiguous, a wave keeps
+// ND_ROWS rows in flight and finishes with a DPP butterfly. up reads W row-major (wb), down reads Finv rows and W columns (wf).
+constexpr int ND_ROWS = 4;     // rows a wave processes together
+constexpr int ND_BW = 4;       // waves per workgroup of the *_b kernels -> ND_ROWS * ND_BW rows per tile
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_sum_step(float v) {
+    const int m = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __int_as_float(m);
+}
+// sum over the 64 lanes, valid in lane 63 (fixed order: bitwise reproducible)
+__device__ __forceinline__ float wave_sum63(float v) {
+    v = dpp_sum_step<0xB1, 0xf>(v);
+    v = dpp_sum_step<0x4E, 0xf>(v);
+    v = dpp_sum_step<0x141, 0xf>(v);
+    v = dpp_sum_step<0x140, 0xf>(v);
+    v = dpp_sum_step<0x142, 0xa>(v);
+    v = dpp_sum_step<0x143, 0xc>(v);
+    return v;
+}
+
+// acc[r][q] += sum_t row_r[t] * sv[t*K+q] for the wave's ND_ROWS rows (row r at base + r * stride_rows), t = lane, lane+64, ...
+template <int K>
+__device__ __forceinline__ void dot_rows(const float* __restrict__ base, size_t stride_rows, int nrows, int len,
+                                         const float* __restrict__ sv, float (&acc)[ND_ROWS][K]) {
+    const int lane = threadIdx.x & 63;
+    for (int t0 = 0; t0 < len; t0 += 64 * 4) {
+        float a[ND_ROWS][4];
+#pragma unroll
+        for (int r = 0; r < ND_ROWS; ++r) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int t = t0 + e * 64 + lane;
+                a[r][e] = (r < nrows && t < len) ? base[(size_t)r * stride_rows + t] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int t = t0 + e * 64 + lane;
+            if (t < len) {
+                float v[K];
+#pragma unroll
+                for (int q = 0; q < K; ++q) v[q] = sv[t * K + q];
+#pragma unroll
+                for (int r = 0; r < ND_ROWS; ++r) {
+#pragma unroll
+                    for (int q = 0; q < K; ++q) acc[r][q] = fmaf(a[r][e], v[q], acc[r][q]);
+                }
+            }
+        }
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(64 * ND_BW) void k_nd_up_b(const Tile* __restrict__ tiles, const int* __restrict__ perm,
+                                                        const int* __restrict__ map0, const int* __restrict__ map1,
+                                                        const int* __restrict__ ppos, const float* __restrict__ wb,
+                                                        const float* __restrict__ b_in, float* __restrict__ bprime,
+                                                        float* slots, int s_cap) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* sb = sm;
+    const Tile t = tiles[blockIdx.x];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int s = t.s, b = t.b;
+    const bool has_children = t.c0_off >= 0;
+    const int i0 = t.row0 + w * ND_ROWS;                       // this wave's rows i0 .. i0 + ND_ROWS
+    const int nrows = max(0, min(ND_ROWS, b - i0));
+    // per-row epilogue data (lane r of the wave serves row i0 + r), requested before anything else
+    int pp = 0;
+    float pass[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) pass[q] = 0.0f;
+    if (lane < nrows) {
+        const int i = i0 + lane;
+        pp = ppos[t.bnd_off + i];
+        if (has_children) {
+            const size_t f = (size_t)(t.front_off + s + i);
+            const int m0 = map0[f], m1 = map1[f];
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                const float a0 = slots[(f * 2 + 0) * K + q], a1 = slots[(f * 2 + 1) * K + q];
+                pass[q] = (m0 >= 0 ? a0 : 0.0f) + (m1 >= 0 ? a1 : 0.0f);
+            }
+        }
+    }
+    for (int j = threadIdx.x; j < s; j += blockDim.x) {
+        float v[K];
+        const size_t g = (size_t)perm[t.own_start + j];
+#pragma unroll
+        for (int q = 0; q < K; ++q) v[q] = b_in[g * K + q];
+        if (has_children) {
+            const size_t f = (size_t)(t.front_off + j);
+            const int m0 = map0[f], m1 = map1[f];
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                const float a0 = slots[(f * 2 + 0) * K + q], a1 = slots[(f * 2 + 1) * K + q];
+                v[q] -= (m0 >= 0 ? a0 : 0.0f) + (m1 >= 0 ? a1 : 0.0f);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < K; ++q) sb[j * K + q] = v[q];
+        if (t.row0 == 0) {
+#pragma unroll
+            for (int q = 0; q < K; ++q) bprime[(size_t)(t.own_start + j) * K + q] = v[q];
+        }
+    }
+    __syncthreads();
+    float acc[ND_ROWS][K];
+#pragma unroll
+    for (int r = 0; r < ND_ROWS; ++r) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) acc[r][q] = 0.0f;
+    }
+    if (nrows > 0) dot_rows<K>(wb + t.w_off + (size_t)i0 * s, (size_t)s, nrows, s, sb, acc);
+    float mine[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) mine[q] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < ND_ROWS; ++r) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            const float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum63(acc[r][q])), 63));
+            if (lane == r) mine[q] = tot;
+        }
+    }
+    if (lane < nrows) {
+        const size_t dst = ((size_t)(t.pfront_off + pp) * 2 + t.parity) * K;
+#pragma unroll
+        for (int q = 0; q < K; ++q) slots[dst + q] = mine[q] + pass[q];
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(64 * ND_BW) void k_nd_down_b(const Tile* __restrict__ tiles, const int* __restrict__ perm,
+                                                          const int* __restrict__ map0, const int* __restrict__ map1,
+                                                          const float* __restrict__ finv, const float* __restrict__ wf,
+                                                          const float* __restrict__ bprime, float* xb, float* __restrict__ x_out,
+                                                          int s_cap, int b_cap) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* sb = sm;
+    float* sx = sm + (size_t)s_cap * K;
+    const Tile t = tiles[blockIdx.x];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int s = t.s, b = t.b;
+    const bool has_children = t.c0_off >= 0;
+    if (t.forward) {                       // boundary rows: xb_i -> children
+        const int i = t.row0 + threadIdx.x;
+        if (i < b) {
+            const size_t f = (size_t)(t.front_off + s + i);
+            const int m0 = map0[f], m1 = map1[f];
+            float v[K];
+#pragma unroll
+            for (int q = 0; q < K; ++q) v[q] = xb[(size_t)(t.bnd_off + i) * K + q];
+            if (m0 >= 0) {
+#pragma unroll
+                for (int q = 0; q < K; ++q) xb[(size_t)(t.c0_off + m0) * K + q] = v[q];
+            }
+            if (m1 >= 0) {
+#pragma unroll
+                for (int q = 0; q < K; ++q) xb[(size_t)(t.c1_off + m1) * K + q] = v[q];
+            }
+        }
+        return;
+    }
+    const int j0 = t.row0 + w * ND_ROWS;
+    const int nrows = max(0, min(ND_ROWS, s - j0));
+    int m0 = -1, m1 = -1;
+    size_t g = 0;
+    if (lane < nrows) {
+        g = (size_t)perm[t.own_start + j0 + lane];
+        if (has_children) { m0 = map0[t.front_off + j0 + lane]; m1 = map1[t.front_off + j0 + lane]; }
+    }
+    for (int u = threadIdx.x; u < s; u += blockDim.x) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) sb[u * K + q] = bprime[(size_t)(t.own_start + u) * K + q];
+    }
+    for (int i = threadIdx.x; i < b; i += blockDim.x) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) sx[i * K + q] = -xb[(size_t)(t.bnd_off + i) * K + q];
+    }
+    __syncthreads();
+    float acc[ND_ROWS][K];
+#pragma unroll
+    for (int r = 0; r < ND_ROWS; ++r) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) acc[r][q] = 0.0f;
+    }
+    if (nrows > 0) {
+        dot_rows<K>(finv + t.finv_off + (size_t)j0 * s, (size_t)s, nrows, s, sb, acc);
+        dot_rows<K>(wf + t.w_off + (size_t)j0 * b, (size_t)b, nrows, b, sx, acc);
+    }
+    float mine[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) mine[q] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < ND_ROWS; ++r) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            const float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum63(acc[r][q])), 63));
+            if (lane == r) mine[q] = tot;
+        }
+    }
+    if (lane < nrows) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) x_out[g * K + q] = mine[q];
+        if (m0 >= 0) {
+#pragma unroll
+            for (int q = 0; q < K; ++q) xb[(size_t)(t.c0_off + m0) * K + q] = mine[q];
+        }
+        if (m1 >= 0) {
+#pragma unroll
+            for (int q = 0; q < K; ++q) xb[(size_t)(t.c1_off + m1) * K + q] = mine[q];
+        }
+    }
+}
+
+struct LevelPlan { int up_first = 0, up_tiles = 0, up_nw = 1, down_first = 0, down_tiles = 0, down_nw = 1, s_cap = 0, b_cap = 0, up_b = 0, down_b = 0; };   // down tiles: compute tiles, then forward tiles
+
+}  // namespace ls
+
+using namespace ls;
+
+struct ls_direct {
+    int device = 0, levels = 0, n_nodes = 0, kmax = 4;
+    int64_t V = 0, n_bnd = 0, n_front = 0;
+    int *perm = nullptr, *ppos = nullptr, *map0 = nullptr, *map1 = nullptr;
+    Tile* tiles = nullptr;
+    const float *finv = nullptr, *wf = nullptr, *wb = nullptr;   // owned by the caller
+    float *bp = nullptr, *slots = nullptr, *xb = nullptr;        // b' (V, k); up-sweep slots (n_front, 2, k); x at boundaries (n_bnd, k)
+    std::vector<LevelPlan> plan;
+    int64_t factor_entries = 0;
+    int profile = 0;
+    std::vector<hipEvent_t> ev;
+    double prof_ms[3] = {0, 0, 0};     // up sweep, down sweep, 0 (last profiled solve)
+};
+
+// waves per workgroup: about `target` reduction steps per wave where 16 waves allow it (LS_ND_STEPS overrides: tuning)
+static int pick_nw(int len) {
+    static const int target = [] { const char* e = getenv("LS_ND_STEPS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 64; }();
+    int nw = 1;
+    while (nw < 16 && len > nw * target) nw *= 2;
+    return nw;
+}
+
+extern "C" int ls_direct_create(int64_t V, int levels, const int64_t* h_nodes, const int32_t* h_perm, const int32_t* h_ppos,
+                                int64_t n_bnd, const int32_t* h_map0, const int32_t* h_map1, int64_t n_front,
+                                const float* d_finv, const float* d_wf, const float* d_wb, int device, void* stream,
+                                ls_direct** out) {
+    LS_REQUIRE(out && h_nodes && h_perm && V > 0 && levels >= 1 && levels <= 30 && n_bnd >= 0 && n_front >= V, LS_E_INVALID,
+               "ls_direct_create: bad argument");
+    LS_REQUIRE(V < INT32_MAX && n_bnd < INT32_MAX && 2 * n_front < INT32_MAX, LS_E_OVERFLOW, "ls_direct_create: plan exceeds int32 offsets");
+    *out = nullptr;
+    DeviceGuard g(device);
+    LS_HIP(g.err);
+    hipStream_t st = (hipStream_t)stream;
+    ls_direct* d = new ls_direct();
+    d->device = device; d->levels = levels; d->n_nodes = (1 << levels) - 1; d->V = V; d->n_bnd = n_bnd; d->n_front = n_front;
+    d->finv = d_finv; d->wf = d_wf; d->wb = d_wb;
+    std::vector<NodeDesc> nodes((size_t)d->n_nodes + 1);
+    int64_t fe = 0;
+    for (int i = 1; i <= d->n_nodes; ++i) {
+        const int64_t* r = h_nodes + (size_t)i * 8;
+        NodeDesc& n = nodes[i];
+        n.s = (int)r[0]; n.b = (int)r[1]; n.own_start = (int)r[2]; n.bnd_off = (int)r[3]; n.front_off = (int)r[4]; n.pad = 0;
+        n.finv_off = r[5]; n.w_off = r[6];
+        if (n.s < 0 || n.b < 0 || n.own_start < 0 || (int64_t)n.own_start + n.s > V || (int64_t)n.bnd_off + n.b > n_bnd ||
+            (int64_t)n.front_off + n.s + n.b > n_front || (i == 1 && n.b != 0)) {
+            delete d;
+            set_error("ls_direct_create: node %d of the plan is inconsistent", i);
+            return LS_E_INVALID;
+        }
+        fe += (int64_t)n.s * n.s + 2 * (int64_t)n.s * n.b;
+    }
+    d->factor_entries = fe;
+    // tiles: 64 rows of one node each; NW waves per workgroup split the reduction range
+    std::vector<Tile> tiles;
+    auto tile_of = [&](int i, int r, int lv, int forward) {
+        const NodeDesc& n = nodes[i];
+        Tile t;
+        t.node = i; t.row0 = r; t.s = n.s; t.b = n.b; t.own_start = n.own_start; t.bnd_off = n.bnd_off; t.front_off = n.front_off;
+        t.c0_off = lv + 1 < levels ? nodes[2 * i].bnd_off : -1;
+        t.c1_off = lv + 1 < levels ? nodes[2 * i + 1].bnd_off : -1;
+        t.pfront_off = i > 1 ? nodes[i >> 1].front_off : -1;
+        t.parity = i & 1;
+        t.forward = forward; t.finv_off = n.finv_off; t.w_off = n.w_off;
+        return t;
+    };
+    d->plan.resize(levels);
+    size_t lds_max = 0;
+    for (int lv = 0; lv < levels; ++lv) {
+        LevelPlan& p = d->plan[lv];
+        int red_up = 0, red_down = 0;
+        for (int i = 1 << lv; i < (2 << lv); ++i) {
+            p.s_cap = std::max(p.s_cap, nodes[i].s); p.b_cap = std::max(p.b_cap, nodes[i].b);
+            red_up = std::max(red_up, nodes[i].s); red_down = std::max(red_down, nodes[i].s + nodes[i].b);
+        }
+        // long reductions: lanes along the reduction (k_nd_*_b), ND_ROWS * ND_BW rows per tile; short: a row per lane
+        static const int long_red = [] { const char* e = getenv("LS_ND_LONG"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 160; }();
+        p.up_b = red_up >= long_red; p.down_b = red_down >= long_red;
+        p.up_nw = p.up_b ? ND_BW : pick_nw(red_up); p.down_nw = p.down_b ? ND_BW : pick_nw(red_down);
+        const int up_rows = p.up_b ? ND_ROWS * ND_BW : WAVE, down_rows = p.down_b ? ND_ROWS * ND_BW : WAVE;
+        p.up_first = (int)tiles.size();
+        for (int i = 1 << lv; i < (2 << lv); ++i) {
+            // a node without own vertices still passes its children's updates on; a node without boundary still stores b'
+            const int rows = std::max(nodes[i].b, nodes[i].s ? 1 : 0);
+            for (int r = 0; r < rows; r += up_rows) tiles.push_back(tile_of(i, r, lv, 0));
+        }
+        p.up_tiles = (int)tiles.size() - p.up_first;
+        p.down_first = (int)tiles.size();
+        for (int i = 1 << lv; i < (2 << lv); ++i)
+            for (int r = 0; r < nodes[i].s; r += down_rows) tiles.push_back(tile_of(i, r, lv, 0));
+        if (lv + 1 < levels)
+            for (int i = 1 << lv; i < (2 << lv); ++i)
+                for (int r = 0; r < nodes[i].b; r += WAVE * p.down_nw) tiles.push_back(tile_of(i, r, lv, 1));
+        p.down_tiles = (int)tiles.size() - p.down_first;
+        lds_max = std::max(lds_max, ((size_t)p.s_cap + p.b_cap + 16 * WAVE) * d->kmax * sizeof(float));
+    }
+    if (lds_max > 150 * 1024) {
+        delete d;
+        set_error("ls_direct_create: a front needs %zu bytes of LDS (separator too large for this kernel)", lds_max);
+        return LS_E_INVALID;
+    }
+    int rc = LS_OK;
+    auto up = [&](auto** dst, const auto* src, size_t n) -> int {
+        LS_HIP(hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(**dst)));
+        if (n) LS_HIP(hipMemcpyAsync(*dst, src, n * sizeof(**dst), hipMemcpyHostToDevice, st));
+        return LS_OK;
+    };
+    if (!(rc = up(&d->tiles, tiles.data(), tiles.size())) && !(rc = up(&d->perm, h_perm, (size_t)V)) &&
+        !(rc = up(&d->ppos, h_ppos, (size_t)n_bnd)) && !(rc = up(&d->map0, h_map0, (size_t)n_front)) &&
+        !(rc = up(&d->map1, h_map1, (size_t)n_front))) {
+        hipError_t e = hipMalloc((void**)&d->bp, sizeof(float) * (size_t)V * d->kmax);
+        if (e == hipSuccess) e = hipMalloc((void**)&d->slots, sizeof(float) * (size_t)n_front * 2 * d->kmax);
+        if (e == hipSuccess) e = hipMalloc((void**)&d->xb, sizeof(float) * (size_t)std::max<int64_t>(n_bnd, 1) * d->kmax);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);      // the host vectors above go out of scope
+        if (e != hipSuccess) rc = hip_fail(e, "ls_direct_create allocations", __FILE__, __LINE__);
+    }
+    if (rc != LS_OK) { ls_direct_destroy(d); return rc; }
+    // kernels of the top levels may need more than 64 KiB of dynamic LDS
+#define LS_OPTIN(KK)                                                                                                   \
+    (void)hipFuncSetAttribute((const void*)k_nd_up<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);       \
+    (void)hipFuncSetAttribute((const void*)k_nd_down<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);       \
+    (void)hipFuncSetAttribute((const void*)k_nd_up_b<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
+    (void)hipFuncSetAttribute((const void*)k_nd_down_b<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    LS_OPTIN(1) LS_OPTIN(2) LS_OPTIN(3) LS_OPTIN(4)
+#undef LS_OPTIN
+    *out = d;
+    return LS_OK;
+}
+
+extern "C" int ls_direct_destroy(ls_direct* d) {
+    if (!d) return LS_OK;
+    DeviceGuard g(d->device);
+    (void)hipFree(d->tiles); (void)hipFree(d->perm); (void)hipFree(d->ppos);
+    (void)hipFree(d->map0); (void)hipFree(d->map1); (void)hipFree(d->bp); (void)hipFree(d->slots); (void)hipFree(d->xb);
+    for (hipEvent_t e : d->ev) (void)hipEventDestroy(e);
+    delete d;
+    return LS_OK;
+}
+
+template <int K>
+static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st) {
+    const int D = d->levels - 1;
+    if (d->profile) LS_HIP(hipEventRecord(d->ev[0], st));
+    for (int lv = D; lv >= 0; --lv) {
+        const LevelPlan& p = d->plan[lv];
+        if (!p.up_tiles) continue;
+        const size_t lds = ((size_t)p.s_cap + (size_t)(p.up_nw - 1) * WAVE) * K * sizeof(float);
+        if (p.up_b)
+            hipLaunchKernelGGL(k_nd_up_b<K>, dim3(p.up_tiles), dim3(WAVE * ND_BW), (size_t)p.s_cap * K * sizeof(float), st, d->tiles + p.up_first,
+                               d->perm, d->map0, d->map1, d->ppos, d->wb, b, d->bp, d->slots, p.s_cap);
+        else
+            hipLaunchKernelGGL(k_nd_up<K>, dim3(p.up_tiles), dim3(WAVE * p.up_nw), lds, st, d->tiles + p.up_first, d->perm, d->map0, d->map1,
+                               d->ppos, d->wf, b, d->bp, d->slots, p.s_cap);
+    }
+    if (d->profile) LS_HIP(hipEventRecord(d->ev[1], st));
+    for (int lv = 0; lv <= D; ++lv) {
+        const LevelPlan& p = d->plan[lv];
+        if (!p.down_tiles) continue;
+        const size_t lds = ((size_t)p.s_cap + p.b_cap + (size_t)(p.down_nw - 1) * WAVE) * K * sizeof(float);
+        if (p.down_b)
+            hipLaunchKernelGGL(k_nd_down_b<K>, dim3(p.down_tiles), dim3(WAVE * ND_BW), ((size_t)p.s_cap + p.b_cap) * K * sizeof(float), st,
+                               d->tiles + p.down_first, d->perm, d->map0, d->map1, d->finv, d->wf, (const float*)d->bp, d->xb, x, p.s_cap, p.b_cap);
+        else
+            hipLaunchKernelGGL(k_nd_down<K>, dim3(p.down_tiles), dim3(WAVE * p.down_nw), lds, st, d->tiles + p.down_first, d->perm, d->map0,
+                               d->map1, d->finv, d->wb, (const float*)d->bp, d->xb, x, p.s_cap, p.b_cap);
+    }
+    if (d->profile) LS_HIP(hipEventRecord(d->ev[2], st));
+    LS_HIP(hipGetLastError());
+    if (d->profile) {
+        LS_HIP(hipStreamSynchronize(st));
+        float a = 0, c = 0;
+        LS_HIP(hipEventElapsedTime(&a, d->ev[0], d->ev[1]));
+        LS_HIP(hipEventElapsedTime(&c, d->ev[1], d->ev[2]));
+        d->prof_ms[0] = a; d->prof_ms[1] = c; d->prof_ms[2] = 0.0;
+    }
+    return LS_OK;
+}
+
+extern "C" int ls_direct_solve(ls_direct* d, const float* b, float* x, int k, void* stream) {
+    LS_REQUIRE(d && b && x && k >= 1 && k <= d->kmax, LS_E_INVALID, "ls_direct_solve: bad argument (1 <= k <= %d)", d ? d->kmax : 4);
+    LS_REQUIRE(b != x, LS_E_INVALID, "ls_direct_solve: b and x must not alias");
+    DeviceGuard g(d->device);
+    LS_HIP(g.err);
+    hipStream_t st = (hipStream_t)stream;
+    switch (k) {
+        case 1: return direct_solve_k<1>(d, b, x, st);
+        case 2: return direct_solve_k<2>(d, b, x, st);
+        case 3: return direct_solve_k<3>(d, b, x, st);
+        default: return direct_solve_k<4>(d, b, x, st);
+    }
+}
+
+extern "C" int ls_direct_set(ls_direct* d, const char* name, int value) {
+    LS_REQUIRE(d && name, LS_E_INVALID, "ls_direct_set: bad argument");
+    if (!strcmp(name, "profile")) {
+        DeviceGuard g(d->device);
+        LS_HIP(g.err);
+        d->profile = value ? 1 : 0;
+        while (d->profile && d->ev.size() < 3) { hipEvent_t e; LS_HIP(hipEventCreate(&e)); d->ev.push_back(e); }
+        return LS_OK;
+    }
+    set_error("ls_direct_set: unknown option '%s'", name);
+    return LS_E_INVALID;
+}
+
+extern "C" int ls_direct_info(const ls_direct* d, int64_t* h_factor_entries, int* h_launches, double* h_ms3) {
+    LS_REQUIRE(d, LS_E_INVALID, "ls_direct_info: bad argument");
+    if (h_factor_entries) *h_factor_entries = d->factor_entries;
+    if (h_launches) {
+        int n = 0;
+        for (int lv = 0; lv < d->levels; ++lv) n += (d->plan[lv].up_tiles ? 1 : 0) + (d->plan[lv].down_tiles ? 1 : 0);
+        *h_launches = n;
+    }
+    if (h_ms3) for (int i = 0; i < 3; ++i) h_ms3[i] = d->prof_ms[i];
+    return LS_OK;
+}

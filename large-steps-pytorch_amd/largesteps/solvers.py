@@ -225,20 +225,111 @@ class PCGSolver(Solver):
         return x.squeeze(1) if squeeze else x
 
 
-class CholeskySolver(PCGSolver):
+class IterativeCholeskySolver(PCGSolver):
     """
-    Drop-in for the reference's default solver (solvers.py:26-39: cholespy / CHOLMOD factor + triangular solves).
-
-    No factorisation exists in this package: every solve is a cold-started iteration run to a residual reduction
-    of 1e-6, i.e. the result is a function of b only, like a direct solve, within the fp32 accuracy class of the
-    reference's single-precision Cholesky solve (tolerances: DESIGN.md). For matrices from `compute_matrix`
-    (spectral enclosure known) the iteration is the Chebyshev-accelerated Jacobi method -- one HIP kernel per
-    iteration, no reductions; any other matrix is solved by the Jacobi-PCG.
+    The iterative stand-in for a direct solve: every call is a cold-started iteration run to a residual reduction of
+    1e-6, i.e. the result is a function of b only. For matrices from `compute_matrix` (spectral enclosure known) the
+    iteration is the Chebyshev-accelerated Jacobi method -- one HIP kernel per iteration (or per 8-12 iterations on
+    LDS-resident patches), no reductions; any other matrix is solved by the Jacobi-PCG. Used by `CholeskySolver` when
+    the matrix cannot be factorised by the nested-dissection solver (no vertex positions / fronts too large).
     """
 
     def __init__(self, M, rtol=1e-6, max_iter=10000, chebyshev=True, patch_columns=3):
         super().__init__(M, rtol=rtol, atol=0.0, max_iter=max_iter, warm_start=False, chebyshev=chebyshev,
                          patch_columns=patch_columns)
+
+
+class NestedDissectionSolver(Solver):
+    """
+    Factor-once / re-solve direct solver (what the reference's default method does through cholespy / CHOLMOD,
+    solvers.py:26-39), MI355X-native: geometric nested dissection of the mesh (largesteps/nested.py), multifrontal
+    numeric factorisation on the device in fp64 (largesteps/direct.py), and a re-solve made of one hand-written HIP
+    launch per tree level and sweep (csrc/direct.hip). The result is a function of b only and bitwise reproducible.
+
+    Needs the vertex positions the matrix was assembled from (matrices built by `compute_matrix`); raises ValueError
+    otherwise or when the mesh does not dissect into fronts that fit the kernels.
+    """
+
+    def __init__(self, M, leaf_size=48):
+        from . import direct
+        import time
+        csr = _native.csr_of(M)
+        self._csr = csr
+        self.last_info = None
+        t0 = time.perf_counter()
+        self._direct = direct.build(csr, leaf_size=leaf_size)
+        torch.cuda.synchronize(csr.device)
+        self.build_seconds = time.perf_counter() - t0
+        if self._direct is None:
+            raise ValueError("NestedDissectionSolver: the matrix has no vertex positions attached (not built by "
+                             "compute_matrix) or its fronts exceed the solver's limits")
+        self.plan = self._direct.plan
+
+    def solve(self, b, backward=False):
+        if b.dim() != 2 or b.shape[0] != self._csr.V:
+            raise ValueError(f"Invalid right-hand side shape {tuple(b.shape)}: expected ({self._csr.V}, k)")
+        _native.require_device(b, "b")
+        b32 = b.detach()
+        if b32.dtype != torch.float32 or not b32.is_contiguous():
+            b32 = b32.to(torch.float32).contiguous()
+        x = torch.empty_like(b32)
+        for c0 in range(0, b32.shape[1], _KMAX):
+            c1 = min(b32.shape[1], c0 + _KMAX)
+            if c0 == 0 and c1 == b32.shape[1]:
+                self._direct.solve(b32, x)
+            else:
+                xb = torch.empty((b32.shape[0], c1 - c0), dtype=torch.float32, device=b32.device)
+                self._direct.solve(b32[:, c0:c1].contiguous(), xb)
+                x[:, c0:c1] = xb
+        self.last_info = dict(iterations=0, converged=True, method="nested-dissection")
+        return x
+
+    def set_option(self, name, value):
+        self._direct.set_option(name, value)
+
+    def info(self):
+        return self._direct.info()
+
+
+class CholeskySolver(Solver):
+    """
+    Drop-in for the reference's default solver (solvers.py:26-39: cholespy / CHOLMOD factor in the constructor, two
+    triangular solves per call). Same contract: the constructor factorises, `solve` is a re-solve whose result depends
+    on b only.
+
+    * matrices built by `compute_matrix` (vertex positions known): `NestedDissectionSolver` -- factor once on the
+      device, 2 x (tree levels) HIP launches per solve;
+    * anything else, or a mesh whose fronts exceed that solver's limits: `IterativeCholeskySolver` (Chebyshev-Jacobi /
+      Jacobi-PCG run to a residual reduction `rtol`).
+    `direct=False` (or LARGESTEPS_NO_DIRECT=1) forces the iterative path; `method` says which one is in use and every
+    other attribute is the chosen solver's.
+    """
+
+    def __init__(self, M, rtol=1e-6, max_iter=10000, chebyshev=True, patch_columns=3, direct=None, leaf_size=64):
+        if direct is None:
+            direct = not os.environ.get("LARGESTEPS_NO_DIRECT")
+        self._impl = None
+        self.direct_error = None
+        if direct:
+            try:
+                self._impl = NestedDissectionSolver(M, leaf_size=leaf_size)
+            except (ValueError, RuntimeError) as e:      # no positions / fronts too large / numerically not SPD
+                self.direct_error = str(e)
+        if self._impl is None:
+            self._impl = IterativeCholeskySolver(M, rtol=rtol, max_iter=max_iter, chebyshev=chebyshev, patch_columns=patch_columns)
+        self.method = "nested-dissection" if isinstance(self._impl, NestedDissectionSolver) else "iterative"
+
+    def solve(self, b, backward=False):
+        return self._impl.solve(b, backward=backward)
+
+    @property
+    def last_info(self):
+        return self._impl.last_info
+
+    def __getattr__(self, name):                     # only reached for attributes this facade does not define
+        if name == "_impl":
+            raise AttributeError(name)
+        return getattr(self._impl, name)
 
 
 class ConjugateGradientSolver(PCGSolver):

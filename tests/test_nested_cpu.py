@@ -1,0 +1,121 @@
+"""
+Nested-dissection plan of the direct solver (largesteps/nested.py) on the CPU: structural invariants of the plan, the
+numpy statement of factorisation + sweeps against the fp64 oracle, and the torch factorisation code of
+largesteps/direct.py (device agnostic; here on CPU tensors) against that statement. The HIP sweeps themselves are
+covered by tests/test_gpu_parity.py (-m gpu).
+"""
+import numpy as np
+import pytest
+import torch
+
+from largesteps import synthetic
+from largesteps.nested import NDPlan
+from oracle import laplacian as ol
+from oracle import solve as osv
+
+
+def csr_of(v, f, **kw):
+    r, c, val = ol.compute_matrix(v, f, **kw)
+    V = v.shape[0]
+    rowptr = np.zeros(V + 1, np.int64)
+    np.add.at(rowptr, r + 1, 1)
+    return r, np.cumsum(rowptr), c, val
+
+
+def soup(seed):
+    rng = np.random.default_rng(seed)
+    V = int(rng.integers(40, 400))
+    F = int(rng.integers(V, 3 * V))
+    f = rng.integers(0, int(V * 0.9), size=(F, 3)).astype(np.int64)
+    f[: F // 5, 0] = int(rng.integers(0, V))           # a hub vertex
+    return rng.standard_normal((V, 3)).astype(np.float32), f
+
+
+MESHES = {
+    "plane30": lambda: synthetic.plane(30),
+    "ico10": lambda: synthetic.icosphere(10),
+    "tiny": lambda: synthetic.icosphere(1),
+    "soup0": lambda: soup(0),
+    "soup1": lambda: soup(1),
+}
+
+
+@pytest.mark.parametrize("leaf", [4, 16, 64])
+@pytest.mark.parametrize("name", list(MESHES))
+def test_plan_invariants(name, leaf):
+    v, f = MESHES[name]()
+    r, rowptr, c, val = csr_of(v, f, lambda_=5.0)
+    V = v.shape[0]
+    p = NDPlan.build(rowptr, c, v, leaf_size=leaf)
+    assert sorted(p.perm.tolist()) == list(range(V)) and np.array_equal(p.inv[p.perm], np.arange(V))
+    assert int(p.s[1:].sum()) == V and p.b[1] == 0 and p.s[0] == 0 and p.b[0] == 0
+    nn = p.node_of_new
+    # contiguous own ranges, deepest level first
+    for i in range(1, p.n_nodes + 1):
+        assert (nn[p.own_start[i]:p.own_start[i] + p.s[i]] == i).all()
+    # separator property: an entry only links a vertex to its own node, an ancestor or a descendant
+    pr, pc = p.inv[r], p.inv[c]
+    a, d = nn[pr], nn[pc]
+    la, ld = np.floor(np.log2(a)).astype(int), np.floor(np.log2(d)).astype(int)
+    hi = np.where(la <= ld, a, d)
+    lo = np.where(la <= ld, d, a)
+    assert ((lo >> np.abs(la - ld)) == hi).all()
+    # boundary sets: sorted, strictly after the own range, inside the ancestors; children's boundaries nest
+    for i in range(1, p.n_nodes + 1):
+        bi = p.bnd[p.bnd_off[i]:p.bnd_off[i] + p.b[i]]
+        assert (np.diff(bi) > 0).all() and (bi >= p.own_start[i] + p.s[i]).all()
+        anc = nn[bi]
+        lv = np.floor(np.log2(np.maximum(anc, 1))).astype(int)
+        assert ((i >> (int(np.floor(np.log2(i))) - lv)) == anc).all(), "boundary vertices live in ancestors"
+        if i > 1:
+            par = i >> 1
+            front = np.concatenate([np.arange(p.own_start[par], p.own_start[par] + p.s[par]),
+                                    p.bnd[p.bnd_off[par]:p.bnd_off[par] + p.b[par]]])
+            pp = p.ppos[p.bnd_off[i]:p.bnd_off[i] + p.b[i]]
+            assert np.array_equal(front[pp], bi)
+            mp = (p.map0, p.map1)[i & 1][p.front_off[par]:p.front_off[par] + p.s[par] + p.b[par]]
+            assert np.array_equal(np.flatnonzero(mp >= 0), np.sort(pp)) and np.array_equal(mp[pp], np.arange(p.b[i]))
+    assert p.factor_entries == int((p.s * p.s + 2 * p.s * p.b).sum())
+    with pytest.raises(ValueError):
+        NDPlan.build(rowptr, c, v[:-1], leaf_size=leaf)
+
+
+@pytest.mark.parametrize("name,kw", [("plane30", dict(lambda_=30.0)), ("ico10", dict(lambda_=0.0, alpha=0.9, cotan=True)),
+                                      ("soup0", dict(lambda_=3.0)), ("soup1", dict(lambda_=0.0, alpha=0.5)), ("tiny", dict(lambda_=1.0))])
+def test_numpy_statement_vs_oracle(name, kw):
+    v, f = MESHES[name]()
+    if kw.get("cotan"):
+        v = synthetic.perturb(v, radial=0.05, tangential=0.1, edge=0.1, seed=1)
+    r, rowptr, c, val = csr_of(v, f, **kw)
+    p = NDPlan.build(rowptr, c, v, leaf_size=12)
+    finv, w = p.factor_reference(rowptr, c, val)
+    b = np.random.default_rng(0).standard_normal((v.shape[0], 3))
+    x = p.solve_reference(finv, w, b)
+    x64 = osv.from_differential(r, c, val, b)
+    assert np.abs(x - x64).max() <= 1e-10 * np.abs(x64).max()
+
+
+@pytest.mark.parametrize("name,kw", [("plane30", dict(lambda_=30.0)), ("ico10", dict(lambda_=0.0, alpha=0.9, cotan=True)), ("soup0", dict(lambda_=3.0))])
+def test_torch_factorisation_matches_statement(name, kw):
+    """largesteps.direct.factorize (what runs on the MI355X, here on CPU tensors): padded level batches, extend-add by
+    index arithmetic, packing into the three flat fp32 arrays of the C ABI."""
+    from largesteps.direct import factorize
+    v, f = MESHES[name]()
+    r, rowptr, c, val = csr_of(v, f, **kw)
+    p = NDPlan.build(rowptr, c, v, leaf_size=10)
+    finv, w = p.factor_reference(rowptr, c, val)
+    finv_t, wf_t, wb_t = factorize(p, rowptr, c, torch.from_numpy(val), torch.device("cpu"))
+    scale = np.abs(finv).max()
+    assert np.abs(finv_t.numpy()[:p.finv_size] - finv).max() <= 2e-7 * scale
+    assert np.abs(wb_t.numpy()[:p.w_size] - w).max() <= 2e-7 * max(np.abs(w).max(), 1e-30)
+    for i in range(1, p.n_nodes + 1):
+        s, b = int(p.s[i]), int(p.b[i])
+        if s and b:
+            W = wb_t.numpy()[p.w_off[i]:p.w_off[i] + s * b].reshape(b, s)
+            Wf = wf_t.numpy()[p.w_off[i]:p.w_off[i] + s * b].reshape(s, b)
+            assert np.array_equal(Wf, W.T)
+    # and the fp32 factor solves the system to fp32 accuracy through the numpy sweeps
+    b = np.random.default_rng(1).standard_normal((v.shape[0], 2))
+    x = p.solve_reference(finv_t.numpy()[:p.finv_size].astype(np.float64), wb_t.numpy()[:p.w_size].astype(np.float64), b)
+    x64 = osv.from_differential(r, c, val, b)
+    assert np.abs(x - x64).max() <= 1e-5 * np.abs(x64).max()

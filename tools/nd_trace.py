@@ -1,0 +1,12 @@
+"""print the per-launch durations of the LAST solve in a rocprofv3 kernel trace csv: python tools/nd_trace.py file.csv"""
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k_nd_" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+# a solve starts with the first k_nd_up after a k_nd_down
+starts = [i for i, r in enumerate(rows) if "k_nd_up" in r["Kernel_Name"] and (i == 0 or "k_nd_down" in rows[i - 1]["Kernel_Name"])]
+last = rows[starts[-1]:]
+t0 = int(last[0]["Start_Timestamp"])
+for r in last:
+    name = r["Kernel_Name"].split("(")[0].replace("void ls::", "")
+    print(f"{name:28s} start {(int(r['Start_Timestamp']) - t0) / 1e3:8.1f} us  dur {(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:7.1f} us  grid {r.get('Grid_Size_X', r.get('Grid_Size', '?'))} wg {r.get('Workgroup_Size_X', r.get('Workgroup_Size', '?'))}")
+print("total", (int(last[-1]["End_Timestamp"]) - t0) / 1e3, "us")
