@@ -195,25 +195,26 @@ int ls_gather_rows(const float* src, const int32_t* idx, int64_t n, int k, float
  * scratch: at least 4096 bytes of device memory owned by the caller.
  * --------------------------------------------------------------------------------------------- */
 /* ---- factor-once / re-solve direct solver (nested dissection, multifrontal; plan: largesteps/nested.py) ---------
- * The elimination tree is a complete binary tree of `levels` levels in heap numbering (root 1, children 2i, 2i+1);
- * the vertices are renumbered deepest level first (h_perm[new] = old), node i owns the new ids [own_start, own_start+s)
- * and has b boundary vertices in its ancestors; h_ppos[bnd_off + i] = position of boundary vertex i in the PARENT's front
- * [own | boundary] (n_bnd entries in all). Factor arrays (DEVICE, fp32, owned
- * by the caller and kept alive for the handle's lifetime): d_finv[finv_off + t*s + j] = (F_ss^-1)[t][j];
- * W = F_bs F_ss^-1 twice: d_wf[w_off + j*b + i] and d_wb[w_off + i*s + j] = W[i][j].
- * h_nodes: (2^levels, 8) int64, row i = {s, b, own_start, bnd_off, front_off, finv_off, w_off, 0} (row 0 unused).
- * h_map0 / h_map1: for every front position p of node i (h_map[front_off + p], p < s + b): index of that vertex in
- * the boundary list of child 2i / 2i+1, or -1.
+ * The elimination tree is a complete `arity`-ary tree (2, 4 or 8) of `levels` levels; node ids are 1-based and
+ * level-major (level l: arity^l nodes, node (l, q) has the children (l+1, arity*q + c)). The vertices are renumbered
+ * deepest level first (h_perm[new] = old); node i owns the new ids [own_start, own_start + s) and has b boundary
+ * vertices in its ancestors; its front is [own | boundary] and front_off is its offset in the concatenation of all
+ * fronts (n_front positions). h_ppos[bnd_off + i] = position of boundary vertex i in the PARENT's front (n_bnd entries).
+ * h_push_ptr (n_front + 1) / h_push_tgt (n_bnd): CSR lists, front position -> indices (into the concatenated boundary
+ * vectors) of the children's boundary entries that are this vertex.
+ * Factor arrays (DEVICE, fp32, owned by the caller and kept alive for the handle's lifetime):
+ * d_finv[finv_off + t*s + j] = (F_ss^-1)[t][j]; W = F_bs F_ss^-1 twice: d_wf[w_off + j*b + i] = d_wb[w_off + i*s + j] = W[i][j].
+ * h_nodes: (n_nodes + 1, 8) int64, row i = {s, b, own_start, bnd_off, front_off, finv_off, w_off, parent} (row 0 unused).
  * One solve = one launch per level upwards
  *     b'_s = b_s - (children's updates at own_i);   upd_i = W_i b'_s + (children's updates at bnd_i)
- * (children push into two slots per parent front position), one launch per level downwards
+ * (children push into one slot per child of every parent front position), one launch per level downwards
  *     x_s = F_ss^-1 b'_s - W_i^T x[bnd_i]          (parents push x into the children's boundary vectors);
  * b is read and x written in the caller's numbering. No atomics: bitwise reproducible.
  * ls_direct_create is SYNC (copies the host tables). */
 typedef struct ls_direct ls_direct;
-int ls_direct_create(int64_t V, int levels, const int64_t* h_nodes, const int32_t* h_perm, const int32_t* h_ppos,
-                     int64_t n_bnd, const int32_t* h_map0, const int32_t* h_map1, int64_t n_front, const float* d_finv,
-                     const float* d_wf, const float* d_wb, int device, void* stream, ls_direct** out);
+int ls_direct_create(int64_t V, int levels, int arity, const int64_t* h_nodes, const int32_t* h_perm, const int32_t* h_ppos,
+                     int64_t n_bnd, const int32_t* h_push_ptr, const int32_t* h_push_tgt, int64_t n_front,
+                     const float* d_finv, const float* d_wf, const float* d_wb, int device, void* stream, ls_direct** out);
 int ls_direct_destroy(ls_direct* d);
 /* x = M^-1 b for k <= 4 interleaved columns ((V, k) row-major, b != x) */
 int ls_direct_solve(ls_direct* d, const float* b, float* x, int k, void* stream);

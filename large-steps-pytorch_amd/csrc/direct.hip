@@ -3,10 +3,17 @@
 // Replaces the two sparse triangular solves of the reference's default method (largesteps/solvers.py:36-39,
 // cholespy/CHOLMOD `solver.solve(b, x)`). Plan and notation: largesteps/nested.py. The factor arrays (fp32) are
 // produced once per matrix by largesteps/direct.py and stay resident in HBM:
-//     Finv_i = F_ss^-1 (s x s, symmetric),  W_i = F_bs F_ss^-1 stored twice: wf[j*b + i] (up sweep, lanes = boundary
-//     rows i) and wb[i*s + j] (down sweep, lanes = own rows j) -- both sweeps read 512-byte coalesced wave rows.
-// One launch per tree level and sweep; a workgroup = 64 rows x NW waves that split the reduction range and meet in
-// LDS. The up sweep PULLS the children's updates through index maps (no atomics: bitwise reproducible).
+//     Finv_i = F_ss^-1 (s x s, symmetric),  W_i = F_bs F_ss^-1 stored twice: wf[j*b + i] and wb[i*s + j] = W[i][j],
+//     so that either sweep can read it along either index with 256-byte coalesced wave loads.
+// One launch per tree level and sweep. Data flow between levels (no atomics, bitwise reproducible):
+//     up    a child pushes its update for boundary vertex i into slot `child index` of the parent's front position
+//           ppos[i]; the parent reads the slots of a position with one contiguous load, gated by a static bit mask
+//     down  a parent pushes x of every front position into the boundary vectors of the children that contain that
+//           vertex (static push lists), so a node reads its x_bnd contiguously
+// A level is latency bound (launch + ~3 dependent memory round trips), hence the index-free critical paths, the
+// prefetch of the first matrix rows before the right-hand side is assembled, and two kernel shapes:
+//     k_nd_up / k_nd_down      a row per lane, NW waves split the reduction range and meet in LDS (short reductions)
+//     k_nd_up_b / k_nd_down_b  lanes ALONG the reduction, a wave owns ND_ROWS rows, DPP butterfly (long reductions)
 #include "common.h"
 #include <vector>
 #include <algorithm>
@@ -14,19 +21,128 @@
 
 namespace ls {
 
-struct NodeDesc { int s, b, own_start, bnd_off, front_off, pad; long long finv_off, w_off; };
+struct NodeDesc { int s, b, own_start, bnd_off, front_off, parent; long long finv_off, w_off; };
 
-// one workgroup's job: 64 rows (from row0) of one node; everything the kernels need in one 64-byte record
+// one workgroup's job: a range of rows (from row0) of one node; everything the kernels need in one 64-byte record
 struct alignas(64) Tile {
-    int node, row0, s, b, own_start, bnd_off, front_off;
-    int c0_off, c1_off;        // children's bnd_off, -1 = leaf
-    int pfront_off, parity;    // parent's front_off (-1 = root) and which child of it this node is
+    int store;                 // up sweep: 0 = compute rows, 1 = compute rows and store all of b', 2 = only store b' of [row0, row0 + blockDim)
+    int row0, s, b, own_start, bnd_off, front_off;
+    int leaf;                  // 1: no children (nothing was pushed into this node's slots)
+    int pfront_off, cix;       // parent's front_off (-1 = root) and this node's index among its siblings
     int forward;               // down sweep: 1 = rows are boundary rows that only hand x down to the children
+    int arity;
     long long finv_off, w_off;
 };
 
-constexpr int ND_UNROLL = 8;   // independent matrix loads in flight per lane
+constexpr int ND_UNROLL = 8;   // independent matrix loads in flight per lane (row-per-lane kernels)
+constexpr int ND_ROWS = 4;     // rows a wave processes together (lanes-along-the-reduction kernels)
+constexpr int ND_BW = 4;       // waves per workgroup of the *_b kernels -> ND_ROWS * ND_BW rows per tile
 
+// Sum of the valid child slots of front position f: slots[(f * A + c) * K + q], valid iff bit c of m. All A slots are
+// loaded unconditionally (contiguous; never-written ones hold garbage and are masked out): no load waits for the mask.
+template <int K, int A>
+__device__ __forceinline__ void load_slots(const float* slots, size_t f, float (&raw)[A * K]) {
+#pragma unroll
+    for (int e = 0; e < A * K; ++e) raw[e] = slots[f * (A * K) + e];
+}
+template <int K, int A>
+__device__ __forceinline__ void sum_slots(const float (&raw)[A * K], unsigned m, float (&v)[K]) {
+#pragma unroll
+    for (int q = 0; q < K; ++q) v[q] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < A; ++c) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) v[q] += ((m >> c) & 1u) ? raw[c * K + q] : 0.0f;
+    }
+}
+template <int K>
+__device__ __forceinline__ void pull_slots(const float* slots, const unsigned char* __restrict__ mask, size_t f, int A, float (&v)[K]) {
+    const unsigned m = mask[f];
+    if (A == 4) { float raw[4 * K]; load_slots<K, 4>(slots, f, raw); sum_slots<K, 4>(raw, m, v); }
+    else if (A == 2) { float raw[2 * K]; load_slots<K, 2>(slots, f, raw); sum_slots<K, 2>(raw, m, v); }
+    else { float raw[8 * K]; load_slots<K, 8>(slots, f, raw); sum_slots<K, 8>(raw, m, v); }
+}
+
+// b'_j = b_j - (slots at own position j) for rows [j_lo, j_hi) of the node: R rows per thread are in flight together
+// (index loads, then value loads, then the arithmetic) -- the chain perm -> b is 2 round trips per batch, not per row.
+template <int K, int A, int R>
+__device__ __forceinline__ void fill_rows(const Tile& t, int j_lo, int j_hi, const int* __restrict__ perm,
+                                          const unsigned char* __restrict__ mask, const float* slots,
+                                          const float* __restrict__ b_in, float* __restrict__ bprime, float* __restrict__ sb) {
+    for (int jb = j_lo + threadIdx.x; jb < j_hi; jb += blockDim.x * R) {
+        size_t g[R];
+        unsigned m[R];
+        float raw[R][A * K];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int j = jb + r * blockDim.x;
+            const bool ok = j < j_hi;
+            g[r] = ok ? (size_t)perm[t.own_start + j] : 0;
+            m[r] = (ok && !t.leaf) ? mask[t.front_off + j] : 0u;
+            if (ok && !t.leaf) load_slots<K, A>(slots, (size_t)(t.front_off + j), raw[r]);
+        }
+        float v[R][K];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int j = jb + r * blockDim.x;
+#pragma unroll
+            for (int q = 0; q < K; ++q) v[r][q] = (j < j_hi) ? b_in[g[r] * K + q] : 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int j = jb + r * blockDim.x;
+            if (j < j_hi) {
+                if (!t.leaf) {
+                    float u[K];
+                    sum_slots<K, A>(raw[r], m[r], u);
+#pragma unroll
+                    for (int q = 0; q < K; ++q) v[r][q] -= u[q];
+                }
+                if (sb) {
+#pragma unroll
+                    for (int q = 0; q < K; ++q) sb[j * K + q] = v[r][q];
+                }
+                if (bprime) {
+#pragma unroll
+                    for (int q = 0; q < K; ++q) bprime[(size_t)(t.own_start + j) * K + q] = v[r][q];
+                }
+            }
+        }
+    }
+}
+
+// all s rows of the node into LDS (compute tiles); `store` = 1 also keeps them for the down sweep
+template <int K>
+__device__ __forceinline__ void fill_bprime(const Tile& t, const int* __restrict__ perm, const unsigned char* __restrict__ mask,
+                                            const float* slots, const float* __restrict__ b_in, float* __restrict__ bprime,
+                                            float* __restrict__ sb) {
+    float* keep = t.store == 1 ? bprime : nullptr;
+    if (t.arity == 4) fill_rows<K, 4, 4>(t, 0, t.s, perm, mask, slots, b_in, keep, sb);
+    else if (t.arity == 2) fill_rows<K, 2, 4>(t, 0, t.s, perm, mask, slots, b_in, keep, sb);
+    else fill_rows<K, 8, 2>(t, 0, t.s, perm, mask, slots, b_in, keep, sb);
+}
+
+// store-only tiles of the up sweep (large nodes): b' of own rows [row0, row0 + blockDim.x), nothing else
+template <int K>
+__device__ __forceinline__ void store_bprime(const Tile& t, const int* __restrict__ perm, const unsigned char* __restrict__ mask,
+                                             const float* slots, const float* __restrict__ b_in, float* __restrict__ bprime) {
+    const int hi = min(t.s, t.row0 + (int)blockDim.x);
+    if (t.arity == 4) fill_rows<K, 4, 1>(t, t.row0, hi, perm, mask, slots, b_in, bprime, nullptr);
+    else if (t.arity == 2) fill_rows<K, 2, 1>(t, t.row0, hi, perm, mask, slots, b_in, bprime, nullptr);
+    else fill_rows<K, 8, 1>(t, t.row0, hi, perm, mask, slots, b_in, bprime, nullptr);
+}
+
+// hand x of a front position down: xb[target] = v for every child boundary entry that is this vertex
+template <int K>
+__device__ __forceinline__ void push_down(const int* __restrict__ push_tgt, int p0, int p1, float* xb, const float (&v)[K]) {
+    for (int p = p0; p < p1; ++p) {
+        const size_t tgt = (size_t)push_tgt[p];
+#pragma unroll
+        for (int q = 0; q < K; ++q) xb[tgt * K + q] = v[q];
+    }
+}
+
+// ---- a row per lane ---------------------------------------------------------------------------------------------
 // acc += sum_{u in [u0, u1)} col[u * stride] * sv[u * K + q]; the first ND_UNROLL values were prefetched
 template <int K>
 __device__ __forceinline__ void dot_strided(const float* __restrict__ col, size_t stride, int u0, int u1,
@@ -79,24 +195,21 @@ __device__ __forceinline__ void reduce_waves(float (&acc)[K], float* __restrict_
     }
 }
 
-// Up sweep, one tree level. Every front position p of a node has two input slots, slots[(front_off + p) * 2 + c],
-// into which child c PUSHED its update for that vertex (valid iff map_c[front_off + p] >= 0): the parent reads them
-// with one contiguous load -- no index indirection on the critical path, no atomics, no zero fill.
-//   b'_s = b_s - (slots at own_i)  [stored for the down sweep];   upd_i = W_i b'_s + (slots at bnd_i) -> parent's slots
+// Up sweep, one tree level:  b'_s = b_s - (slots at own_i)  [stored for the down sweep];
+//                            upd_i = W_i b'_s + (slots at bnd_i)  -> the parent's slots
 template <int K>
 __global__ __launch_bounds__(1024) void k_nd_up(const Tile* __restrict__ tiles, const int* __restrict__ perm,
-                                                const int* __restrict__ map0, const int* __restrict__ map1,
-                                                const int* __restrict__ ppos, const float* __restrict__ wf,
-                                                const float* __restrict__ b_in, float* __restrict__ bprime,
-                                                float* slots, int s_cap) {   // slots: own front read, parent's front written
+                                                const unsigned char* __restrict__ mask, const int* __restrict__ ppos,
+                                                const float* __restrict__ wf, const float* __restrict__ b_in,
+                                                float* __restrict__ bprime, float* slots, int s_cap) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sb = sm;
     float* red = sm + (size_t)s_cap * K;
     const Tile t = tiles[blockIdx.x];
+    if (t.store == 2) { store_bprime<K>(t, perm, mask, slots, b_in, bprime); return; }
     const int nw = blockDim.x >> 6, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i = t.row0 + lane, s = t.s, b = t.b;
     const int chunk = (s + nw - 1) / nw, j0 = min(s, w * chunk), j1 = min(s, j0 + chunk);
-    const bool has_children = t.c0_off >= 0;
     const bool row = i < b;
     // everything that does not depend on this level's arithmetic is requested up front
     const float* __restrict__ col = wf + t.w_off + (row ? i : 0);
@@ -108,37 +221,9 @@ __global__ __launch_bounds__(1024) void k_nd_up(const Tile* __restrict__ tiles, 
     for (int q = 0; q < K; ++q) pass[q] = 0.0f;
     if (w == 0 && row) {
         pp = ppos[t.bnd_off + i];
-        if (has_children) {
-            const size_t f = (size_t)(t.front_off + s + i);
-            const int m0 = map0[f], m1 = map1[f];
-#pragma unroll
-            for (int q = 0; q < K; ++q) {
-                const float a0 = slots[(f * 2 + 0) * K + q], a1 = slots[(f * 2 + 1) * K + q];
-                pass[q] = (m0 >= 0 ? a0 : 0.0f) + (m1 >= 0 ? a1 : 0.0f);
-            }
-        }
+        if (!t.leaf) pull_slots<K>(slots, mask, (size_t)(t.front_off + s + i), t.arity, pass);
     }
-    for (int j = threadIdx.x; j < s; j += blockDim.x) {
-        float v[K];
-        const size_t g = (size_t)perm[t.own_start + j];
-#pragma unroll
-        for (int q = 0; q < K; ++q) v[q] = b_in[g * K + q];
-        if (has_children) {
-            const size_t f = (size_t)(t.front_off + j);
-            const int m0 = map0[f], m1 = map1[f];
-#pragma unroll
-            for (int q = 0; q < K; ++q) {
-                const float a0 = slots[(f * 2 + 0) * K + q], a1 = slots[(f * 2 + 1) * K + q];
-                v[q] -= (m0 >= 0 ? a0 : 0.0f) + (m1 >= 0 ? a1 : 0.0f);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < K; ++q) sb[j * K + q] = v[q];
-        if (t.row0 == 0) {
-#pragma unroll
-            for (int q = 0; q < K; ++q) bprime[(size_t)(t.own_start + j) * K + q] = v[q];
-        }
-    }
+    fill_bprime<K>(t, perm, mask, slots, b_in, bprime, sb);
     __syncthreads();
     float acc[K];
 #pragma unroll
@@ -146,18 +231,30 @@ __global__ __launch_bounds__(1024) void k_nd_up(const Tile* __restrict__ tiles, 
     if (row) dot_strided<K>(col, (size_t)b, j0, j1, sb, pre, acc);
     reduce_waves<K>(acc, red);
     if (w == 0 && row) {
-        const size_t dst = ((size_t)(t.pfront_off + pp) * 2 + t.parity) * K;
+        const size_t dst = ((size_t)(t.pfront_off + pp) * t.arity + t.cix) * K;
 #pragma unroll
         for (int q = 0; q < K; ++q) slots[dst + q] = acc[q] + pass[q];
     }
 }
 
-// Down sweep, one tree level: x_s = Finv_i b'_s - W_i^T xb_i, where xb_i (x at the boundary vertices) was PUSHED by
-// the parent; every front position then hands its x to the children's xb (map0 / map1). Forward tiles only do that
-// for the boundary rows. x leaves in the caller's numbering.
+// boundary rows of the down sweep: xb_i -> children (forward tiles; blockDim.x rows per tile)
+template <int K>
+__device__ __forceinline__ void forward_rows(const Tile& t, const int* __restrict__ push_ptr, const int* __restrict__ push_tgt, float* xb) {
+    const int i = t.row0 + threadIdx.x;
+    if (i < t.b) {
+        const size_t f = (size_t)(t.front_off + t.s + i);
+        const int p0 = push_ptr[f], p1 = push_ptr[f + 1];
+        float v[K];
+#pragma unroll
+        for (int q = 0; q < K; ++q) v[q] = xb[(size_t)(t.bnd_off + i) * K + q];
+        push_down<K>(push_tgt, p0, p1, xb, v);
+    }
+}
+
+// Down sweep, one tree level:  x_s = Finv_i b'_s - W_i^T xb_i;  x leaves in the caller's numbering and is pushed down
 template <int K>
 __global__ __launch_bounds__(1024) void k_nd_down(const Tile* __restrict__ tiles, const int* __restrict__ perm,
-                                                  const int* __restrict__ map0, const int* __restrict__ map1,
+                                                  const int* __restrict__ push_ptr, const int* __restrict__ push_tgt,
                                                   const float* __restrict__ finv, const float* __restrict__ wb,
                                                   const float* __restrict__ bprime, float* xb, float* __restrict__ x_out,
                                                   int s_cap, int b_cap) {   // xb: own rows read, children's rows written
@@ -166,28 +263,9 @@ __global__ __launch_bounds__(1024) void k_nd_down(const Tile* __restrict__ tiles
     float* sx = sm + (size_t)s_cap * K;
     float* red = sx + (size_t)b_cap * K;
     const Tile t = tiles[blockIdx.x];
+    if (t.forward) { forward_rows<K>(t, push_ptr, push_tgt, xb); return; }
     const int nw = blockDim.x >> 6, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int s = t.s, b = t.b, L = s + b;
-    const bool has_children = t.c0_off >= 0;
-    if (t.forward) {                       // boundary rows: xb_i -> children
-        const int i = t.row0 + threadIdx.x;
-        if (i < b) {
-            const size_t f = (size_t)(t.front_off + s + i);
-            const int m0 = map0[f], m1 = map1[f];
-            float v[K];
-#pragma unroll
-            for (int q = 0; q < K; ++q) v[q] = xb[(size_t)(t.bnd_off + i) * K + q];
-            if (m0 >= 0) {
-#pragma unroll
-                for (int q = 0; q < K; ++q) xb[(size_t)(t.c0_off + m0) * K + q] = v[q];
-            }
-            if (m1 >= 0) {
-#pragma unroll
-                for (int q = 0; q < K; ++q) xb[(size_t)(t.c1_off + m1) * K + q] = v[q];
-            }
-        }
-        return;
-    }
     const int j = t.row0 + lane;
     const bool row = j < s;
     const int chunk = (L + nw - 1) / nw, t0 = min(L, w * chunk), t1 = min(L, t0 + chunk);
@@ -197,11 +275,11 @@ __global__ __launch_bounds__(1024) void k_nd_down(const Tile* __restrict__ tiles
     float pre_f[ND_UNROLL], pre_w[ND_UNROLL];
     prefetch_strided(fcol, (size_t)s, f0, row ? f1 : f0, pre_f);
     prefetch_strided(wcol, (size_t)s, g0, row ? g1 : g0, pre_w);
-    int m0 = -1, m1 = -1;
+    int p0 = 0, p1 = 0;
     size_t g = 0;
     if (w == 0 && row) {
         g = (size_t)perm[t.own_start + j];
-        if (has_children) { m0 = map0[t.front_off + j]; m1 = map1[t.front_off + j]; }
+        if (!t.leaf) { p0 = push_ptr[t.front_off + j]; p1 = push_ptr[t.front_off + j + 1]; }
     }
     for (int u = threadIdx.x; u < s; u += blockDim.x) {
 #pragma unroll
@@ -223,24 +301,11 @@ __global__ __launch_bounds__(1024) void k_nd_down(const Tile* __restrict__ tiles
     if (w == 0 && row) {
 #pragma unroll
         for (int q = 0; q < K; ++q) x_out[g * K + q] = acc[q];
-        if (m0 >= 0) {
-#pragma unroll
-            for (int q = 0; q < K; ++q) xb[(size_t)(t.c0_off + m0) * K + q] = acc[q];
-        }
-        if (m1 >= 0) {
-#pragma unroll
-            for (int q = 0; q < K; ++q) xb[(size_t)(t.c1_off + m1) * K + q] = acc[q];
-        }
+        push_down<K>(push_tgt, p0, p1, xb, acc);
     }
 }
 
-// ---- long reductions (the upper tree levels): lanes run ALONG the reduction, one wave per output row -----------
-// The row-per-lane kernels above walk the reduction sequentially (steps / ND_UNROLL dependent memory round trips per
-// wave); with a whole row spread over the 64 lanes every load of a row is independent and 256 B contiguous, a wave keeps
-// ND_ROWS rows in flight and finishes with a DPP butterfly. up reads W row-major (wb), down reads Finv rows and W columns (wf).
-constexpr int ND_ROWS = 4;     // rows a wave processes together
-constexpr int ND_BW = 4;       // waves per workgroup of the *_b kernels -> ND_ROWS * ND_BW rows per tile
-
+// ---- lanes along the reduction ----------------------------------------------------------------------------------
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_sum_step(float v) {
     const int m = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
@@ -257,100 +322,56 @@ __device__ __forceinline__ float wave_sum63(float v) {
     return v;
 }
 
-// acc[r][q] += sum_t row_r[t] * sv[t*K+q] for the wave's ND_ROWS rows (row r at base + r * stride_rows), t = lane, lane+64, ...
-template <int K>
-__device__ __forceinline__ void dot_rows(const float* __restrict__ base, size_t stride_rows, int nrows, int len,
-                                         const float* __restrict__ sv, float (&acc)[ND_ROWS][K]) {
+// One batch = ND_E x 64 reduction steps of the wave's ND_ROWS rows (row r at base + r * stride_rows): every load of a
+// batch is independent and 256 B contiguous across the wave.
+constexpr int ND_E = 8;
+__device__ __forceinline__ void rows_load(const float* __restrict__ base, size_t stride_rows, int nrows, int len, int t0,
+                                          float (&a)[ND_ROWS][ND_E]) {
     const int lane = threadIdx.x & 63;
-    for (int t0 = 0; t0 < len; t0 += 64 * 4) {
-        float a[ND_ROWS][4];
 #pragma unroll
-        for (int r = 0; r < ND_ROWS; ++r) {
+    for (int r = 0; r < ND_ROWS; ++r) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int t = t0 + e * 64 + lane;
-                a[r][e] = (r < nrows && t < len) ? base[(size_t)r * stride_rows + t] : 0.0f;
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < ND_E; ++e) {
             const int t = t0 + e * 64 + lane;
-            if (t < len) {
-                float v[K];
+            a[r][e] = (r < nrows && t < len) ? base[(size_t)r * stride_rows + t] : 0.0f;
+        }
+    }
+}
+template <int K>
+__device__ __forceinline__ void rows_fma(const float (&a)[ND_ROWS][ND_E], int len, int t0, const float* __restrict__ sv,
+                                         float (&acc)[ND_ROWS][K]) {
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-                for (int q = 0; q < K; ++q) v[q] = sv[t * K + q];
+    for (int e = 0; e < ND_E; ++e) {
+        const int t = t0 + e * 64 + lane;
+        if (t < len) {
+            float v[K];
 #pragma unroll
-                for (int r = 0; r < ND_ROWS; ++r) {
+            for (int q = 0; q < K; ++q) v[q] = sv[t * K + q];
 #pragma unroll
-                    for (int q = 0; q < K; ++q) acc[r][q] = fmaf(a[r][e], v[q], acc[r][q]);
-                }
+            for (int r = 0; r < ND_ROWS; ++r) {
+#pragma unroll
+                for (int q = 0; q < K; ++q) acc[r][q] = fmaf(a[r][e], v[q], acc[r][q]);
             }
         }
     }
 }
-
+// acc[r][q] += sum_t row_r[t] * sv[t*K+q]; `first` holds the already loaded batch t0 = 0
 template <int K>
-__global__ __launch_bounds__(64 * ND_BW) void k_nd_up_b(const Tile* __restrict__ tiles, const int* __restrict__ perm,
-                                                        const int* __restrict__ map0, const int* __restrict__ map1,
-                                                        const int* __restrict__ ppos, const float* __restrict__ wb,
-                                                        const float* __restrict__ b_in, float* __restrict__ bprime,
-                                                        float* slots, int s_cap) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* sb = sm;
-    const Tile t = tiles[blockIdx.x];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int s = t.s, b = t.b;
-    const bool has_children = t.c0_off >= 0;
-    const int i0 = t.row0 + w * ND_ROWS;                       // this wave's rows i0 .. i0 + ND_ROWS
-    const int nrows = max(0, min(ND_ROWS, b - i0));
-    // per-row epilogue data (lane r of the wave serves row i0 + r), requested before anything else
-    int pp = 0;
-    float pass[K];
-#pragma unroll
-    for (int q = 0; q < K; ++q) pass[q] = 0.0f;
-    if (lane < nrows) {
-        const int i = i0 + lane;
-        pp = ppos[t.bnd_off + i];
-        if (has_children) {
-            const size_t f = (size_t)(t.front_off + s + i);
-            const int m0 = map0[f], m1 = map1[f];
-#pragma unroll
-            for (int q = 0; q < K; ++q) {
-                const float a0 = slots[(f * 2 + 0) * K + q], a1 = slots[(f * 2 + 1) * K + q];
-                pass[q] = (m0 >= 0 ? a0 : 0.0f) + (m1 >= 0 ? a1 : 0.0f);
-            }
-        }
+__device__ __forceinline__ void dot_rows(const float* __restrict__ base, size_t stride_rows, int nrows, int len,
+                                         const float* __restrict__ sv, const float (&first)[ND_ROWS][ND_E], float (&acc)[ND_ROWS][K]) {
+    rows_fma<K>(first, len, 0, sv, acc);
+    for (int t0 = 64 * ND_E; t0 < len; t0 += 64 * ND_E) {
+        float a[ND_ROWS][ND_E];
+        rows_load(base, stride_rows, nrows, len, t0, a);
+        rows_fma<K>(a, len, t0, sv, acc);
     }
-    for (int j = threadIdx.x; j < s; j += blockDim.x) {
-        float v[K];
-        const size_t g = (size_t)perm[t.own_start + j];
-#pragma unroll
-        for (int q = 0; q < K; ++q) v[q] = b_in[g * K + q];
-        if (has_children) {
-            const size_t f = (size_t)(t.front_off + j);
-            const int m0 = map0[f], m1 = map1[f];
-#pragma unroll
-            for (int q = 0; q < K; ++q) {
-                const float a0 = slots[(f * 2 + 0) * K + q], a1 = slots[(f * 2 + 1) * K + q];
-                v[q] -= (m0 >= 0 ? a0 : 0.0f) + (m1 >= 0 ? a1 : 0.0f);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < K; ++q) sb[j * K + q] = v[q];
-        if (t.row0 == 0) {
-#pragma unroll
-            for (int q = 0; q < K; ++q) bprime[(size_t)(t.own_start + j) * K + q] = v[q];
-        }
-    }
-    __syncthreads();
-    float acc[ND_ROWS][K];
-#pragma unroll
-    for (int r = 0; r < ND_ROWS; ++r) {
-#pragma unroll
-        for (int q = 0; q < K; ++q) acc[r][q] = 0.0f;
-    }
-    if (nrows > 0) dot_rows<K>(wb + t.w_off + (size_t)i0 * s, (size_t)s, nrows, s, sb, acc);
-    float mine[K];
+}
+
+// lane r of the wave ends up with the total of row r
+template <int K>
+__device__ __forceinline__ void rows_to_lanes(const float (&acc)[ND_ROWS][K], float (&mine)[K]) {
+    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int q = 0; q < K; ++q) mine[q] = 0.0f;
 #pragma unroll
@@ -361,8 +382,46 @@ __global__ __launch_bounds__(64 * ND_BW) void k_nd_up_b(const Tile* __restrict__
             if (lane == r) mine[q] = tot;
         }
     }
+}
+
+template <int K>
+__global__ __launch_bounds__(64 * ND_BW) void k_nd_up_b(const Tile* __restrict__ tiles, const int* __restrict__ perm,
+                                                        const unsigned char* __restrict__ mask, const int* __restrict__ ppos,
+                                                        const float* __restrict__ wb, const float* __restrict__ b_in,
+                                                        float* __restrict__ bprime, float* slots, int s_cap) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* sb = sm;
+    const Tile t = tiles[blockIdx.x];
+    if (t.store == 2) { store_bprime<K>(t, perm, mask, slots, b_in, bprime); return; }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int s = t.s, b = t.b;
+    const int i0 = t.row0 + w * ND_ROWS;                       // this wave's rows i0 .. i0 + ND_ROWS
+    const int nrows = max(0, min(ND_ROWS, b - i0));
+    // per-row epilogue data (lane r of the wave serves row i0 + r), requested before anything else
+    int pp = 0;
+    float pass[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) pass[q] = 0.0f;
+    const float* __restrict__ wrow = wb + t.w_off + (size_t)i0 * s;
+    float first[ND_ROWS][ND_E];
+    rows_load(wrow, (size_t)s, nrows, s, 0, first);            // in flight while b' is assembled
     if (lane < nrows) {
-        const size_t dst = ((size_t)(t.pfront_off + pp) * 2 + t.parity) * K;
+        pp = ppos[t.bnd_off + i0 + lane];
+        if (!t.leaf) pull_slots<K>(slots, mask, (size_t)(t.front_off + s + i0 + lane), t.arity, pass);
+    }
+    fill_bprime<K>(t, perm, mask, slots, b_in, bprime, sb);
+    __syncthreads();
+    float acc[ND_ROWS][K];
+#pragma unroll
+    for (int r = 0; r < ND_ROWS; ++r) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) acc[r][q] = 0.0f;
+    }
+    if (nrows > 0) dot_rows<K>(wrow, (size_t)s, nrows, s, sb, first, acc);
+    float mine[K];
+    rows_to_lanes<K>(acc, mine);
+    if (lane < nrows) {
+        const size_t dst = ((size_t)(t.pfront_off + pp) * t.arity + t.cix) * K;
 #pragma unroll
         for (int q = 0; q < K; ++q) slots[dst + q] = mine[q] + pass[q];
     }
@@ -370,7 +429,7 @@ __global__ __launch_bounds__(64 * ND_BW) void k_nd_up_b(const Tile* __restrict__
 
 template <int K>
 __global__ __launch_bounds__(64 * ND_BW) void k_nd_down_b(const Tile* __restrict__ tiles, const int* __restrict__ perm,
-                                                          const int* __restrict__ map0, const int* __restrict__ map1,
+                                                          const int* __restrict__ push_ptr, const int* __restrict__ push_tgt,
                                                           const float* __restrict__ finv, const float* __restrict__ wf,
                                                           const float* __restrict__ bprime, float* xb, float* __restrict__ x_out,
                                                           int s_cap, int b_cap) {
@@ -378,35 +437,21 @@ __global__ __launch_bounds__(64 * ND_BW) void k_nd_down_b(const Tile* __restrict
     float* sb = sm;
     float* sx = sm + (size_t)s_cap * K;
     const Tile t = tiles[blockIdx.x];
+    if (t.forward) { forward_rows<K>(t, push_ptr, push_tgt, xb); return; }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int s = t.s, b = t.b;
-    const bool has_children = t.c0_off >= 0;
-    if (t.forward) {                       // boundary rows: xb_i -> children
-        const int i = t.row0 + threadIdx.x;
-        if (i < b) {
-            const size_t f = (size_t)(t.front_off + s + i);
-            const int m0 = map0[f], m1 = map1[f];
-            float v[K];
-#pragma unroll
-            for (int q = 0; q < K; ++q) v[q] = xb[(size_t)(t.bnd_off + i) * K + q];
-            if (m0 >= 0) {
-#pragma unroll
-                for (int q = 0; q < K; ++q) xb[(size_t)(t.c0_off + m0) * K + q] = v[q];
-            }
-            if (m1 >= 0) {
-#pragma unroll
-                for (int q = 0; q < K; ++q) xb[(size_t)(t.c1_off + m1) * K + q] = v[q];
-            }
-        }
-        return;
-    }
     const int j0 = t.row0 + w * ND_ROWS;
     const int nrows = max(0, min(ND_ROWS, s - j0));
-    int m0 = -1, m1 = -1;
+    const float* __restrict__ frow = finv + t.finv_off + (size_t)j0 * s;
+    const float* __restrict__ wrow = wf + t.w_off + (size_t)j0 * b;
+    float first_f[ND_ROWS][ND_E], first_w[ND_ROWS][ND_E];
+    rows_load(frow, (size_t)s, nrows, s, 0, first_f);          // in flight while the vectors are staged
+    rows_load(wrow, (size_t)b, nrows, b, 0, first_w);
+    int p0 = 0, p1 = 0;
     size_t g = 0;
     if (lane < nrows) {
         g = (size_t)perm[t.own_start + j0 + lane];
-        if (has_children) { m0 = map0[t.front_off + j0 + lane]; m1 = map1[t.front_off + j0 + lane]; }
+        if (!t.leaf) { p0 = push_ptr[t.front_off + j0 + lane]; p1 = push_ptr[t.front_off + j0 + lane + 1]; }
     }
     for (int u = threadIdx.x; u < s; u += blockDim.x) {
 #pragma unroll
@@ -424,47 +469,33 @@ __global__ __launch_bounds__(64 * ND_BW) void k_nd_down_b(const Tile* __restrict
         for (int q = 0; q < K; ++q) acc[r][q] = 0.0f;
     }
     if (nrows > 0) {
-        dot_rows<K>(finv + t.finv_off + (size_t)j0 * s, (size_t)s, nrows, s, sb, acc);
-        dot_rows<K>(wf + t.w_off + (size_t)j0 * b, (size_t)b, nrows, b, sx, acc);
+        dot_rows<K>(frow, (size_t)s, nrows, s, sb, first_f, acc);
+        dot_rows<K>(wrow, (size_t)b, nrows, b, sx, first_w, acc);
     }
     float mine[K];
-#pragma unroll
-    for (int q = 0; q < K; ++q) mine[q] = 0.0f;
-#pragma unroll
-    for (int r = 0; r < ND_ROWS; ++r) {
-#pragma unroll
-        for (int q = 0; q < K; ++q) {
-            const float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum63(acc[r][q])), 63));
-            if (lane == r) mine[q] = tot;
-        }
-    }
+    rows_to_lanes<K>(acc, mine);
     if (lane < nrows) {
 #pragma unroll
         for (int q = 0; q < K; ++q) x_out[g * K + q] = mine[q];
-        if (m0 >= 0) {
-#pragma unroll
-            for (int q = 0; q < K; ++q) xb[(size_t)(t.c0_off + m0) * K + q] = mine[q];
-        }
-        if (m1 >= 0) {
-#pragma unroll
-            for (int q = 0; q < K; ++q) xb[(size_t)(t.c1_off + m1) * K + q] = mine[q];
-        }
+        push_down<K>(push_tgt, p0, p1, xb, mine);
     }
 }
 
-struct LevelPlan { int up_first = 0, up_tiles = 0, up_nw = 1, down_first = 0, down_tiles = 0, down_nw = 1, s_cap = 0, b_cap = 0, up_b = 0, down_b = 0; };   // down tiles: compute tiles, then forward tiles
+// down tiles of a level: compute tiles, then forward tiles
+struct LevelPlan { int up_first = 0, up_tiles = 0, up_nw = 1, down_first = 0, down_tiles = 0, down_nw = 1, s_cap = 0, b_cap = 0, up_b = 0, down_b = 0; };
 
 }  // namespace ls
 
 using namespace ls;
 
 struct ls_direct {
-    int device = 0, levels = 0, n_nodes = 0, kmax = 4;
+    int device = 0, levels = 0, arity = 2, n_nodes = 0, kmax = 4;
     int64_t V = 0, n_bnd = 0, n_front = 0;
-    int *perm = nullptr, *ppos = nullptr, *map0 = nullptr, *map1 = nullptr;
+    int *perm = nullptr, *ppos = nullptr, *push_ptr = nullptr, *push_tgt = nullptr;
+    unsigned char* mask = nullptr;
     Tile* tiles = nullptr;
     const float *finv = nullptr, *wf = nullptr, *wb = nullptr;   // owned by the caller
-    float *bp = nullptr, *slots = nullptr, *xb = nullptr;        // b' (V, k); up-sweep slots (n_front, 2, k); x at boundaries (n_bnd, k)
+    float *bp = nullptr, *slots = nullptr, *xb = nullptr;        // b' (V, k); up-sweep slots (n_front, arity, k); x at boundaries (n_bnd, k)
     std::vector<LevelPlan> plan;
     int64_t factor_entries = 0;
     int profile = 0;
@@ -472,37 +503,48 @@ struct ls_direct {
     double prof_ms[3] = {0, 0, 0};     // up sweep, down sweep, 0 (last profiled solve)
 };
 
-// waves per workgroup: about `target` reduction steps per wave where 16 waves allow it (LS_ND_STEPS overrides: tuning)
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); const int v = e ? atoi(e) : 0; return v > 0 ? v : dflt; }
+
+// waves per workgroup of the row-per-lane kernels: about LS_ND_STEPS reduction steps per wave where 16 waves allow it
 static int pick_nw(int len) {
-    static const int target = [] { const char* e = getenv("LS_ND_STEPS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 64; }();
+    static const int target = env_int("LS_ND_STEPS", 64);
     int nw = 1;
     while (nw < 16 && len > nw * target) nw *= 2;
     return nw;
 }
 
-extern "C" int ls_direct_create(int64_t V, int levels, const int64_t* h_nodes, const int32_t* h_perm, const int32_t* h_ppos,
-                                int64_t n_bnd, const int32_t* h_map0, const int32_t* h_map1, int64_t n_front,
-                                const float* d_finv, const float* d_wf, const float* d_wb, int device, void* stream,
-                                ls_direct** out) {
-    LS_REQUIRE(out && h_nodes && h_perm && V > 0 && levels >= 1 && levels <= 30 && n_bnd >= 0 && n_front >= V, LS_E_INVALID,
-               "ls_direct_create: bad argument");
-    LS_REQUIRE(V < INT32_MAX && n_bnd < INT32_MAX && 2 * n_front < INT32_MAX, LS_E_OVERFLOW, "ls_direct_create: plan exceeds int32 offsets");
+extern "C" int ls_direct_create(int64_t V, int levels, int arity, const int64_t* h_nodes, const int32_t* h_perm,
+                                const int32_t* h_ppos, int64_t n_bnd, const int32_t* h_push_ptr, const int32_t* h_push_tgt,
+                                int64_t n_front, const float* d_finv, const float* d_wf, const float* d_wb, int device,
+                                void* stream, ls_direct** out) {
+    LS_REQUIRE(out && h_nodes && h_perm && h_push_ptr && V > 0 && levels >= 1 && levels <= 30 && n_bnd >= 0 && n_front >= V &&
+               (arity == 2 || arity == 4 || arity == 8), LS_E_INVALID, "ls_direct_create: bad argument");
+    LS_REQUIRE(V < INT32_MAX && n_bnd < INT32_MAX && n_front * arity < INT32_MAX, LS_E_OVERFLOW, "ls_direct_create: plan exceeds int32 offsets");
     *out = nullptr;
+    std::vector<int64_t> level_off((size_t)levels + 1);
+    {
+        int64_t cnt = 1, off = 1;
+        for (int lv = 0; lv <= levels; ++lv) {
+            level_off[lv] = off; off += cnt; cnt *= arity;
+            LS_REQUIRE(off < ((int64_t)1 << 30), LS_E_OVERFLOW, "ls_direct_create: tree too large");
+        }
+    }
+    const int n_nodes = (int)(level_off[levels] - 1);
     DeviceGuard g(device);
     LS_HIP(g.err);
     hipStream_t st = (hipStream_t)stream;
     ls_direct* d = new ls_direct();
-    d->device = device; d->levels = levels; d->n_nodes = (1 << levels) - 1; d->V = V; d->n_bnd = n_bnd; d->n_front = n_front;
+    d->device = device; d->levels = levels; d->arity = arity; d->n_nodes = n_nodes; d->V = V; d->n_bnd = n_bnd; d->n_front = n_front;
     d->finv = d_finv; d->wf = d_wf; d->wb = d_wb;
-    std::vector<NodeDesc> nodes((size_t)d->n_nodes + 1);
+    std::vector<NodeDesc> nodes((size_t)n_nodes + 1);
     int64_t fe = 0;
-    for (int i = 1; i <= d->n_nodes; ++i) {
+    for (int i = 1; i <= n_nodes; ++i) {
         const int64_t* r = h_nodes + (size_t)i * 8;
         NodeDesc& n = nodes[i];
-        n.s = (int)r[0]; n.b = (int)r[1]; n.own_start = (int)r[2]; n.bnd_off = (int)r[3]; n.front_off = (int)r[4]; n.pad = 0;
-        n.finv_off = r[5]; n.w_off = r[6];
+        n.s = (int)r[0]; n.b = (int)r[1]; n.own_start = (int)r[2]; n.bnd_off = (int)r[3]; n.front_off = (int)r[4];
+        n.finv_off = r[5]; n.w_off = r[6]; n.parent = (int)r[7];
         if (n.s < 0 || n.b < 0 || n.own_start < 0 || (int64_t)n.own_start + n.s > V || (int64_t)n.bnd_off + n.b > n_bnd ||
-            (int64_t)n.front_off + n.s + n.b > n_front || (i == 1 && n.b != 0)) {
+            (int64_t)n.front_off + n.s + n.b > n_front || (i == 1 ? n.b != 0 : (n.parent < 1 || n.parent >= i))) {
             delete d;
             set_error("ls_direct_create: node %d of the plan is inconsistent", i);
             return LS_E_INVALID;
@@ -510,45 +552,70 @@ extern "C" int ls_direct_create(int64_t V, int levels, const int64_t* h_nodes, c
         fe += (int64_t)n.s * n.s + 2 * (int64_t)n.s * n.b;
     }
     d->factor_entries = fe;
-    // tiles: 64 rows of one node each; NW waves per workgroup split the reduction range
+    // which children contribute to a front position: bit c of mask[f]
+    std::vector<unsigned char> mask((size_t)n_front, 0);
+    for (int lv = 1; lv < levels; ++lv)
+        for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i) {
+            const NodeDesc& n = nodes[i];
+            const int cix = (int)((i - level_off[lv]) % arity);
+            const NodeDesc& p = nodes[n.parent];
+            for (int k = 0; k < n.b; ++k) {
+                const int pp = h_ppos[n.bnd_off + k];
+                if (pp < 0 || pp >= p.s + p.b) {
+                    delete d;
+                    set_error("ls_direct_create: ppos out of range at node %lld", (long long)i);
+                    return LS_E_INVALID;
+                }
+                mask[(size_t)p.front_off + pp] |= (unsigned char)(1u << cix);
+            }
+        }
+    // tiles: a range of rows of one node each
     std::vector<Tile> tiles;
-    auto tile_of = [&](int i, int r, int lv, int forward) {
+    auto tile_of = [&](int64_t i, int r, int lv, int forward) {
         const NodeDesc& n = nodes[i];
         Tile t;
-        t.node = i; t.row0 = r; t.s = n.s; t.b = n.b; t.own_start = n.own_start; t.bnd_off = n.bnd_off; t.front_off = n.front_off;
-        t.c0_off = lv + 1 < levels ? nodes[2 * i].bnd_off : -1;
-        t.c1_off = lv + 1 < levels ? nodes[2 * i + 1].bnd_off : -1;
-        t.pfront_off = i > 1 ? nodes[i >> 1].front_off : -1;
-        t.parity = i & 1;
-        t.forward = forward; t.finv_off = n.finv_off; t.w_off = n.w_off;
+        t.store = 0; t.row0 = r; t.s = n.s; t.b = n.b; t.own_start = n.own_start; t.bnd_off = n.bnd_off; t.front_off = n.front_off;
+        t.leaf = lv + 1 >= levels;
+        t.pfront_off = i > 1 ? nodes[n.parent].front_off : -1;
+        t.cix = lv ? (int)((i - level_off[lv]) % arity) : 0;
+        t.forward = forward; t.arity = arity; t.finv_off = n.finv_off; t.w_off = n.w_off;
         return t;
     };
     d->plan.resize(levels);
     size_t lds_max = 0;
+    static const int long_red = env_int("LS_ND_LONG", 160);
     for (int lv = 0; lv < levels; ++lv) {
         LevelPlan& p = d->plan[lv];
         int red_up = 0, red_down = 0;
-        for (int i = 1 << lv; i < (2 << lv); ++i) {
+        for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i) {
             p.s_cap = std::max(p.s_cap, nodes[i].s); p.b_cap = std::max(p.b_cap, nodes[i].b);
             red_up = std::max(red_up, nodes[i].s); red_down = std::max(red_down, nodes[i].s + nodes[i].b);
         }
         // long reductions: lanes along the reduction (k_nd_*_b), ND_ROWS * ND_BW rows per tile; short: a row per lane
-        static const int long_red = [] { const char* e = getenv("LS_ND_LONG"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 160; }();
         p.up_b = red_up >= long_red; p.down_b = red_down >= long_red;
         p.up_nw = p.up_b ? ND_BW : pick_nw(red_up); p.down_nw = p.down_b ? ND_BW : pick_nw(red_down);
         const int up_rows = p.up_b ? ND_ROWS * ND_BW : WAVE, down_rows = p.down_b ? ND_ROWS * ND_BW : WAVE;
         p.up_first = (int)tiles.size();
-        for (int i = 1 << lv; i < (2 << lv); ++i) {
-            // a node without own vertices still passes its children's updates on; a node without boundary still stores b'
-            const int rows = std::max(nodes[i].b, nodes[i].s ? 1 : 0);
-            for (int r = 0; r < rows; r += up_rows) tiles.push_back(tile_of(i, r, lv, 0));
+        const int up_threads = WAVE * p.up_nw;
+        for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i) {
+            // b' of the own rows is kept for the down sweep: by the first compute tile (small nodes, or nodes whose only
+            // tile exists for that purpose), or by store-only tiles of blockDim rows each (large nodes: the one tile
+            // would walk s / blockDim dependent load chains)
+            const bool store_tiles = nodes[i].s > 2 * up_threads;
+            const int rows = std::max(nodes[i].b, (nodes[i].s && !store_tiles) ? 1 : 0);
+            for (int r = 0; r < rows; r += up_rows) {
+                tiles.push_back(tile_of(i, r, lv, 0));
+                tiles.back().store = (r == 0 && !store_tiles) ? 1 : 0;
+            }
+            if (store_tiles)
+                for (int r = 0; r < nodes[i].s; r += up_threads) { tiles.push_back(tile_of(i, r, lv, 0)); tiles.back().store = 2; }
         }
         p.up_tiles = (int)tiles.size() - p.up_first;
         p.down_first = (int)tiles.size();
-        for (int i = 1 << lv; i < (2 << lv); ++i)
+        for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i)
             for (int r = 0; r < nodes[i].s; r += down_rows) tiles.push_back(tile_of(i, r, lv, 0));
         if (lv + 1 < levels)
-            for (int i = 1 << lv; i < (2 << lv); ++i)
+            for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i)
                 for (int r = 0; r < nodes[i].b; r += WAVE * p.down_nw) tiles.push_back(tile_of(i, r, lv, 1));
         p.down_tiles = (int)tiles.size() - p.down_first;
         lds_max = std::max(lds_max, ((size_t)p.s_cap + p.b_cap + 16 * WAVE) * d->kmax * sizeof(float));
@@ -565,10 +632,10 @@ extern "C" int ls_direct_create(int64_t V, int levels, const int64_t* h_nodes, c
         return LS_OK;
     };
     if (!(rc = up(&d->tiles, tiles.data(), tiles.size())) && !(rc = up(&d->perm, h_perm, (size_t)V)) &&
-        !(rc = up(&d->ppos, h_ppos, (size_t)n_bnd)) && !(rc = up(&d->map0, h_map0, (size_t)n_front)) &&
-        !(rc = up(&d->map1, h_map1, (size_t)n_front))) {
+        !(rc = up(&d->ppos, h_ppos, (size_t)n_bnd)) && !(rc = up(&d->push_ptr, h_push_ptr, (size_t)n_front + 1)) &&
+        !(rc = up(&d->push_tgt, h_push_tgt, (size_t)n_bnd)) && !(rc = up(&d->mask, mask.data(), mask.size()))) {
         hipError_t e = hipMalloc((void**)&d->bp, sizeof(float) * (size_t)V * d->kmax);
-        if (e == hipSuccess) e = hipMalloc((void**)&d->slots, sizeof(float) * (size_t)n_front * 2 * d->kmax);
+        if (e == hipSuccess) e = hipMalloc((void**)&d->slots, sizeof(float) * (size_t)n_front * arity * d->kmax);
         if (e == hipSuccess) e = hipMalloc((void**)&d->xb, sizeof(float) * (size_t)std::max<int64_t>(n_bnd, 1) * d->kmax);
         if (e == hipSuccess) e = hipStreamSynchronize(st);      // the host vectors above go out of scope
         if (e != hipSuccess) rc = hip_fail(e, "ls_direct_create allocations", __FILE__, __LINE__);
@@ -577,7 +644,7 @@ extern "C" int ls_direct_create(int64_t V, int levels, const int64_t* h_nodes, c
     // kernels of the top levels may need more than 64 KiB of dynamic LDS
 #define LS_OPTIN(KK)                                                                                                   \
     (void)hipFuncSetAttribute((const void*)k_nd_up<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);       \
-    (void)hipFuncSetAttribute((const void*)k_nd_down<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);       \
+    (void)hipFuncSetAttribute((const void*)k_nd_down<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
     (void)hipFuncSetAttribute((const void*)k_nd_up_b<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
     (void)hipFuncSetAttribute((const void*)k_nd_down_b<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     LS_OPTIN(1) LS_OPTIN(2) LS_OPTIN(3) LS_OPTIN(4)
@@ -589,8 +656,8 @@ extern "C" int ls_direct_create(int64_t V, int levels, const int64_t* h_nodes, c
 extern "C" int ls_direct_destroy(ls_direct* d) {
     if (!d) return LS_OK;
     DeviceGuard g(d->device);
-    (void)hipFree(d->tiles); (void)hipFree(d->perm); (void)hipFree(d->ppos);
-    (void)hipFree(d->map0); (void)hipFree(d->map1); (void)hipFree(d->bp); (void)hipFree(d->slots); (void)hipFree(d->xb);
+    (void)hipFree(d->tiles); (void)hipFree(d->perm); (void)hipFree(d->ppos); (void)hipFree(d->push_ptr); (void)hipFree(d->push_tgt);
+    (void)hipFree(d->mask); (void)hipFree(d->bp); (void)hipFree(d->slots); (void)hipFree(d->xb);
     for (hipEvent_t e : d->ev) (void)hipEventDestroy(e);
     delete d;
     return LS_OK;
@@ -598,30 +665,30 @@ extern "C" int ls_direct_destroy(ls_direct* d) {
 
 template <int K>
 static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st) {
-    const int D = d->levels - 1;
+    const int top = d->levels - 1;
     if (d->profile) LS_HIP(hipEventRecord(d->ev[0], st));
-    for (int lv = D; lv >= 0; --lv) {
+    for (int lv = top; lv >= 0; --lv) {
         const LevelPlan& p = d->plan[lv];
         if (!p.up_tiles) continue;
-        const size_t lds = ((size_t)p.s_cap + (size_t)(p.up_nw - 1) * WAVE) * K * sizeof(float);
         if (p.up_b)
             hipLaunchKernelGGL(k_nd_up_b<K>, dim3(p.up_tiles), dim3(WAVE * ND_BW), (size_t)p.s_cap * K * sizeof(float), st, d->tiles + p.up_first,
-                               d->perm, d->map0, d->map1, d->ppos, d->wb, b, d->bp, d->slots, p.s_cap);
+                               d->perm, d->mask, d->ppos, d->wb, b, d->bp, d->slots, p.s_cap);
         else
-            hipLaunchKernelGGL(k_nd_up<K>, dim3(p.up_tiles), dim3(WAVE * p.up_nw), lds, st, d->tiles + p.up_first, d->perm, d->map0, d->map1,
-                               d->ppos, d->wf, b, d->bp, d->slots, p.s_cap);
+            hipLaunchKernelGGL(k_nd_up<K>, dim3(p.up_tiles), dim3(WAVE * p.up_nw), ((size_t)p.s_cap + (size_t)(p.up_nw - 1) * WAVE) * K * sizeof(float),
+                               st, d->tiles + p.up_first, d->perm, d->mask, d->ppos, d->wf, b, d->bp, d->slots, p.s_cap);
     }
     if (d->profile) LS_HIP(hipEventRecord(d->ev[1], st));
-    for (int lv = 0; lv <= D; ++lv) {
+    for (int lv = 0; lv <= top; ++lv) {
         const LevelPlan& p = d->plan[lv];
         if (!p.down_tiles) continue;
-        const size_t lds = ((size_t)p.s_cap + p.b_cap + (size_t)(p.down_nw - 1) * WAVE) * K * sizeof(float);
         if (p.down_b)
             hipLaunchKernelGGL(k_nd_down_b<K>, dim3(p.down_tiles), dim3(WAVE * ND_BW), ((size_t)p.s_cap + p.b_cap) * K * sizeof(float), st,
-                               d->tiles + p.down_first, d->perm, d->map0, d->map1, d->finv, d->wf, (const float*)d->bp, d->xb, x, p.s_cap, p.b_cap);
+                               d->tiles + p.down_first, d->perm, d->push_ptr, d->push_tgt, d->finv, d->wf, (const float*)d->bp, d->xb, x,
+                               p.s_cap, p.b_cap);
         else
-            hipLaunchKernelGGL(k_nd_down<K>, dim3(p.down_tiles), dim3(WAVE * p.down_nw), lds, st, d->tiles + p.down_first, d->perm, d->map0,
-                               d->map1, d->finv, d->wb, (const float*)d->bp, d->xb, x, p.s_cap, p.b_cap);
+            hipLaunchKernelGGL(k_nd_down<K>, dim3(p.down_tiles), dim3(WAVE * p.down_nw),
+                               ((size_t)p.s_cap + p.b_cap + (size_t)(p.down_nw - 1) * WAVE) * K * sizeof(float), st, d->tiles + p.down_first,
+                               d->perm, d->push_ptr, d->push_tgt, d->finv, d->wb, (const float*)d->bp, d->xb, x, p.s_cap, p.b_cap);
     }
     if (d->profile) LS_HIP(hipEventRecord(d->ev[2], st));
     LS_HIP(hipGetLastError());

@@ -9,7 +9,7 @@ constructor, two triangular solves per call). Here the constructor
      largest front), assembled by index arithmetic and factorised in fp64 with torch.linalg (rocSOLVER / rocBLAS):
      Finv = F_ss^-1, W = F_bs Finv, U = F_bb - W F_sb -> parent,
   3. packs Finv and W (twice: both sweep layouts) in fp32 and hands the device pointers to ls_direct_create.
-Every solve afterwards is 2 * levels + 1 hand-written HIP launches that read the factor once (W twice).
+Every solve afterwards is 2 * levels hand-written HIP launches that read the factor once (W twice).
 """
 import ctypes
 
@@ -29,7 +29,7 @@ def _level_tables(plan, lv):
 def factorize(plan, rowptr, col, val, device):
     """Numeric factorisation on `device`. rowptr/col: host int arrays (CSR pattern, original numbering), val: device
     fp32 tensor in CSR order. Returns (finv, wf, wb): flat fp32 device tensors in the layout of include/largesteps_hip.h."""
-    V, D = plan.V, plan.D
+    V, A, top = plan.V, plan.arity, plan.levels - 1
     rows = _row_index(np.asarray(rowptr).astype(np.int64))
     prow, pcol = plan.inv[rows], plan.inv[np.asarray(col).astype(np.int64)]
     node = plan.node_of_new[prow]
@@ -44,7 +44,7 @@ def factorize(plan, rowptr, col, val, device):
         up_pos[is_up] = at - plan.bnd_off[node[is_up]]
     r_loc = prow - plan.own_start[node]
     c_loc = pcol - plan.own_start[node]
-    level = np.floor(np.log2(np.maximum(node, 1))).astype(np.int64)
+    level = plan.level_of[node]
     val64 = val.to(torch.float64)
     finv = torch.zeros(max(plan.finv_size, 1), dtype=torch.float32, device=device)
     wf = torch.zeros(max(plan.w_size, 1), dtype=torch.float32, device=device)
@@ -52,7 +52,7 @@ def factorize(plan, rowptr, col, val, device):
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)   # noqa: E731
     U_child = None
     child_B = 0
-    for lv in range(D, -1, -1):
+    for lv in range(top, -1, -1):
         nodes, s, b, S, B = _level_tables(plan, lv)
         n, m = nodes.shape[0], S + B
         first = int(nodes[0])
@@ -81,7 +81,7 @@ def factorize(plan, rowptr, col, val, device):
             v = val64[dev(idx_e[e_up])]
             flat[dev(q[e_up] * stride * stride + bb * stride + rr)] = v
             flat[dev(q[e_up] * stride * stride + rr * stride + bb)] = v
-        if lv < D and U_child is not None and child_B > 0:
+        if lv < top and U_child is not None and child_B > 0:
             ch = plan.level_nodes(lv + 1)
             bc = plan.b[ch]
             P = np.full((ch.shape[0], child_B), m, dtype=np.int64)
@@ -89,13 +89,13 @@ def factorize(plan, rowptr, col, val, device):
             valid = kk < bc[:, None]
             src = (plan.bnd_off[ch][:, None] + kk)[valid]
             pp = plan.ppos[src]
-            par_s = np.repeat(plan.s[ch >> 1], bc)
+            par_s = np.repeat(plan.s[plan.parent[ch]], bc)
             P[valid] = np.where(pp < par_s, pp, pp - par_s + S)
             P_t = dev(P)
             ar_n = torch.arange(n, device=device)[:, None, None]
-            for parity in (0, 1):
-                Pq = P_t[parity::2]
-                F[ar_n, Pq[:, :, None], Pq[:, None, :]] += U_child[parity::2]
+            for c in range(A):                       # child c of every parent: a strided slice of the child level
+                Pq = P_t[c::A]
+                F[ar_n, Pq[:, :, None], Pq[:, None, :]] += U_child[c::A]
         Fbs = F[:, S:m, :S]
         Fbb = F[:, S:m, S:m]
         if S:
@@ -130,14 +130,15 @@ class DirectHandle:
         self.plan, self.finv, self.wf, self.wb, self.device = plan, finv, wf, wb, device
         nodes = np.zeros((plan.n_nodes + 1, 8), dtype=np.int64)
         nodes[:, 0], nodes[:, 1], nodes[:, 2], nodes[:, 3] = plan.s, plan.b, plan.own_start, plan.bnd_off
-        nodes[:, 4], nodes[:, 5], nodes[:, 6] = plan.front_off, plan.finv_off, plan.w_off
+        nodes[:, 4], nodes[:, 5], nodes[:, 6], nodes[:, 7] = plan.front_off, plan.finv_off, plan.w_off, plan.parent
         perm32 = plan.perm.astype(np.int32)
         ppos32 = plan.ppos.astype(np.int32)
+        ptr32, tgt32 = plan.push_ptr.astype(np.int32), plan.push_tgt.astype(np.int32)
         as_p = lambda a: a.ctypes.data_as(ctypes.c_void_p)   # noqa: E731
         self._h = ctypes.c_void_p(None)
         with torch.cuda.device(device):
-            _native.check(_native.lib().ls_direct_create(plan.V, plan.D + 1, as_p(nodes), as_p(perm32), as_p(ppos32), ppos32.shape[0],
-                                                         as_p(plan.map0), as_p(plan.map1), plan.map0.shape[0],
+            _native.check(_native.lib().ls_direct_create(plan.V, plan.levels, plan.arity, as_p(nodes), as_p(perm32), as_p(ppos32),
+                                                         ppos32.shape[0], as_p(ptr32), as_p(tgt32), ptr32.shape[0] - 1,
                                                          _native.ptr(finv), _native.ptr(wf), _native.ptr(wb), device.index,
                                                          _native.stream_of(device), ctypes.byref(self._h)))
 
@@ -165,14 +166,18 @@ class DirectHandle:
         return dict(factor_entries=fe.value, launches=nl.value, up_ms=ms[0], down_ms=ms[1], perm_ms=ms[2])
 
 
-def build(csr, leaf_size=48, max_front=8000, max_entries=3_000_000_000):
+def build(csr, leaf_size=32, arity=4, max_front=8000, max_entries=3_000_000_000, max_level_bytes=48e9):
     """Plan + factorisation + native handle for the CSR side car of a matrix (needs csr.positions). Returns None when
     the mesh does not dissect well enough for this solver (front too large for LDS / factor too large)."""
     if csr.positions is None:
         return None
     rowptr, col = csr.rowptr.cpu().numpy(), csr.col.cpu().numpy()
-    plan = NDPlan.build(rowptr, col, csr.positions.cpu().numpy(), leaf_size=leaf_size)
+    plan = NDPlan.build(rowptr, col, csr.positions.cpu().numpy(), leaf_size=leaf_size, arity=arity)
     if int((plan.s + plan.b).max()) > max_front or plan.factor_entries > max_entries:
         return None
+    for lv in range(plan.levels):                      # the factorisation pads a level to its largest front (fp64)
+        nodes, s, b, S, B = _level_tables(plan, lv)
+        if nodes.shape[0] * float(S + B + 1) ** 2 * 8 * 3 > max_level_bytes:
+            return None
     finv, wf, wb = factorize(plan, rowptr, col, csr.val, csr.device)
     return DirectHandle(plan, finv, wf, wb, csr.device)

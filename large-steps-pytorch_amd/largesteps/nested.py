@@ -8,18 +8,18 @@ nested-dissection elimination tree has log2(V / leaf) levels, and with the *mult
 one batch of small dense matrix-vector products:
 
     tree      geometric bisection of the vertex positions (median split along the longest axis); the separator of a
-              domain = its side-0 vertices that touch side 1. Node i owns its separator (leaves: their whole domain),
-              children 2i, 2i+1 (heap numbering), D = depth of the leaves.
+              domain = its side-0 vertices that touch side 1. A tree node merges log2(arity) bisection rounds: it owns
+              the separators of those rounds (leaves: their whole domain) and has `arity` children.
     ordering  deepest level first, root last: the vertices of a node are one contiguous range of the new numbering.
     front i   [own_i | bnd_i], bnd_i = the ancestors' vertices the subtree of i touches (filled graph), sorted.
     factor    F_i = A[front_i, front_i] restricted to entries with a row or column in own_i, plus the children's Schur
               complements U_c (extend-add). Stored per node, fp32:   Finv_i = F_ss^-1  (s x s),
               W_i = F_bs F_ss^-1 (b x s);  U_i = F_bb - W_i F_sb goes to the parent.
     solve     up   (leaves -> root): b'_s = b_s - (children's updates at own_i);  upd_i = W_i b'_s + (children's
-                   updates at bnd_i)                       [pull: no atomics, one launch per level]
+                   updates at bnd_i)                       [no atomics, one launch per level]
               down (root -> leaves): x_s = Finv_i b'_s - W_i^T x[bnd_i]
 
-Per solve the GPU reads every W twice and every Finv once -- and launches 2 D + 1 kernels.
+Per solve the GPU reads every W twice and every Finv once -- and launches 2 * levels kernels.
 """
 import numpy as np
 
@@ -29,21 +29,30 @@ def _row_index(rowptr):
 
 
 class NDPlan:
-    """Arrays indexed by heap node id carry one unused slot 0 (root = 1, children of i = 2i, 2i+1)."""
+    """Node ids are 1-based and level-major: level l holds arity^l nodes starting at level_off[l]; node (l, q) has the
+    children (l + 1, arity * q + c). Arrays indexed by node id carry one unused slot 0."""
 
     @staticmethod
-    def build(rowptr, col, positions, leaf_size=48):
+    def build(rowptr, col, positions, leaf_size=48, arity=4):
+        """arity (2, 4 or 8): every tree node merges log2(arity) rounds of bisection -- its own block is the union of
+        the 1 + 2 + .. separators of those rounds, its children are the arity sub-domains. Fewer, fatter levels:
+        the re-solve is latency bound (one dependent launch per level and sweep), so trading a few percent more
+        factor entries for half (a third) of the launches pays. The leaf domains always form their own last level."""
         rowptr = np.asarray(rowptr).astype(np.int64)
         col = np.asarray(col).astype(np.int64)
         pos = np.asarray(positions, dtype=np.float64)
         V = rowptr.shape[0] - 1
         if V <= 0 or pos.shape[0] != V:
             raise ValueError("NDPlan.build: positions must have one row per matrix row")
+        if arity not in (2, 4, 8):
+            raise ValueError("NDPlan.build: arity must be 2, 4 or 8")
+        m = int(np.log2(arity))
         D = 0
         while (V >> D) > leaf_size:
             D += 1
+        D = -(-D // m) * m                                   # bisection rounds: a multiple of log2(arity)
         rows = _row_index(rowptr)
-        node = np.ones(V, dtype=np.int64)
+        node = np.ones(V, dtype=np.int64)                    # binary heap id of the domain a vertex lives in
         fixed = np.zeros(V, dtype=bool)
         side_of = np.zeros(V, dtype=np.int8)
         for _ in range(D):
@@ -62,52 +71,66 @@ class NDPlan:
                 rank = np.arange(idx.shape[0]) - starts[seg]      # seg is already sorted: o2 keeps the segments
                 side_of[idx[o2]] = (rank >= (counts[seg] // 2)).astype(np.int8)
             live = ~fixed
-            m = live[rows] & live[col] & (node[rows] == node[col]) & (side_of[rows] == 0) & (side_of[col] == 1)
+            msk = live[rows] & live[col] & (node[rows] == node[col]) & (side_of[rows] == 0) & (side_of[col] == 1)
             sep = np.zeros(V, dtype=bool)
-            sep[rows[m]] = True
+            sep[rows[msk]] = True
             fixed |= sep
             move = ~fixed
             node[move] = 2 * node[move] + side_of[move]
-        return NDPlan._finish(V, D, rows, col, node)
+        # binary (level lb, heap id) -> merged (level, index): separators of rounds m*l .. m*l + m - 1 form level l,
+        # the leaf domains (binary level D) form the last level D / m
+        lb = np.floor(np.log2(node)).astype(np.int64)
+        lvl = np.where(lb == D, D // m, lb // m)
+        anc = node >> np.where(lb == D, 0, lb - m * (lb // m))
+        q = anc - (np.int64(1) << (m * lvl))
+        return NDPlan._finish(V, D // m + 1, arity, rows, col, lvl, q)
 
     @staticmethod
-    def _finish(V, D, rows, col, node):
-        n_nodes = (1 << (D + 1)) - 1
+    def _finish(V, levels, arity, rows, col, lvl, q):
+        level_off = np.array([1 + (arity ** l - 1) // (arity - 1) for l in range(levels + 1)], dtype=np.int64)
+        n_nodes = int(level_off[levels] - 1)
+        node = level_off[lvl] + q                                        # node id of every vertex
         level_of = np.zeros(n_nodes + 1, dtype=np.int64)
-        for lv in range(D + 1):
-            level_of[1 << lv:1 << (lv + 1)] = lv
-        perm = np.lexsort((np.arange(V), node, -level_of[node]))      # new -> old
+        parent = np.zeros(n_nodes + 1, dtype=np.int64)
+        child_ix = np.zeros(n_nodes + 1, dtype=np.int64)
+        for l in range(levels):
+            ids = np.arange(level_off[l], level_off[l + 1])
+            level_of[ids] = l
+            if l:
+                parent[ids] = level_off[l - 1] + (ids - level_off[l]) // arity
+                child_ix[ids] = (ids - level_off[l]) % arity
+        perm = np.lexsort((np.arange(V), node, -level_of[node]))         # new -> old: deepest level first
         inv = np.empty(V, dtype=np.int64)
         inv[perm] = np.arange(V)
         s = np.bincount(node, minlength=n_nodes + 1).astype(np.int64)
-        node_order = np.concatenate([np.arange(1 << lv, 1 << (lv + 1)) for lv in range(D, -1, -1)])
+        node_order = np.concatenate([np.arange(level_off[l], level_off[l + 1]) for l in range(levels - 1, -1, -1)])
         own_start = np.zeros(n_nodes + 1, dtype=np.int64)
         own_start[node_order] = np.cumsum(s[node_order]) - s[node_order]
         own_end = own_start + s
-        nn = node[perm]                                               # node of every new id
+        nn = node[perm]                                                  # node of every new id
         prow, pcol = inv[rows], inv[col]
-        up = pcol >= own_end[nn[prow]]                                # entries that reach an ancestor
+        up = pcol >= own_end[nn[prow]]                                   # entries that reach an ancestor
         a_node, a_w = nn[prow[up]], pcol[up]
         a_level = level_of[a_node]
         # boundary sets, deepest level first (a node's set needs its children's)
-        keys_by_level = [np.empty(0, np.int64)] * (D + 1)
-        for lv in range(D, 0, -1):
-            m = a_level == lv
-            keys = a_node[m] * V + a_w[m]
-            if lv < D:
-                ck = keys_by_level[lv + 1]
+        keys_by_level = [np.empty(0, np.int64)] * levels
+        for l in range(levels - 1, 0, -1):
+            msk = a_level == l
+            keys = a_node[msk] * V + a_w[msk]
+            if l < levels - 1:
+                ck = keys_by_level[l + 1]
                 c_node, c_w = ck // V, ck % V
-                par = c_node >> 1
+                par = parent[c_node]
                 keep = c_w >= own_end[par]
                 keys = np.concatenate([keys, par[keep] * V + c_w[keep]])
-            keys_by_level[lv] = np.unique(keys)
-        keys = np.concatenate(keys_by_level[1:]) if D > 0 else np.empty(0, np.int64)    # sorted by (node, w)
+            keys_by_level[l] = np.unique(keys)
+        keys = np.concatenate(keys_by_level[1:]) if levels > 1 else np.empty(0, np.int64)    # sorted by (node, w)
         k_node, bnd = keys // V, keys % V
         b = np.bincount(k_node, minlength=n_nodes + 1).astype(np.int64)
         bnd_off = np.concatenate([[0], np.cumsum(b)])[:-1]
         front_off = np.concatenate([[0], np.cumsum(s + b)])[:-1]
-        # position of every boundary vertex of node c in its parent's front, and the inverse (pull) maps
-        par = k_node >> 1
+        # position of every boundary vertex of a node in its parent's front [own | boundary]
+        par = parent[k_node]
         in_own = bnd < own_end[par]
         assert (bnd[in_own] >= own_start[par[in_own]]).all(), "separator property violated"
         ppos = np.where(in_own, bnd - own_start[par], 0)
@@ -115,16 +138,21 @@ class NDPlan:
             at = np.searchsorted(keys, par[~in_own] * V + bnd[~in_own])
             assert (keys[at] == par[~in_own] * V + bnd[~in_own]).all(), "child boundary not contained in parent front"
             ppos[~in_own] = s[par[~in_own]] + at - bnd_off[par[~in_own]]
-        local_k = np.arange(keys.shape[0]) - bnd_off[k_node]
-        maps = np.full((2, int((s + b).sum())), -1, dtype=np.int32)
-        maps[k_node & 1, front_off[par] + ppos] = local_k
+        # push lists of the down sweep: front position -> the children's boundary entries that are this vertex
+        gpos = front_off[par] + ppos                                     # global front position of every boundary entry
+        order = np.argsort(gpos, kind="stable")
+        n_front = int((s + b).sum())
+        push_ptr = np.concatenate([[0], np.cumsum(np.bincount(gpos, minlength=n_front))]).astype(np.int64)
+        push_tgt = order.astype(np.int64)                                # index into the concatenated boundary vectors
         plan = NDPlan()
-        plan.V, plan.D, plan.n_nodes = int(V), int(D), int(n_nodes)
+        plan.V, plan.levels, plan.arity, plan.n_nodes = int(V), int(levels), int(arity), int(n_nodes)
+        plan.D = plan.levels - 1
+        plan.level_off, plan.level_of, plan.parent, plan.child_ix = level_off, level_of, parent, child_ix
         plan.perm, plan.inv = perm, inv
         plan.s, plan.b, plan.own_start = s, b, own_start
         plan.bnd, plan.bnd_off, plan.front_off = bnd.astype(np.int64), bnd_off, front_off
         plan.ppos = ppos.astype(np.int64)
-        plan.map0, plan.map1 = maps[0], maps[1]
+        plan.push_ptr, plan.push_tgt = push_ptr, push_tgt
         plan.finv_off = np.concatenate([[0], np.cumsum(s * s)])[:-1]
         plan.w_off = np.concatenate([[0], np.cumsum(s * b)])[:-1]
         plan.finv_size, plan.w_size = int((s * s).sum()), int((s * b).sum())
@@ -132,7 +160,14 @@ class NDPlan:
         return plan
 
     def level_nodes(self, lv):
-        return np.arange(1 << lv, 1 << (lv + 1))
+        return np.arange(self.level_off[lv], self.level_off[lv + 1])
+
+    def children(self, i):
+        lv = int(self.level_of[i])
+        if lv + 1 >= self.levels:
+            return []
+        first = int(self.level_off[lv + 1] + (i - self.level_off[lv]) * self.arity)
+        return list(range(first, first + self.arity))
 
     @property
     def factor_entries(self):
@@ -150,7 +185,7 @@ class NDPlan:
         ent_off = np.concatenate([[0], np.cumsum(np.bincount(self.node_of_new[prow], minlength=self.n_nodes + 1))])
         finv, w = np.zeros(self.finv_size), np.zeros(self.w_size)
         U = {}
-        for lv in range(self.D, -1, -1):
+        for lv in range(self.levels - 1, -1, -1):
             for i in self.level_nodes(lv):
                 s, b, o = int(self.s[i]), int(self.b[i]), int(self.own_start[i])
                 F = np.zeros((s + b, s + b))
@@ -162,12 +197,11 @@ class NDPlan:
                 bi = s + np.searchsorted(self.bnd[self.bnd_off[i]:self.bnd_off[i] + b], c[upm])
                 F[bi, r[upm]] = v[upm]
                 F[r[upm], bi] = v[upm]
-                if lv < self.D:
-                    for ch in (2 * i, 2 * i + 1):
-                        bc = int(self.b[ch])
-                        if bc:
-                            pp = self.ppos[self.bnd_off[ch]:self.bnd_off[ch] + bc]
-                            F[np.ix_(pp, pp)] += U.pop(ch)
+                for ch in self.children(i):
+                    bc = int(self.b[ch])
+                    if bc:
+                        pp = self.ppos[self.bnd_off[ch]:self.bnd_off[ch] + bc]
+                        F[np.ix_(pp, pp)] += U.pop(ch)
                 if s:
                     Fi = np.linalg.inv(F[:s, :s])
                     Fi = 0.5 * (Fi + Fi.T)
@@ -180,33 +214,36 @@ class NDPlan:
         return finv, w
 
     def solve_reference(self, finv, w, rhs):
-        """rhs in the ORIGINAL numbering, (V, k); returns x in the original numbering."""
+        """rhs in the ORIGINAL numbering, (V, k); returns x in the original numbering. Same data flow as csrc/direct.hip:
+        `slots` (one per front position and child, zero unless pushed) upwards, push lists downwards."""
         bp = np.asarray(rhs, dtype=np.float64)[self.perm]
         k = bp.shape[1]
-        upd = np.zeros((self.bnd.shape[0], k))
+        n_front = int((self.s + self.b).sum())
+        slots = np.zeros((n_front, self.arity, k))
         bprime = bp.copy()
-
-        def pulled(i, lo, hi):          # children's updates at front positions [lo, hi) of node i
-            out = np.zeros((hi - lo, k))
-            if i * 2 <= self.n_nodes:
-                for ch, mp in ((2 * i, self.map0), (2 * i + 1, self.map1)):
-                    m = mp[self.front_off[i] + lo:self.front_off[i] + hi]
-                    out[m >= 0] += upd[self.bnd_off[ch] + m[m >= 0]]
-            return out
-
-        for lv in range(self.D, -1, -1):
+        for lv in range(self.levels - 1, -1, -1):
             for i in self.level_nodes(lv):
-                s, b, o = int(self.s[i]), int(self.b[i]), int(self.own_start[i])
-                bprime[o:o + s] = bp[o:o + s] - pulled(i, 0, s)
+                s, b, o, f = int(self.s[i]), int(self.b[i]), int(self.own_start[i]), int(self.front_off[i])
+                bprime[o:o + s] = bp[o:o + s] - slots[f:f + s].sum(axis=1)
                 W = w[self.w_off[i]:self.w_off[i] + b * s].reshape(b, s)
-                upd[self.bnd_off[i]:self.bnd_off[i] + b] = W @ bprime[o:o + s] + pulled(i, s, s + b)
+                upd = W @ bprime[o:o + s] + slots[f + s:f + s + b].sum(axis=1)
+                if b:
+                    pf = int(self.front_off[self.parent[i]])
+                    slots[pf + self.ppos[self.bnd_off[i]:self.bnd_off[i] + b], int(self.child_ix[i])] = upd
         x = np.zeros_like(bp)
-        for lv in range(0, self.D + 1):
+        xb = np.zeros((self.bnd.shape[0], k))
+        for lv in range(self.levels):
             for i in self.level_nodes(lv):
-                s, b, o = int(self.s[i]), int(self.b[i]), int(self.own_start[i])
+                s, b, o, f = int(self.s[i]), int(self.b[i]), int(self.own_start[i]), int(self.front_off[i])
                 Fi = finv[self.finv_off[i]:self.finv_off[i] + s * s].reshape(s, s)
                 W = w[self.w_off[i]:self.w_off[i] + b * s].reshape(b, s)
-                x[o:o + s] = Fi @ bprime[o:o + s] - W.T @ x[self.bnd[self.bnd_off[i]:self.bnd_off[i] + b]]
+                xbi = xb[self.bnd_off[i]:self.bnd_off[i] + b]
+                x[o:o + s] = Fi @ bprime[o:o + s] - W.T @ xbi
+                front_x = np.concatenate([x[o:o + s], xbi])
+                for p_ in range(s + b):
+                    t0, t1 = self.push_ptr[f + p_], self.push_ptr[f + p_ + 1]
+                    xb[self.push_tgt[t0:t1]] = front_x[p_]
+        assert np.array_equal(x[self.bnd], xb), "every boundary entry received its vertex's x"
         out = np.empty_like(x)
         out[self.perm] = x
         return out

@@ -250,14 +250,14 @@ class NestedDissectionSolver(Solver):
     otherwise or when the mesh does not dissect into fronts that fit the kernels.
     """
 
-    def __init__(self, M, leaf_size=48):
+    def __init__(self, M, leaf_size=32, arity=4):
         from . import direct
         import time
         csr = _native.csr_of(M)
         self._csr = csr
         self.last_info = None
         t0 = time.perf_counter()
-        self._direct = direct.build(csr, leaf_size=leaf_size)
+        self._direct = direct.build(csr, leaf_size=leaf_size, arity=arity)
         torch.cuda.synchronize(csr.device)
         self.build_seconds = time.perf_counter() - t0
         if self._direct is None:
@@ -305,14 +305,14 @@ class CholeskySolver(Solver):
     other attribute is the chosen solver's.
     """
 
-    def __init__(self, M, rtol=1e-6, max_iter=10000, chebyshev=True, patch_columns=3, direct=None, leaf_size=64):
+    def __init__(self, M, rtol=1e-6, max_iter=10000, chebyshev=True, patch_columns=3, direct=None, leaf_size=32, arity=4):
         if direct is None:
             direct = not os.environ.get("LARGESTEPS_NO_DIRECT")
         self._impl = None
         self.direct_error = None
         if direct:
             try:
-                self._impl = NestedDissectionSolver(M, leaf_size=leaf_size)
+                self._impl = NestedDissectionSolver(M, leaf_size=leaf_size, arity=arity)
             except (ValueError, RuntimeError) as e:      # no positions / fronts too large / numerically not SPD
                 self.direct_error = str(e)
         if self._impl is None:

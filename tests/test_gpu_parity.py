@@ -385,8 +385,8 @@ def test_direct_solver_all_golden_meshes(golden, dev, name, case):
 
 
 @pytest.mark.parametrize("k", [1, 2, 3, 4, 7])
-@pytest.mark.parametrize("leaf", [8, 64])
-def test_direct_solver_widths_and_trees(dev, k, leaf):
+@pytest.mark.parametrize("leaf,arity", [(8, 2), (8, 4), (64, 4), (16, 8)])
+def test_direct_solver_widths_and_trees(dev, k, leaf, arity):
     """Column counts (k > 4 goes through column groups), deep trees (leaf 8) and the level kernels of both kinds."""
     from largesteps.geometry import compute_matrix
     from largesteps.solvers import NestedDissectionSolver
@@ -397,7 +397,7 @@ def test_direct_solver_widths_and_trees(dev, k, leaf):
     idx, val = M.indices().cpu().numpy(), M.values().cpu().numpy()
     b = np.random.default_rng(k).standard_normal((v.shape[0], k)).astype(np.float32)
     x64 = osv.from_differential(idx[0], idx[1], val, b)
-    s = NestedDissectionSolver(M, leaf_size=leaf)
+    s = NestedDissectionSolver(M, leaf_size=leaf, arity=arity)
     x = s.solve(_t(b, dev))
     assert np.abs(x.cpu().numpy() - x64).max() <= 2e-5 * np.abs(x64).max()
     assert torch.equal(x, s.solve(_t(b, dev))), "no atomics: bitwise reproducible"

@@ -40,54 +40,72 @@ MESHES = {
 }
 
 
+def ancestor_at(p, i, lv):
+    while p.level_of[i] > lv:
+        i = p.parent[i]
+    return i
+
+
+@pytest.mark.parametrize("arity", [2, 4, 8])
 @pytest.mark.parametrize("leaf", [4, 16, 64])
 @pytest.mark.parametrize("name", list(MESHES))
-def test_plan_invariants(name, leaf):
+def test_plan_invariants(name, leaf, arity):
     v, f = MESHES[name]()
     r, rowptr, c, val = csr_of(v, f, lambda_=5.0)
     V = v.shape[0]
-    p = NDPlan.build(rowptr, c, v, leaf_size=leaf)
+    p = NDPlan.build(rowptr, c, v, leaf_size=leaf, arity=arity)
     assert sorted(p.perm.tolist()) == list(range(V)) and np.array_equal(p.inv[p.perm], np.arange(V))
     assert int(p.s[1:].sum()) == V and p.b[1] == 0 and p.s[0] == 0 and p.b[0] == 0
+    assert p.n_nodes == sum(arity ** l for l in range(p.levels))
     nn = p.node_of_new
     # contiguous own ranges, deepest level first
     for i in range(1, p.n_nodes + 1):
         assert (nn[p.own_start[i]:p.own_start[i] + p.s[i]] == i).all()
+        assert [int(p.parent[ch]) for ch in p.children(i)] == [i] * len(p.children(i))
     # separator property: an entry only links a vertex to its own node, an ancestor or a descendant
     pr, pc = p.inv[r], p.inv[c]
-    a, d = nn[pr], nn[pc]
-    la, ld = np.floor(np.log2(a)).astype(int), np.floor(np.log2(d)).astype(int)
-    hi = np.where(la <= ld, a, d)
-    lo = np.where(la <= ld, d, a)
-    assert ((lo >> np.abs(la - ld)) == hi).all()
+    for a, d in set(zip(nn[pr].tolist(), nn[pc].tolist())):
+        lo, hi = (a, d) if p.level_of[a] >= p.level_of[d] else (d, a)
+        assert ancestor_at(p, lo, p.level_of[hi]) == hi
     # boundary sets: sorted, strictly after the own range, inside the ancestors; children's boundaries nest
     for i in range(1, p.n_nodes + 1):
         bi = p.bnd[p.bnd_off[i]:p.bnd_off[i] + p.b[i]]
         assert (np.diff(bi) > 0).all() and (bi >= p.own_start[i] + p.s[i]).all()
-        anc = nn[bi]
-        lv = np.floor(np.log2(np.maximum(anc, 1))).astype(int)
-        assert ((i >> (int(np.floor(np.log2(i))) - lv)) == anc).all(), "boundary vertices live in ancestors"
+        for a in set(nn[bi].tolist()):
+            assert p.level_of[a] < p.level_of[i] and ancestor_at(p, i, p.level_of[a]) == a, "boundary vertices live in ancestors"
         if i > 1:
-            par = i >> 1
+            par = int(p.parent[i])
             front = np.concatenate([np.arange(p.own_start[par], p.own_start[par] + p.s[par]),
                                     p.bnd[p.bnd_off[par]:p.bnd_off[par] + p.b[par]]])
             pp = p.ppos[p.bnd_off[i]:p.bnd_off[i] + p.b[i]]
             assert np.array_equal(front[pp], bi)
-            mp = (p.map0, p.map1)[i & 1][p.front_off[par]:p.front_off[par] + p.s[par] + p.b[par]]
-            assert np.array_equal(np.flatnonzero(mp >= 0), np.sort(pp)) and np.array_equal(mp[pp], np.arange(p.b[i]))
+    # push lists: front position -> exactly the children's boundary entries that are the same vertex
+    n_front = int((p.s + p.b).sum())
+    assert p.push_ptr.shape[0] == n_front + 1 and p.push_ptr[-1] == p.bnd.shape[0]
+    assert sorted(p.push_tgt.tolist()) == list(range(p.bnd.shape[0]))
+    for i in range(1, p.n_nodes + 1):
+        front = np.concatenate([np.arange(p.own_start[i], p.own_start[i] + p.s[i]), p.bnd[p.bnd_off[i]:p.bnd_off[i] + p.b[i]]])
+        for q_, vert in enumerate(front):
+            tg = p.push_tgt[p.push_ptr[p.front_off[i] + q_]:p.push_ptr[p.front_off[i] + q_ + 1]]
+            assert (p.bnd[tg] == vert).all()
+            owners = np.searchsorted(p.bnd_off, tg, side="right") - 1       # node of every target entry (skips empty nodes)
+            assert all(int(p.parent[o]) == i for o in owners)
     assert p.factor_entries == int((p.s * p.s + 2 * p.s * p.b).sum())
     with pytest.raises(ValueError):
         NDPlan.build(rowptr, c, v[:-1], leaf_size=leaf)
+    with pytest.raises(ValueError):
+        NDPlan.build(rowptr, c, v, arity=3)
 
 
 @pytest.mark.parametrize("name,kw", [("plane30", dict(lambda_=30.0)), ("ico10", dict(lambda_=0.0, alpha=0.9, cotan=True)),
                                       ("soup0", dict(lambda_=3.0)), ("soup1", dict(lambda_=0.0, alpha=0.5)), ("tiny", dict(lambda_=1.0))])
-def test_numpy_statement_vs_oracle(name, kw):
+@pytest.mark.parametrize("arity", [2, 4, 8])
+def test_numpy_statement_vs_oracle(name, kw, arity):
     v, f = MESHES[name]()
     if kw.get("cotan"):
         v = synthetic.perturb(v, radial=0.05, tangential=0.1, edge=0.1, seed=1)
     r, rowptr, c, val = csr_of(v, f, **kw)
-    p = NDPlan.build(rowptr, c, v, leaf_size=12)
+    p = NDPlan.build(rowptr, c, v, leaf_size=12, arity=arity)
     finv, w = p.factor_reference(rowptr, c, val)
     b = np.random.default_rng(0).standard_normal((v.shape[0], 3))
     x = p.solve_reference(finv, w, b)
@@ -96,13 +114,14 @@ def test_numpy_statement_vs_oracle(name, kw):
 
 
 @pytest.mark.parametrize("name,kw", [("plane30", dict(lambda_=30.0)), ("ico10", dict(lambda_=0.0, alpha=0.9, cotan=True)), ("soup0", dict(lambda_=3.0))])
-def test_torch_factorisation_matches_statement(name, kw):
+@pytest.mark.parametrize("arity", [2, 4, 8])
+def test_torch_factorisation_matches_statement(name, kw, arity):
     """largesteps.direct.factorize (what runs on the MI355X, here on CPU tensors): padded level batches, extend-add by
     index arithmetic, packing into the three flat fp32 arrays of the C ABI."""
     from largesteps.direct import factorize
     v, f = MESHES[name]()
     r, rowptr, c, val = csr_of(v, f, **kw)
-    p = NDPlan.build(rowptr, c, v, leaf_size=10)
+    p = NDPlan.build(rowptr, c, v, leaf_size=10, arity=arity)
     finv, w = p.factor_reference(rowptr, c, val)
     finv_t, wf_t, wb_t = factorize(p, rowptr, c, torch.from_numpy(val), torch.device("cpu"))
     scale = np.abs(finv).max()

@@ -9,18 +9,19 @@ from largesteps.solvers import NestedDissectionSolver
 cfg_name = sys.argv[1] if len(sys.argv) > 1 else "cfg4_plane1m"
 leaf = int(sys.argv[2]) if len(sys.argv) > 2 else 96
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+arity = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 dev = torch.device("cuda:0")
 v, f, cfg = synthetic.config_mesh(cfg_name)
 tv, tf = torch.from_numpy(v).to(dev), torch.from_numpy(f).to(dev)
 M = compute_matrix(tv, tf, cfg["lambda_"] if cfg["lambda_"] is not None else 0.0, alpha=cfg["alpha"], cotan=cfg["cotan"])
 u = to_differential(M, tv)
-s = NestedDissectionSolver(M, leaf_size=leaf)
+s = NestedDissectionSolver(M, leaf_size=leaf, arity=arity)
 for _ in range(3): x = s.solve(u)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(n): x = s.solve(u)
 torch.cuda.synchronize()
-print(f"{cfg_name} leaf {leaf}: {(time.perf_counter() - t0) / n * 1e3:.3f} ms/solve, err {float((x - tv).abs().max()):.2e}, D={s.plan.D}")
+print(f"{cfg_name} leaf {leaf} arity {arity}: {(time.perf_counter() - t0) / n * 1e3:.3f} ms/solve, err {float((x - tv).abs().max()):.2e}, levels={s.plan.levels}, entries/V={s.plan.factor_entries / v.shape[0]:.1f}, build {s.build_seconds:.1f}s")
 p = s.plan
-for lv in range(p.D + 1):
+for lv in range(p.levels):
     nd = p.level_nodes(lv)
     print("level", lv, "nodes", nd.shape[0], "s", int(p.s[nd].max()), "b", int(p.b[nd].max()), "entries", int((p.s[nd] ** 2 + 2 * p.s[nd] * p.b[nd]).sum()))
