@@ -69,9 +69,10 @@ def pmc_traffic(kernel_prefix, workload):
             d = json.load(fh)
         if d.get("workload") != workload:
             return None
-        for name, rec in d["kernels"].items():
-            if name.startswith(kernel_prefix):
-                return rec["traffic_bytes"]
+        hits = [rec for name, rec in d["kernels"].items() if name.startswith(kernel_prefix)]
+        if hits:      # several kernels share the prefix (the tree-level kernels): dispatch-weighted mean per launch
+            n = sum(r.get("dispatches", 1) for r in hits)
+            return sum(r["traffic_bytes"] * r.get("dispatches", 1) for r in hits) / max(n, 1)
     except (OSError, ValueError, KeyError):
         pass
     return None

@@ -368,18 +368,16 @@ __device__ __forceinline__ void dot_rows(const float* __restrict__ base, size_t 
     }
 }
 
-// lane r of the wave ends up with the total of row r
+// lane (lane0 + r) of the wave takes the total of row r
 template <int K>
-__device__ __forceinline__ void rows_to_lanes(const float (&acc)[ND_ROWS][K], float (&mine)[K]) {
+__device__ __forceinline__ void rows_to_lanes(const float (&acc)[ND_ROWS][K], int lane0, float (&mine)[K]) {
     const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int q = 0; q < K; ++q) mine[q] = 0.0f;
 #pragma unroll
     for (int r = 0; r < ND_ROWS; ++r) {
 #pragma unroll
         for (int q = 0; q < K; ++q) {
             const float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum63(acc[r][q])), 63));
-            if (lane == r) mine[q] = tot;
+            if (lane == lane0 + r) mine[q] = tot;
         }
     }
 }
@@ -388,39 +386,47 @@ template <int K>
 __global__ __launch_bounds__(64 * ND_BW) void k_nd_up_b(const Tile* __restrict__ tiles, const int* __restrict__ perm,
                                                         const unsigned char* __restrict__ mask, const int* __restrict__ ppos,
                                                         const float* __restrict__ wb, const float* __restrict__ b_in,
-                                                        float* __restrict__ bprime, float* slots, int s_cap) {
+                                                        float* __restrict__ bprime, float* slots, int s_cap, int chunks) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sb = sm;
     const Tile t = tiles[blockIdx.x];
     if (t.store == 2) { store_bprime<K>(t, perm, mask, slots, b_in, bprime); return; }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int s = t.s, b = t.b;
-    const int i0 = t.row0 + w * ND_ROWS;                       // this wave's rows i0 .. i0 + ND_ROWS
-    const int nrows = max(0, min(ND_ROWS, b - i0));
-    // per-row epilogue data (lane r of the wave serves row i0 + r), requested before anything else
+    const int iw = t.row0 + w * ND_ROWS * chunks;              // this wave's rows iw .. iw + ND_ROWS * chunks
+    const int wrows = max(0, min(ND_ROWS * chunks, b - iw));
+    const float* __restrict__ wrow = wb + t.w_off + (size_t)iw * s;
+    float first[ND_ROWS][ND_E];
+    rows_load(wrow, (size_t)s, min(wrows, ND_ROWS), s, 0, first);   // in flight while b' is assembled
+    // per-row epilogue data (lane r of the wave serves row iw + r), requested before anything else
     int pp = 0;
     float pass[K];
 #pragma unroll
     for (int q = 0; q < K; ++q) pass[q] = 0.0f;
-    const float* __restrict__ wrow = wb + t.w_off + (size_t)i0 * s;
-    float first[ND_ROWS][ND_E];
-    rows_load(wrow, (size_t)s, nrows, s, 0, first);            // in flight while b' is assembled
-    if (lane < nrows) {
-        pp = ppos[t.bnd_off + i0 + lane];
-        if (!t.leaf) pull_slots<K>(slots, mask, (size_t)(t.front_off + s + i0 + lane), t.arity, pass);
+    if (lane < wrows) {
+        pp = ppos[t.bnd_off + iw + lane];
+        if (!t.leaf) pull_slots<K>(slots, mask, (size_t)(t.front_off + s + iw + lane), t.arity, pass);
     }
     fill_bprime<K>(t, perm, mask, slots, b_in, bprime, sb);
     __syncthreads();
-    float acc[ND_ROWS][K];
-#pragma unroll
-    for (int r = 0; r < ND_ROWS; ++r) {
-#pragma unroll
-        for (int q = 0; q < K; ++q) acc[r][q] = 0.0f;
-    }
-    if (nrows > 0) dot_rows<K>(wrow, (size_t)s, nrows, s, sb, first, acc);
     float mine[K];
-    rows_to_lanes<K>(acc, mine);
-    if (lane < nrows) {
+#pragma unroll
+    for (int q = 0; q < K; ++q) mine[q] = 0.0f;
+    for (int c = 0; c < chunks; ++c) {
+        const int nrows = max(0, min(ND_ROWS, wrows - c * ND_ROWS));
+        if (nrows == 0) break;
+        float acc[ND_ROWS][K];
+#pragma unroll
+        for (int r = 0; r < ND_ROWS; ++r) {
+#pragma unroll
+            for (int q = 0; q < K; ++q) acc[r][q] = 0.0f;
+        }
+        const float* __restrict__ rowc = wrow + (size_t)c * ND_ROWS * s;
+        if (c) rows_load(rowc, (size_t)s, nrows, s, 0, first);
+        dot_rows<K>(rowc, (size_t)s, nrows, s, sb, first, acc);
+        rows_to_lanes<K>(acc, c * ND_ROWS, mine);
+    }
+    if (lane < wrows) {
         const size_t dst = ((size_t)(t.pfront_off + pp) * t.arity + t.cix) * K;
 #pragma unroll
         for (int q = 0; q < K; ++q) slots[dst + q] = mine[q] + pass[q];
@@ -432,7 +438,7 @@ __global__ __launch_bounds__(64 * ND_BW) void k_nd_down_b(const Tile* __restrict
                                                           const int* __restrict__ push_ptr, const int* __restrict__ push_tgt,
                                                           const float* __restrict__ finv, const float* __restrict__ wf,
                                                           const float* __restrict__ bprime, float* xb, float* __restrict__ x_out,
-                                                          int s_cap, int b_cap) {
+                                                          int s_cap, int b_cap, int chunks) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sb = sm;
     float* sx = sm + (size_t)s_cap * K;
@@ -440,18 +446,18 @@ __global__ __launch_bounds__(64 * ND_BW) void k_nd_down_b(const Tile* __restrict
     if (t.forward) { forward_rows<K>(t, push_ptr, push_tgt, xb); return; }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int s = t.s, b = t.b;
-    const int j0 = t.row0 + w * ND_ROWS;
-    const int nrows = max(0, min(ND_ROWS, s - j0));
-    const float* __restrict__ frow = finv + t.finv_off + (size_t)j0 * s;
-    const float* __restrict__ wrow = wf + t.w_off + (size_t)j0 * b;
+    const int jw = t.row0 + w * ND_ROWS * chunks;
+    const int wrows = max(0, min(ND_ROWS * chunks, s - jw));
+    const float* __restrict__ frow = finv + t.finv_off + (size_t)jw * s;
+    const float* __restrict__ wrow = wf + t.w_off + (size_t)jw * b;
     float first_f[ND_ROWS][ND_E], first_w[ND_ROWS][ND_E];
-    rows_load(frow, (size_t)s, nrows, s, 0, first_f);          // in flight while the vectors are staged
-    rows_load(wrow, (size_t)b, nrows, b, 0, first_w);
+    rows_load(frow, (size_t)s, min(wrows, ND_ROWS), s, 0, first_f);          // in flight while the vectors are staged
+    rows_load(wrow, (size_t)b, min(wrows, ND_ROWS), b, 0, first_w);
     int p0 = 0, p1 = 0;
     size_t g = 0;
-    if (lane < nrows) {
-        g = (size_t)perm[t.own_start + j0 + lane];
-        if (!t.leaf) { p0 = push_ptr[t.front_off + j0 + lane]; p1 = push_ptr[t.front_off + j0 + lane + 1]; }
+    if (lane < wrows) {
+        g = (size_t)perm[t.own_start + jw + lane];
+        if (!t.leaf) { p0 = push_ptr[t.front_off + jw + lane]; p1 = push_ptr[t.front_off + jw + lane + 1]; }
     }
     for (int u = threadIdx.x; u < s; u += blockDim.x) {
 #pragma unroll
@@ -462,19 +468,26 @@ __global__ __launch_bounds__(64 * ND_BW) void k_nd_down_b(const Tile* __restrict
         for (int q = 0; q < K; ++q) sx[i * K + q] = -xb[(size_t)(t.bnd_off + i) * K + q];
     }
     __syncthreads();
-    float acc[ND_ROWS][K];
-#pragma unroll
-    for (int r = 0; r < ND_ROWS; ++r) {
-#pragma unroll
-        for (int q = 0; q < K; ++q) acc[r][q] = 0.0f;
-    }
-    if (nrows > 0) {
-        dot_rows<K>(frow, (size_t)s, nrows, s, sb, first_f, acc);
-        dot_rows<K>(wrow, (size_t)b, nrows, b, sx, first_w, acc);
-    }
     float mine[K];
-    rows_to_lanes<K>(acc, mine);
-    if (lane < nrows) {
+#pragma unroll
+    for (int q = 0; q < K; ++q) mine[q] = 0.0f;
+    for (int c = 0; c < chunks; ++c) {
+        const int nrows = max(0, min(ND_ROWS, wrows - c * ND_ROWS));
+        if (nrows == 0) break;
+        float acc[ND_ROWS][K];
+#pragma unroll
+        for (int r = 0; r < ND_ROWS; ++r) {
+#pragma unroll
+            for (int q = 0; q < K; ++q) acc[r][q] = 0.0f;
+        }
+        const float* __restrict__ fc = frow + (size_t)c * ND_ROWS * s;
+        const float* __restrict__ wc = wrow + (size_t)c * ND_ROWS * b;
+        if (c) { rows_load(fc, (size_t)s, nrows, s, 0, first_f); rows_load(wc, (size_t)b, nrows, b, 0, first_w); }
+        dot_rows<K>(fc, (size_t)s, nrows, s, sb, first_f, acc);
+        dot_rows<K>(wc, (size_t)b, nrows, b, sx, first_w, acc);
+        rows_to_lanes<K>(acc, c * ND_ROWS, mine);
+    }
+    if (lane < wrows) {
 #pragma unroll
         for (int q = 0; q < K; ++q) x_out[g * K + q] = mine[q];
         push_down<K>(push_tgt, p0, p1, xb, mine);
@@ -482,7 +495,7 @@ __global__ __launch_bounds__(64 * ND_BW) void k_nd_down_b(const Tile* __restrict
 }
 
 // down tiles of a level: compute tiles, then forward tiles
-struct LevelPlan { int up_first = 0, up_tiles = 0, up_nw = 1, down_first = 0, down_tiles = 0, down_nw = 1, s_cap = 0, b_cap = 0, up_b = 0, down_b = 0; };
+struct LevelPlan { int up_first = 0, up_tiles = 0, up_nw = 1, down_first = 0, down_tiles = 0, down_nw = 1, s_cap = 0, b_cap = 0, up_b = 0, down_b = 0, up_chunks = 1, down_chunks = 1; };
 
 }  // namespace ls
 
@@ -507,7 +520,7 @@ static int env_int(const char* name, int dflt) { const char* e = getenv(name); c
 
 // waves per workgroup of the row-per-lane kernels: about LS_ND_STEPS reduction steps per wave where 16 waves allow it
 static int pick_nw(int len) {
-    static const int target = env_int("LS_ND_STEPS", 64);
+    static const int target = env_int("LS_ND_STEPS", 128);
     int nw = 1;
     while (nw < 16 && len > nw * target) nw *= 2;
     return nw;
@@ -583,7 +596,7 @@ extern "C" int ls_direct_create(int64_t V, int levels, int arity, const int64_t*
     };
     d->plan.resize(levels);
     size_t lds_max = 0;
-    static const int long_red = env_int("LS_ND_LONG", 160);
+    static const int long_red = env_int("LS_ND_LONG", 256);
     for (int lv = 0; lv < levels; ++lv) {
         LevelPlan& p = d->plan[lv];
         int red_up = 0, red_down = 0;
@@ -594,7 +607,12 @@ extern "C" int ls_direct_create(int64_t V, int levels, int arity, const int64_t*
         // long reductions: lanes along the reduction (k_nd_*_b), ND_ROWS * ND_BW rows per tile; short: a row per lane
         p.up_b = red_up >= long_red; p.down_b = red_down >= long_red;
         p.up_nw = p.up_b ? ND_BW : pick_nw(red_up); p.down_nw = p.down_b ? ND_BW : pick_nw(red_down);
-        const int up_rows = p.up_b ? ND_ROWS * ND_BW : WAVE, down_rows = p.down_b ? ND_ROWS * ND_BW : WAVE;
+        // *_b kernels: a wave keeps about ND_INFLIGHT row loads in flight -> short rows come in several chunks of ND_ROWS
+        static const int inflight = env_int("LS_ND_INFLIGHT", 24);
+        const int lpr_up = div_up(std::max(p.s_cap, 1), WAVE), lpr_down = lpr_up + div_up(std::max(p.b_cap, 1), WAVE);
+        p.up_chunks = std::min(4, std::max(1, div_up(inflight, ND_ROWS * lpr_up)));
+        p.down_chunks = std::min(4, std::max(1, div_up(inflight, ND_ROWS * lpr_down)));
+        const int up_rows = p.up_b ? ND_ROWS * ND_BW * p.up_chunks : WAVE, down_rows = p.down_b ? ND_ROWS * ND_BW * p.down_chunks : WAVE;
         p.up_first = (int)tiles.size();
         const int up_threads = WAVE * p.up_nw;
         for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i) {
@@ -672,7 +690,7 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
         if (!p.up_tiles) continue;
         if (p.up_b)
             hipLaunchKernelGGL(k_nd_up_b<K>, dim3(p.up_tiles), dim3(WAVE * ND_BW), (size_t)p.s_cap * K * sizeof(float), st, d->tiles + p.up_first,
-                               d->perm, d->mask, d->ppos, d->wb, b, d->bp, d->slots, p.s_cap);
+                               d->perm, d->mask, d->ppos, d->wb, b, d->bp, d->slots, p.s_cap, p.up_chunks);
         else
             hipLaunchKernelGGL(k_nd_up<K>, dim3(p.up_tiles), dim3(WAVE * p.up_nw), ((size_t)p.s_cap + (size_t)(p.up_nw - 1) * WAVE) * K * sizeof(float),
                                st, d->tiles + p.up_first, d->perm, d->mask, d->ppos, d->wf, b, d->bp, d->slots, p.s_cap);
@@ -684,7 +702,7 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
         if (p.down_b)
             hipLaunchKernelGGL(k_nd_down_b<K>, dim3(p.down_tiles), dim3(WAVE * ND_BW), ((size_t)p.s_cap + p.b_cap) * K * sizeof(float), st,
                                d->tiles + p.down_first, d->perm, d->push_ptr, d->push_tgt, d->finv, d->wf, (const float*)d->bp, d->xb, x,
-                               p.s_cap, p.b_cap);
+                               p.s_cap, p.b_cap, p.down_chunks);
         else
             hipLaunchKernelGGL(k_nd_down<K>, dim3(p.down_tiles), dim3(WAVE * p.down_nw),
                                ((size_t)p.s_cap + p.b_cap + (size_t)(p.down_nw - 1) * WAVE) * K * sizeof(float), st, d->tiles + p.down_first,

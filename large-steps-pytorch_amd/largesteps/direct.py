@@ -166,7 +166,7 @@ class DirectHandle:
         return dict(factor_entries=fe.value, launches=nl.value, up_ms=ms[0], down_ms=ms[1], perm_ms=ms[2])
 
 
-def build(csr, leaf_size=32, arity=4, max_front=8000, max_entries=3_000_000_000, max_level_bytes=48e9):
+def build(csr, leaf_size=64, arity=4, max_front=8000, max_entries=3_000_000_000, max_level_bytes=48e9):
     """Plan + factorisation + native handle for the CSR side car of a matrix (needs csr.positions). Returns None when
     the mesh does not dissect well enough for this solver (front too large for LDS / factor too large)."""
     if csr.positions is None:

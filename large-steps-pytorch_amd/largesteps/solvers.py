@@ -250,7 +250,7 @@ class NestedDissectionSolver(Solver):
     otherwise or when the mesh does not dissect into fronts that fit the kernels.
     """
 
-    def __init__(self, M, leaf_size=32, arity=4):
+    def __init__(self, M, leaf_size=64, arity=4):
         from . import direct
         import time
         csr = _native.csr_of(M)
@@ -305,7 +305,7 @@ class CholeskySolver(Solver):
     other attribute is the chosen solver's.
     """
 
-    def __init__(self, M, rtol=1e-6, max_iter=10000, chebyshev=True, patch_columns=3, direct=None, leaf_size=32, arity=4):
+    def __init__(self, M, rtol=1e-6, max_iter=10000, chebyshev=True, patch_columns=3, direct=None, leaf_size=64, arity=4):
         if direct is None:
             direct = not os.environ.get("LARGESTEPS_NO_DIRECT")
         self._impl = None
