@@ -14,6 +14,7 @@
 // prefetch of the first matrix rows before the right-hand side is assembled, and two kernel shapes:
 //     k_nd_up / k_nd_down      a row per lane, NW waves split the reduction range and meet in LDS (short reductions)
 //     k_nd_up_b / k_nd_down_b  lanes ALONG the reduction, a wave owns ND_ROWS rows, DPP butterfly (long reductions)
+//     k_nd_up_s / k_nd_down_s  small nodes: the node's whole matrix staged in LDS by one coalesced burst, a row per thread
 #include "common.h"
 #include <vector>
 #include <algorithm>
@@ -494,8 +495,125 @@ __global__ __launch_bounds__(64 * ND_BW) void k_nd_down_b(const Tile* __restrict
     }
 }
 
+// ---- small nodes (the lower tree levels): the node's whole matrix staged in LDS ------------------------------------
+// A leaf front is a few thousand numbers. Walking it row-per-lane from HBM means s (+ b) dependent, partly filled
+// 256-byte loads per wave; instead the workgroup copies the node's contiguous matrix block(s) into LDS with one burst
+// of independent, fully coalesced loads (every lane busy whatever s and b are) and multiplies out of LDS, a row per
+// thread, conflict free (consecutive threads read consecutive words).
+__device__ __forceinline__ void stage_block(const float* __restrict__ src, int n, float* __restrict__ dst) {
+    constexpr int U = 16;     // loads in flight per thread: the copy is a burst, not a chain of load -> store pairs
+    for (int e0 = threadIdx.x; e0 < n; e0 += blockDim.x * U) {
+        float v[U];
+#pragma unroll
+        for (int r = 0; r < U; ++r) { const int e = e0 + r * blockDim.x; v[r] = e < n ? src[e] : 0.0f; }
+#pragma unroll
+        for (int r = 0; r < U; ++r) { const int e = e0 + r * blockDim.x; if (e < n) dst[e] = v[r]; }
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void k_nd_up_s(const Tile* __restrict__ tiles, const int* __restrict__ perm,
+                                                 const unsigned char* __restrict__ mask, const int* __restrict__ ppos,
+                                                 const float* __restrict__ wf, const float* __restrict__ b_in,
+                                                 float* __restrict__ bprime, float* slots, int s_cap, int b_cap) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* sb = sm;                                  // s_cap * K
+    float* mw = sm + (size_t)s_cap * K;              // s * b: W^T, mw[j * b + i]
+    const Tile t = tiles[blockIdx.x];
+    const int s = t.s, b = t.b, i = threadIdx.x;
+    stage_block(wf + t.w_off, s * b, mw);
+    int pp = 0;
+    float pass[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) pass[q] = 0.0f;
+    if (i < b) {
+        pp = ppos[t.bnd_off + i];
+        if (!t.leaf) pull_slots<K>(slots, mask, (size_t)(t.front_off + s + i), t.arity, pass);
+    }
+    fill_bprime<K>(t, perm, mask, slots, b_in, bprime, sb);
+    __syncthreads();
+    if (i < b) {
+        float acc[K];
+#pragma unroll
+        for (int q = 0; q < K; ++q) acc[q] = 0.0f;
+#pragma unroll 4
+        for (int j = 0; j < s; ++j) {
+            const float a = mw[j * b + i];
+#pragma unroll
+            for (int q = 0; q < K; ++q) acc[q] = fmaf(a, sb[j * K + q], acc[q]);
+        }
+        const size_t dst = ((size_t)(t.pfront_off + pp) * t.arity + t.cix) * K;
+#pragma unroll
+        for (int q = 0; q < K; ++q) slots[dst + q] = acc[q] + pass[q];
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void k_nd_down_s(const Tile* __restrict__ tiles, const int* __restrict__ perm,
+                                                   const int* __restrict__ push_ptr, const int* __restrict__ push_tgt,
+                                                   const float* __restrict__ finv, const float* __restrict__ wb,
+                                                   const float* __restrict__ bprime, float* xb, float* __restrict__ x_out,
+                                                   int s_cap, int b_cap) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* sb = sm;                                  // s_cap * K
+    float* sx = sm + (size_t)s_cap * K;              // b_cap * K
+    float* mf = sx + (size_t)b_cap * K;              // s * s: Finv, mf[t * s + j]
+    const Tile t = tiles[blockIdx.x];
+    if (t.forward) { forward_rows<K>(t, push_ptr, push_tgt, xb); return; }
+    const int s = t.s, b = t.b, j = threadIdx.x;
+    float* mw = mf + (size_t)s * s;                  // b * s: W, mw[i * s + j]
+    stage_block(finv + t.finv_off, s * s, mf);
+    stage_block(wb + t.w_off, b * s, mw);
+    int p0 = 0, p1 = 0;
+    size_t g = 0;
+    if (j < s) {
+        g = (size_t)perm[t.own_start + j];
+        if (!t.leaf) { p0 = push_ptr[t.front_off + j]; p1 = push_ptr[t.front_off + j + 1]; }
+    }
+    for (int u = threadIdx.x; u < s; u += blockDim.x) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) sb[u * K + q] = bprime[(size_t)(t.own_start + u) * K + q];
+    }
+    for (int i = threadIdx.x; i < b; i += blockDim.x) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) sx[i * K + q] = -xb[(size_t)(t.bnd_off + i) * K + q];
+    }
+    __syncthreads();
+    // the boundary rows hand x down while the own rows multiply (leaf levels have nothing to hand down)
+    if (!t.leaf) {
+        for (int i = threadIdx.x; i < b; i += blockDim.x) {
+            const size_t f = (size_t)(t.front_off + s + i);
+            const int q0 = push_ptr[f], q1 = push_ptr[f + 1];
+            float v[K];
+#pragma unroll
+            for (int q = 0; q < K; ++q) v[q] = -sx[i * K + q];
+            push_down<K>(push_tgt, q0, q1, xb, v);
+        }
+    }
+    if (j < s) {
+        float acc[K];
+#pragma unroll
+        for (int q = 0; q < K; ++q) acc[q] = 0.0f;
+#pragma unroll 4
+        for (int u = 0; u < s; ++u) {
+            const float a = mf[u * s + j];
+#pragma unroll
+            for (int q = 0; q < K; ++q) acc[q] = fmaf(a, sb[u * K + q], acc[q]);
+        }
+#pragma unroll 4
+        for (int i = 0; i < b; ++i) {
+            const float a = mw[i * s + j];
+#pragma unroll
+            for (int q = 0; q < K; ++q) acc[q] = fmaf(a, sx[i * K + q], acc[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < K; ++q) x_out[g * K + q] = acc[q];
+        push_down<K>(push_tgt, p0, p1, xb, acc);
+    }
+}
+
 // down tiles of a level: compute tiles, then forward tiles
-struct LevelPlan { int up_first = 0, up_tiles = 0, up_nw = 1, down_first = 0, down_tiles = 0, down_nw = 1, s_cap = 0, b_cap = 0, up_b = 0, down_b = 0, up_chunks = 1, down_chunks = 1; };
+struct LevelPlan { int up_first = 0, up_tiles = 0, up_nw = 1, down_first = 0, down_tiles = 0, down_nw = 1, s_cap = 0, b_cap = 0, up_b = 0, down_b = 0, up_chunks = 1, down_chunks = 1, up_s = 0, down_s = 0; };
 
 }  // namespace ls
 
@@ -520,7 +638,7 @@ static int env_int(const char* name, int dflt) { const char* e = getenv(name); c
 
 // waves per workgroup of the row-per-lane kernels: about LS_ND_STEPS reduction steps per wave where 16 waves allow it
 static int pick_nw(int len) {
-    static const int target = env_int("LS_ND_STEPS", 128);
+    const int target = env_int("LS_ND_STEPS", 128);     // read at every create: tests and tuning runs toggle it
     int nw = 1;
     while (nw < 16 && len > nw * target) nw *= 2;
     return nw;
@@ -596,7 +714,7 @@ extern "C" int ls_direct_create(int64_t V, int levels, int arity, const int64_t*
     };
     d->plan.resize(levels);
     size_t lds_max = 0;
-    static const int long_red = env_int("LS_ND_LONG", 256);
+    const int long_red = env_int("LS_ND_LONG", 256);
     for (int lv = 0; lv < levels; ++lv) {
         LevelPlan& p = d->plan[lv];
         int red_up = 0, red_down = 0;
@@ -608,20 +726,30 @@ extern "C" int ls_direct_create(int64_t V, int levels, int arity, const int64_t*
         p.up_b = red_up >= long_red; p.down_b = red_down >= long_red;
         p.up_nw = p.up_b ? ND_BW : pick_nw(red_up); p.down_nw = p.down_b ? ND_BW : pick_nw(red_down);
         // *_b kernels: a wave keeps about ND_INFLIGHT row loads in flight -> short rows come in several chunks of ND_ROWS
-        static const int inflight = env_int("LS_ND_INFLIGHT", 24);
+        const int inflight = env_int("LS_ND_INFLIGHT", 24);
         const int lpr_up = div_up(std::max(p.s_cap, 1), WAVE), lpr_down = lpr_up + div_up(std::max(p.b_cap, 1), WAVE);
         p.up_chunks = std::min(4, std::max(1, div_up(inflight, ND_ROWS * lpr_up)));
         p.down_chunks = std::min(4, std::max(1, div_up(inflight, ND_ROWS * lpr_down)));
         const int up_rows = p.up_b ? ND_ROWS * ND_BW * p.up_chunks : WAVE, down_rows = p.down_b ? ND_ROWS * ND_BW * p.down_chunks : WAVE;
+        // small nodes: whole matrix staged in LDS, one workgroup per node, a row per thread
+        const int small_lds = env_int("LS_ND_SMALL_KB", 40) * 1024;
+        const size_t up_s_bytes = ((size_t)p.s_cap * p.b_cap + (size_t)p.s_cap * d->kmax) * sizeof(float);
+        const size_t down_s_bytes = ((size_t)p.s_cap * (p.s_cap + p.b_cap) + (size_t)(p.s_cap + p.b_cap) * d->kmax) * sizeof(float);
+        p.up_s = p.b_cap <= 256 && p.s_cap <= 256 && up_s_bytes <= (size_t)small_lds && !getenv("LS_ND_NO_SMALL");
+        // (measured at 1M: staging pays for the up sweep -- W only, 42 + 18 + 15 us against 45 + 21 + 17 -- but not for the
+        //  down sweep, whose Finv + W footprint leaves 6 single-wave workgroups per CU: 151 us against 57; LS_ND_SMALL_DOWN=1 enables it)
+        p.down_s = p.s_cap <= 256 && down_s_bytes <= (size_t)small_lds && getenv("LS_ND_SMALL_DOWN") && !getenv("LS_ND_NO_SMALL");
+        if (p.up_s) { p.up_b = 0; p.up_nw = std::max(1, div_up(p.b_cap, WAVE)); }
+        if (p.down_s) { p.down_b = 0; p.down_nw = std::max(1, div_up(p.s_cap, WAVE)); }
         p.up_first = (int)tiles.size();
         const int up_threads = WAVE * p.up_nw;
         for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i) {
             // b' of the own rows is kept for the down sweep: by the first compute tile (small nodes, or nodes whose only
             // tile exists for that purpose), or by store-only tiles of blockDim rows each (large nodes: the one tile
             // would walk s / blockDim dependent load chains)
-            const bool store_tiles = nodes[i].s > 2 * up_threads;
+            const bool store_tiles = !p.up_s && nodes[i].s > 2 * up_threads;
             const int rows = std::max(nodes[i].b, (nodes[i].s && !store_tiles) ? 1 : 0);
-            for (int r = 0; r < rows; r += up_rows) {
+            for (int r = 0; r < rows; r += (p.up_s ? 1 << 30 : up_rows)) {
                 tiles.push_back(tile_of(i, r, lv, 0));
                 tiles.back().store = (r == 0 && !store_tiles) ? 1 : 0;
             }
@@ -631,10 +759,11 @@ extern "C" int ls_direct_create(int64_t V, int levels, int arity, const int64_t*
         p.up_tiles = (int)tiles.size() - p.up_first;
         p.down_first = (int)tiles.size();
         for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i)
-            for (int r = 0; r < nodes[i].s; r += down_rows) tiles.push_back(tile_of(i, r, lv, 0));
-        if (lv + 1 < levels)
+            for (int r = 0; r < nodes[i].s; r += (p.down_s ? 1 << 30 : down_rows)) tiles.push_back(tile_of(i, r, lv, 0));
+        if (lv + 1 < levels)      // forward tiles: boundary rows of every node (staged kernel: only of nodes without own rows)
             for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i)
-                for (int r = 0; r < nodes[i].b; r += WAVE * p.down_nw) tiles.push_back(tile_of(i, r, lv, 1));
+                if (!p.down_s || !nodes[i].s)
+                    for (int r = 0; r < nodes[i].b; r += WAVE * p.down_nw) tiles.push_back(tile_of(i, r, lv, 1));
         p.down_tiles = (int)tiles.size() - p.down_first;
         lds_max = std::max(lds_max, ((size_t)p.s_cap + p.b_cap + 16 * WAVE) * d->kmax * sizeof(float));
     }
@@ -664,7 +793,9 @@ extern "C" int ls_direct_create(int64_t V, int levels, int arity, const int64_t*
     (void)hipFuncSetAttribute((const void*)k_nd_up<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);       \
     (void)hipFuncSetAttribute((const void*)k_nd_down<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
     (void)hipFuncSetAttribute((const void*)k_nd_up_b<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
-    (void)hipFuncSetAttribute((const void*)k_nd_down_b<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_nd_down_b<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
+    (void)hipFuncSetAttribute((const void*)k_nd_up_s<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
+    (void)hipFuncSetAttribute((const void*)k_nd_down_s<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     LS_OPTIN(1) LS_OPTIN(2) LS_OPTIN(3) LS_OPTIN(4)
 #undef LS_OPTIN
     *out = d;
@@ -688,7 +819,10 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
     for (int lv = top; lv >= 0; --lv) {
         const LevelPlan& p = d->plan[lv];
         if (!p.up_tiles) continue;
-        if (p.up_b)
+        if (p.up_s)
+            hipLaunchKernelGGL(k_nd_up_s<K>, dim3(p.up_tiles), dim3(WAVE * p.up_nw), ((size_t)p.s_cap * p.b_cap + (size_t)p.s_cap * K) * sizeof(float), st,
+                               d->tiles + p.up_first, d->perm, d->mask, d->ppos, d->wf, b, d->bp, d->slots, p.s_cap, p.b_cap);
+        else if (p.up_b)
             hipLaunchKernelGGL(k_nd_up_b<K>, dim3(p.up_tiles), dim3(WAVE * ND_BW), (size_t)p.s_cap * K * sizeof(float), st, d->tiles + p.up_first,
                                d->perm, d->mask, d->ppos, d->wb, b, d->bp, d->slots, p.s_cap, p.up_chunks);
         else
@@ -699,7 +833,11 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
     for (int lv = 0; lv <= top; ++lv) {
         const LevelPlan& p = d->plan[lv];
         if (!p.down_tiles) continue;
-        if (p.down_b)
+        if (p.down_s)
+            hipLaunchKernelGGL(k_nd_down_s<K>, dim3(p.down_tiles), dim3(WAVE * p.down_nw),
+                               ((size_t)p.s_cap * (p.s_cap + p.b_cap) + (size_t)(p.s_cap + p.b_cap) * K) * sizeof(float), st, d->tiles + p.down_first,
+                               d->perm, d->push_ptr, d->push_tgt, d->finv, d->wb, (const float*)d->bp, d->xb, x, p.s_cap, p.b_cap);
+        else if (p.down_b)
             hipLaunchKernelGGL(k_nd_down_b<K>, dim3(p.down_tiles), dim3(WAVE * ND_BW), ((size_t)p.s_cap + p.b_cap) * K * sizeof(float), st,
                                d->tiles + p.down_first, d->perm, d->push_ptr, d->push_tgt, d->finv, d->wf, (const float*)d->bp, d->xb, x,
                                p.s_cap, p.b_cap, p.down_chunks);

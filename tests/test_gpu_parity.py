@@ -409,6 +409,28 @@ def test_direct_solver_widths_and_trees(dev, k, leaf, arity):
     assert inf["factor_entries"] == s.plan.factor_entries and inf["launches"] >= 1
 
 
+@pytest.mark.parametrize("env", [{"LS_ND_NO_SMALL": "1"}, {"LS_ND_SMALL_DOWN": "1", "LS_ND_SMALL_KB": "150"}, {"LS_ND_LONG": "16"},
+                                 {"LS_ND_LONG": "100000", "LS_ND_STEPS": "8"}, {"LS_ND_INFLIGHT": "200", "LS_ND_LONG": "16"}])
+def test_direct_solver_kernel_shapes(dev, monkeypatch, env):
+    """Every kernel shape of the re-solve (row per lane with 1..16 waves, lanes along the reduction with 1..4 row chunks,
+    LDS-staged small nodes in either sweep) forced onto the same tree: same answer."""
+    from largesteps.geometry import compute_matrix
+    from largesteps.solvers import NestedDissectionSolver
+    from largesteps import synthetic
+    v, f = synthetic.plane(120)
+    M = compute_matrix(_t(v, dev), _t(f, dev), 25.0)
+    idx, val = M.indices().cpu().numpy(), M.values().cpu().numpy()
+    b = np.random.default_rng(5).standard_normal((v.shape[0], 3)).astype(np.float32)
+    x64 = osv.from_differential(idx[0], idx[1], val, b)
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    for arity in (2, 4):
+        s = NestedDissectionSolver(M, leaf_size=24, arity=arity)
+        x = s.solve(_t(b, dev))
+        assert np.abs(x.cpu().numpy() - x64).max() <= 2e-5 * np.abs(x64).max()
+        assert torch.equal(x, s.solve(_t(b, dev)))
+
+
 def test_direct_solver_needs_positions(golden, dev):
     """A foreign matrix has no vertex positions: NestedDissectionSolver refuses, CholeskySolver iterates."""
     from largesteps.solvers import CholeskySolver, NestedDissectionSolver
