@@ -555,10 +555,17 @@ def bench_sharded(workload, device, steps, warmup, shard="auto"):
         info = local.last_info if local.last_info is not None else dict(iterations=0, converged=True, method="idle")
         its = torch.tensor([info["iterations"], int(info["converged"])], dtype=torch.int64, device=device)
         dist.all_reduce(its, op=dist.ReduceOp.MAX)
-        out.update(iterations=int(its[0]), converged=bool(its[1]), halo=0, method="chebyshev", depth=0, rows_per_rank=v.shape[0],
-                   solver=(f"HIP Chebyshev-Jacobi (LDS-resident patch kernel), the {k} right-hand-side columns solved on "
-                           f"{min(world, k)} of {world} ranks, one all-gather of the solution per solve (RCCL), no "
-                           f"per-iteration communication"))
+        active = min(world, k)
+        if local.method == "nested-dissection":
+            what = (f"HIP nested-dissection direct solver (factor once per rank, {local.info()['launches']} launches per re-solve)")
+            # every active rank reads the whole factor for its column(s)
+            out["solve_bytes"] = int(active * 4 * local.plan.factor_entries + 4 * k * 4 * v.shape[0])
+        else:
+            what = "HIP Chebyshev-Jacobi / Jacobi-PCG iteration"
+            out["solve_bytes"] = None
+        out.update(iterations=int(its[0]), converged=bool(its[1]), halo=0, method=local.method, depth=0, rows_per_rank=v.shape[0],
+                   solver=(f"{what}; the {k} right-hand-side columns solved on {active} of {world} ranks, one all-gather of the "
+                           f"solution per solve (RCCL), no per-iteration communication"))
         return out
     halo = torch.tensor([plan.n_halo], dtype=torch.int64, device=device)
     dist.all_reduce(halo, op=dist.ReduceOp.MAX)
