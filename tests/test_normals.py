@@ -1,0 +1,128 @@
+"""
+Vertex / face normals: oracle vs the reference-generated fixture (CPU), HIP kernels vs
+oracle and fixture (-m gpu). Fixture: tests/golden/reference_normals.npz = outputs AND torch-autograd gradients of the
+reference's own scripts/geometry.py (tests/golden/make_golden_normals.py).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import normals as on
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MESHES = ["tetra", "quad", "ico3", "ico8_noisy", "plane9", "unreferenced"]
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return np.load(os.path.join(HERE, "golden", "reference_normals.npz"))
+
+
+def close(a, b, atol):
+    ok = np.isfinite(b)
+    assert np.array_equal(np.isfinite(a), ok), "NaN pattern differs from the reference"
+    assert np.abs(a[ok] - b[ok]).max(initial=0.0) <= atol
+
+
+@pytest.mark.parametrize("name", MESHES)
+def test_oracle_vs_reference(ref, name):
+    v, f = ref[f"{name}/verts"], ref[f"{name}/faces"]
+    fn = on.face_normals(v, f)
+    close(fn, ref[f"{name}/face_normals"], 3e-7)
+    close(on.vertex_normals(v, f, fn), ref[f"{name}/vertex_normals"], 3e-7)
+    gscale = max(np.abs(ref[f"{name}/grad_all"]).max(), 1e-3)
+    close(on.face_normals_backward(v, f, ref[f"{name}/w_f"]), ref[f"{name}/grad_face"], 1e-6 * max(np.abs(ref[f"{name}/grad_face"]).max(), 1.0))
+    gv, gfn = on.vertex_normals_backward(v, f, ref[f"{name}/face_normals"].astype(np.float64), ref[f"{name}/w_v"])
+    close(gv, ref[f"{name}/grad_vn_verts"], 2e-6 * gscale)
+    close(gfn, ref[f"{name}/grad_vn_fn"], 1e-6 * max(np.abs(ref[f"{name}/grad_vn_fn"]).max(), 1.0))
+    close(gv + on.face_normals_backward(v, f, gfn), ref[f"{name}/grad_all"], 2e-6 * gscale)
+
+
+def test_oracle_gradients_are_derivatives():
+    """central differences of the oracle's own forward, incl. the global-norm terms"""
+    from largesteps import synthetic
+    v, f = synthetic.icosphere(2)
+    v = (v * (1.0 + 0.1 * np.random.default_rng(0).standard_normal((v.shape[0], 1)))).astype(np.float64)
+    w = np.random.default_rng(1).standard_normal(v.shape)
+    loss = lambda x: float((on.vertex_normals(x, f, on.face_normals(x, f)) * w).sum())    # noqa: E731
+    fn = on.face_normals(v, f)
+    gv, gfn = on.vertex_normals_backward(v, f, fn, w)
+    g = gv + on.face_normals_backward(v, f, gfn)
+    rng = np.random.default_rng(2)
+    for _ in range(6):
+        d = rng.standard_normal(v.shape)
+        h = 1e-6
+        fd = (loss(v + h * d) - loss(v - h * d)) / (2 * h)
+        assert abs(fd - (g * d).sum()) <= 1e-6 * max(1.0, abs(fd))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from largesteps import _native
+    _native.lib()
+    return torch.device("cuda:0")
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idx", [np.int64, np.int32])
+@pytest.mark.parametrize("name", MESHES)
+def test_hip_vs_reference(ref, dev, name, idx):
+    from largesteps.normals import compute_face_normals, compute_vertex_normals
+    v, f = ref[f"{name}/verts"], ref[f"{name}/faces"].astype(idx)
+    tv = _t(v, dev).requires_grad_(True)
+    tf = _t(f, dev)
+    fn = compute_face_normals(tv, tf)
+    vn = compute_vertex_normals(tv, tf, fn)
+    assert fn.shape == (3, f.shape[0]) and vn.shape == v.shape and fn.dtype == torch.float32
+    # fp32 kernels vs the reference's fp32 torch ops: a few ulp (different summation order in the scatter / norms)
+    close(fn.detach().cpu().numpy(), ref[f"{name}/face_normals"], 1e-6)
+    close(vn.detach().cpu().numpy(), ref[f"{name}/vertex_normals"], 2e-6)
+    gscale = max(np.abs(ref[f"{name}/grad_all"]).max(), 1e-3)
+    g_all, = torch.autograd.grad((vn * _t(ref[f"{name}/w_v"], dev)).sum(), tv, retain_graph=True)
+    close(g_all.cpu().numpy(), ref[f"{name}/grad_all"], 2e-5 * gscale)
+    g_face, = torch.autograd.grad((fn * _t(ref[f"{name}/w_f"], dev)).sum(), tv, retain_graph=True)
+    close(g_face.cpu().numpy(), ref[f"{name}/grad_face"], 1e-5 * max(np.abs(ref[f"{name}/grad_face"]).max(), 1.0))
+    # face normals as an independent input (the reference's signature allows it)
+    fn_c = _t(ref[f"{name}/face_normals"], dev).requires_grad_(True)
+    tv2 = _t(v, dev).requires_grad_(True)
+    vn2 = compute_vertex_normals(tv2, tf, fn_c)
+    gv, gfn = torch.autograd.grad((vn2 * _t(ref[f"{name}/w_v"], dev)).sum(), (tv2, fn_c))
+    close(gv.cpu().numpy(), ref[f"{name}/grad_vn_verts"], 2e-5 * gscale)
+    close(gfn.cpu().numpy(), ref[f"{name}/grad_vn_fn"], 1e-5 * max(np.abs(ref[f"{name}/grad_vn_fn"]).max(), 1.0))
+
+
+@pytest.mark.gpu
+def test_hip_large_mesh_vs_oracle_and_errors(dev):
+    from largesteps import synthetic
+    from largesteps.normals import compute_face_normals, compute_vertex_normals
+    v, f, _ = synthetic.config_mesh("cfg2_bunny70k")
+    tv, tf = _t(v, dev).requires_grad_(True), _t(f, dev)
+    fn = compute_face_normals(tv, tf)
+    vn = compute_vertex_normals(tv, tf, fn)
+    fn64 = on.face_normals(v, f)
+    vn64 = on.vertex_normals(v, f, fn64)
+    assert np.abs(fn.detach().cpu().numpy() - fn64).max() <= 2e-6
+    assert np.abs(vn.detach().cpu().numpy() - vn64).max() <= 5e-6
+    w = np.random.default_rng(0).standard_normal(v.shape).astype(np.float32)
+    g, = torch.autograd.grad((vn * _t(w, dev)).sum(), tv)
+    gv, gfn = on.vertex_normals_backward(v, f, fn64, w)
+    g64 = gv + on.face_normals_backward(v, f, gfn)
+    assert np.abs(g.cpu().numpy() - g64).max() <= 2e-4 * np.abs(g64).max()
+    # size-independent property: unit length wherever a vertex is referenced
+    assert float((vn.detach().norm(dim=1) - 1).abs().max()) <= 1e-5
+    with pytest.raises(IndexError):
+        compute_face_normals(tv, _t(np.array([[0, 1, v.shape[0]]]), dev))
+    with pytest.raises(RuntimeError):
+        compute_face_normals(torch.from_numpy(v), torch.from_numpy(f))
+    with pytest.raises(ValueError):
+        compute_vertex_normals(tv, tf, fn[:, :-1])
+    with pytest.raises(TypeError):
+        compute_face_normals(tv, tf.to(torch.int16))
