@@ -2,8 +2,11 @@
 Sparse SPD solvers of the parameterization path (reference: largesteps/solvers.py).
 
 Same classes and protocol as the reference (Solver :6, CholeskySolver :26, ConjugateGradientSolver :41,
-DifferentiableSolve :128, solve :148). Both concrete solvers run the hand-written HIP Jacobi-PCG
-(csrc/pcg.hip) through one native handle per matrix; neither cholespy/CHOLMOD nor torch sparse ops are used.
+DifferentiableSolve :128, solve :148).
+    CholeskySolver            factor once / re-solve: NestedDissectionSolver (csrc/direct.hip) for matrices built by
+                              compute_matrix, IterativeCholeskySolver (Chebyshev-Jacobi / Jacobi-PCG, csrc/pcg.hip) otherwise
+    ConjugateGradientSolver   the reference's stopping rule and warm start on the HIP Jacobi-PCG
+Neither cholespy/CHOLMOD nor torch sparse ops are used; there is no CPU path.
 """
 import ctypes
 import os

@@ -431,6 +431,26 @@ def test_direct_solver_kernel_shapes(dev, monkeypatch, env):
         assert torch.equal(x, s.solve(_t(b, dev)))
 
 
+@pytest.mark.parametrize("seed", [0, 1])
+def test_cholesky_on_random_soup(dev, seed):
+    """Random connectivity has no small separators: whatever CholeskySolver decides (huge fronts -> iteration, or a
+    dense-ish factor), the answer matches the fp64 oracle; several components and unreferenced vertices included."""
+    from largesteps.geometry import compute_matrix
+    from largesteps.solvers import CholeskySolver
+    rng = np.random.default_rng(seed)
+    V = 3000
+    f = rng.integers(0, int(V * 0.9), size=(2 * V, 3)).astype(np.int64)
+    f = f[(f[:, 0] != f[:, 1]) & (f[:, 1] != f[:, 2]) & (f[:, 0] != f[:, 2])]
+    v = rng.standard_normal((V, 3)).astype(np.float32)
+    M = compute_matrix(_t(v, dev), _t(f, dev), 2.0)
+    idx, val = M.indices().cpu().numpy(), M.values().cpu().numpy()
+    b = rng.standard_normal((V, 3)).astype(np.float32)
+    x64 = osv.from_differential(idx[0], idx[1], val, b)
+    s = CholeskySolver(M)
+    x = s.solve(_t(b, dev)).cpu().numpy()
+    assert np.abs(x - x64).max() <= 1e-4 * np.abs(x64).max(), (s.method, s.direct_error)
+
+
 def test_direct_solver_needs_positions(golden, dev):
     """A foreign matrix has no vertex positions: NestedDissectionSolver refuses, CholeskySolver iterates."""
     from largesteps.solvers import CholeskySolver, NestedDissectionSolver

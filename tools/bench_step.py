@@ -1,0 +1,34 @@
+"""One optimisation step of the path at the 1M-vertex config, as the reference's loop runs it (scripts/main.py:170-200):
+   v = from_differential(M, u) -> face / vertex normals -> loss -> backward (normals, then the adjoint solve) -> AdamUniform.
+   python tools/bench_step.py [workload] [steps]"""
+import os, sys, time
+sys.path[:0] = [os.getcwd(), os.path.join(os.getcwd(), "large-steps-pytorch_amd")]
+import torch
+from largesteps import synthetic
+from largesteps.geometry import compute_matrix
+from largesteps.parameterize import to_differential, from_differential
+from largesteps.normals import compute_face_normals, compute_vertex_normals
+from largesteps.optimize import AdamUniform
+workload = sys.argv[1] if len(sys.argv) > 1 else "cfg4_plane1m"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+dev = torch.device("cuda:0")
+v, f, cfg = synthetic.config_mesh(workload)
+tv, tf = torch.from_numpy(v).to(dev), torch.from_numpy(f).to(dev)
+M = compute_matrix(tv, tf, cfg["lambda_"] if cfg["lambda_"] is not None else 0.0, alpha=cfg["alpha"], cotan=cfg["cotan"])
+u = to_differential(M, tv).requires_grad_(True)
+opt = AdamUniform([u], 3e-2)
+target_n = compute_vertex_normals(tv, tf, compute_face_normals(tv, tf)).detach()
+target_v = tv + 0.01 * torch.randn_like(tv)
+def step():
+    x = from_differential(M, u, "Cholesky")
+    n = compute_vertex_normals(x, tf, compute_face_normals(x, tf))
+    loss = (x - target_v).square().mean() + (n - target_n).square().mean()
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    return loss
+for _ in range(3): step()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(steps): l = step()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+print(f"{workload}: {dt*1e3:.3f} ms per optimisation step (forward solve + normals + loss + backward incl. adjoint solve + AdamUniform), loss {float(l):.3e}")
