@@ -15,6 +15,7 @@
 //     k_nd_up / k_nd_down      a row per lane, NW waves split the reduction range and meet in LDS (short reductions)
 //     k_nd_up_b / k_nd_down_b  lanes ALONG the reduction, a wave owns ND_ROWS rows, DPP butterfly (long reductions)
 //     k_nd_up_s / k_nd_down_s  small nodes: the node's whole matrix staged in LDS by one coalesced burst, a row per thread
+//     k_nd_up_p / k_nd_down_p  tiny nodes: up to 8 consecutive nodes share a wave (lane -> (node, row))
 #include "common.h"
 #include <vector>
 #include <algorithm>
@@ -612,8 +613,153 @@ __global__ __launch_bounds__(256) void k_nd_down_s(const Tile* __restrict__ tile
     }
 }
 
+// ---- tiny nodes (the deepest levels): several nodes per wave --------------------------------------------------------
+// A node with a dozen rows leaves most of a 64-lane wave idle and there are tens of thousands of them. A packed tile is
+// a run of up to 8 consecutive nodes of one level whose rows together fill a wave: lane -> (node, row). Consecutive
+// nodes own consecutive vertex ranges and consecutive boundary vectors, so b' / x_bnd of the whole tile are staged
+// with contiguous loads.
+constexpr int ND_PACK = 8;
+struct NodeP { int s, b, own_start, bnd_off, front_off, pfront_off, cix, pad; long long finv_off, w_off; };
+struct alignas(64) PackedTile {
+    int n, leaf, arity, pad;
+    int row0[ND_PACK + 1];      // prefix of the packed row dimension (up: boundary rows, down: own rows)
+    int sb0[ND_PACK + 1];       // prefix of s: where a node's b' starts in the tile's LDS vector
+    int sx0[ND_PACK + 1];       // prefix of b: where a node's x_bnd starts
+    NodeP d[ND_PACK];
+};
+
+__device__ __forceinline__ int find_group(const int* __restrict__ prefix, int n, int r) {
+    int g = 0;
+#pragma unroll
+    for (int c = 1; c < ND_PACK; ++c) g += (c < n && r >= prefix[c]) ? 1 : 0;
+    return g;
+}
+
+template <int K, int A>
+__device__ __forceinline__ void packed_fill(const PackedTile& t, const int* __restrict__ perm, const unsigned char* __restrict__ mask,
+                                            const float* slots, const float* __restrict__ b_in, float* __restrict__ bprime,
+                                            float* __restrict__ sb) {
+    const int S = t.sb0[t.n], first = t.d[0].own_start;
+    for (int r = threadIdx.x; r < S; r += blockDim.x) {
+        const int h = find_group(t.sb0, t.n, r);
+        const int j = r - t.sb0[h];
+        const size_t g = (size_t)perm[first + r];            // own ranges of consecutive nodes are consecutive
+        float v[K];
+#pragma unroll
+        for (int q = 0; q < K; ++q) v[q] = b_in[g * K + q];
+        if (!t.leaf) {
+            const size_t f = (size_t)(t.d[h].front_off + j);
+            float raw[A * K], u[K];
+            load_slots<K, A>(slots, f, raw);
+            sum_slots<K, A>(raw, mask[f], u);
+#pragma unroll
+            for (int q = 0; q < K; ++q) v[q] -= u[q];
+        }
+#pragma unroll
+        for (int q = 0; q < K; ++q) { sb[r * K + q] = v[q]; bprime[(size_t)(first + r) * K + q] = v[q]; }
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(64) void k_nd_up_p(const PackedTile* __restrict__ tiles, const int* __restrict__ perm,
+                                                const unsigned char* __restrict__ mask, const int* __restrict__ ppos,
+                                                const float* __restrict__ wf, const float* __restrict__ b_in,
+                                                float* __restrict__ bprime, float* slots) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* sb = sm;
+    const PackedTile& t = tiles[blockIdx.x];
+    const int lane = threadIdx.x;
+    const bool row = lane < t.row0[t.n];
+    const int g = find_group(t.row0, t.n, lane);
+    const NodeP d = t.d[g];
+    const int i = lane - t.row0[g];
+    const float* __restrict__ col = wf + d.w_off + (row ? i : 0);
+    float pre[ND_UNROLL];
+    prefetch_strided(col, (size_t)d.b, 0, row ? d.s : 0, pre);
+    int pp = 0;
+    float pass[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) pass[q] = 0.0f;
+    if (row) {
+        pp = ppos[d.bnd_off + i];
+        if (!t.leaf) pull_slots<K>(slots, mask, (size_t)(d.front_off + d.s + i), t.arity, pass);
+    }
+    if (t.arity == 4) packed_fill<K, 4>(t, perm, mask, slots, b_in, bprime, sb);
+    else if (t.arity == 2) packed_fill<K, 2>(t, perm, mask, slots, b_in, bprime, sb);
+    else packed_fill<K, 8>(t, perm, mask, slots, b_in, bprime, sb);
+    __syncthreads();
+    if (row) {
+        float acc[K];
+#pragma unroll
+        for (int q = 0; q < K; ++q) acc[q] = 0.0f;
+        dot_strided<K>(col, (size_t)d.b, 0, d.s, sb + (size_t)t.sb0[g] * K, pre, acc);
+        const size_t dst = ((size_t)(d.pfront_off + pp) * t.arity + d.cix) * K;
+#pragma unroll
+        for (int q = 0; q < K; ++q) slots[dst + q] = acc[q] + pass[q];
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(64) void k_nd_down_p(const PackedTile* __restrict__ tiles, const int* __restrict__ perm,
+                                                  const int* __restrict__ push_ptr, const int* __restrict__ push_tgt,
+                                                  const float* __restrict__ finv, const float* __restrict__ wb,
+                                                  const float* __restrict__ bprime, float* xb, float* __restrict__ x_out, int s_sum_cap) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* sb = sm;                                     // b' of the tile's own rows
+    float* sx = sm + (size_t)s_sum_cap * K;             // -x_bnd of the tile's boundary rows
+    const PackedTile& t = tiles[blockIdx.x];
+    const int lane = threadIdx.x;
+    const bool row = lane < t.row0[t.n];
+    const int g = find_group(t.row0, t.n, lane);
+    const NodeP d = t.d[g];
+    const int j = lane - t.row0[g];
+    const float* __restrict__ fcol = finv + d.finv_off + (row ? j : 0);
+    const float* __restrict__ wcol = wb + d.w_off + (row ? j : 0);
+    float pre_f[ND_UNROLL], pre_w[ND_UNROLL];
+    prefetch_strided(fcol, (size_t)d.s, 0, row ? d.s : 0, pre_f);
+    prefetch_strided(wcol, (size_t)d.s, 0, row ? d.b : 0, pre_w);
+    int p0 = 0, p1 = 0;
+    size_t gx = 0;
+    if (row) {
+        gx = (size_t)perm[d.own_start + j];
+        if (!t.leaf) { p0 = push_ptr[d.front_off + j]; p1 = push_ptr[d.front_off + j + 1]; }
+    }
+    const int S = t.sb0[t.n], B = t.sx0[t.n], first = t.d[0].own_start, bfirst = t.d[0].bnd_off;
+    for (int r = threadIdx.x; r < S; r += blockDim.x) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) sb[r * K + q] = bprime[(size_t)(first + r) * K + q];
+    }
+    for (int r = threadIdx.x; r < B; r += blockDim.x) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) sx[r * K + q] = -xb[(size_t)(bfirst + r) * K + q];
+    }
+    __syncthreads();
+    if (!t.leaf) {              // boundary rows hand x down
+        for (int r = threadIdx.x; r < B; r += blockDim.x) {
+            const int h = find_group(t.sx0, t.n, r);
+            const size_t f = (size_t)(t.d[h].front_off + t.d[h].s + (r - t.sx0[h]));
+            const int q0 = push_ptr[f], q1 = push_ptr[f + 1];
+            float v[K];
+#pragma unroll
+            for (int q = 0; q < K; ++q) v[q] = -sx[r * K + q];
+            push_down<K>(push_tgt, q0, q1, xb, v);
+        }
+    }
+    if (row) {
+        float acc[K];
+#pragma unroll
+        for (int q = 0; q < K; ++q) acc[q] = 0.0f;
+        dot_strided<K>(fcol, (size_t)d.s, 0, d.s, sb + (size_t)t.sb0[g] * K, pre_f, acc);
+        dot_strided<K>(wcol, (size_t)d.s, 0, d.b, sx + (size_t)t.sx0[g] * K, pre_w, acc);
+#pragma unroll
+        for (int q = 0; q < K; ++q) x_out[gx * K + q] = acc[q];
+        push_down<K>(push_tgt, p0, p1, xb, acc);
+    }
+}
+
 // down tiles of a level: compute tiles, then forward tiles
-struct LevelPlan { int up_first = 0, up_tiles = 0, up_nw = 1, down_first = 0, down_tiles = 0, down_nw = 1, s_cap = 0, b_cap = 0, up_b = 0, down_b = 0, up_chunks = 1, down_chunks = 1, up_s = 0, down_s = 0; };
+struct LevelPlan { int up_first = 0, up_tiles = 0, up_nw = 1, down_first = 0, down_tiles = 0, down_nw = 1, s_cap = 0, b_cap = 0, up_b = 0, down_b = 0, up_chunks = 1, down_chunks = 1, up_s = 0, down_s = 0,
+                   up_p = 0, down_p = 0, up_p_first = 0, up_p_tiles = 0, down_p_first = 0, down_p_tiles = 0, up_p_lds = 0, down_p_s = 0, down_p_lds = 0; };
 
 }  // namespace ls
 
@@ -625,6 +771,7 @@ struct ls_direct {
     int *perm = nullptr, *ppos = nullptr, *push_ptr = nullptr, *push_tgt = nullptr;
     unsigned char* mask = nullptr;
     Tile* tiles = nullptr;
+    PackedTile* ptiles = nullptr;
     const float *finv = nullptr, *wf = nullptr, *wb = nullptr;   // owned by the caller
     float *bp = nullptr, *slots = nullptr, *xb = nullptr;        // b' (V, k); up-sweep slots (n_front, arity, k); x at boundaries (n_bnd, k)
     std::vector<LevelPlan> plan;
@@ -702,6 +849,7 @@ extern "C" int ls_direct_create(int64_t V, int levels, int arity, const int64_t*
         }
     // tiles: a range of rows of one node each
     std::vector<Tile> tiles;
+    std::vector<PackedTile> ptiles;
     auto tile_of = [&](int64_t i, int r, int lv, int forward) {
         const NodeDesc& n = nodes[i];
         Tile t;
@@ -741,6 +889,41 @@ extern "C" int ls_direct_create(int64_t V, int levels, int arity, const int64_t*
         p.down_s = p.s_cap <= 256 && down_s_bytes <= (size_t)small_lds && getenv("LS_ND_SMALL_DOWN") && !getenv("LS_ND_NO_SMALL");
         if (p.up_s) { p.up_b = 0; p.up_nw = std::max(1, div_up(p.b_cap, WAVE)); }
         if (p.down_s) { p.down_b = 0; p.down_nw = std::max(1, div_up(p.s_cap, WAVE)); }
+        // tiny nodes: several nodes per wave (packed tiles), when at least two nodes of the level fit a wave
+        const bool no_pack = getenv("LS_ND_NO_PACK") != nullptr;
+        p.up_p = !no_pack && p.b_cap <= WAVE / 2 && p.s_cap <= 256 && lv > 0;
+        p.down_p = !no_pack && p.s_cap <= WAVE / 2;
+        auto pack_level = [&](bool up_sweep, int& first, int& count, int& lds_rows_s, int& lds_rows_b) {
+            first = (int)ptiles.size();
+            lds_rows_s = lds_rows_b = 0;
+            int64_t i = level_off[lv];
+            while (i < level_off[lv + 1]) {
+                PackedTile t;
+                memset(&t, 0, sizeof(t));
+                t.leaf = lv + 1 >= levels; t.arity = arity;
+                int rows = 0;
+                while (i < level_off[lv + 1] && t.n < ND_PACK) {
+                    const NodeDesc& nd = nodes[i];
+                    const int r = up_sweep ? nd.b : nd.s;
+                    if (t.n && rows + r > WAVE) break;
+                    NodeP& q = t.d[t.n];
+                    q.s = nd.s; q.b = nd.b; q.own_start = nd.own_start; q.bnd_off = nd.bnd_off; q.front_off = nd.front_off;
+                    q.pfront_off = i > 1 ? nodes[nd.parent].front_off : -1;
+                    q.cix = lv ? (int)((i - level_off[lv]) % arity) : 0; q.pad = 0; q.finv_off = nd.finv_off; q.w_off = nd.w_off;
+                    t.row0[t.n + 1] = t.row0[t.n] + r;
+                    t.sb0[t.n + 1] = t.sb0[t.n] + nd.s;
+                    t.sx0[t.n + 1] = t.sx0[t.n] + nd.b;
+                    rows += r; ++t.n; ++i;
+                }
+                for (int c = t.n + 1; c <= ND_PACK; ++c) { t.row0[c] = t.row0[t.n]; t.sb0[c] = t.sb0[t.n]; t.sx0[c] = t.sx0[t.n]; }
+                lds_rows_s = std::max(lds_rows_s, t.sb0[t.n]); lds_rows_b = std::max(lds_rows_b, t.sx0[t.n]);
+                ptiles.push_back(t);
+            }
+            count = (int)ptiles.size() - first;
+        };
+        int dummy = 0;
+        if (p.up_p) { pack_level(true, p.up_p_first, p.up_p_tiles, p.up_p_lds, dummy); p.up_s = 0; p.up_b = 0; }
+        if (p.down_p) { pack_level(false, p.down_p_first, p.down_p_tiles, p.down_p_s, p.down_p_lds); p.down_s = 0; p.down_b = 0; }
         p.up_first = (int)tiles.size();
         const int up_threads = WAVE * p.up_nw;
         for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i) {
@@ -778,7 +961,8 @@ extern "C" int ls_direct_create(int64_t V, int levels, int arity, const int64_t*
         if (n) LS_HIP(hipMemcpyAsync(*dst, src, n * sizeof(**dst), hipMemcpyHostToDevice, st));
         return LS_OK;
     };
-    if (!(rc = up(&d->tiles, tiles.data(), tiles.size())) && !(rc = up(&d->perm, h_perm, (size_t)V)) &&
+    if (!(rc = up(&d->tiles, tiles.data(), tiles.size())) && !(rc = up(&d->ptiles, ptiles.data(), ptiles.size())) &&
+        !(rc = up(&d->perm, h_perm, (size_t)V)) &&
         !(rc = up(&d->ppos, h_ppos, (size_t)n_bnd)) && !(rc = up(&d->push_ptr, h_push_ptr, (size_t)n_front + 1)) &&
         !(rc = up(&d->push_tgt, h_push_tgt, (size_t)n_bnd)) && !(rc = up(&d->mask, mask.data(), mask.size()))) {
         hipError_t e = hipMalloc((void**)&d->bp, sizeof(float) * (size_t)V * d->kmax);
@@ -805,7 +989,7 @@ extern "C" int ls_direct_create(int64_t V, int levels, int arity, const int64_t*
 extern "C" int ls_direct_destroy(ls_direct* d) {
     if (!d) return LS_OK;
     DeviceGuard g(d->device);
-    (void)hipFree(d->tiles); (void)hipFree(d->perm); (void)hipFree(d->ppos); (void)hipFree(d->push_ptr); (void)hipFree(d->push_tgt);
+    (void)hipFree(d->tiles); (void)hipFree(d->ptiles); (void)hipFree(d->perm); (void)hipFree(d->ppos); (void)hipFree(d->push_ptr); (void)hipFree(d->push_tgt);
     (void)hipFree(d->mask); (void)hipFree(d->bp); (void)hipFree(d->slots); (void)hipFree(d->xb);
     for (hipEvent_t e : d->ev) (void)hipEventDestroy(e);
     delete d;
@@ -818,8 +1002,11 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
     if (d->profile) LS_HIP(hipEventRecord(d->ev[0], st));
     for (int lv = top; lv >= 0; --lv) {
         const LevelPlan& p = d->plan[lv];
-        if (!p.up_tiles) continue;
-        if (p.up_s)
+        if (!(p.up_p ? p.up_p_tiles : p.up_tiles)) continue;
+        if (p.up_p)
+            hipLaunchKernelGGL(k_nd_up_p<K>, dim3(p.up_p_tiles), dim3(WAVE), (size_t)std::max(p.up_p_lds, 1) * K * sizeof(float), st,
+                               d->ptiles + p.up_p_first, d->perm, d->mask, d->ppos, d->wf, b, d->bp, d->slots);
+        else if (p.up_s)
             hipLaunchKernelGGL(k_nd_up_s<K>, dim3(p.up_tiles), dim3(WAVE * p.up_nw), ((size_t)p.s_cap * p.b_cap + (size_t)p.s_cap * K) * sizeof(float), st,
                                d->tiles + p.up_first, d->perm, d->mask, d->ppos, d->wf, b, d->bp, d->slots, p.s_cap, p.b_cap);
         else if (p.up_b)
@@ -832,8 +1019,12 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
     if (d->profile) LS_HIP(hipEventRecord(d->ev[1], st));
     for (int lv = 0; lv <= top; ++lv) {
         const LevelPlan& p = d->plan[lv];
-        if (!p.down_tiles) continue;
-        if (p.down_s)
+        if (!(p.down_p ? p.down_p_tiles : p.down_tiles)) continue;
+        if (p.down_p)
+            hipLaunchKernelGGL(k_nd_down_p<K>, dim3(p.down_p_tiles), dim3(WAVE), (size_t)std::max(p.down_p_s + p.down_p_lds, 1) * K * sizeof(float), st,
+                               d->ptiles + p.down_p_first, d->perm, d->push_ptr, d->push_tgt, d->finv, d->wb, (const float*)d->bp, d->xb, x,
+                               p.down_p_s);
+        else if (p.down_s)
             hipLaunchKernelGGL(k_nd_down_s<K>, dim3(p.down_tiles), dim3(WAVE * p.down_nw),
                                ((size_t)p.s_cap * (p.s_cap + p.b_cap) + (size_t)(p.s_cap + p.b_cap) * K) * sizeof(float), st, d->tiles + p.down_first,
                                d->perm, d->push_ptr, d->push_tgt, d->finv, d->wb, (const float*)d->bp, d->xb, x, p.s_cap, p.b_cap);
@@ -890,7 +1081,10 @@ extern "C" int ls_direct_info(const ls_direct* d, int64_t* h_factor_entries, int
     if (h_factor_entries) *h_factor_entries = d->factor_entries;
     if (h_launches) {
         int n = 0;
-        for (int lv = 0; lv < d->levels; ++lv) n += (d->plan[lv].up_tiles ? 1 : 0) + (d->plan[lv].down_tiles ? 1 : 0);
+        for (int lv = 0; lv < d->levels; ++lv) {
+            const LevelPlan& p = d->plan[lv];
+            n += ((p.up_p ? p.up_p_tiles : p.up_tiles) ? 1 : 0) + ((p.down_p ? p.down_p_tiles : p.down_tiles) ? 1 : 0);
+        }
         *h_launches = n;
     }
     if (h_ms3) for (int i = 0; i < 3; ++i) h_ms3[i] = d->prof_ms[i];

@@ -409,7 +409,7 @@ def test_direct_solver_widths_and_trees(dev, k, leaf, arity):
     assert inf["factor_entries"] == s.plan.factor_entries and inf["launches"] >= 1
 
 
-@pytest.mark.parametrize("env", [{"LS_ND_NO_SMALL": "1"}, {"LS_ND_SMALL_DOWN": "1", "LS_ND_SMALL_KB": "150"}, {"LS_ND_LONG": "16"},
+@pytest.mark.parametrize("env", [{"LS_ND_NO_SMALL": "1"}, {"LS_ND_NO_PACK": "1"}, {"LS_ND_NO_PACK": "1", "LS_ND_NO_SMALL": "1"}, {"LS_ND_SMALL_DOWN": "1", "LS_ND_SMALL_KB": "150"}, {"LS_ND_LONG": "16"},
                                  {"LS_ND_LONG": "100000", "LS_ND_STEPS": "8"}, {"LS_ND_INFLIGHT": "200", "LS_ND_LONG": "16"}])
 def test_direct_solver_kernel_shapes(dev, monkeypatch, env):
     """Every kernel shape of the re-solve (row per lane with 1..16 waves, lanes along the reduction with 1..4 row chunks,
@@ -424,8 +424,8 @@ def test_direct_solver_kernel_shapes(dev, monkeypatch, env):
     x64 = osv.from_differential(idx[0], idx[1], val, b)
     for k_, v_ in env.items():
         monkeypatch.setenv(k_, v_)
-    for arity in (2, 4):
-        s = NestedDissectionSolver(M, leaf_size=24, arity=arity)
+    for arity, leaf in ((2, 24), (4, 24), (4, 6)):          # leaf 6: the deepest levels run several nodes per wave
+        s = NestedDissectionSolver(M, leaf_size=leaf, arity=arity)
         x = s.solve(_t(b, dev))
         assert np.abs(x.cpu().numpy() - x64).max() <= 2e-5 * np.abs(x64).max()
         assert torch.equal(x, s.solve(_t(b, dev)))
