@@ -181,17 +181,19 @@ __global__ __launch_bounds__(BLOCK) void k_scatter(const IdxT* __restrict__ face
         if (i0 < 0 || i1 < 0 || i2 < 0 || i0 >= V || i1 >= V || i2 >= V) continue;
         float wa = 1.0f, wb = 1.0f, wc = 1.0f;
         if (COT) face_cot(verts, i0, i1, i2, wa, wb, wc);
-        // geometry.py:43-50: cota -> (f1,f2), cotb -> (f2,f0), cotc -> (f0,f1), then symmetrised
-        const int64_t ep[3] = {i1, i2, i0}, eq[3] = {i2, i0, i1};
-        const float ew[3] = {wa, wb, wc};
+        // geometry.py:43-50: cota -> (f1,f2), cotb -> (f2,f0), cotc -> (f0,f1), then symmetrised: every vertex of the face
+        // receives the two half-edges towards the other two. One cursor atomic per vertex reserves both slots; rows hold
+        // an even number of slots, so the pair is 8-byte aligned and goes out as one int2 / float2 store.
+        const int64_t row[3] = {i0, i1, i2};
+        const int c0[3] = {(int)i2, (int)i2, (int)i1}, c1[3] = {(int)i1, (int)i0, (int)i0};
+        const float w0[3] = {wb, wa, wa}, w1[3] = {wc, wc, wb};
+        int slot[3];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) slot[e] = slot_ptr[row[e]] + atomicAdd(&fill[row[e]], 2);
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
-            int s = slot_ptr[ep[e]] + atomicAdd(&fill[ep[e]], 1);
-            slot_col[s] = (int)eq[e];
-            slot_val[s] = ew[e];
-            s = slot_ptr[eq[e]] + atomicAdd(&fill[eq[e]], 1);
-            slot_col[s] = (int)ep[e];
-            slot_val[s] = ew[e];
+            *reinterpret_cast<int2*>(slot_col + slot[e]) = make_int2(c0[e], c1[e]);
+            *reinterpret_cast<float2*>(slot_val + slot[e]) = make_float2(w0[e], w1[e]);
         }
     }
 }
