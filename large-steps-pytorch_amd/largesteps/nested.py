@@ -8,7 +8,7 @@ nested-dissection elimination tree has log2(V / leaf) levels, and with the *mult
 one batch of small dense matrix-vector products:
 
     tree      geometric bisection of the vertex positions (median split along the longest axis); the separator of a
-              domain = its side-0 vertices that touch side 1. A tree node merges log2(arity) bisection rounds: it owns
+              domain = the end points of its cut edges on one side (the side with fewer of them). A tree node merges log2(arity) bisection rounds: it owns
               the separators of those rounds (leaves: their whole domain) and has `arity` children.
     ordering  deepest level first, root last: the vertices of a node are one contiguous range of the new numbering.
     front i   [own_i | bnd_i], bnd_i = the ancestors' vertices the subtree of i touches (filled graph), sorted.
@@ -81,8 +81,14 @@ class NDPlan:
                 side_of[idx[o2]] = (rank >= (counts[seg] // 2)).astype(np.int8)
             live = ~fixed
             msk = live[rows] & live[col] & (node[rows] == node[col]) & (side_of[rows] == 0) & (side_of[col] == 1)
-            sep = np.zeros(V, dtype=bool)
-            sep[rows[msk]] = True
+            # the end points of the cut edges on either side separate the domain: take the smaller set, per domain
+            end0 = np.zeros(V, dtype=bool)
+            end1 = np.zeros(V, dtype=bool)
+            end0[rows[msk]] = True
+            end1[col[msk]] = True
+            n_dom = int(node.max()) + 1
+            use1 = np.bincount(node[end1], minlength=n_dom) < np.bincount(node[end0], minlength=n_dom)
+            sep = np.where(use1[node], end1, end0)
             fixed |= sep
             move = ~fixed
             node[move] = 2 * node[move] + side_of[move]
