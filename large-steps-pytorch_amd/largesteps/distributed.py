@@ -426,25 +426,28 @@ class ColumnSharded:
         if b.dim() != 2 or b.shape[1] != self.k:
             raise ValueError(f"expected a (V, {self.k}) right-hand side, got {tuple(b.shape)}")
         V = b.shape[0]
-        # every rank contributes a (max_cols, V) block (idle ranks / short ranks pad with zeros): one all-gather
-        mine = torch.zeros((self.max_cols, V), dtype=b.dtype, device=b.device)
+        key = (V, b.dtype, b.device)
+        if getattr(self, "_key", None) != key:        # staging buffers, reused across solves (padding rows stay zero)
+            self._key = key
+            self._mine = torch.zeros((self.max_cols, V), dtype=b.dtype, device=b.device)
+            self._flat = torch.empty((self.P * self.max_cols, V), dtype=b.dtype, device=b.device)
+            self._rows = torch.tensor([(c % self.active) * self.max_cols + c // self.active for c in range(self.k)],
+                                      dtype=torch.int64, device=b.device)
+        mine = self._mine
         if self.columns:
             x = self.solve_columns(b[:, self.columns].contiguous())
-            mine[: len(self.columns)] = x.t()
+            mine[: len(self.columns)].copy_(x.t())
         if self.P == 1:
             return mine[: self.k].t().contiguous()
+        # every rank contributes a (max_cols, V) block (idle / short ranks: zero rows): one all-gather
         if mine.is_cuda and dist.get_backend(self.group) == "gloo":      # loopback smoke mode: stage through the host
             host = torch.empty((self.P * self.max_cols, V), dtype=b.dtype)
             dist.all_gather_into_tensor(host, mine.cpu(), group=self.group)
             flat = host.to(b.device)
         else:
-            flat = torch.empty((self.P * self.max_cols, V), dtype=b.dtype, device=b.device)
+            flat = self._flat
             dist.all_gather_into_tensor(flat, mine, group=self.group)
-        allx = flat.view(self.P, self.max_cols, V)
-        out = torch.empty((V, self.k), dtype=b.dtype, device=b.device)
-        for c in range(self.k):
-            out[:, c] = allx[c % self.active, c // self.active]
-        return out
+        return flat.index_select(0, self._rows).t().contiguous()
 
 
 def pick_depth(rowptr, col, V, P, max_depth=64, max_overhead=1.0):
@@ -511,7 +514,8 @@ def shard_from_matrix(M, group=None, device=None, method="auto", depth=None, **s
 def bench_sharded(workload, device, steps, warmup, shard="auto"):
     """bench.py's N > 1 leg: one from_differential solve of the whole mesh over the ranks of the default group.
     shard = 'columns' (right-hand sides across ranks, no per-iteration communication), 'vertex' (contiguous vertex
-    blocks, halo exchange) or 'auto' (columns when the system fits one GPU and has >= 2 columns)."""
+    blocks, halo exchange), 'auto' (columns when the system fits one GPU and has >= 2 columns) or 'replicas' (every rank
+    solves its own copy of the system -- independent meshes, weak scaling, no communication at all)."""
     import time
     from . import synthetic
     from .geometry import compute_matrix
@@ -526,7 +530,12 @@ def bench_sharded(workload, device, steps, warmup, shard="auto"):
     k = u_full.shape[1]
     if shard == "auto":
         shard = "columns" if k >= 2 else "vertex"
-    if shard == "columns":
+    if shard == "replicas":
+        local = CholeskySolver(M)
+        solver = local
+        u, ref, plan = u_full, tv, None
+        pick = lambda x: x                                          # noqa: E731
+    elif shard == "columns":
         # the single-GPU default path on this rank's columns; fewer columns per rank -> deeper patch plan
         local = CholeskySolver(M, patch_columns=max(1, min(3, -(-k // min(world, k)))))
         solver = ColumnSharded(lambda bc: local.solve(bc), k)
@@ -551,6 +560,11 @@ def bench_sharded(workload, device, steps, warmup, shard="auto"):
     err = (pick(x) - ref).abs().max().reshape(1).double()
     dist.all_reduce(err, op=dist.ReduceOp.MAX)
     out = dict(V=v.shape[0], nnz=int(M._nnz()), ms_per_step=float(elapsed.item()) / steps * 1e3, err=float(err.item()), shard=shard)
+    if shard == "replicas":
+        out.update(iterations=0, converged=True, halo=0, method=local.method, depth=0, rows_per_rank=v.shape[0], replicas=world,
+                   solve_bytes=(int(world * 4 * local.plan.factor_entries) if local.method == "nested-dissection" else None),
+                   solver=f"{world} independent replicas of the single-GPU solver ({local.method}), one full system per rank, no communication")
+        return out
     if shard == "columns":
         info = local.last_info if local.last_info is not None else dict(iterations=0, converged=True, method="idle")
         its = torch.tensor([info["iterations"], int(info["converged"])], dtype=torch.int64, device=device)
