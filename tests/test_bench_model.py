@@ -1,0 +1,63 @@
+"""
+bench.py's byte model and JSON plumbing, on the CPU (no GPU, no solver): the algorithmic-bytes accounting must be the one
+SURVEY.md section 8(d) states, and the PMC traffic lookup must combine the tree-level kernels by dispatch count.
+"""
+import importlib.util
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load_bench():
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_algorithmic_bytes_match_survey():
+    b = load_bench()
+    V, nnz, k = 1000000, 6992002, 3
+    pcg = b.algorithmic_bytes(V, nnz, k, 136, "pcg")
+    # B_iter = 8 nnz + 144 V = 199.9 MB at config 4 (the + 4 is rowptr's V + 1-th entry)
+    assert abs(pcg["iter"] - (8 * nnz + 144 * V)) <= 8 and round(pcg["iter"] / 1e6, 1) == 199.9
+    assert pcg["k1"] == 8 * nnz + 4 * (V + 1) + 2 * 4 * k * V                      # B_spmv = 8 nnz + 28 V
+    assert pcg["solve"] == (4 * k + 1) * 4 * V + 136 * pcg["iter"]
+    cheb = b.algorithmic_bytes(V, nnz, k, 180, "chebyshev")
+    assert cheb["iter"] == 8 * nnz + 4 * (V + 1) + (4 * k + 1) * 4 * V
+    imp = b.algorithmic_bytes(V, nnz, k, 180, "chebyshev", implicit_values=True)
+    assert imp["iter"] == 4 * (nnz - V) + 4 * (V + 1) + (4 * k + 1) * 4 * V and round(imp["iter"] / 1e6) == 80
+    assert b.HBM_PEAK_GBS == 8000.0 and b.WORKLOAD == "cfg4_plane1m"
+
+
+def test_pmc_traffic_lookup(tmp_path, monkeypatch):
+    b = load_bench()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (prof / "r01_pmc_traffic.json").write_text(json.dumps(dict(workload="cfg4_plane1m", kernels={
+        "ls::k_nd_down<3>": dict(dispatches=3, traffic_bytes=100.0),
+        "ls::k_nd_down_b<3>": dict(dispatches=5, traffic_bytes=20.0),
+        "ls::k_cheb<3, 512, false>": dict(dispatches=7, traffic_bytes=9.0)})))
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+    assert b.pmc_traffic("ls::k_nd_down", "cfg4_plane1m") == (3 * 100.0 + 5 * 20.0) / 8
+    assert b.pmc_traffic("ls::k_cheb<3", "cfg4_plane1m") == 9.0
+    assert b.pmc_traffic("ls::k_nd_down", "another_workload") is None
+    assert b.pmc_traffic("ls::nothing", "cfg4_plane1m") is None
+
+
+def test_committed_profiles_are_consistent():
+    """the committed bench line of the final run carries the contract's keys and agrees with itself"""
+    path = os.path.join(ROOT, "profiles", "r01_run18_bench_direct.json")
+    line = [ln for ln in open(path).read().splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d
+    assert d["metric"] == "from_differential_solves_per_sec" and d["n_gpus"] == 1 and d["vs_baseline"] is None
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-9
+    assert abs(r["achieved"] - r["bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) <= 1e-6 * r["achieved"]
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
