@@ -171,8 +171,11 @@ def build(csr, leaf_size=64, arity=4, max_front=8000, max_entries=3_000_000_000,
     the mesh does not dissect well enough for this solver (front too large for LDS / factor too large)."""
     if csr.positions is None:
         return None
+    import time
+    t0 = time.perf_counter()
     rowptr, col = csr.rowptr.cpu().numpy(), csr.col.cpu().numpy()
     plan = NDPlan.build(rowptr, col, csr.positions.cpu().numpy(), leaf_size=leaf_size, arity=arity)
+    t1 = time.perf_counter()
     if int((plan.s + plan.b).max()) > max_front or plan.factor_entries > max_entries:
         return None
     for lv in range(plan.levels):                      # the factorisation pads a level to its largest front (fp64)
@@ -180,4 +183,8 @@ def build(csr, leaf_size=64, arity=4, max_front=8000, max_entries=3_000_000_000,
         if nodes.shape[0] * float(S + B + 1) ** 2 * 8 * 3 > max_level_bytes:
             return None
     finv, wf, wb = factorize(plan, rowptr, col, csr.val, csr.device)
-    return DirectHandle(plan, finv, wf, wb, csr.device)
+    torch.cuda.synchronize(csr.device) if csr.device.type == "cuda" else None
+    t2 = time.perf_counter()
+    handle = DirectHandle(plan, finv, wf, wb, csr.device)
+    handle.timings = dict(plan_seconds=t1 - t0, factor_seconds=t2 - t1, handle_seconds=time.perf_counter() - t2)
+    return handle

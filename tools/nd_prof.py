@@ -21,6 +21,7 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(n): x = s.solve(u)
 torch.cuda.synchronize()
 print(f"{cfg_name} leaf {leaf} arity {arity}: {(time.perf_counter() - t0) / n * 1e3:.3f} ms/solve, err {float((x - tv).abs().max()):.2e}, levels={s.plan.levels}, entries/V={s.plan.factor_entries / v.shape[0]:.1f}, build {s.build_seconds:.1f}s")
+print("constructor:", {k: round(v, 2) for k, v in s._direct.timings.items()})
 p = s.plan
 for lv in range(p.levels):
     nd = p.level_nodes(lv)
