@@ -862,7 +862,8 @@ extern "C" int ls_direct_create(int64_t V, int levels, int arity, const int64_t*
     };
     d->plan.resize(levels);
     size_t lds_max = 0;
-    const int long_red = env_int("LS_ND_LONG", 256);
+    const int long_red = env_int("LS_ND_LONG", 256);            // down sweep (reduction s + b)
+    const int long_up = env_int("LS_ND_LONG_UP", long_red);     // up sweep (reduction s)
     for (int lv = 0; lv < levels; ++lv) {
         LevelPlan& p = d->plan[lv];
         int red_up = 0, red_down = 0;
@@ -871,7 +872,7 @@ extern "C" int ls_direct_create(int64_t V, int levels, int arity, const int64_t*
             red_up = std::max(red_up, nodes[i].s); red_down = std::max(red_down, nodes[i].s + nodes[i].b);
         }
         // long reductions: lanes along the reduction (k_nd_*_b), ND_ROWS * ND_BW rows per tile; short: a row per lane
-        p.up_b = red_up >= long_red; p.down_b = red_down >= long_red;
+        p.up_b = red_up >= long_up; p.down_b = red_down >= long_red;
         p.up_nw = p.up_b ? ND_BW : pick_nw(red_up); p.down_nw = p.down_b ? ND_BW : pick_nw(red_down);
         // *_b kernels: a wave keeps about ND_INFLIGHT row loads in flight -> short rows come in several chunks of ND_ROWS
         const int inflight = env_int("LS_ND_INFLIGHT", 24);
