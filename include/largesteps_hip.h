@@ -232,22 +232,23 @@ int ls_direct_info(const ls_direct* d, int64_t* h_factor_entries, int* h_launche
  * them. Semantics of scripts/geometry.py kept to the letter: a degenerate face / an unreferenced vertex gives NaN, and
  * the corner "angles" are acos(clamp(e_a . e_b / (||E_a||_F ||E_b||_F))) with the FROBENIUS norms of the whole edge
  * matrices (geometry.py:138-141), not per-face lengths. Indices are not range checked (the host wrapper does that).
- * vptr (V + 1) / vcorner (3 F): the corner ids 3 f + i grouped by vertex (CSR); the per-face kernels write one vector per
- * corner and a per-vertex kernel sums them in list order -- no atomics, bitwise reproducible for a given list. */
+ * vptr (V + 1) / cpos (3 F): corner 3 f + i has rank cpos[3 f + i] in the vertex-major order of all corners and vertex
+ * v owns the ranks [vptr[v], vptr[v + 1]); the per-face kernels store one vector per corner at its rank and a
+ * per-vertex kernel sums its contiguous range in rank order -- no atomics, bitwise reproducible for a given ranking. */
 int ls_normals_workspace_bytes(int64_t F, int64_t V, size_t* h_bytes);
 int ls_face_normals(const float* verts, const void* faces, int idx_bytes, int64_t F, int64_t V, float* fn, int device, void* stream);
 /* grad_verts (V, 3) = d sum(g_fn * fn) / d verts; overwritten */
 int ls_face_normals_backward(const float* verts, const void* faces, int idx_bytes, int64_t F, int64_t V, const int32_t* vptr,
-                             const int32_t* vcorner, const float* g_fn, float* grad_verts, void* workspace, size_t ws_bytes,
+                             const int32_t* cpos, const float* g_fn, float* grad_verts, void* workspace, size_t ws_bytes,
                              int device, void* stream);
 /* out (V, 3) normalised vertex normals; raw (V, 3) the unnormalised sums and norms[3] = {||E01||, ||E02||, ||E12||} are
  * kept by the caller for the backward pass */
 int ls_vertex_normals(const float* verts, const void* faces, int idx_bytes, int64_t F, int64_t V, const int32_t* vptr,
-                      const int32_t* vcorner, const float* fn, float* out, float* raw, float* norms, void* workspace,
+                      const int32_t* cpos, const float* fn, float* out, float* raw, float* norms, void* workspace,
                       size_t ws_bytes, int device, void* stream);
 /* grad_verts (V, 3) and grad_fn (3, F) of sum(g_out * out) with the face normals an independent input; both overwritten */
 int ls_vertex_normals_backward(const float* verts, const void* faces, int idx_bytes, int64_t F, int64_t V, const int32_t* vptr,
-                               const int32_t* vcorner, const float* fn, const float* raw, const float* norms, const float* g_out,
+                               const int32_t* cpos, const float* fn, const float* raw, const float* norms, const float* g_out,
                                float* grad_verts, float* grad_fn, void* workspace, size_t ws_bytes, int device, void* stream);
 
 int ls_adam_uniform_step(float* param, const float* grad, float* g1, float* g2, int64_t n, float lr,

@@ -13,7 +13,7 @@
 //                                    vertex gives NaN (0 / 0), as in the reference.
 // Three distinct global norms exist: ||E01||, ||E02||, ||E12|| (E_ab = all faces' edges v_b - v_a), each used by two corners.
 // No atomics: per-face kernels write one 3-vector per CORNER (coalesced), a per-vertex kernel sums the corners of a vertex
-// through a vertex -> corner list built once per face tensor (measured at 2M faces: 18M fp32 atomics took 0.44 ms per
+// through a vertex-major corner ranking built once per face tensor (measured at 2M faces: 18M fp32 atomics took 0.44 ms per
 // scatter, the two-pass form ~0.05 ms) -- and the result is bitwise reproducible, unlike the reference's index_add_.
 #include "common.h"
 #include <algorithm>
@@ -58,7 +58,8 @@ __global__ __launch_bounds__(BLOCK) void k_face_normals(const float* __restrict_
 // d/dv of sum(g * n), n = c / |c|, c = a x b: g_c = (g - n (n.g)) / |c|, dL/da = b x g_c, dL/db = g_c x a
 template <typename IDX>
 __global__ __launch_bounds__(BLOCK) void k_face_normals_bwd(const float* __restrict__ verts, const IDX* __restrict__ faces, int64_t F,
-                                                            const float* __restrict__ g_fn, float* __restrict__ corner) {
+                                                            const float* __restrict__ g_fn, const int* __restrict__ cpos,
+                                                            float* __restrict__ corner) {
     const int64_t f = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (f >= F) return;
     int id[3];
@@ -75,25 +76,26 @@ __global__ __launch_bounds__(BLOCK) void k_face_normals_bwd(const float* __restr
     for (int q = 0; q < 3; ++q) gc[q] = (g[q] - n[q] * ng) / len;
     cross3(b, gc, ga);
     cross3(gc, a, gb);
+    const size_t p0 = (size_t)cpos[f * 3] * 3, p1 = (size_t)cpos[f * 3 + 1] * 3, p2 = (size_t)cpos[f * 3 + 2] * 3;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-        corner[(size_t)f * 9 + 3 + q] = ga[q];
-        corner[(size_t)f * 9 + 6 + q] = gb[q];
-        corner[(size_t)f * 9 + q] = -ga[q] - gb[q];
+        corner[p1 + q] = ga[q];
+        corner[p2 + q] = gb[q];
+        corner[p0 + q] = -ga[q] - gb[q];
     }
 }
 
-// dst[v] = sum of the corner vectors of vertex v, in list order (vcorner lists corner ids 3 f + i, grouped by vertex);
-// normalize: also writes the normalised vector to `out`
-__global__ __launch_bounds__(BLOCK) void k_gather_corners(const int* __restrict__ vptr, const int* __restrict__ vcorner,
-                                                          const float* __restrict__ corner, int64_t V, float* __restrict__ dst,
-                                                          float* __restrict__ out) {
+// dst[v] = sum of the corner vectors of vertex v: the per-face kernels store the vector of corner 3 f + i at slot
+// cpos[3 f + i], the corner's rank in vertex-major order, so a vertex's vectors are the contiguous slots
+// [vptr[v], vptr[v + 1]) -- consecutive threads read consecutive memory. normalize: also writes the unit vector to `out`.
+__global__ __launch_bounds__(BLOCK) void k_gather_corners(const int* __restrict__ vptr, const float* __restrict__ corner, int64_t V,
+                                                          float* __restrict__ dst, float* __restrict__ out) {
     const int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (v >= V) return;
     float x = 0.0f, y = 0.0f, z = 0.0f;
-    for (int e = vptr[v]; e < vptr[v + 1]; ++e) {
-        const size_t c = (size_t)vcorner[e] * 3;
-        x += corner[c]; y += corner[c + 1]; z += corner[c + 2];
+    const int e1 = vptr[v + 1];
+    for (int e = vptr[v]; e < e1; ++e) {
+        x += corner[(size_t)e * 3]; y += corner[(size_t)e * 3 + 1]; z += corner[(size_t)e * 3 + 2];
     }
     dst[v * 3] = x; dst[v * 3 + 1] = y; dst[v * 3 + 2] = z;
     if (out) {
@@ -169,7 +171,7 @@ __device__ __forceinline__ Corner corner_of(const float (&p)[3][3], int i, const
 template <typename IDX>
 __global__ __launch_bounds__(BLOCK) void k_vertex_normals_scatter(const float* __restrict__ verts, const IDX* __restrict__ faces, int64_t F,
                                                                   const float* __restrict__ fn, const float* __restrict__ norms,
-                                                                  float* __restrict__ corner) {
+                                                                  const int* __restrict__ cpos, float* __restrict__ corner) {
     const int64_t f = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (f >= F) return;
     int id[3];
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(BLOCK) void k_vertex_normals_scatter(const float* _
     for (int i = 0; i < 3; ++i) {
         const Corner c = corner_of(p, i, norms);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) corner[(size_t)f * 9 + i * 3 + q] = n[q] * c.theta;
+        for (int q = 0; q < 3; ++q) corner[(size_t)cpos[f * 3 + i] * 3 + q] = n[q] * c.theta;
     }
 }
 
@@ -246,7 +248,7 @@ template <typename IDX>
 __global__ __launch_bounds__(BLOCK) void k_vertex_normals_bwd2(const float* __restrict__ verts, const IDX* __restrict__ faces, int64_t F,
                                                                const float* __restrict__ fn, const float* __restrict__ norms,
                                                                const float* __restrict__ g_raw, const float* __restrict__ gN,
-                                                               float* __restrict__ corner) {
+                                                               const int* __restrict__ cpos, float* __restrict__ corner) {
     const int64_t f = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (f >= F) return;
     int id[3];
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(BLOCK) void k_vertex_normals_bwd2(const float* __re
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) corner[(size_t)f * 9 + i * 3 + q] = gv[i][q];
+        for (int q = 0; q < 3; ++q) corner[(size_t)cpos[f * 3 + i] * 3 + q] = gv[i][q];
     }
 }
 
@@ -339,13 +341,13 @@ extern "C" int ls_face_normals(const float* verts, const void* faces, int idx_by
 }
 
 extern "C" int ls_face_normals_backward(const float* verts, const void* faces, int idx_bytes, int64_t F, int64_t V, const int32_t* vptr,
-                                        const int32_t* vcorner, const float* g_fn, float* grad_verts, void* workspace, size_t ws_bytes,
+                                        const int32_t* cpos, const float* g_fn, float* grad_verts, void* workspace, size_t ws_bytes,
                                         int device, void* stream) {
     int rc = check_mesh_args(verts, faces, idx_bytes, F, V, "ls_face_normals_backward");
     if (rc) return rc;
     size_t need = 0;
     ls_normals_workspace_bytes(F, V, &need);
-    LS_REQUIRE(grad_verts && vptr && workspace && ((g_fn && vcorner) || F == 0), LS_E_INVALID, "ls_face_normals_backward: null argument");
+    LS_REQUIRE(grad_verts && vptr && workspace && ((g_fn && cpos) || F == 0), LS_E_INVALID, "ls_face_normals_backward: null argument");
     LS_REQUIRE(ws_bytes >= need, LS_E_WORKSPACE, "ls_face_normals_backward: workspace too small (%zu < %zu bytes)", ws_bytes, need);
     DeviceGuard g(device);
     LS_HIP(g.err);
@@ -353,21 +355,21 @@ extern "C" int ls_face_normals_backward(const float* verts, const void* faces, i
     const NormalsWs w = carve(workspace, V);
     if (F > 0)
         LS_IDX(idx_bytes, hipLaunchKernelGGL(k_face_normals_bwd<IDX>, dim3(div_up(F, BLOCK)), dim3(BLOCK), 0, st, verts, (const IDX*)faces, F, g_fn,
-                                             w.corner));
-    hipLaunchKernelGGL(k_gather_corners, dim3(div_up(V, BLOCK)), dim3(BLOCK), 0, st, vptr, vcorner, (const float*)w.corner, V, grad_verts,
+                                             cpos, w.corner));
+    hipLaunchKernelGGL(k_gather_corners, dim3(div_up(V, BLOCK)), dim3(BLOCK), 0, st, vptr, (const float*)w.corner, V, grad_verts,
                        (float*)nullptr);
     LS_HIP(hipGetLastError());
     return LS_OK;
 }
 
 extern "C" int ls_vertex_normals(const float* verts, const void* faces, int idx_bytes, int64_t F, int64_t V, const int32_t* vptr,
-                                 const int32_t* vcorner, const float* fn, float* out, float* raw, float* norms, void* workspace,
+                                 const int32_t* cpos, const float* fn, float* out, float* raw, float* norms, void* workspace,
                                  size_t ws_bytes, int device, void* stream) {
     int rc = check_mesh_args(verts, faces, idx_bytes, F, V, "ls_vertex_normals");
     if (rc) return rc;
     size_t need = 0;
     ls_normals_workspace_bytes(F, V, &need);
-    LS_REQUIRE(out && raw && norms && workspace && vptr && ((fn && vcorner) || F == 0), LS_E_INVALID, "ls_vertex_normals: null argument");
+    LS_REQUIRE(out && raw && norms && workspace && vptr && ((fn && cpos) || F == 0), LS_E_INVALID, "ls_vertex_normals: null argument");
     LS_REQUIRE(ws_bytes >= need, LS_E_WORKSPACE, "ls_vertex_normals: workspace too small (%zu < %zu bytes)", ws_bytes, need);
     DeviceGuard g(device);
     LS_HIP(g.err);
@@ -378,23 +380,23 @@ extern "C" int ls_vertex_normals(const float* verts, const void* faces, int idx_
         LS_IDX(idx_bytes, hipLaunchKernelGGL(k_edge_norm_partials<IDX>, dim3(G), dim3(BLOCK), 0, st, verts, (const IDX*)faces, F, w.part));
         hipLaunchKernelGGL(k_finish3, dim3(1), dim3(BLOCK), 0, st, (const double*)w.part, G, 1, norms);
         LS_IDX(idx_bytes, hipLaunchKernelGGL(k_vertex_normals_scatter<IDX>, dim3(div_up(F, BLOCK)), dim3(BLOCK), 0, st, verts, (const IDX*)faces,
-                                             F, fn, (const float*)norms, w.corner));
+                                             F, fn, (const float*)norms, cpos, w.corner));
     } else {
         LS_HIP(hipMemsetAsync(norms, 0, sizeof(float) * 3, st));
     }
-    hipLaunchKernelGGL(k_gather_corners, dim3(div_up(V, BLOCK)), dim3(BLOCK), 0, st, vptr, vcorner, (const float*)w.corner, V, raw, out);
+    hipLaunchKernelGGL(k_gather_corners, dim3(div_up(V, BLOCK)), dim3(BLOCK), 0, st, vptr, (const float*)w.corner, V, raw, out);
     LS_HIP(hipGetLastError());
     return LS_OK;
 }
 
 extern "C" int ls_vertex_normals_backward(const float* verts, const void* faces, int idx_bytes, int64_t F, int64_t V, const int32_t* vptr,
-                                          const int32_t* vcorner, const float* fn, const float* raw, const float* norms, const float* g_out,
+                                          const int32_t* cpos, const float* fn, const float* raw, const float* norms, const float* g_out,
                                           float* grad_verts, float* grad_fn, void* workspace, size_t ws_bytes, int device, void* stream) {
     int rc = check_mesh_args(verts, faces, idx_bytes, F, V, "ls_vertex_normals_backward");
     if (rc) return rc;
     size_t need = 0;
     ls_normals_workspace_bytes(F, V, &need);
-    LS_REQUIRE(raw && norms && g_out && grad_verts && workspace && vptr && ((fn && grad_fn && vcorner) || F == 0), LS_E_INVALID,
+    LS_REQUIRE(raw && norms && g_out && grad_verts && workspace && vptr && ((fn && grad_fn && cpos) || F == 0), LS_E_INVALID,
                "ls_vertex_normals_backward: null argument");
     LS_REQUIRE(ws_bytes >= need, LS_E_WORKSPACE, "ls_vertex_normals_backward: workspace too small (%zu < %zu bytes)", ws_bytes, need);
     DeviceGuard g(device);
@@ -408,9 +410,9 @@ extern "C" int ls_vertex_normals_backward(const float* verts, const void* faces,
                                              (const float*)w.g_raw, grad_fn, w.part));
         hipLaunchKernelGGL(k_finish3, dim3(1), dim3(BLOCK), 0, st, (const double*)w.part, G, 0, w.gN);
         LS_IDX(idx_bytes, hipLaunchKernelGGL(k_vertex_normals_bwd2<IDX>, dim3(div_up(F, BLOCK)), dim3(BLOCK), 0, st, verts, (const IDX*)faces, F, fn,
-                                             norms, (const float*)w.g_raw, (const float*)w.gN, w.corner));
+                                             norms, (const float*)w.g_raw, (const float*)w.gN, cpos, w.corner));
     }
-    hipLaunchKernelGGL(k_gather_corners, dim3(div_up(V, BLOCK)), dim3(BLOCK), 0, st, vptr, vcorner, (const float*)w.corner, V, grad_verts,
+    hipLaunchKernelGGL(k_gather_corners, dim3(div_up(V, BLOCK)), dim3(BLOCK), 0, st, vptr, (const float*)w.corner, V, grad_verts,
                        (float*)nullptr);
     LS_HIP(hipGetLastError());
     return LS_OK;

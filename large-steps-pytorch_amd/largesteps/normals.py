@@ -18,8 +18,9 @@ from . import _native
 
 
 # Per face tensor (keyed by storage address + version, like torch's own caches): range check of the indices (syncs the
-# host once) and the vertex -> corner lists the gather kernels walk. One-off integer plumbing per mesh connectivity:
-# a stable sort of the 3 F corner vertex ids groups the corners by vertex, in ascending corner id (deterministic sums).
+# host once) and the vertex-major ranking of the corners. One-off integer plumbing per mesh connectivity: a stable sort
+# of the 3 F corner vertex ids groups the corners by vertex, in ascending corner id (deterministic sums); cpos is the
+# inverse permutation (corner -> rank), vptr the ranks each vertex owns.
 _plans = {}
 
 
@@ -31,7 +32,9 @@ def _plan(f, V):
     if f.shape[0] and (int(f.min()) < 0 or int(f.max()) >= V):
         raise IndexError(f"face index out of range for {V} vertices")
     flat = f.reshape(-1).long()
-    vcorner = torch.argsort(flat, stable=True).to(torch.int32)
+    order = torch.argsort(flat, stable=True)
+    vcorner = torch.empty(flat.numel(), dtype=torch.int32, device=f.device)       # corner -> rank ("cpos" of the C ABI)
+    vcorner[order] = torch.arange(flat.numel(), dtype=torch.int32, device=f.device)
     vptr = torch.zeros(V + 1, dtype=torch.int32, device=f.device)
     if flat.numel():
         vptr[1:] = torch.cumsum(torch.bincount(flat, minlength=V), 0).to(torch.int32)
