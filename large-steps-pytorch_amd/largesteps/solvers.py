@@ -318,6 +318,9 @@ class CholeskySolver(Solver):
                 self._impl = NestedDissectionSolver(M, leaf_size=leaf_size, arity=arity)
             except (ValueError, RuntimeError) as e:      # no positions / fronts too large / numerically not SPD
                 self.direct_error = str(e)
+                if _native.csr_of(M).positions is not None:      # unexpected for a compute_matrix matrix: say so once
+                    warnings.warn(f"CholeskySolver: the direct solver is not usable for this matrix ({e}); iterating instead",
+                                  RuntimeWarning, stacklevel=2)
         if self._impl is None:
             self._impl = IterativeCholeskySolver(M, rtol=rtol, max_iter=max_iter, chebyshev=chebyshev, patch_columns=patch_columns)
         self.method = "nested-dissection" if isinstance(self._impl, NestedDissectionSolver) else "iterative"
