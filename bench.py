@@ -128,7 +128,7 @@ def run_single(args):
         x = from_differential(M, u, method_name)
         solver = parameterize._cache[(id(M), method_name)][0]
     if args.pcg:                                          # A/B: the Jacobi-PCG at the same cold-start / 1e-6 setting
-        solver.rtol, solver.atol, solver.warm_start = 1e-6, 0.0, False
+        solver.rtol, solver.atol, solver.warm_start, solver.chebyshev = 1e-6, 0.0, False, False
     if args.block is not None:
         solver.set_option("block", args.block)
     if args.grid:

@@ -96,12 +96,14 @@ class PCGSolver(Solver):
         self.patch_plan = None            # PatchPlan of the LDS-resident s-step kernel, if one is in use
         if csr.a_min is not None:
             _native.check(_native.lib().ls_solver_set_spectrum(self._handle, float(csr.a_min)))
-            if chebyshev and self.rtol > 0.0:
+            if chebyshev and (self.rtol > 0.0 or self.atol > 0.0):
                 # The count is known a priori from the enclosure. A Chebyshev step costs ~0.4 of a PCG iteration, but
                 # PCG adapts to the actual spectrum: with a loose enclosure (cotangent weights of sliver triangles, one
                 # vertex of very high valence) the bound explodes and PCG wins -- keep Chebyshev only below the cap.
                 n = ctypes.c_int(0)
-                _native.check(_native.lib().ls_solver_chebyshev_iterations(self._handle, self.rtol, ctypes.byref(n)))
+                # (absolute tolerance only: the count depends on the starting residual -- judge the enclosure by a 1e-6 reduction)
+                _native.check(_native.lib().ls_solver_chebyshev_iterations(self._handle, self.rtol if self.rtol > 0.0 else 1e-6,
+                                                                           ctypes.byref(n)))
                 self.chebyshev_iterations = n.value
                 self.chebyshev = n.value <= int(chebyshev_cap)
                 if self.chebyshev and csr.uniform is not None and not os.environ.get("LARGESTEPS_EXPLICIT_VALUES"):
@@ -343,11 +345,14 @@ class ConjugateGradientSolver(PCGSolver):
     Conjugate gradients solver with the reference's stopping rule and warm start (solvers.py:41-126):
     every column iterates until ||r||_2 <= 1e-5 (absolute), starting from the previous forward /
     backward solution. Differences: Jacobi preconditioning, all columns share each matrix pass, an iteration
-    cap, and no strong reference to M.
+    cap, and no strong reference to M. For matrices with a certified spectral enclosure (built by `compute_matrix`)
+    the same stopping rule is served by the Chebyshev-accelerated Jacobi iteration (a-priori count from the starting
+    residual, true residual verified at the end, PCG if that check fails): same answer to the same tolerance, no dot
+    products, and on large uniform meshes the LDS-resident patch kernel; `chebyshev=False` forces the PCG.
     """
 
-    def __init__(self, M, atol=1e-5, max_iter=10000):
-        super().__init__(M, rtol=0.0, atol=atol, max_iter=max_iter, warm_start=True, chebyshev=False)
+    def __init__(self, M, atol=1e-5, max_iter=10000, chebyshev=True):
+        super().__init__(M, rtol=0.0, atol=atol, max_iter=max_iter, warm_start=True, chebyshev=chebyshev)
 
     def solve(self, b, backward=False):
         if len(b.shape) != 2:
