@@ -201,28 +201,3 @@ class PatchPlan:
         cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.empty(0, dt)  # noqa: E731
         return PatchPlan(V, perm, depth, patch_size, np.asarray(tables, dtype=np.int32).reshape(-1, TABLE_COLS),
                          cat(gids, np.int32), cat(colss, np.uint16), cat(diags, np.float32), max_local, max_rows, max_width)
-
-    # ---- numpy statement of k_patch_cheb (used by the CPU tests) -----------------------------------------------
-    def simulate(self, offdiag, b_new, cur, prev, c1, c2):
-        """One launch: len(c1) <= depth Chebyshev steps on every patch from the global iterates (cur, prev) in the
-        NEW numbering; returns the two newest iterates (newest, second newest) on the owned rows."""
-        out_cur, out_prev = cur.copy(), prev.copy()
-        S = len(c1)
-        for row in self.table:
-            own_start, n_own, n_rows, n_local, W, og, oc, od = (int(t) for t in row[:8])
-            lim = row[8:]
-            gid = np.concatenate([np.arange(own_start, own_start + n_own), self.ghost_gid[og:og + n_local - n_own]])
-            A = np.vstack([cur[gid], np.zeros((1, cur.shape[1]), cur.dtype)])
-            B = np.vstack([prev[gid], np.zeros((1, cur.shape[1]), cur.dtype)])
-            ell = self.cols16[oc:oc + W * n_rows].reshape(W, n_rows).astype(np.int64)
-            d = self.diag[od:od + n_rows][:, None]
-            bl = b_new[gid[:n_rows]]
-            for j, (a1, a2) in enumerate(zip(c1, c2)):
-                m = int(lim[S - 1 - j])                        # rows still needed by the own vertices
-                s = A[ell[:, :m]].sum(axis=0)                  # (m, k) sum of the neighbours
-                ax = d[:m] * A[:m] + offdiag * s
-                B[:m] = A[:m] + a1 * (A[:m] - B[:m]) + a2 * (bl[:m] - ax) / d[:m]
-                A, B = B, A
-            out_cur[own_start:own_start + n_own] = A[:n_own]
-            out_prev[own_start:own_start + n_own] = B[:n_own]
-        return out_cur, out_prev

@@ -10,6 +10,7 @@ import torch
 
 from largesteps import synthetic
 from largesteps.nested import NDPlan
+from statements import nd_factor, nd_solve
 from oracle import laplacian as ol
 from oracle import solve as osv
 
@@ -106,9 +107,9 @@ def test_numpy_statement_vs_oracle(name, kw, arity):
         v = synthetic.perturb(v, radial=0.05, tangential=0.1, edge=0.1, seed=1)
     r, rowptr, c, val = csr_of(v, f, **kw)
     p = NDPlan.build(rowptr, c, v, leaf_size=12, arity=arity)
-    finv, w = p.factor_reference(rowptr, c, val)
+    finv, w = nd_factor(p, rowptr, c, val)
     b = np.random.default_rng(0).standard_normal((v.shape[0], 3))
-    x = p.solve_reference(finv, w, b)
+    x = nd_solve(p, finv, w, b)
     x64 = osv.from_differential(r, c, val, b)
     assert np.abs(x - x64).max() <= 1e-10 * np.abs(x64).max()
 
@@ -122,7 +123,7 @@ def test_torch_factorisation_matches_statement(name, kw, arity):
     v, f = MESHES[name]()
     r, rowptr, c, val = csr_of(v, f, **kw)
     p = NDPlan.build(rowptr, c, v, leaf_size=10, arity=arity)
-    finv, w = p.factor_reference(rowptr, c, val)
+    finv, w = nd_factor(p, rowptr, c, val)
     finv_t, wf_t, wb_t = factorize(p, rowptr, c, torch.from_numpy(val), torch.device("cpu"))
     scale = np.abs(finv).max()
     assert np.abs(finv_t.numpy()[:p.finv_size] - finv).max() <= 2e-7 * scale
@@ -135,7 +136,7 @@ def test_torch_factorisation_matches_statement(name, kw, arity):
             assert np.array_equal(Wf, W.T)
     # and the fp32 factor solves the system to fp32 accuracy through the numpy sweeps
     b = np.random.default_rng(1).standard_normal((v.shape[0], 2))
-    x = p.solve_reference(finv_t.numpy()[:p.finv_size].astype(np.float64), wb_t.numpy()[:p.w_size].astype(np.float64), b)
+    x = nd_solve(p, finv_t.numpy()[:p.finv_size].astype(np.float64), wb_t.numpy()[:p.w_size].astype(np.float64), b)
     x64 = osv.from_differential(r, c, val, b)
     assert np.abs(x - x64).max() <= 1e-5 * np.abs(x64).max()
 
@@ -154,7 +155,7 @@ def test_smoothed_positions_give_thin_separators():
     v = synthetic.perturb(v, radial=0.05, seed=1)
     r, rowptr, c, val = csr_of(v, f, lambda_=10.0)
     plan = NDPlan.build(rowptr, c, v, leaf_size=16, arity=4, smooth=4)
-    finv, w = plan.factor_reference(rowptr, c, val)
+    finv, w = nd_factor(plan, rowptr, c, val)
     b = np.random.default_rng(0).standard_normal((v.shape[0], 2))
     x64 = osv.from_differential(r, c, val, b)
-    assert np.abs(plan.solve_reference(finv, w, b) - x64).max() <= 1e-10 * np.abs(x64).max()
+    assert np.abs(nd_solve(plan, finv, w, b) - x64).max() <= 1e-10 * np.abs(x64).max()

@@ -11,6 +11,7 @@ import scipy.sparse as sp
 
 from largesteps import synthetic
 from largesteps.patches import PatchPlan, cell_patches
+from statements import patch_steps
 from oracle import laplacian as ol
 
 
@@ -74,7 +75,7 @@ def test_patch_plan_reproduces_global_iteration(name, patch_size, depth):
     bn = b[plan.perm]
     cur, prev = np.zeros_like(b), np.zeros_like(b)
     for it0 in range(0, n, plan.depth):
-        cur, prev = plan.simulate(-lam, bn, cur, prev, c1[it0:it0 + plan.depth], c2[it0:it0 + plan.depth])
+        cur, prev = patch_steps(plan, -lam, bn, cur, prev, c1[it0:it0 + plan.depth], c2[it0:it0 + plan.depth])
     x = np.empty_like(cur)
     x[plan.perm] = cur
     assert np.abs(x - xc).max() <= 1e-12 * np.abs(xc).max(), "s steps on overlapping patches == s global steps"
