@@ -37,7 +37,10 @@ struct alignas(64) Tile {
 };
 
 constexpr int ND_UNROLL = 8;   // independent matrix loads in flight per lane (row-per-lane kernels)
-constexpr int ND_ROWS = 4;     // rows a wave processes together (lanes-along-the-reduction kernels)
+#ifndef LS_ND_ROWS
+#define LS_ND_ROWS 2
+#endif
+constexpr int ND_ROWS = LS_ND_ROWS;     // rows a wave processes together (lanes-along-the-reduction kernels)
 constexpr int ND_BW = 4;       // waves per workgroup of the *_b kernels -> ND_ROWS * ND_BW rows per tile
 
 // Sum of the valid child slots of front position f: slots[(f * A + c) * K + q], valid iff bit c of m. All A slots are
@@ -326,7 +329,10 @@ __device__ __forceinline__ float wave_sum63(float v) {
 
 // One batch = ND_E x 64 reduction steps of the wave's ND_ROWS rows (row r at base + r * stride_rows): every load of a
 // batch is independent and 256 B contiguous across the wave.
-constexpr int ND_E = 8;
+#ifndef LS_ND_E
+#define LS_ND_E 8
+#endif
+constexpr int ND_E = LS_ND_E;
 __device__ __forceinline__ void rows_load(const float* __restrict__ base, size_t stride_rows, int nrows, int len, int t0,
                                           float (&a)[ND_ROWS][ND_E]) {
     const int lane = threadIdx.x & 63;
