@@ -36,7 +36,10 @@ struct alignas(64) Tile {
     long long finv_off, w_off;
 };
 
-constexpr int ND_UNROLL = 8;   // independent matrix loads in flight per lane (row-per-lane kernels)
+#ifndef LS_ND_UNROLL
+#define LS_ND_UNROLL 8
+#endif
+constexpr int ND_UNROLL = LS_ND_UNROLL;   // independent matrix loads in flight per lane (row-per-lane kernels)
 #ifndef LS_ND_ROWS
 #define LS_ND_ROWS 2
 #endif
