@@ -79,10 +79,10 @@ def pmc_traffic(kernel_prefix, workload):
     return None
 
 
-def cpu_baseline(v, f, lam, u_np, seconds_cap=120.0):
+def cpu_baseline(v, f, cfg, u_np, seconds_cap=120.0):
     """Oracle direct solver timed on the host: factor once (reported, not counted), then re-solves."""
     from oracle import laplacian as ol, solve as osv
-    r, c, val = ol.compute_matrix(v, f, lam)
+    r, c, val = ol.compute_matrix(v, f, cfg["lambda_"] if cfg["lambda_"] is not None else 0.0, alpha=cfg["alpha"], cotan=cfg["cotan"])
     t0 = time.perf_counter()
     ds = osv.DirectSolver(r, c, val, v.shape[0])
     t_factor = time.perf_counter() - t0
@@ -96,9 +96,19 @@ def cpu_baseline(v, f, lam, u_np, seconds_cap=120.0):
     err = float(np.abs(x - v).max())
     t = float(np.median(times))
     return dict(value=1.0 / t, unit="solves/s", cores=1, kind="port",
-                sample=f"oracle.DirectSolver (scipy SuperLU fp64, symmetric mode, 1 thread) on the same 1M-vertex system: "
+                sample=f"oracle.DirectSolver (scipy SuperLU fp64, symmetric mode, 1 thread) on the same {v.shape[0]}-vertex system: "
                        f"1 factorisation ({t_factor:.1f} s, not counted) + {len(times)} timed 3-RHS solves, median {t * 1e3:.0f} ms; "
                        f"round-trip max-abs error {err:.1e}; host logical cores {os.cpu_count()}"), x
+
+
+def describe(workload, cfg, V, nnz):
+    """one-line description of a synthetic config (largesteps.synthetic.CONFIGS)"""
+    mesh = {"cfg4_plane1m": "1000x1000 plane", "cfg5_plane4m": "2000x2000 plane"}.get(workload, "noisy geodesic sphere (stand-in mesh)")
+    if cfg["alpha"] is not None:
+        mat = f"M=(1-{cfg['alpha']:g})I+{cfg['alpha']:g}*L_{'cot' if cfg['cotan'] else 'uniform'}"
+    else:
+        mat = f"M=I+{cfg['lambda_']:g}*L_{'cot' if cfg['cotan'] else 'uniform'}"
+    return f"{workload}: {mesh}, V={V}, nnz(M)={nnz}, {mat}, u=M v, k=3"
 
 
 def run_single(args):
@@ -109,7 +119,7 @@ def run_single(args):
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     v, f, cfg = synthetic.config_mesh(args.workload)
-    lam = cfg["lambda_"]
+    lam = cfg["lambda_"] if cfg["lambda_"] is not None else 0.0
     tv, tf = torch.from_numpy(v).to(dev), torch.from_numpy(f).to(dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -148,7 +158,7 @@ def run_single(args):
     ms = elapsed / args.steps * 1e3
     method = info["method"]
     if method == "nested-dissection":
-        return report_direct(args, solver, M, u, x, tv, v, f, lam, ms, t_assemble)
+        return report_direct(args, solver, M, u, x, tv, v, f, cfg, ms, t_assemble)
 
     # profiled pass right after the timed region, same workload: HIP events on the solve's own stream
     # (chebyshev: two events around the n back-to-back launches; pcg: events around every kernel)
@@ -208,8 +218,7 @@ def run_single(args):
         metric="from_differential_solves_per_sec", value=1e3 / ms, unit="solves/s", n_gpus=1, steps=args.steps,
         warmup=args.warmup, ms_per_step=ms, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32",
         data="synthetic",
-        config=dict(workload=f"{args.workload}: 1000x1000 plane, V={V}, nnz(M)={nnz}, M=I+{lam:g}*L_uniform, u=M v, k=3, "
-                             f"cold start, residual reduction 1e-6", solver=solver_desc, method=method,
+        config=dict(workload=describe(args.workload, cfg, V, nnz) + ", cold start, residual reduction 1e-6", solver=solver_desc, method=method,
                     iterations=info["iterations"], converged=info["converged"],
                     rel_residual=[float(r / b) for r, b in zip(info["rnorm"], info["bnorm"])],
                     max_abs_err_vs_v=err, assemble_ms=t_assemble * 1e3,
@@ -226,14 +235,14 @@ def run_single(args):
                       patch=patch_note),
     )
     if not args.no_cpu_baseline:
-        base, _ = cpu_baseline(v, f, lam, u.cpu().numpy())
+        base, _ = cpu_baseline(v, f, cfg, u.cpu().numpy())
         out["cpu_baseline"] = base
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out), flush=True)
 
 
-def report_direct(args, solver, M, u, x, tv, v, f, lam, ms, t_assemble):
+def report_direct(args, solver, M, u, x, tv, v, f, cfg, ms, t_assemble):
     """JSON line for the factor-once / re-solve direct solver (largesteps.solvers.NestedDissectionSolver)."""
     from largesteps.parameterize import to_differential
     V, nnz, k = v.shape[0], M._nnz(), 3
@@ -263,8 +272,7 @@ def report_direct(args, solver, M, u, x, tv, v, f, lam, ms, t_assemble):
         metric="from_differential_solves_per_sec", value=1e3 / ms, unit="solves/s", n_gpus=1, steps=args.steps,
         warmup=args.warmup, ms_per_step=ms, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32",
         data="synthetic",
-        config=dict(workload=f"{args.workload}: 1000x1000 plane, V={V}, nnz(M)={nnz}, M=I+{lam:g}*L_uniform, u=M v, k=3, "
-                             f"factor once (not timed), re-solve timed",
+        config=dict(workload=describe(args.workload, cfg, V, nnz) + ", factor once (not timed), re-solve timed",
                     solver=(f"HIP nested-dissection multifrontal direct solver: {plan.D + 1} tree levels, fp64 factorisation on "
                             f"the device (once), fp32 factor {plan.factor_entries / 1e6:.1f} M numbers; re-solve = "
                             f"{inf['launches']} launches (one per level and sweep), no atomics"),
@@ -284,7 +292,7 @@ def report_direct(args, solver, M, u, x, tv, v, f, lam, ms, t_assemble):
                            "(~8 us of launch + memory round trips), only the leaf levels stream enough bytes to matter"),
     )
     if not args.no_cpu_baseline:
-        base, _ = cpu_baseline(v, f, lam, u.cpu().numpy())
+        base, _ = cpu_baseline(v, f, cfg, u.cpu().numpy())
         out["cpu_baseline"] = base
     else:
         out["cpu_baseline"] = None
