@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import _native
-from .nested import NDPlan, _row_index
+from .nested import NDPlan, _row_index, graph_embedding
 
 
 def _level_tables(plan, lv):
@@ -167,14 +167,19 @@ class DirectHandle:
 
 
 def build(csr, leaf_size=64, arity=4, max_front=8000, max_entries=3_000_000_000, max_level_bytes=48e9):
-    """Plan + factorisation + native handle for the CSR side car of a matrix (needs csr.positions). Returns None when
-    the mesh does not dissect well enough for this solver (front too large for LDS / factor too large)."""
-    if csr.positions is None:
-        return None
+    """Plan + factorisation + native handle for the CSR side car of a matrix. Vertex positions come from compute_matrix;
+    a matrix built elsewhere gets graph-distance pseudo-positions (nested.graph_embedding) if it is symmetric. Returns
+    None when the mesh does not dissect well enough for this solver (front too large for LDS / factor too large)."""
     import time
     t0 = time.perf_counter()
     rowptr, col = csr.rowptr.cpu().numpy(), csr.col.cpu().numpy()
-    plan = NDPlan.build(rowptr, col, csr.positions.cpu().numpy(), leaf_size=leaf_size, arity=arity)
+    if csr.positions is not None:
+        positions = csr.positions.cpu().numpy()
+    elif csr.symmetric:
+        positions = graph_embedding(rowptr, col, csr.V)
+    else:
+        return None
+    plan = NDPlan.build(rowptr, col, positions, leaf_size=leaf_size, arity=arity)
     t1 = time.perf_counter()
     if int((plan.s + plan.b).max()) > max_front or plan.factor_entries > max_entries:
         return None

@@ -28,6 +28,61 @@ def _row_index(rowptr):
     return np.repeat(np.arange(rowptr.shape[0] - 1, dtype=np.int64), np.diff(rowptr))
 
 
+def _bfs(rowptr, col, V, start, dist):
+    """level-synchronous BFS from `start` over the CSR pattern; fills dist (float64, -1 = unreached); returns the last vertex reached"""
+    dist[start] = 0.0
+    frontier = np.array([start], dtype=np.int64)
+    last, d = start, 0.0
+    while frontier.shape[0]:
+        last = int(frontier[0])
+        lens = rowptr[frontier + 1] - rowptr[frontier]
+        total = int(lens.sum())
+        if total == 0:
+            break
+        first = np.cumsum(lens) - lens
+        nb = col[np.arange(total, dtype=np.int64) - np.repeat(first, lens) + np.repeat(rowptr[frontier], lens)]
+        nb = np.unique(nb[dist[nb] < 0])
+        d += 1.0
+        dist[nb] = d
+        frontier = nb
+    return last
+
+
+def graph_embedding(rowptr, col, V):
+    """Pseudo-positions for a matrix that comes without vertex positions (not built by compute_matrix): graph distances
+    from three mutually far landmarks (double-sweep BFS), per connected component; components are laid out side by side.
+    Only the spatial ORDER these coordinates induce matters to the bisection -- level sets of a graph distance are
+    separators as thin as the mesh allows."""
+    rowptr = np.asarray(rowptr).astype(np.int64)
+    col = np.asarray(col).astype(np.int64)
+    pos = np.zeros((V, 3), dtype=np.float64)
+    done = np.zeros(V, dtype=bool)
+    offset = 0.0
+    while not done.all():
+        seed = int(np.flatnonzero(~done)[0])
+        d0 = np.full(V, -1.0)
+        p1 = _bfs(rowptr, col, V, seed, d0)
+        comp = d0 >= 0
+        d1 = np.full(V, -1.0)
+        p2 = _bfs(rowptr, col, V, p1, d1)
+        d2 = np.full(V, -1.0)
+        _bfs(rowptr, col, V, p2, d2)
+        p3 = int(np.argmax(np.where(comp, np.minimum(d1, d2), -1.0)))      # far from both landmarks
+        d3 = np.full(V, -1.0)
+        _bfs(rowptr, col, V, p3, d3)
+        pos[comp, 0] = d1[comp] + offset
+        pos[comp, 1] = d2[comp]
+        pos[comp, 2] = d3[comp]
+        offset += float(d1[comp].max()) + 2.0
+        done |= comp
+        if comp.sum() <= 2 and (~done).sum() > 4096:
+            # a swarm of isolated vertices (unreferenced rows): no structure to find, lay the rest out in index order
+            rest = np.flatnonzero(~done)
+            pos[rest, 0] = offset + np.arange(rest.shape[0])
+            break
+    return pos
+
+
 class NDPlan:
     """Node ids are 1-based and level-major: level l holds arity^l nodes starting at level_off[l]; node (l, q) has the
     children (l + 1, arity * q + c). Arrays indexed by node id carry one unused slot 0."""

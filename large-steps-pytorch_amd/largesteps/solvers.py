@@ -251,8 +251,9 @@ class NestedDissectionSolver(Solver):
     numeric factorisation on the device in fp64 (largesteps/direct.py), and a re-solve made of one hand-written HIP
     launch per tree level and sweep (csrc/direct.hip). The result is a function of b only and bitwise reproducible.
 
-    Needs the vertex positions the matrix was assembled from (matrices built by `compute_matrix`); raises ValueError
-    otherwise or when the mesh does not dissect into fronts that fit the kernels.
+    The dissection uses the vertex positions the matrix was assembled from (`compute_matrix`); a symmetric matrix built
+    elsewhere gets graph-distance pseudo-positions instead. Raises ValueError when the matrix is not symmetric or the
+    mesh does not dissect into fronts that fit the kernels.
     """
 
     def __init__(self, M, leaf_size=64, arity=4):
@@ -261,13 +262,18 @@ class NestedDissectionSolver(Solver):
         csr = _native.csr_of(M)
         self._csr = csr
         self.last_info = None
+        if csr.symmetric is None:          # a matrix that was not built by compute_matrix: the factorisation needs M = M^T
+            idx, val, V = M.indices(), M.values(), M.shape[0]
+            k1, k2 = idx[0] * V + idx[1], idx[1] * V + idx[0]
+            order = torch.argsort(k2)
+            csr.symmetric = bool(torch.equal(k2[order], k1)) and bool(
+                (val[order] - val).abs().max() <= 1e-6 * val.abs().max()) if val.numel() else True
         t0 = time.perf_counter()
         self._direct = direct.build(csr, leaf_size=leaf_size, arity=arity)
         torch.cuda.synchronize(csr.device)
         self.build_seconds = time.perf_counter() - t0
         if self._direct is None:
-            raise ValueError("NestedDissectionSolver: the matrix has no vertex positions attached (not built by "
-                             "compute_matrix) or its fronts exceed the solver's limits")
+            raise ValueError("NestedDissectionSolver: the matrix is not symmetric, or its fronts exceed the solver's limits")
         self.plan = self._direct.plan
 
     def solve(self, b, backward=False):
@@ -320,7 +326,7 @@ class CholeskySolver(Solver):
                 self._impl = NestedDissectionSolver(M, leaf_size=leaf_size, arity=arity)
             except (ValueError, RuntimeError) as e:      # no positions / fronts too large / numerically not SPD
                 self.direct_error = str(e)
-                if _native.csr_of(M).positions is not None:      # unexpected for a compute_matrix matrix: say so once
+                if _native.csr_of(M).positions is not None:      # unexpected for a compute_matrix matrix: say so
                     warnings.warn(f"CholeskySolver: the direct solver is not usable for this matrix ({e}); iterating instead",
                                   RuntimeWarning, stacklevel=2)
         if self._impl is None:

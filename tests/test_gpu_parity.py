@@ -451,16 +451,25 @@ def test_cholesky_on_random_soup(dev, seed):
     assert np.abs(x - x64).max() <= 1e-4 * np.abs(x64).max(), (s.method, s.direct_error)
 
 
-def test_direct_solver_needs_positions(golden, dev):
-    """A foreign matrix has no vertex positions: NestedDissectionSolver refuses, CholeskySolver iterates."""
+def test_direct_solver_without_positions(golden, dev):
+    """A foreign matrix has no vertex positions: the dissection runs on graph-distance pseudo-positions; a matrix that
+    is not symmetric is refused and CholeskySolver iterates."""
     from largesteps.solvers import CholeskySolver, NestedDissectionSolver
-    idx, val = golden["ico3/uni_l10/idx"], golden["ico3/uni_l10/val"]
+    idx, val = golden["ico6/cot_a0p9/idx"], golden["ico6/cot_a0p9/val"]
     V = int(idx.max()) + 1
     M = torch.sparse_coo_tensor(_t(idx, dev), _t(val, dev), (V, V)).coalesce()
-    with pytest.raises(ValueError):
-        NestedDissectionSolver(M)
+    b = np.random.default_rng(0).standard_normal((V, 3)).astype(np.float32)
+    x64 = osv.from_differential(idx[0], idx[1], val, b)
     s = CholeskySolver(M)
-    assert s.method == "iterative" and s.direct_error
+    assert s.method == "nested-dissection"
+    assert np.abs(s.solve(_t(b, dev)).cpu().numpy() - x64).max() <= 2e-5 * np.abs(x64).max()
+    bad = val.copy()
+    bad[1] *= 1.5                                    # an off-diagonal entry without its mirror image
+    Mb = torch.sparse_coo_tensor(_t(idx, dev), _t(bad, dev), (V, V)).coalesce()
+    with pytest.raises(ValueError):
+        NestedDissectionSolver(Mb)
+    sb = CholeskySolver(Mb)
+    assert sb.method == "iterative" and sb.direct_error
 
 
 def test_determinism_and_fresh_output(dev, chol_path):

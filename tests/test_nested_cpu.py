@@ -159,3 +159,32 @@ def test_smoothed_positions_give_thin_separators():
     b = np.random.default_rng(0).standard_normal((v.shape[0], 2))
     x64 = osv.from_differential(r, c, val, b)
     assert np.abs(nd_solve(plan, finv, w, b) - x64).max() <= 1e-10 * np.abs(x64).max()
+
+
+def test_graph_embedding_replaces_positions():
+    """No positions (a matrix built elsewhere): graph distances from three far landmarks order the vertices well enough
+    for thin separators; disconnected components and isolated vertices are laid out side by side."""
+    from largesteps.nested import graph_embedding
+    v, f = synthetic.plane(60)
+    r, rowptr, c, val = csr_of(v, f, lambda_=5.0)
+    pos = graph_embedding(rowptr, c, v.shape[0])
+    assert pos.shape == v.shape and np.isfinite(pos).all()
+    with_pos = NDPlan.build(rowptr, c, v, leaf_size=32)
+    without = NDPlan.build(rowptr, c, pos, leaf_size=32)
+    assert without.factor_entries < 2.0 * with_pos.factor_entries
+    finv, w = nd_factor(without, rowptr, c, val)
+    b = np.random.default_rng(0).standard_normal((v.shape[0], 2))
+    x64 = osv.from_differential(r, c, val, b)
+    assert np.abs(nd_solve(without, finv, w, b) - x64).max() <= 1e-10 * np.abs(x64).max()
+    # two components + unreferenced vertices
+    v2, f2 = synthetic.icosphere(4)
+    vv = np.concatenate([v2, v2 + 5.0, np.zeros((3, 3), np.float32)])
+    ff = np.concatenate([f2, f2 + v2.shape[0]])
+    r, rowptr, c, val = csr_of(vv, ff, lambda_=2.0)
+    pos = graph_embedding(rowptr, c, vv.shape[0])
+    assert np.isfinite(pos).all() and pos[:v2.shape[0], 0].max() < pos[v2.shape[0]:2 * v2.shape[0], 0].min()
+    plan = NDPlan.build(rowptr, c, pos, leaf_size=16)
+    finv, w = nd_factor(plan, rowptr, c, val)
+    b = np.random.default_rng(1).standard_normal((vv.shape[0], 1))
+    x64 = osv.from_differential(r, c, val, b)
+    assert np.abs(nd_solve(plan, finv, w, b) - x64).max() <= 1e-10 * np.abs(x64).max()
