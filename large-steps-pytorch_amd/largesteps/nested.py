@@ -116,6 +116,8 @@ class NDPlan:
             cnt = np.diff(rowptr).astype(np.float64)[:, None]
             for _ in range(int(smooth)):                     # p_i <- mean of p over row i's columns (diagonal included)
                 pos = np.add.reduceat(pos[col], rowptr[:-1], axis=0) / cnt
+        one_way = rows < col
+        er, ec = rows[one_way], col[one_way]                 # every undirected edge once
         node = np.ones(V, dtype=np.int64)                    # binary heap id of the domain a vertex lives in
         fixed = np.zeros(V, dtype=bool)
         side_of = np.zeros(V, dtype=np.int8)
@@ -129,18 +131,28 @@ class NDPlan:
                 counts = np.diff(np.concatenate([starts, [idx.shape[0]]]))
                 seg = np.repeat(np.arange(starts.shape[0]), counts)
                 p = pos[idx]
-                ext = np.maximum.reduceat(p, starts, axis=0) - np.minimum.reduceat(p, starts, axis=0)
-                key = p[np.arange(idx.shape[0]), np.argmax(ext, axis=1)[seg]]
-                o2 = np.lexsort((key, seg))                       # by domain, then along the domain's longest axis
+                lo = np.minimum.reduceat(p, starts, axis=0)
+                ext = np.maximum.reduceat(p, starts, axis=0) - lo
+                ax = np.argmax(ext, axis=1)
+                sel = np.arange(starts.shape[0])
+                key = p[np.arange(idx.shape[0]), ax[seg]]
+                # by domain, then along the domain's longest axis: one sort of (domain index + position fraction in [0, 1))
+                frac = (key - lo[sel, ax][seg]) / np.maximum(ext[sel, ax], 1e-300)[seg]
+                o2 = np.argsort(seg + np.minimum(frac, 1.0 - 1e-9), kind="stable")
                 rank = np.arange(idx.shape[0]) - starts[seg]      # seg is already sorted: o2 keeps the segments
                 side_of[idx[o2]] = (rank >= (counts[seg] // 2)).astype(np.int8)
-            live = ~fixed
-            msk = live[rows] & live[col] & (node[rows] == node[col]) & (side_of[rows] == 0) & (side_of[col] == 1)
+            # edges that can still be cut: both ends live and in the same domain (domains only ever split, separator
+            # vertices never come back: an edge that fails this once is dropped for good -- the list shrinks every round)
+            keep = (node[er] == node[ec]) & ~fixed[er] & ~fixed[ec]
+            er, ec = er[keep], ec[keep]
+            s_r, s_c = side_of[er], side_of[ec]
+            cut = s_r != s_c
+            r_cut, c_cut, r0 = er[cut], ec[cut], s_r[cut] == 0
             # the end points of the cut edges on either side separate the domain: take the smaller set, per domain
             end0 = np.zeros(V, dtype=bool)
             end1 = np.zeros(V, dtype=bool)
-            end0[rows[msk]] = True
-            end1[col[msk]] = True
+            end0[np.where(r0, r_cut, c_cut)] = True
+            end1[np.where(r0, c_cut, r_cut)] = True
             n_dom = int(node.max()) + 1
             use1 = np.bincount(node[end1], minlength=n_dom) < np.bincount(node[end0], minlength=n_dom)
             sep = np.where(use1[node], end1, end0)
