@@ -188,3 +188,28 @@ def test_graph_embedding_replaces_positions():
     b = np.random.default_rng(1).standard_normal((vv.shape[0], 1))
     x64 = osv.from_differential(r, c, val, b)
     assert np.abs(nd_solve(plan, finv, w, b) - x64).max() <= 1e-10 * np.abs(x64).max()
+
+
+@pytest.mark.parametrize("shape", ["fan", "strip"])
+def test_extreme_meshes(shape):
+    """A hub of valence 3000 and a 2 x 6000 strip: the separators stay tiny (the hub itself / two vertices), with the
+    real positions and with graph-distance pseudo-positions."""
+    from largesteps.nested import graph_embedding
+    if shape == "fan":
+        n = 3000
+        ang = np.linspace(0, 2 * np.pi, n, endpoint=False)
+        v = np.concatenate([[[0, 0, 0]], np.stack([np.cos(ang), np.sin(ang), 0 * ang], 1)]).astype(np.float32)
+        f = np.stack([np.zeros(n, int), 1 + np.arange(n), 1 + (np.arange(n) + 1) % n], 1).astype(np.int64)
+    else:
+        m = 6000
+        v = np.stack([np.tile(np.arange(m), 2), np.repeat([0, 1], m), np.zeros(2 * m)], 1).astype(np.float32)
+        a = np.arange(m - 1)
+        f = np.concatenate([np.stack([a, a + 1, m + a], 1), np.stack([a + 1, m + a + 1, m + a], 1)]).astype(np.int64)
+    r, rowptr, c, val = csr_of(v, f, lambda_=10.0)
+    b = np.random.default_rng(0).standard_normal((v.shape[0], 2))
+    x64 = osv.from_differential(r, c, val, b)
+    for pos in (v, graph_embedding(rowptr, c, v.shape[0])):
+        p = NDPlan.build(rowptr, c, pos, leaf_size=64, arity=4)
+        assert int((p.s + p.b).max()) <= 80 and p.factor_entries <= 80 * v.shape[0]
+        finv, w = nd_factor(p, rowptr, c, val)
+        assert np.abs(nd_solve(p, finv, w, b) - x64).max() <= 1e-10 * np.abs(x64).max()
