@@ -13,7 +13,8 @@ What is restated (reference = rgl-epfl/large-steps-pytorch @ 0.2.2, paths relati
   solve.to_differential         largesteps/parameterize.py:19-30
   solve.from_differential       largesteps/parameterize.py:32-61 + solvers.py:26-39 ('Cholesky')
   solve.reference_cg            largesteps/solvers.py:58-126     ('CG', fp32, abs 1e-5 stop)
-  solve.jacobi_pcg              fp64 statement of the algorithm the HIP solver implements
+  solve.jacobi_pcg              fp64 statement of the algorithm the HIP PCG implements
+  normals.face_normals / vertex_normals (+ *_backward)   scripts/geometry.py:91-110, :115-147 and their analytic gradients
 
 Third-party dependency holding the default solver's arithmetic: `cholespy` (requirements.txt:1,
 `cholespy>=0.1.4`, unpinned, a nanobind wrapper of SuiteSparse CHOLMOD). It is absent from
@@ -24,9 +25,11 @@ LL^T factorisation computed in double precision -- is restated by an fp64 sparse
 Parity pinning: geometry.py / parameterize.py / solvers.py (CG + autograd) of the reference were
 executed in the dev container (CPU tensors; tests/golden/make_golden.py) and their outputs are
 committed under tests/golden/. The oracle is checked against every one of them, and against the
-hand-checked vectors G1-G7 of SURVEY.md §8c, in tests/test_oracle.py. The 'Cholesky' arithmetic
+hand-checked vectors G1-G7 of SURVEY.md §8c, in tests/test_oracle.py; scripts/geometry.py was executed the same way
+(tests/golden/make_golden_normals.py: outputs and torch-autograd gradients) and oracle.normals is checked against it in
+tests/test_normals.py. The 'Cholesky' arithmetic
 itself (cholespy) could not be executed anywhere: for that single call the parity is pinned only by
 the mathematical definition (residual of the fp64 solve), i.e. "parity unpinned" at the cholespy
 boundary.
 """
-from . import laplacian, solve  # noqa: F401
+from . import laplacian, normals, solve  # noqa: F401
