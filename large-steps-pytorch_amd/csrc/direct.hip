@@ -793,8 +793,9 @@ struct ls_direct {
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); const int v = e ? atoi(e) : 0; return v > 0 ? v : dflt; }
 
 // waves per workgroup of the row-per-lane kernels: about LS_ND_STEPS reduction steps per wave where 16 waves allow it
-static int pick_nw(int len) {
-    const int target = env_int("LS_ND_STEPS", 128);     // read at every create: tests and tuning runs toggle it
+static int pick_nw(int len, bool up_sweep = false) {
+    // read at every create: tests and tuning runs toggle it
+    const int target = up_sweep ? env_int("LS_ND_STEPS_UP", 32) : env_int("LS_ND_STEPS", 128);
     int nw = 1;
     while (nw < 16 && len > nw * target) nw *= 2;
     return nw;
@@ -882,7 +883,7 @@ extern "C" int ls_direct_create(int64_t V, int levels, int arity, const int64_t*
         }
         // long reductions: lanes along the reduction (k_nd_*_b), ND_ROWS * ND_BW rows per tile; short: a row per lane
         p.up_b = red_up >= long_up; p.down_b = red_down >= long_red;
-        p.up_nw = p.up_b ? ND_BW : pick_nw(red_up); p.down_nw = p.down_b ? ND_BW : pick_nw(red_down);
+        p.up_nw = p.up_b ? ND_BW : pick_nw(red_up, true); p.down_nw = p.down_b ? ND_BW : pick_nw(red_down);
         // *_b kernels: a wave keeps about ND_INFLIGHT row loads in flight -> short rows come in several chunks of ND_ROWS
         const int inflight = env_int("LS_ND_INFLIGHT", 24);
         const int lpr_up = div_up(std::max(p.s_cap, 1), WAVE), lpr_down = lpr_up + div_up(std::max(p.b_cap, 1), WAVE);
