@@ -116,6 +116,10 @@ def test_hip_large_mesh_vs_oracle_and_errors(dev):
     gv, gfn = on.vertex_normals_backward(v, f, fn64, w)
     g64 = gv + on.face_normals_backward(v, f, gfn)
     assert np.abs(g.cpu().numpy() - g64).max() <= 2e-4 * np.abs(g64).max()
+    # no atomics anywhere: forward and backward are bitwise reproducible
+    vn_b = compute_vertex_normals(tv, tf, compute_face_normals(tv, tf))
+    g_b, = torch.autograd.grad((vn_b * _t(w, dev)).sum(), tv)
+    assert torch.equal(vn_b, vn) and torch.equal(g_b, g)
     # size-independent property: unit length wherever a vertex is referenced
     assert float((vn.detach().norm(dim=1) - 1).abs().max()) <= 1e-5
     with pytest.raises(IndexError):
