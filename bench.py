@@ -235,8 +235,10 @@ def run_single(args):
                       patch=patch_note),
     )
     if not args.no_cpu_baseline:
-        base, _ = cpu_baseline(v, f, cfg, u.cpu().numpy())
+        base, x_oracle = cpu_baseline(v, f, cfg, u.cpu().numpy())
         out["cpu_baseline"] = base
+        out["config"]["max_abs_err_vs_oracle"] = float(np.abs(x.cpu().numpy() - x_oracle).max())
+        out["config"]["max_abs_oracle"] = float(np.abs(x_oracle).max())
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out), flush=True)
@@ -292,8 +294,11 @@ def report_direct(args, solver, M, u, x, tv, v, f, cfg, ms, t_assemble):
                            "(~8 us of launch + memory round trips), only the leaf levels stream enough bytes to matter"),
     )
     if not args.no_cpu_baseline:
-        base, _ = cpu_baseline(v, f, cfg, u.cpu().numpy())
+        base, x_oracle = cpu_baseline(v, f, cfg, u.cpu().numpy())
         out["cpu_baseline"] = base
+        # parity of the timed solve's result with the oracle's fp64 solution of the same system (tolerance: 1e-4 relative)
+        out["config"]["max_abs_err_vs_oracle"] = float(np.abs(x.cpu().numpy() - x_oracle).max())
+        out["config"]["max_abs_oracle"] = float(np.abs(x_oracle).max())
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out), flush=True)

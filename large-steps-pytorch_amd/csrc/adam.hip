@@ -7,6 +7,15 @@
 
 namespace ls {
 
+// max that keeps a NaN (fmaxf drops it): the reference's `m2.sqrt().max()` (optimize.py:40) is NaN as soon as one
+// gradient is, which poisons every parameter and makes a divergence visible -- same here.
+__device__ __forceinline__ float nan_max(float a, float b) { return (a != a) ? a : ((b != b) ? b : fmaxf(a, b)); }
+__device__ __forceinline__ float wave_nan_max(float x) {
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) x = nan_max(x, __shfl_down(x, off, WAVE));
+    return x;
+}
+
 __global__ __launch_bounds__(BLOCK) void k_adam_moments(const float* __restrict__ grad, float* __restrict__ g1, float* __restrict__ g2,
                                                         int64_t n, float b1, float b2, float inv_c2, float* __restrict__ pmax) {
     __shared__ float s_max[BLOCK / WAVE];
@@ -17,13 +26,13 @@ __global__ __launch_bounds__(BLOCK) void k_adam_moments(const float* __restrict_
         const float v = g2[i] * b2 + (1.0f - b2) * (g * g);
         g1[i] = a;
         g2[i] = v;
-        m = fmaxf(m, sqrtf(v * inv_c2));
+        m = nan_max(m, sqrtf(v * inv_c2));
     }
-    m = wave_max(m);
+    m = wave_nan_max(m);
     if ((threadIdx.x & (WAVE - 1)) == 0) s_max[threadIdx.x / WAVE] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int j = 1; j < BLOCK / WAVE; ++j) m = fmaxf(m, s_max[j]);
+        for (int j = 1; j < BLOCK / WAVE; ++j) m = nan_max(m, s_max[j]);
         pmax[blockIdx.x] = m;
     }
 }
@@ -32,12 +41,12 @@ __global__ __launch_bounds__(BLOCK) void k_adam_apply(float* __restrict__ param,
                                                       float inv_c1, const float* __restrict__ pmax, int G) {
     __shared__ float s_max[BLOCK / WAVE];
     float m = 0.0f;
-    for (int g = threadIdx.x; g < G; g += BLOCK) m = fmaxf(m, pmax[g]);
-    m = wave_max(m);
+    for (int g = threadIdx.x; g < G; g += BLOCK) m = nan_max(m, pmax[g]);
+    m = wave_nan_max(m);
     if ((threadIdx.x & (WAVE - 1)) == 0) s_max[threadIdx.x / WAVE] = m;
     __syncthreads();
     m = s_max[0];
-    for (int j = 1; j < BLOCK / WAVE; ++j) m = fmaxf(m, s_max[j]);
+    for (int j = 1; j < BLOCK / WAVE; ++j) m = nan_max(m, s_max[j]);
     const float denom = 1e-8f + m;
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK)
         param[i] = param[i] - lr * ((g1[i] * inv_c1) / denom);

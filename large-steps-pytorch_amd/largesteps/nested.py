@@ -214,11 +214,14 @@ class NDPlan:
         # position of every boundary vertex of a node in its parent's front [own | boundary]
         par = parent[k_node]
         in_own = bnd < own_end[par]
-        assert (bnd[in_own] >= own_start[par[in_own]]).all(), "separator property violated"
+        if not (bnd[in_own] >= own_start[par[in_own]]).all():
+            raise ValueError("NDPlan: separator property violated")
         ppos = np.where(in_own, bnd - own_start[par], 0)
         if (~in_own).any():
             at = np.searchsorted(keys, par[~in_own] * V + bnd[~in_own])
-            assert (keys[at] == par[~in_own] * V + bnd[~in_own]).all(), "child boundary not contained in parent front"
+            at = np.minimum(at, keys.shape[0] - 1)
+            if not (keys[at] == par[~in_own] * V + bnd[~in_own]).all():
+                raise ValueError("NDPlan: child boundary not contained in parent front")
             ppos[~in_own] = s[par[~in_own]] + at - bnd_off[par[~in_own]]
         # push lists of the down sweep: front position -> the children's boundary entries that are this vertex
         gpos = front_off[par] + ppos                                     # global front position of every boundary entry

@@ -10,6 +10,7 @@ forward and backward are a handful of hand-written HIP kernels each (csrc/normal
 There is no CPU path.
 """
 import ctypes
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -17,18 +18,23 @@ from torch.autograd import Function
 from . import _native
 
 
-# Per face tensor (keyed by storage address + version, like torch's own caches): range check of the indices (syncs the
-# host once) and the vertex-major ranking of the corners. One-off integer plumbing per mesh connectivity: a stable sort
-# of the 3 F corner vertex ids groups the corners by vertex, in ascending corner id (deterministic sums); cpos is the
-# inverse permutation (corner -> rank), vptr the ranks each vertex owns.
+# Per face TENSOR OBJECT: range check of the indices (syncs the host once) and the vertex-major ranking of the corners.
+# One-off integer plumbing per mesh connectivity: a stable sort of the 3 F corner vertex ids groups the corners by
+# vertex, in ascending corner id (deterministic sums); cpos is the inverse permutation (corner -> rank), vptr the ranks
+# each vertex owns. An entry is valid only for the very tensor it was built from (weak reference + version counter):
+# a storage address is recycled by the caching allocator as soon as a face tensor dies, so it cannot be the identity.
 _plans = {}
 
 
 def _plan(f, V):
-    key = (f.data_ptr(), f._version, f.shape[0], V, f.dtype)
+    key = id(f)
     hit = _plans.get(key)
     if hit is not None:
-        return hit
+        ref, version, shape, dtype, ptr, v_count, plan = hit
+        if ref() is f and version == f._version and shape == tuple(f.shape) and dtype == f.dtype and ptr == f.data_ptr() \
+                and v_count == V:
+            return plan
+        del _plans[key]
     if f.shape[0] and (int(f.min()) < 0 or int(f.max()) >= V):
         raise IndexError(f"face index out of range for {V} vertices")
     flat = f.reshape(-1).long()
@@ -38,10 +44,16 @@ def _plan(f, V):
     vptr = torch.zeros(V + 1, dtype=torch.int32, device=f.device)
     if flat.numel():
         vptr[1:] = torch.cumsum(torch.bincount(flat, minlength=V), 0).to(torch.int32)
+    for k in [k for k, h in _plans.items() if h[0]() is None]:      # entries of dead tensors
+        del _plans[k]
     if len(_plans) >= 8:
         _plans.clear()
-    _plans[key] = (vptr, vcorner)
-    return vptr, vcorner
+    plan = (vptr, vcorner)
+    try:
+        _plans[key] = (weakref.ref(f), f._version, tuple(f.shape), f.dtype, f.data_ptr(), V, plan)
+    except TypeError:           # an object that cannot be weakly referenced: do not cache
+        pass
+    return plan
 
 
 def _prep(verts, faces):

@@ -277,12 +277,15 @@ class NestedDissectionSolver(Solver):
         self.plan = self._direct.plan
 
     def solve(self, b, backward=False):
-        if b.dim() != 2 or b.shape[0] != self._csr.V:
-            raise ValueError(f"Invalid right-hand side shape {tuple(b.shape)}: expected ({self._csr.V}, k)")
         _native.require_device(b, "b")
-        b32 = b.detach()
-        if b32.dtype != torch.float32 or not b32.is_contiguous():
-            b32 = b32.to(torch.float32).contiguous()
+        if b.device != self._csr.device:
+            raise RuntimeError(f"matrix ({self._csr.device}) and b ({b.device}) must be on the same device")
+        if b.dtype != torch.float32:
+            raise TypeError(f"b must be float32, got {b.dtype}")
+        if b.dim() not in (1, 2) or b.shape[0] != self._csr.V:
+            raise ValueError(f"Invalid right-hand side shape {tuple(b.shape)}: expected ({self._csr.V}, k)")
+        squeeze = b.dim() == 1
+        b32 = (b.detach().unsqueeze(1) if squeeze else b.detach()).contiguous()
         x = torch.empty_like(b32)
         for c0 in range(0, b32.shape[1], _KMAX):
             c1 = min(b32.shape[1], c0 + _KMAX)
@@ -293,7 +296,7 @@ class NestedDissectionSolver(Solver):
                 self._direct.solve(b32[:, c0:c1].contiguous(), xb)
                 x[:, c0:c1] = xb
         self.last_info = dict(iterations=0, converged=True, method="nested-dissection")
-        return x
+        return x.squeeze(1) if squeeze else x
 
     def set_option(self, name, value):
         self._direct.set_option(name, value)

@@ -509,6 +509,80 @@ def test_configs_vs_oracle(dev, cfg, chol_path):
             x = from_differential(M, _t(b_np, dev), method).cpu().numpy()
             # stated fp32 tolerance: ||x - x*||_inf <= 1e-4 ||x*||_inf vs the fp64 direct solve
             assert np.abs(x - x64).max() <= 1e-4 * np.abs(x64).max(), (cfg, method)
+    from largesteps import parameterize
+    chol = parameterize._cache[(id(M), "Cholesky")][0]
+    # the leg under test must be the one that ran: a silent fall-back to the iteration would also pass the tolerance
+    assert chol.method == ("nested-dissection" if chol_path == "direct" else "iterative"), chol.direct_error
+
+
+def _config_system(cfg, dev):
+    from largesteps.geometry import compute_matrix
+    from largesteps import synthetic
+    v, f, c = synthetic.config_mesh(cfg)
+    tv, tf = _t(v, dev), _t(f, dev)
+    M = compute_matrix(tv, tf, c["lambda_"] if c["lambda_"] is not None else 0.0, alpha=c["alpha"], cotan=c["cotan"])
+    return v, tv, M
+
+
+def test_cfg1_icosphere_both_methods(dev, chol_path):
+    """BASELINE.json config 1 (geodesic n = 16, lambda = 10): the reference's CPU-runnable case through both methods."""
+    from largesteps.parameterize import from_differential, to_differential
+    from largesteps import parameterize
+    v, tv, M = _config_system("cfg1_icosphere2k", dev)
+    assert v.shape[0] == 2562
+    idx, val = M.indices().cpu().numpy(), M.values().cpu().numpy()
+    u = to_differential(M, tv)
+    direct = osv.DirectSolver(idx[0], idx[1], val, v.shape[0])
+    rhs = np.random.default_rng(3).standard_normal(v.shape).astype(np.float32)
+    for b_np in (u.cpu().numpy(), rhs):
+        x64 = direct.solve(b_np)
+        for method in ("Cholesky", "CG"):
+            x = from_differential(M, _t(b_np, dev), method).cpu().numpy()
+            assert np.abs(x - x64).max() <= 1e-4 * np.abs(x64).max(), method
+    chol = parameterize._cache[(id(M), "Cholesky")][0]
+    assert chol.method == ("nested-dissection" if chol_path == "direct" else "iterative"), chol.direct_error
+    assert np.abs(from_differential(M, u, "Cholesky").cpu().numpy() - v).max() <= 2e-5
+
+
+def test_cfg4_one_million_vs_oracle(dev):
+    """Config 4 at full size against the oracle's SOLUTION (fp64 SuperLU, ~10 s of host time), not only through
+    properties: 'Cholesky' (must be the nested-dissection solver) and 'CG', smooth and white right-hand sides,
+    stated tolerance 1e-4 * ||x*||_inf."""
+    from largesteps.parameterize import from_differential, to_differential
+    from largesteps import parameterize
+    v, tv, M = _config_system("cfg4_plane1m", dev)
+    idx, val = M.indices().cpu().numpy(), M.values().cpu().numpy()
+    direct = osv.DirectSolver(idx[0], idx[1], val, v.shape[0])
+    u = to_differential(M, tv)
+    rhs = np.random.default_rng(11).standard_normal(v.shape).astype(np.float32)
+    for b_np in (u.cpu().numpy(), rhs):
+        x64 = direct.solve(b_np)
+        for method in ("Cholesky", "CG"):
+            x = from_differential(M, _t(b_np, dev), method).cpu().numpy()
+            assert np.abs(x - x64).max() <= 1e-4 * np.abs(x64).max(), method
+    chol = parameterize._cache[(id(M), "Cholesky")][0]
+    assert chol.method == "nested-dissection", chol.direct_error
+
+
+def test_cfg5_four_million_vs_oracle(dev):
+    """Config 5 (2000 x 2000 plane, 4M vertices) on one GPU: 'Cholesky' against the fp64 oracle -- SuperLU if the host
+    has the memory for its factor (~6 GB), otherwise the oracle's fp64 Jacobi-PCG run to 1e-12."""
+    from largesteps.parameterize import from_differential, to_differential
+    from largesteps import parameterize
+    v, tv, M = _config_system("cfg5_plane4m", dev)
+    assert v.shape[0] == 4_000_000
+    idx, val = M.indices().cpu().numpy(), M.values().cpu().numpy()
+    u = to_differential(M, tv)
+    b_np = u.cpu().numpy()
+    try:
+        x64 = osv.DirectSolver(idx[0], idx[1], val, v.shape[0]).solve(b_np)
+    except (MemoryError, RuntimeError):
+        x64, _ = osv.jacobi_pcg(idx[0], idx[1], val, b_np, rtol=1e-12, max_iter=5000)
+    x = from_differential(M, u, "Cholesky").cpu().numpy()
+    chol = parameterize._cache[(id(M), "Cholesky")][0]
+    assert chol.method == "nested-dissection", chol.direct_error
+    assert np.abs(x - x64).max() <= 1e-4 * np.abs(x64).max()
+    assert np.abs(x - v).max() <= 1e-4
 
 
 def test_one_million_vertices_properties(dev, chol_path):
