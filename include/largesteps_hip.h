@@ -208,24 +208,67 @@ int ls_gather_rows(const float* src, const int32_t* idx, int64_t n, int k, float
  * Factor arrays (DEVICE, fp32, owned by the caller and kept alive for the handle's lifetime):
  * d_finv[finv_off + t*s + j] = (F_ss^-1)[t][j]; W = F_bs F_ss^-1 twice: d_wf[w_off + j*b + i] = d_wb[w_off + i*s + j] = W[i][j].
  * h_nodes: (n_nodes + 1, 8) int64, row i = {s, b, own_start, bnd_off, front_off, finv_off, w_off, parent} (row 0 unused).
- * One solve = one launch per level upwards
+ * One solve = one launch per upper level upwards
  *     b'_s = b_s - (children's updates at own_i);   upd_i = W_i b'_s + (children's updates at bnd_i)
- * (children push into one slot per child of every parent front position), one launch per level downwards
+ * (children push into one slot per child of every parent front position), one launch per upper level downwards
  *     x_s = F_ss^-1 b'_s - W_i^T x[bnd_i]          (parents push x into the children's boundary vectors);
- * b is read and x written in the caller's numbering. No atomics: bitwise reproducible.
- * ls_direct_create is SYNC (copies the host tables). */
+ * the levels stored in the tier layouts run as ONE launch per sweep, a workgroup per subtree (csrc/nd_tier.h).
+ * b is read and x written in the caller's numbering. No atomics: bitwise reproducible. A handle owns one workspace:
+ * solves issued on different streams are serialised on the device (event wait), concurrent host threads must not
+ * share a handle. ls_direct_create is SYNC (copies the host tables). */
 typedef struct ls_direct ls_direct;
-int ls_direct_create(int64_t V, int levels, int arity, const int64_t* h_nodes, const int32_t* h_perm, const int32_t* h_ppos,
-                     int64_t n_bnd, const int32_t* h_push_ptr, const int32_t* h_push_tgt, int64_t n_front,
-                     const float* d_finv, const float* d_wf, const float* d_wb, int device, void* stream, ls_direct** out);
+/* The plan and the factor of one matrix, as plain arrays. h_* live on the host and are copied; d_* are DEVICE arrays
+ * owned by the caller and kept alive for the handle's lifetime.
+ * h_nodes: (n_nodes + 1, LS_DIRECT_NODE_COLS) int64, row i = {s, b, own_start, bnd_off, front_off, finv_off, w_off, parent,
+ *          tri_off, spb_off, sps_off, quad} (row 0 unused). The deepest levels may be stored in the layouts of the tier
+ *          kernels (csrc/nd_tier.h), which then run them as ONE launch per sweep, a workgroup per subtree:
+ *          quad != 0: a dense node whose two matrix streams are quad-interleaved along the reduction (a lane reads 16 bytes
+ *              = 4 consecutive reduction entries; reductions padded to multiples of 4 with zeros; s4 = s rounded up to 4):
+ *              d_u4[w_off + ((j / 4) * b + i) * 4 + j % 4] = W[i][j]                                        (up sweep)
+ *              d_d4[finv_off + ((t / 4) * s + j) * 4 + t % 4] = [F_ss^-1 (padded to s4 columns) | W^T][j][t]  (down sweep)
+ *              (finv_off, w_off multiples of 4 floats);
+ *          tri_off >= 0: a SPARSE LEAF (last level, 1 <= s <= 64; all leaves with s >= 1 alike): instead of dense arrays
+ *              it owns  d_tri[tri_off + r (r + 1) / 2 + c] = (F_ss^-1)[r][c], c <= r  (packed rows of the lower triangle,
+ *              tri_off a multiple of 4 floats), and its off-diagonal block A_bs of the matrix itself as two CSR lists in
+ *              d_sp_ptr / d_sp_ent: boundary row i owns the entries d_sp_ptr[spb_off + i] .. d_sp_ptr[spb_off + i + 1]
+ *              ({value, own-row index}), own row j the entries d_sp_ptr[sps_off + j] .. [sps_off + j + 1] ({value, boundary
+ *              index}). Up sweep  y = F_ss^-1 b_s, update = A_bs y;  down sweep  x_s = y - F_ss^-1 (A_sb x_bnd).
+ *          Tier-layout levels must be the deepest ones, complete levels, at most 6 of them. */
+#define LS_DIRECT_NODE_COLS 12
+typedef struct ls_direct_arrays {
+    int64_t V;
+    int32_t levels, arity;
+    const int64_t* h_nodes;
+    const int32_t* h_perm;
+    const int32_t* h_ppos;
+    int64_t n_bnd;
+    const int32_t* h_push_ptr;
+    const int32_t* h_push_tgt;
+    int64_t n_front;
+    const float* d_finv;
+    const float* d_wf;
+    const float* d_wb;
+    const float* d_u4;
+    const float* d_d4;
+    const float* d_tri;
+    const int32_t* d_sp_ptr;
+    const void* d_sp_ent;          /* {float value; int32 index} pairs */
+    int64_t n_sp_ptr, n_sp_ent;    /* lengths of the two sparse-leaf arrays (accounting only) */
+} ls_direct_arrays;
+int ls_direct_create(const ls_direct_arrays* arrays, int device, void* stream, ls_direct** out);
 int ls_direct_destroy(ls_direct* d);
 /* x = M^-1 b for k <= 4 interleaved columns ((V, k) row-major, b != x) */
 int ls_direct_solve(ls_direct* d, const float* b, float* x, int k, void* stream);
-/* knobs: "profile" (1: the next solves time up sweep / down sweep / permutations with HIP events and synchronise) */
+/* knobs: "profile" (1: the next solves time the up sweep and the down sweep with HIP events and synchronise; 2: the
+ * tier kernels also record shader-clock stamps per wave, read back by ls_direct_tier_stamps) */
 int ls_direct_set(ls_direct* d, const char* name, int value);
-/* host-only: fp32 factor numbers one solve reads, kernel launches per solve, {up, down, permutations} ms of the last
- * profiled solve (any pointer may be NULL) */
+/* host-only: 4-byte words of factor data one solve reads, kernel launches per solve, {up sweep, down sweep, 0} ms of the
+ * last profiled solve (any pointer may be NULL) */
 int ls_direct_info(const ls_direct* d, int64_t* h_factor_entries, int* h_launches, double* h_ms3);
+/* SYNC, profiling only ("profile" = 2): 32 stamps per wave of the last up-sweep tier launch (tier workgroups x 4 waves),
+ * then the same for the down sweep: [0] start, [1 + 2p] / [2 + 2p] work of phase p done / its barrier passed,
+ * [16 + r] the wave's r-th leaf done. h_out: n int64 values, n <= 2 x workgroups x 4 x 32. */
+int ls_direct_tier_stamps(const ls_direct* d, long long* h_out, int64_t n);
 
 /* ---- normals ----------------------------------------------------------------------
  * faces: (F, 3) int32 or int64 (idx_bytes 4 / 8), verts (V, 3) fp32. Face normals are (3, F) like the reference returns

@@ -766,6 +766,10 @@ __global__ __launch_bounds__(64) void k_nd_down_p(const PackedTile* __restrict__
     }
 }
 
+}  // namespace ls
+#include "nd_tier.h"
+namespace ls {
+
 // down tiles of a level: compute tiles, then forward tiles
 struct LevelPlan { int up_first = 0, up_tiles = 0, up_nw = 1, down_first = 0, down_tiles = 0, down_nw = 1, s_cap = 0, b_cap = 0, up_b = 0, down_b = 0, up_chunks = 1, down_chunks = 1, up_s = 0, down_s = 0,
                    up_p = 0, down_p = 0, up_p_first = 0, up_p_tiles = 0, down_p_first = 0, down_p_tiles = 0, up_p_lds = 0, down_p_s = 0, down_p_lds = 0; };
@@ -782,7 +786,20 @@ struct ls_direct {
     Tile* tiles = nullptr;
     PackedTile* ptiles = nullptr;
     const float *finv = nullptr, *wf = nullptr, *wb = nullptr;   // owned by the caller
+    const float *u4 = nullptr, *d4 = nullptr;                    // dense tier nodes: quad-interleaved streams (caller)
+    const float* tri = nullptr;                                  // sparse leaves: packed triangles (caller)
+    const int* sp_ptr = nullptr;                                 // sparse leaves: row pointers (caller)
+    const SpEnt* sp_ent = nullptr;                               // sparse leaves: entries (caller)
+    float* braw = nullptr;                                       // tier kernels: gathered right-hand side of the inner-node rows (V, k)
     float *bp = nullptr, *slots = nullptr, *xb = nullptr;        // b' (V, k); up-sweep slots (n_front, arity, k); x at boundaries (n_bnd, k)
+    // bottom tier: levels [tier_root, levels) run as one launch per sweep, one workgroup per subtree (nd_tier.h)
+    int tier_root = 0, tier_phases = 0, tier_wgs = 0, tier_region = 0, tier_vec = 0, tier_tri = 0;
+    TierItem* d_items = nullptr;
+    TierWG* d_wgs = nullptr;
+    long long* dbg = nullptr;           // profile = 2: per-wave clock stamps of the tier kernels (2 x tier_wgs x TIER_WAVES x 32)
+    hipEvent_t busy = nullptr;          // recorded after every solve: a solve on another stream waits for it (one workspace)
+    hipStream_t last_stream = nullptr;
+    bool used = false;
     std::vector<LevelPlan> plan;
     int64_t factor_entries = 0;
     int profile = 0;
@@ -801,11 +818,97 @@ static int pick_nw(int len, bool up_sweep = false) {
     return nw;
 }
 
-extern "C" int ls_direct_create(int64_t V, int levels, int arity, const int64_t* h_nodes, const int32_t* h_perm,
-                                const int32_t* h_ppos, int64_t n_bnd, const int32_t* h_push_ptr, const int32_t* h_push_tgt,
-                                int64_t n_front, const float* d_finv, const float* d_wf, const float* d_wb, int device,
-                                void* stream, ls_direct** out) {
-    LS_REQUIRE(out && h_nodes && h_perm && h_push_ptr && V > 0 && levels >= 1 && levels <= 30 && n_bnd >= 0 && n_front >= V &&
+static int env_int0(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+
+// Bottom tier (nd_tier.h): cut the subtrees rooted at level `root` into wave-sized items. Returns the LDS floats a wave
+// needs (0 = the tier does not fit), fills items / wgs.
+static size_t plan_tier(const std::vector<NodeD>& nd, const std::vector<int64_t>& level_off, int levels, int arity, int root,
+                        std::vector<TierItem>& items, std::vector<TierWG>& wgs, int& vec_floats, int& tri_floats) {
+    const int H = levels - root;
+    const int64_t n_wg = level_off[root + 1] - level_off[root];
+    items.clear(); wgs.assign((size_t)n_wg, TierWG());
+    int vec_need = 0, pbuf_need = 0, leaf_need = 0, tri_cap = 0;
+    for (int64_t i = level_off[levels - 1]; i < level_off[levels]; ++i)
+        if (nd[i].flags & NODE_SPARSE) tri_cap = std::max(tri_cap, (nd[i].s * (nd[i].s + 1) / 2 + 3) & ~3);
+    tri_floats = tri_cap;
+    for (int64_t q = 0; q < n_wg; ++q) {
+        TierWG& g = wgs[(size_t)q];
+        g.up_split = g.down_split = g.up_leaf = g.down_leaf = 0;
+        g.n_dense = 0; g.pad = 0;
+        for (int t = 0; t < 2 * TIER_MAX_H; ++t) g.dense_rng[t] = 0;
+        for (int lv = root, t = 0; lv < levels - 1; ++lv, ++t) {  // own rows of the inner nodes: contiguous per level (leaf level: not gathered)
+            int64_t span = 1;
+            for (int u = root; u < lv; ++u) span *= arity;
+            const int64_t first = level_off[lv] + q * span;
+            int lo = -1, hi = -1;
+            for (int64_t i = first; i < first + span; ++i)
+                if (!(nd[i].flags & NODE_SPARSE) && nd[i].s > 0) { if (lo < 0) lo = nd[i].own_start; hi = nd[i].own_start + nd[i].s; }
+            if (lo >= 0) { g.dense_rng[2 * t] = lo; g.dense_rng[2 * t + 1] = hi - lo; g.n_dense += hi - lo; }
+        }
+        for (int sweep = 0; sweep < 2; ++sweep) {
+            const bool up = sweep == 0;
+            int* off = up ? g.up_off : g.down_off;
+            for (int ph = 0; ph < H; ++ph) {
+                off[ph] = (int)items.size();
+                const int lv = up ? levels - 1 - ph : root + ph;
+                int64_t span = 1;
+                for (int t = root; t < lv; ++t) span *= arity;
+                const int64_t first = level_off[lv] + q * span;
+                int base = 0;
+                bool sparse = false;
+                for (int64_t i = first; i < first + span; ++i) {
+                    const NodeD& n = nd[i];
+                    if (n.flags & NODE_SPARSE) { sparse = true; continue; }
+                    if (n.s == 0 && n.b == 0) continue;
+                    base += std::max(1, div_up(up ? n.b : n.s, WAVE));
+                }
+                bool all_sparse = span > 0;
+                for (int64_t i = first; i < first + span; ++i) {
+                    const NodeD& n = nd[i];
+                    if (!(n.flags & NODE_SPARSE) && (n.s || n.b)) all_sparse = false;
+                    TierItem it;
+                    memset(&it, 0, sizeof(it));
+                    it.s = n.s; it.b = n.b; it.own_start = n.own_start; it.bnd_off = n.bnd_off; it.front_off = n.front_off;
+                    it.pfront_off = n.pfront_off; it.cix = n.cix; it.flags = n.flags; it.finv_off = n.finv_off; it.w_off = n.w_off;
+                    it.spb_off = n.spb_off; it.sps_off = n.sps_off; it.nparts = 1;
+                    if (n.flags & NODE_SPARSE) {
+                        items.push_back(it);
+                        leaf_need = std::max(leaf_need, tri_cap + 256 + 4 * n.b);
+                        continue;
+                    }
+                    if (n.s == 0 && n.b == 0) continue;
+                    // reduction in the padded index space of the quad-interleaved streams, parts cut at multiples of 4
+                    const int rows = up ? n.b : n.s, L = up ? ((n.s + 3) & ~3) : ((n.s + 3) & ~3) + ((n.b + 3) & ~3);
+                    int nparts = 1;
+                    if (!sparse && base < TIER_WAVES) nparts = std::max(1, std::min(TIER_WAVES / std::max(base, 1), L / 16));
+                    for (int r = 0; r < std::max(rows, 1); r += WAVE)
+                        for (int pt = 0; pt < nparts; ++pt) {
+                            it.row0 = r; it.r0 = (int)((int64_t)(L / 4) * pt / nparts) * 4; it.r1 = (int)((int64_t)(L / 4) * (pt + 1) / nparts) * 4;
+                            it.part = pt; it.nparts = nparts;
+                            items.push_back(it);
+                            vec_need = std::max(vec_need, 4 * (it.r1 - it.r0 + 16));             // read as registers of 16 entries
+                        }
+                    if (nparts > 1) { if (up) g.up_split |= 1u << ph; else g.down_split |= 1u << ph; }
+                }
+                if (all_sparse) { if (up) g.up_leaf |= 1u << ph; else g.down_leaf |= 1u << ph; }
+                else if (sparse) return 0;        // a level mixing sparse and dense leaves is not supported (the caller stores all leaves alike)
+                const int n_items = (int)items.size() - off[ph];
+                if (((up ? g.up_split : g.down_split) >> ph) & 1u) pbuf_need = std::max(pbuf_need, div_up(n_items, TIER_WAVES) * 256);
+            }
+            off[H] = (int)items.size();
+        }
+    }
+    vec_floats = (vec_need + 3) & ~3;
+    return (size_t)std::max(vec_floats + pbuf_need, leaf_need);
+}
+
+extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* stream, ls_direct** out) {
+    LS_REQUIRE(A && out, LS_E_INVALID, "ls_direct_create: null argument");
+    const int64_t V = A->V, n_bnd = A->n_bnd, n_front = A->n_front;
+    const int levels = A->levels, arity = A->arity;
+    const int64_t* h_nodes = A->h_nodes;
+    const int32_t *h_perm = A->h_perm, *h_ppos = A->h_ppos, *h_push_ptr = A->h_push_ptr, *h_push_tgt = A->h_push_tgt;
+    LS_REQUIRE(h_nodes && h_perm && h_push_ptr && V > 0 && levels >= 1 && levels <= 30 && n_bnd >= 0 && n_front >= V &&
                (arity == 2 || arity == 4 || arity == 8), LS_E_INVALID, "ls_direct_create: bad argument");
     LS_REQUIRE(V < INT32_MAX && n_bnd < INT32_MAX && n_front * arity < INT32_MAX, LS_E_OVERFLOW, "ls_direct_create: plan exceeds int32 offsets");
     *out = nullptr;
@@ -823,23 +926,45 @@ extern "C" int ls_direct_create(int64_t V, int levels, int arity, const int64_t*
     hipStream_t st = (hipStream_t)stream;
     ls_direct* d = new ls_direct();
     d->device = device; d->levels = levels; d->arity = arity; d->n_nodes = n_nodes; d->V = V; d->n_bnd = n_bnd; d->n_front = n_front;
-    d->finv = d_finv; d->wf = d_wf; d->wb = d_wb;
+    d->finv = A->d_finv; d->wf = A->d_wf; d->wb = A->d_wb;
+    d->u4 = A->d_u4; d->d4 = A->d_d4;
+    d->tri = A->d_tri; d->sp_ptr = A->d_sp_ptr; d->sp_ent = (const SpEnt*)A->d_sp_ent;
     std::vector<NodeDesc> nodes((size_t)n_nodes + 1);
+    std::vector<NodeD> nd((size_t)n_nodes + 1);
+    memset(nd.data(), 0, nd.size() * sizeof(NodeD));
     int64_t fe = 0;
     for (int i = 1; i <= n_nodes; ++i) {
-        const int64_t* r = h_nodes + (size_t)i * 8;
+        const int64_t* r = h_nodes + (size_t)i * LS_DIRECT_NODE_COLS;
         NodeDesc& n = nodes[i];
         n.s = (int)r[0]; n.b = (int)r[1]; n.own_start = (int)r[2]; n.bnd_off = (int)r[3]; n.front_off = (int)r[4];
         n.finv_off = r[5]; n.w_off = r[6]; n.parent = (int)r[7];
+        const bool sparse = r[8] >= 0, quad = r[11] != 0;
         if (n.s < 0 || n.b < 0 || n.own_start < 0 || (int64_t)n.own_start + n.s > V || (int64_t)n.bnd_off + n.b > n_bnd ||
-            (int64_t)n.front_off + n.s + n.b > n_front || (i == 1 ? n.b != 0 : (n.parent < 1 || n.parent >= i))) {
+            (int64_t)n.front_off + n.s + n.b > n_front || (i == 1 ? n.b != 0 : (n.parent < 1 || n.parent >= i)) ||
+            (sparse && (i < level_off[levels - 1] || n.s > 64 || n.s < 1 || !A->d_tri || !A->d_sp_ptr || !A->d_sp_ent || (r[8] & 3))) ||
+            (quad && (sparse || !A->d_u4 || !A->d_d4 || (n.finv_off & 3) || (n.w_off & 3)))) {
             delete d;
             set_error("ls_direct_create: node %d of the plan is inconsistent", i);
             return LS_E_INVALID;
         }
-        fe += (int64_t)n.s * n.s + 2 * (int64_t)n.s * n.b;
+        const int64_t s4 = (n.s + 3) & ~3, b4 = (n.b + 3) & ~3;
+        fe += sparse ? 2 * (((int64_t)n.s * (n.s + 1) / 2 + 3) & ~(int64_t)3)
+                     : quad ? s4 * n.b + (s4 + b4) * n.s : (int64_t)n.s * n.s + 2 * (int64_t)n.s * n.b;
     }
+    fe += 2 * A->n_sp_ent + A->n_sp_ptr;
     d->factor_entries = fe;
+    for (int lv = 0; lv < levels; ++lv)
+        for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i) {
+            const NodeDesc& n = nodes[i];
+            const int64_t* r = h_nodes + (size_t)i * LS_DIRECT_NODE_COLS;
+            NodeD& q = nd[i];
+            q.s = n.s; q.b = n.b; q.own_start = n.own_start; q.bnd_off = n.bnd_off; q.front_off = n.front_off;
+            q.pfront_off = i > 1 ? nodes[n.parent].front_off : -1;
+            q.cix = lv ? (int)((i - level_off[lv]) % arity) : 0;
+            q.flags = (lv + 1 >= levels ? NODE_LEAF : 0) | (r[8] >= 0 ? NODE_SPARSE : 0) | (r[11] != 0 ? NODE_QUAD : 0);
+            q.finv_off = r[8] >= 0 ? r[8] : n.finv_off; q.w_off = n.w_off;
+            q.spb_off = (int)r[9]; q.sps_off = (int)r[10];
+        }
     // which children contribute to a front position: bit c of mask[f]
     std::vector<unsigned char> mask((size_t)n_front, 0);
     for (int lv = 1; lv < levels; ++lv)
@@ -857,7 +982,39 @@ extern "C" int ls_direct_create(int64_t V, int levels, int arity, const int64_t*
                 mask[(size_t)p.front_off + pp] |= (unsigned char)(1u << cix);
             }
         }
-    // tiles: a range of rows of one node each
+    // bottom tier: the levels whose nodes the caller stored in the tier kernels' layouts (quad-interleaved / sparse leaves)
+    // run as one launch per sweep; every level above is one launch per sweep (unpadded finv / wf / wb)
+    std::vector<TierItem> items;
+    std::vector<TierWG> wgs;
+    {
+        int root = levels;
+        for (int lv = levels - 1; lv >= 0; --lv) {
+            bool tiered = false, plain = false;
+            for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i) {
+                if (nd[i].s == 0 && nd[i].b == 0) continue;
+                if (nd[i].flags & (NODE_SPARSE | NODE_QUAD)) tiered = true; else plain = true;
+            }
+            if (tiered && plain) { delete d; set_error("ls_direct_create: level %d mixes tier-layout and plain nodes", lv); return LS_E_INVALID; }
+            if (plain) break;
+            if (tiered && root != lv + 1) { delete d; set_error("ls_direct_create: tier-layout levels must be the deepest ones"); return LS_E_INVALID; }
+            if (tiered) root = lv;
+        }
+        for (int lv = 0; lv < root; ++lv)
+            for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i)
+                if (nd[i].flags & (NODE_SPARSE | NODE_QUAD)) { delete d; set_error("ls_direct_create: tier-layout node above the tier"); return LS_E_INVALID; }
+        d->tier_root = levels;
+        if (root < levels) {
+            const int H = levels - root;
+            size_t region = H <= TIER_MAX_H ? plan_tier(nd, level_off, levels, arity, root, items, wgs, d->tier_vec, d->tier_tri) : 0;
+            if (!region || region * sizeof(float) * TIER_WAVES > 150 * 1024) {
+                delete d;
+                set_error("ls_direct_create: a tier of %d levels does not fit the kernel (LDS per wave: %zu floats)", H, region);
+                return LS_E_WORKSPACE;
+            }
+            d->tier_root = root; d->tier_phases = H; d->tier_wgs = (int)wgs.size(); d->tier_region = (int)((region + 3) & ~(size_t)3);
+        }
+    }
+    // tiles of the upper levels: a range of rows of one node each
     std::vector<Tile> tiles;
     std::vector<PackedTile> ptiles;
     auto tile_of = [&](int64_t i, int r, int lv, int forward) {
@@ -874,7 +1031,7 @@ extern "C" int ls_direct_create(int64_t V, int levels, int arity, const int64_t*
     size_t lds_max = 0;
     const int long_red = env_int("LS_ND_LONG", 256);            // down sweep (reduction s + b)
     const int long_up = env_int("LS_ND_LONG_UP", long_red);     // up sweep (reduction s)
-    for (int lv = 0; lv < levels; ++lv) {
+    for (int lv = 0; lv < d->tier_root; ++lv) {
         LevelPlan& p = d->plan[lv];
         int red_up = 0, red_down = 0;
         for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i) {
@@ -978,10 +1135,14 @@ extern "C" int ls_direct_create(int64_t V, int levels, int arity, const int64_t*
     if (!(rc = up(&d->tiles, tiles.data(), tiles.size())) && !(rc = up(&d->ptiles, ptiles.data(), ptiles.size())) &&
         !(rc = up(&d->perm, h_perm, (size_t)V)) &&
         !(rc = up(&d->ppos, h_ppos, (size_t)n_bnd)) && !(rc = up(&d->push_ptr, h_push_ptr, (size_t)n_front + 1)) &&
-        !(rc = up(&d->push_tgt, h_push_tgt, (size_t)n_bnd)) && !(rc = up(&d->mask, mask.data(), mask.size()))) {
+        !(rc = up(&d->push_tgt, h_push_tgt, (size_t)n_bnd)) && !(rc = up(&d->mask, mask.data(), mask.size())) &&
+        !(rc = up(&d->d_items, items.data(), items.size())) &&
+        !(rc = up(&d->d_wgs, wgs.data(), wgs.size()))) {
         hipError_t e = hipMalloc((void**)&d->bp, sizeof(float) * (size_t)V * d->kmax);
+        if (e == hipSuccess) e = hipMalloc((void**)&d->braw, sizeof(float) * (size_t)V * d->kmax);
         if (e == hipSuccess) e = hipMalloc((void**)&d->slots, sizeof(float) * (size_t)n_front * arity * d->kmax);
         if (e == hipSuccess) e = hipMalloc((void**)&d->xb, sizeof(float) * (size_t)std::max<int64_t>(n_bnd, 1) * d->kmax);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&d->busy, hipEventDisableTiming);
         if (e == hipSuccess) e = hipStreamSynchronize(st);      // the host vectors above go out of scope
         if (e != hipSuccess) rc = hip_fail(e, "ls_direct_create allocations", __FILE__, __LINE__);
     }
@@ -996,6 +1157,11 @@ extern "C" int ls_direct_create(int64_t V, int levels, int arity, const int64_t*
     (void)hipFuncSetAttribute((const void*)k_nd_down_s<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     LS_OPTIN(1) LS_OPTIN(2) LS_OPTIN(3) LS_OPTIN(4)
 #undef LS_OPTIN
+#define LS_OPTIN(KK)                                                                                                       \
+    (void)hipFuncSetAttribute((const void*)k_nd_tier<KK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
+    (void)hipFuncSetAttribute((const void*)k_nd_tier<KK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    LS_OPTIN(1) LS_OPTIN(2) LS_OPTIN(3) LS_OPTIN(4)
+#undef LS_OPTIN
     *out = d;
     return LS_OK;
 }
@@ -1004,7 +1170,9 @@ extern "C" int ls_direct_destroy(ls_direct* d) {
     if (!d) return LS_OK;
     DeviceGuard g(d->device);
     (void)hipFree(d->tiles); (void)hipFree(d->ptiles); (void)hipFree(d->perm); (void)hipFree(d->ppos); (void)hipFree(d->push_ptr); (void)hipFree(d->push_tgt);
-    (void)hipFree(d->mask); (void)hipFree(d->bp); (void)hipFree(d->slots); (void)hipFree(d->xb);
+    (void)hipFree(d->mask); (void)hipFree(d->bp); (void)hipFree(d->braw); (void)hipFree(d->slots); (void)hipFree(d->xb);
+    (void)hipFree(d->d_items); (void)hipFree(d->d_wgs); (void)hipFree(d->dbg);
+    if (d->busy) (void)hipEventDestroy(d->busy);
     for (hipEvent_t e : d->ev) (void)hipEventDestroy(e);
     delete d;
     return LS_OK;
@@ -1012,8 +1180,18 @@ extern "C" int ls_direct_destroy(ls_direct* d) {
 
 template <int K>
 static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st) {
-    const int top = d->levels - 1;
+    const int top = d->tier_root - 1;            // levels [0, tier_root) are one launch each, the rest is the bottom tier
+    TierArgs ta;
+    ta.items = d->d_items; ta.wgs = d->d_wgs; ta.perm = d->perm; ta.mask = d->mask; ta.ppos = d->ppos;
+    ta.push_ptr = d->push_ptr; ta.push_tgt = d->push_tgt; ta.u4 = d->u4; ta.d4 = d->d4; ta.tri = d->tri;
+    ta.sp_ptr = d->sp_ptr; ta.sp_ent = d->sp_ent; ta.bprime = d->bp; ta.braw = d->braw; ta.slots = d->slots; ta.xb = d->xb;
+    ta.arity = d->arity; ta.phases = d->tier_phases; ta.region_floats = d->tier_region; ta.vec_floats = d->tier_vec;
+    ta.dbg = d->profile == 2 ? d->dbg : nullptr;
+    ta.ablate = env_int0("LS_ND_ABLATE", 0);
+    const size_t tier_lds = (size_t)d->tier_region * TIER_WAVES * sizeof(float);
     if (d->profile) LS_HIP(hipEventRecord(d->ev[0], st));
+    if (d->tier_wgs)
+        hipLaunchKernelGGL((k_nd_tier<K, true>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
     for (int lv = top; lv >= 0; --lv) {
         const LevelPlan& p = d->plan[lv];
         if (!(p.up_p ? p.up_p_tiles : p.up_tiles)) continue;
@@ -1051,6 +1229,9 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
                                ((size_t)p.s_cap + p.b_cap + (size_t)(p.down_nw - 1) * WAVE) * K * sizeof(float), st, d->tiles + p.down_first,
                                d->perm, d->push_ptr, d->push_tgt, d->finv, d->wb, (const float*)d->bp, d->xb, x, p.s_cap, p.b_cap);
     }
+    if (ta.dbg) ta.dbg += (size_t)d->tier_wgs * TIER_WAVES * 32;
+    if (d->tier_wgs)
+        hipLaunchKernelGGL((k_nd_tier<K, false>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
     if (d->profile) LS_HIP(hipEventRecord(d->ev[2], st));
     LS_HIP(hipGetLastError());
     if (d->profile) {
@@ -1069,12 +1250,18 @@ extern "C" int ls_direct_solve(ls_direct* d, const float* b, float* x, int k, vo
     DeviceGuard g(d->device);
     LS_HIP(g.err);
     hipStream_t st = (hipStream_t)stream;
+    // one workspace (b', slots, boundary vectors) per handle: a solve issued on another stream than the previous one
+    // waits for it on the device
+    if (d->used && st != d->last_stream) LS_HIP(hipStreamWaitEvent(st, d->busy, 0));
+    int rc;
     switch (k) {
-        case 1: return direct_solve_k<1>(d, b, x, st);
-        case 2: return direct_solve_k<2>(d, b, x, st);
-        case 3: return direct_solve_k<3>(d, b, x, st);
-        default: return direct_solve_k<4>(d, b, x, st);
+        case 1: rc = direct_solve_k<1>(d, b, x, st); break;
+        case 2: rc = direct_solve_k<2>(d, b, x, st); break;
+        case 3: rc = direct_solve_k<3>(d, b, x, st); break;
+        default: rc = direct_solve_k<4>(d, b, x, st); break;
     }
+    if (rc == LS_OK) { LS_HIP(hipEventRecord(d->busy, st)); d->last_stream = st; d->used = true; }
+    return rc;
 }
 
 extern "C" int ls_direct_set(ls_direct* d, const char* name, int value) {
@@ -1082,12 +1269,26 @@ extern "C" int ls_direct_set(ls_direct* d, const char* name, int value) {
     if (!strcmp(name, "profile")) {
         DeviceGuard g(d->device);
         LS_HIP(g.err);
-        d->profile = value ? 1 : 0;
+        d->profile = value < 0 ? 0 : std::min(value, 2);
         while (d->profile && d->ev.size() < 3) { hipEvent_t e; LS_HIP(hipEventCreate(&e)); d->ev.push_back(e); }
+        if (d->profile == 2 && !d->dbg && d->tier_wgs) {
+            LS_HIP(hipMalloc((void**)&d->dbg, sizeof(long long) * 2 * (size_t)d->tier_wgs * TIER_WAVES * 32));
+            LS_HIP(hipMemset(d->dbg, 0, sizeof(long long) * 2 * (size_t)d->tier_wgs * TIER_WAVES * 32));
+        }
         return LS_OK;
     }
     set_error("ls_direct_set: unknown option '%s'", name);
     return LS_E_INVALID;
+}
+
+extern "C" int ls_direct_tier_stamps(const ls_direct* d, long long* h_out, int64_t n) {
+    LS_REQUIRE(d && h_out, LS_E_INVALID, "ls_direct_tier_stamps: bad argument");
+    const int64_t have = d->dbg ? 2 * (int64_t)d->tier_wgs * TIER_WAVES * 32 : 0;
+    LS_REQUIRE(n <= have, LS_E_INVALID, "ls_direct_tier_stamps: %lld stamps recorded (set \"profile\" to 2 and solve first)", (long long)have);
+    DeviceGuard g(d->device);
+    LS_HIP(g.err);
+    LS_HIP(hipMemcpy(h_out, d->dbg, sizeof(long long) * (size_t)n, hipMemcpyDeviceToHost));
+    return LS_OK;
 }
 
 extern "C" int ls_direct_info(const ls_direct* d, int64_t* h_factor_entries, int* h_launches, double* h_ms3) {
@@ -1099,7 +1300,7 @@ extern "C" int ls_direct_info(const ls_direct* d, int64_t* h_factor_entries, int
             const LevelPlan& p = d->plan[lv];
             n += ((p.up_p ? p.up_p_tiles : p.up_tiles) ? 1 : 0) + ((p.down_p ? p.down_p_tiles : p.down_tiles) ? 1 : 0);
         }
-        *h_launches = n;
+        *h_launches = n + (d->tier_wgs ? 2 : 0);
     }
     if (h_ms3) for (int i = 0; i < 3; ++i) h_ms3[i] = d->prof_ms[i];
     return LS_OK;

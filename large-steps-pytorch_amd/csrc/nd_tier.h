@@ -21,6 +21,8 @@
 // copied into LDS with 16-byte loads (contiguous, fully coalesced) and read row-per-lane from there; the packed index
 // T(j) + c, T(j) = j (j + 1) / 2, is conflict free over the 32 lanes of an LDS access group because j -> T(j) mod 32 is a
 // permutation of 0..31 (the triangular-probing property), as is the transposed access T(c) + j (consecutive).
+// A wave software-pipelines its leaves: while leaf r is multiplied out of LDS, the triangle, right-hand side and sparse
+// entries of leaf r + 1 are in flight to registers and the index lists of leaf r + 2 are being fetched.
 #pragma once
 
 namespace ls {
@@ -28,30 +30,38 @@ namespace ls {
 constexpr int TIER_MAX_H = 6;            // tree levels one workgroup may walk
 constexpr int TIER_WAVES = 4;            // waves per tier workgroup
 constexpr int TIER_TRI4 = 9;             // 16-byte loads per lane that hold a leaf triangle (s <= 64: 2080 floats = 520 float4)
+constexpr int TIER_SPE = 4;              // sparse entries per row prefetched to registers (longer rows: loop)
 
-enum : int { NODE_LEAF = 1, NODE_SPARSE = 2 };
-
-struct alignas(64) NodeD {
-    int s, b, own_start, bnd_off, front_off, pfront_off, cix, flags;
-    long long finv_off, w_off;           // sparse leaf: finv_off = offset of the packed triangle in `tri`
-    int spb_off, sps_off;                // sparse leaf: offsets of the row pointers (boundary rows / own rows) in sp_ptr
-    int pad[2];
-};
+enum : int { NODE_LEAF = 1, NODE_SPARSE = 2, NODE_QUAD = 4 };
 
 struct SpEnt { float val; int idx; };
 
-struct alignas(32) TierItem {
-    int node, row0, r0, r1, part, nparts, pad0, pad1;
+struct NodeD {             // host-side node record the planner cuts into items
+    int s, b, own_start, bnd_off, front_off, pfront_off, cix, flags;
+    long long finv_off, w_off;
+    int spb_off, sps_off;
 };
+
+// everything a wave needs for one item, fetched with scalar loads (the item index is wave-uniform)
+struct alignas(32) TierItem {
+    int s, b, own_start, bnd_off, front_off, pfront_off, cix, flags;
+    long long finv_off, w_off;           // sparse leaf: finv_off = offset of the packed triangle in `tri`
+    int spb_off, sps_off;                // sparse leaf: offsets of the row pointers (boundary rows / own rows) in sp_ptr
+    int row0, r0, r1, part, nparts, pad0, pad1, pad2;
+};
+static_assert(sizeof(TierItem) == 96, "TierItem layout");
 
 struct alignas(64) TierWG {
     int up_off[TIER_MAX_H + 1];          // item ranges per phase of the up sweep (deepest level first) into TierItem[]
     int down_off[TIER_MAX_H + 1];        // ... of the down sweep (tier root first)
     unsigned up_split, down_split;       // bit p: phase p has items cut into parts (needs the combine step)
+    unsigned up_leaf, down_leaf;         // bit p: phase p consists of sparse leaves only (pipelined leaf loop)
+    int n_dense, pad;                    // own rows of the subtree's dense nodes: TIER_MAX_H ranges (start, count) in the tree's numbering
+    int dense_rng[2 * TIER_MAX_H];
 };
+static_assert(sizeof(TierWG) == 128, "TierWG layout (read as 32 dwords)");
 
 struct TierArgs {
-    const NodeD* nodes;
     const TierItem* items;
     const TierWG* wgs;
     const int* perm;
@@ -59,17 +69,44 @@ struct TierArgs {
     const int* ppos;
     const int* push_ptr;
     const int* push_tgt;
-    const float* finv;
-    const float* wf;
-    const float* wb;
+    const float* u4;                                 // dense tier nodes, up sweep stream (quad-interleaved, see tier_dot)
+    const float* d4;                                 // dense tier nodes, down sweep stream
     const float* tri;
     const int* sp_ptr;
     const SpEnt* sp_ent;
     float* bprime;
+    float* braw;                                     // b of the tier's inner-node rows in the tree's numbering (up sweep scratch)
     float* slots;
     float* xb;
     int arity, phases, region_floats, vec_floats;    // LDS per wave: [vec_floats | partial sums: rounds x 64 x 4]
+    long long* dbg;                                  // profile = 2: shader-clock stamps, 32 per wave (see k_nd_tier)
+    int ablate;                                      // LS_ND_ABLATE (timing experiments only, WRONG results): 1 no leaf mat-vec, 2 no sparse product,
+                                                     // 4 no dense phases, 8 no leaf phase, 16 no triangle loads
 };
+
+__device__ __forceinline__ void tier_stamp(const TierArgs& a, int slot) {
+    if (a.dbg && (threadIdx.x & 63) == 0)
+        a.dbg[((size_t)blockIdx.x * TIER_WAVES + (threadIdx.x >> 6)) * 32 + slot] = (long long)__builtin_amdgcn_s_memtime();
+}
+
+// Item records and the workgroup header are fetched with VECTOR loads (lane i takes dword i) and unpacked with
+// v_readlane: a scalar load on the critical path costs ~3 us next to a streaming CU (the scalar cache path queues behind
+// the vector traffic), a vector load can be requested two items ahead at the price of one VGPR.
+constexpr int ITEM_DWORDS = 24;
+__device__ __forceinline__ int rec_load(const TierItem* items, int k, int lane) {
+    return lane < ITEM_DWORDS ? reinterpret_cast<const int*>(items)[(size_t)k * ITEM_DWORDS + lane] : 0;
+}
+__device__ __forceinline__ int rl(int v, int i) { return __builtin_amdgcn_readlane(v, i); }
+__device__ __forceinline__ TierItem rec_unpack(int r) {
+    TierItem t;
+    t.s = rl(r, 0); t.b = rl(r, 1); t.own_start = rl(r, 2); t.bnd_off = rl(r, 3); t.front_off = rl(r, 4); t.pfront_off = rl(r, 5);
+    t.cix = rl(r, 6); t.flags = rl(r, 7);
+    t.finv_off = (long long)(((unsigned long long)(unsigned)rl(r, 9) << 32) | (unsigned)rl(r, 8));
+    t.w_off = (long long)(((unsigned long long)(unsigned)rl(r, 11) << 32) | (unsigned)rl(r, 10));
+    t.spb_off = rl(r, 12); t.sps_off = rl(r, 13); t.row0 = rl(r, 14); t.r0 = rl(r, 15); t.r1 = rl(r, 16); t.part = rl(r, 17);
+    t.nparts = rl(r, 18); t.pad0 = t.pad1 = t.pad2 = 0;
+    return t;
+}
 
 // LDS written by some lanes of a wave and read by others of the SAME wave: the LDS queue is in order per wave, only the
 // compiler has to be kept from moving the accesses across this point
@@ -79,154 +116,303 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int K>
 __device__ __forceinline__ float bcast_lane(float v, int c) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), c));
 }
 
 // ---- sparse leaves --------------------------------------------------------------------------------------------------
-struct TriRegs { float4 t[TIER_TRI4]; };
-
-__device__ __forceinline__ void tri_load(const float* __restrict__ tri, long long off, int s, int lane, TriRegs& r) {
-    const float4* __restrict__ p = reinterpret_cast<const float4*>(tri + off);
-    const int n4 = (s * (s + 1) / 2 + 3) >> 2;
-#pragma unroll
-    for (int e = 0; e < TIER_TRI4; ++e) {
-        const int i = lane + e * 64;
-        r.t[e] = i < n4 ? p[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-}
-__device__ __forceinline__ void tri_stage(const TriRegs& r, int s, int lane, float* stage) {
-    float4* d = reinterpret_cast<float4*>(stage);
-    const int n4 = (s * (s + 1) / 2 + 3) >> 2;
-#pragma unroll
-    for (int e = 0; e < TIER_TRI4; ++e) {
-        const int i = lane + e * 64;
-        if (i < n4) d[i] = r.t[e];
-    }
-}
-// acc_j = sum_c Finv[j][c] v_c over the staged triangle; v lives one row per lane (lane c holds v_c)
+struct LeafIdx {           // stage A: loads that depend on the item record only
+    int g, p0, p1, pp;     // up: perm of own row `lane`; row pointers + parent position of boundary row `lane`
+};                         // down: perm of own row `lane`; row pointers of own row `lane`
 template <int K>
-__device__ __forceinline__ void tri_matvec(const float* stage, int s, int lane, const float (&v)[K], float (&acc)[K]) {
+struct LeafDat {           // stage B: the triangle and the loads that depend on stage A
+    float4 t[TIER_TRI4];
+    float v[K];            // up: b of own row `lane`; down: y of own row `lane`
+    float xv[K];           // down: x_bnd of boundary row `lane`
+    SpEnt e[TIER_SPE];
+};
+
+template <bool UP>
+__device__ __forceinline__ void leaf_idx(const TierArgs& a, const TierItem& n, int lane, LeafIdx& ix) {
+    ix.g = lane < n.s ? a.perm[n.own_start + lane] : 0;
+    if (UP) {
+        const bool r = lane < n.b;
+        ix.p0 = r ? a.sp_ptr[n.spb_off + lane] : 0;
+        ix.p1 = r ? a.sp_ptr[n.spb_off + lane + 1] : 0;
+        ix.pp = r ? a.ppos[n.bnd_off + lane] : 0;
+    } else {
+        const bool r = lane < n.s;
+        ix.p0 = r ? a.sp_ptr[n.sps_off + lane] : 0;
+        ix.p1 = r ? a.sp_ptr[n.sps_off + lane + 1] : 0;
+        ix.pp = 0;
+    }
+}
+
+template <int K, bool UP>
+__device__ __forceinline__ void leaf_dat(const TierArgs& a, const TierItem& n, const LeafIdx& ix, const float* __restrict__ b_in,
+                                         int lane, LeafDat<K>& d) {
+    const float4* __restrict__ p = reinterpret_cast<const float4*>(a.tri + n.finv_off);
+    const int n4 = (a.ablate & 16) ? 0 : (n.s * (n.s + 1) / 2 + 3) >> 2;
+#pragma unroll
+    for (int e = 0; e < TIER_TRI4; ++e) {
+        const int i = lane + e * 64;
+        d.t[e] = i < n4 ? p[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+        if (UP) d.v[q] = lane < n.s ? b_in[(size_t)ix.g * K + q] : 0.0f;
+        else {
+            d.v[q] = lane < n.s ? a.bprime[(size_t)(n.own_start + lane) * K + q] : 0.0f;
+            d.xv[q] = lane < n.b ? a.xb[(size_t)(n.bnd_off + lane) * K + q] : 0.0f;
+        }
+    }
+    // always a load from a valid address (a conditional load of a struct becomes a flat load through a scratch copy, and
+    // flat loads would tie the LDS counter to these global loads): entry 0 of the array exists, unused values are zeroed
+    const float2* __restrict__ ent = reinterpret_cast<const float2*>(a.sp_ent);
+#pragma unroll
+    for (int t = 0; t < TIER_SPE; ++t) {
+        const bool ok = ix.p0 + t < ix.p1;
+        const float2 r = ent[ok ? ix.p0 + t : 0];
+        d.e[t].val = ok ? r.x : 0.0f;
+        d.e[t].idx = ok ? __float_as_int(r.y) : 0;
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void tri_stage(const LeafDat<K>& d, int s, int lane, float* stage) {
+    float4* o = reinterpret_cast<float4*>(stage);
+    const int n4 = (s * (s + 1) / 2 + 3) >> 2;
+#pragma unroll
+    for (int e = 0; e < TIER_TRI4; ++e) {
+        const int i = lane + e * 64;
+        if (i < n4) o[i] = d.t[e];
+    }
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// The 4 x 4 x 1 matrix instruction in its 16-block form IS a row-per-lane mat-vec step for K <= 4 right-hand sides:
+// block i = lanes 4i .. 4i + 3 computes D_i[m][n] += A_i[m] * B_i[n], and with A BROADCAST from one block (cbsz = 4,
+// abid = e) every lane l gets  acc[m] += A_e[m] * B[l]:  A_e = the K values of vector entry e (lanes 4e .. 4e + 3 of a
+// register that holds 16 consecutive entries of a [entry][4] vector -- ONE contiguous LDS read), B[l] = this lane's
+// matrix element. One instruction per matrix element instead of K FMAs + K broadcasts; exact fp32 (an fmaf chain).
+// Probed on the hardware: tools/mfma4x4_probe.hip.
+template <int E>
+__device__ __forceinline__ f32x4 mv_step(float vec16, float m, f32x4 acc) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(vec16, m, acc, 4, E, 0);
+}
+
+// acc[q] = sum_c Finv[row lane][c] v_c[q] over the staged packed triangle; vec4: the vector as [c][4] in LDS (entries
+// c >= s and components q >= K must be finite). Two accumulators break the dependent chain; fixed order.
+template <int T>
+__device__ __forceinline__ void tri_chunk(const float* stage, const float* vec4, int s, int lane, int j, int tj, f32x4& a0, f32x4& a1) {
+    if (16 * T >= s) return;
+    const float v16 = vec4[64 * T + lane];
+#define LS_TRI_STEP(E)                                                                      \
+    if (16 * T + E < s) {                                                                   \
+        constexpr int c = 16 * T + E;                                                       \
+        const float lo = stage[tj + c], hi = stage[c * (c + 1) / 2 + j];                    \
+        const float m = lane >= c ? lo : hi;                                                \
+        if (E & 1) a1 = mv_step<E>(v16, m, a1); else a0 = mv_step<E>(v16, m, a0);           \
+    }
+    LS_TRI_STEP(0) LS_TRI_STEP(1) LS_TRI_STEP(2) LS_TRI_STEP(3) LS_TRI_STEP(4) LS_TRI_STEP(5) LS_TRI_STEP(6) LS_TRI_STEP(7)
+    LS_TRI_STEP(8) LS_TRI_STEP(9) LS_TRI_STEP(10) LS_TRI_STEP(11) LS_TRI_STEP(12) LS_TRI_STEP(13) LS_TRI_STEP(14) LS_TRI_STEP(15)
+#undef LS_TRI_STEP
+}
+template <int K>
+__device__ __forceinline__ void tri_matvec(const float* stage, const float* vec4, int s, int lane, float (&acc)[K]) {
     const int j = min(lane, s - 1);
     const int tj = j * (j + 1) / 2;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    tri_chunk<0>(stage, vec4, s, lane, j, tj, a0, a1);
+    tri_chunk<1>(stage, vec4, s, lane, j, tj, a0, a1);
+    tri_chunk<2>(stage, vec4, s, lane, j, tj, a0, a1);
+    tri_chunk<3>(stage, vec4, s, lane, j, tj, a0, a1);
 #pragma unroll
-    for (int q = 0; q < K; ++q) acc[q] = 0.0f;
-    int tc = 0;                                   // T(c)
-    for (int c = 0; c < s; ++c) {
-        const float a = stage[c <= j ? tj + c : tc + j];
+    for (int q = 0; q < K; ++q) acc[q] = a0[q] + a1[q];
+}
+
+// row `lane` of the sparse block times a vector staged in LDS (4 floats per entry): prefetched entries, then the tail
+template <int K>
+__device__ __forceinline__ void sparse_row(const TierArgs& a, const LeafIdx& ix, const SpEnt (&e)[TIER_SPE], const float* vec4, float (&u)[K]) {
 #pragma unroll
-        for (int q = 0; q < K; ++q) acc[q] = fmaf(a, bcast_lane<K>(v[q], c), acc[q]);
-        tc += c + 1;
+    for (int q = 0; q < K; ++q) u[q] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < TIER_SPE; ++t) {
+        if (ix.p0 + t < ix.p1) {
+#pragma unroll
+            for (int q = 0; q < K; ++q) u[q] = fmaf(e[t].val, vec4[e[t].idx * 4 + q], u[q]);
+        }
+    }
+    for (int p = ix.p0 + TIER_SPE; p < ix.p1; ++p) {
+        const SpEnt z = a.sp_ent[p];
+#pragma unroll
+        for (int q = 0; q < K; ++q) u[q] = fmaf(z.val, vec4[z.idx * 4 + q], u[q]);
     }
 }
 
-// LDS of a leaf item: [triangle: tri_floats][vec: 64 x 4][xbv: b x 4]
+// LDS of a leaf item: [triangle: tri_floats][y: 64 x 4][x_bnd: b x 4]
 template <int K>
-__device__ __forceinline__ void leaf_up(const TierArgs& a, const NodeD& n, const float* __restrict__ b_in, float* region, int tri_floats) {
+__device__ __forceinline__ void leaf_up_compute(const TierArgs& a, const TierItem& n, const LeafIdx& ix, const float (&bj)[K],
+                                                const SpEnt (&e)[TIER_SPE], float* region, int tri_floats) {
     const int lane = threadIdx.x & 63, s = n.s, b = n.b;
-    float* stage = region;
     float* yv = region + tri_floats;
-    TriRegs tr;
-    tri_load(a.tri, n.finv_off, s, lane, tr);
-    float bj[K];
     {
-        const size_t g = lane < s ? (size_t)a.perm[n.own_start + lane] : 0;
-#pragma unroll
-        for (int q = 0; q < K; ++q) bj[q] = lane < s ? b_in[g * K + q] : 0.0f;
+        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < s) { w.x = bj[0]; if (K > 1) w.y = bj[K > 1 ? 1 : 0]; if (K > 2) w.z = bj[K > 2 ? 2 : 0]; if (K > 3) w.w = bj[K > 3 ? 3 : 0]; }
+        reinterpret_cast<float4*>(yv)[lane] = w;
     }
-    tri_stage(tr, s, lane, stage);
     wave_lds_sync();
     float y[K];
-    tri_matvec<K>(stage, s, lane, bj, y);
+    if (a.ablate & 1) { for (int q = 0; q < K; ++q) y[q] = bj[q]; } else
+    tri_matvec<K>(region, yv, s, lane, y);
+    tier_stamp(a, 29);
+    wave_lds_sync();
     if (lane < s) {
 #pragma unroll
         for (int q = 0; q < K; ++q) { yv[lane * 4 + q] = y[q]; a.bprime[(size_t)(n.own_start + lane) * K + q] = y[q]; }
     }
     wave_lds_sync();
-    if (n.pfront_off < 0) return;
-    for (int i = lane; i < b; i += 64) {
-        const int p0 = a.sp_ptr[n.spb_off + i], p1 = a.sp_ptr[n.spb_off + i + 1];
-        const int pp = a.ppos[n.bnd_off + i];
-        float u[K];
+    if (n.pfront_off >= 0 && !(a.ablate & 2)) {
+        if (lane < b) {
+            float u[K];
+            sparse_row<K>(a, ix, e, yv, u);
+            const size_t dst = ((size_t)(n.pfront_off + ix.pp) * a.arity + n.cix) * K;
 #pragma unroll
-        for (int q = 0; q < K; ++q) u[q] = 0.0f;
-        for (int p = p0; p < p1; ++p) {
-            const SpEnt e = a.sp_ent[p];
-#pragma unroll
-            for (int q = 0; q < K; ++q) u[q] = fmaf(e.val, yv[e.idx * 4 + q], u[q]);
+            for (int q = 0; q < K; ++q) a.slots[dst + q] = u[q];
         }
-        const size_t dst = ((size_t)(n.pfront_off + pp) * a.arity + n.cix) * K;
+        for (int i = lane + 64; i < b; i += 64) {          // leaves with more than 64 boundary rows: no prefetch
+            const int p0 = a.sp_ptr[n.spb_off + i], p1 = a.sp_ptr[n.spb_off + i + 1], pp = a.ppos[n.bnd_off + i];
+            float u[K];
 #pragma unroll
-        for (int q = 0; q < K; ++q) a.slots[dst + q] = u[q];
+            for (int q = 0; q < K; ++q) u[q] = 0.0f;
+            for (int p = p0; p < p1; ++p) {
+                const SpEnt z = a.sp_ent[p];
+#pragma unroll
+                for (int q = 0; q < K; ++q) u[q] = fmaf(z.val, yv[z.idx * 4 + q], u[q]);
+            }
+            const size_t dst = ((size_t)(n.pfront_off + pp) * a.arity + n.cix) * K;
+#pragma unroll
+            for (int q = 0; q < K; ++q) a.slots[dst + q] = u[q];
+        }
     }
+    wave_lds_sync();
 }
 
 template <int K>
-__device__ __forceinline__ void leaf_down(const TierArgs& a, const NodeD& n, float* __restrict__ x_out, float* region, int tri_floats) {
+__device__ __forceinline__ void leaf_down_compute(const TierArgs& a, const TierItem& n, const LeafIdx& ix, const float (&yj)[K],
+                                                  const float (&xv)[K], const SpEnt (&e)[TIER_SPE], float* __restrict__ x_out,
+                                                  float* region, int tri_floats) {
     const int lane = threadIdx.x & 63, s = n.s, b = n.b;
-    float* stage = region;
     float* xbv = region + tri_floats + 64 * 4;
-    TriRegs tr;
-    tri_load(a.tri, n.finv_off, s, lane, tr);
-    float yj[K];
-    size_t g = 0;
-    int p0 = 0, p1 = 0;
-    if (lane < s) {
-        g = (size_t)a.perm[n.own_start + lane];
-        p0 = a.sp_ptr[n.sps_off + lane]; p1 = a.sp_ptr[n.sps_off + lane + 1];
-    }
+    if (lane < b) {
 #pragma unroll
-    for (int q = 0; q < K; ++q) yj[q] = lane < s ? a.bprime[(size_t)(n.own_start + lane) * K + q] : 0.0f;
-    for (int i = lane; i < b; i += 64) {
+        for (int q = 0; q < K; ++q) xbv[lane * 4 + q] = xv[q];
+    }
+    for (int i = lane + 64; i < b; i += 64) {
 #pragma unroll
         for (int q = 0; q < K; ++q) xbv[i * 4 + q] = a.xb[(size_t)(n.bnd_off + i) * K + q];
     }
-    tri_stage(tr, s, lane, stage);
     wave_lds_sync();
     float t[K];
-#pragma unroll
-    for (int q = 0; q < K; ++q) t[q] = 0.0f;
-    for (int p = p0; p < p1; ++p) {
-        const SpEnt e = a.sp_ent[p];
-#pragma unroll
-        for (int q = 0; q < K; ++q) t[q] = fmaf(e.val, xbv[e.idx * 4 + q], t[q]);
-    }
-    float z[K];
-    tri_matvec<K>(stage, s, lane, t, z);
-    if (lane < s) {
-#pragma unroll
-        for (int q = 0; q < K; ++q) x_out[g * K + q] = yj[q] - z[q];
+    if (a.ablate & 2) { for (int q = 0; q < K; ++q) t[q] = yj[q]; } else
+    sparse_row<K>(a, ix, e, xbv, t);
+    float* tv = region + tri_floats;
+    {
+        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < s) { w.x = t[0]; if (K > 1) w.y = t[K > 1 ? 1 : 0]; if (K > 2) w.z = t[K > 2 ? 2 : 0]; if (K > 3) w.w = t[K > 3 ? 3 : 0]; }
+        reinterpret_cast<float4*>(tv)[lane] = w;
     }
     wave_lds_sync();
+    float z[K];
+    if (a.ablate & 1) { for (int q = 0; q < K; ++q) z[q] = t[q]; } else
+    tri_matvec<K>(region, tv, s, lane, z);
+    if (lane < s) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) x_out[(size_t)ix.g * K + q] = yj[q] - z[q];
+    }
+    wave_lds_sync();
+}
+
+// the leaves of this wave in one phase: items k0, k0 + stride, ... < k1. Software pipeline per leaf r:
+//   record (r + 3) requested | data (r + 1): triangle, right-hand side, sparse entries | indices (r + 2) | multiply (r)
+template <int K, bool UP>
+__device__ __forceinline__ void leaf_phase(const TierArgs& a, int k0, int k1, const float* __restrict__ b_in, float* __restrict__ x_out,
+                                           float* region, int tri_floats) {
+    const int lane = threadIdx.x & 63;
+    if (k0 >= k1) return;
+    constexpr int S = TIER_WAVES;
+    tier_stamp(a, 24);
+    int rec_n = k0 + S < k1 ? rec_load(a.items, k0 + S, lane) : 0;
+    int rec_nn = k0 + 2 * S < k1 ? rec_load(a.items, k0 + 2 * S, lane) : 0;
+    TierItem it_c = rec_unpack(rec_load(a.items, k0, lane)), it_n = it_c;
+    LeafIdx ix_c, ix_n;
+    LeafDat<K> d;
+    leaf_idx<UP>(a, it_c, lane, ix_c);
+    ix_n = ix_c;
+    if (k0 + S < k1) { it_n = rec_unpack(rec_n); leaf_idx<UP>(a, it_n, lane, ix_n); }
+    leaf_dat<K, UP>(a, it_c, ix_c, b_in, lane, d);
+    for (int k = k0; k < k1; k += S) {
+        // the current leaf's loads -> LDS / a few registers; its big registers are free for the next leaf
+        tri_stage<K>(d, it_c.s, lane, region);
+        float v[K], xv[K];
+        SpEnt e[TIER_SPE];
+#pragma unroll
+        for (int q = 0; q < K; ++q) { v[q] = d.v[q]; xv[q] = UP ? 0.0f : d.xv[q]; }
+#pragma unroll
+        for (int t = 0; t < TIER_SPE; ++t) e[t] = d.e[t];
+        wave_lds_sync();
+        if (k == k0) tier_stamp(a, 27);
+        const bool more = k + S < k1, more2 = k + 2 * S < k1;
+        const int rec_3 = k + 3 * S < k1 ? rec_load(a.items, k + 3 * S, lane) : 0;   // record of leaf r + 3
+        if (more) leaf_dat<K, UP>(a, it_n, ix_n, b_in, lane, d);                       // data of leaf r + 1
+        TierItem it_nn = it_n;
+        LeafIdx ix_nn = ix_n;
+        if (more2) { it_nn = rec_unpack(rec_nn); leaf_idx<UP>(a, it_nn, lane, ix_nn); }   // indices of leaf r + 2 (record asked for an iteration ago)
+        if (k == k0) tier_stamp(a, 28);
+        if (UP) leaf_up_compute<K>(a, it_c, ix_c, v, e, region, tri_floats);
+        else leaf_down_compute<K>(a, it_c, ix_c, v, xv, e, x_out, region, tri_floats);
+        it_c = it_n; ix_c = ix_n; it_n = it_nn; ix_n = ix_nn; rec_nn = rec_3;
+        tier_stamp(a, 16 + min(7, (k - k0) / S));
+    }
 }
 
 // ---- dense nodes inside the tier ---------------------------------------------------------------------------------------
-constexpr int TIER_U = 8;        // strided matrix loads per lane and batch; two batches in flight
+// Dense nodes of the tier keep their matrices QUAD-INTERLEAVED along the reduction: entry (row, t) of a stream sits at
+// ((t / 4) * rows + row) * 4 + t % 4, reduction padded to a multiple of 4 with zeros. A lane owns a row and reads 16 bytes
+// = 4 consecutive reduction entries per load; the 64 lanes of a wave read 1 KB contiguous -- the access the memory system
+// wants (4-byte-per-lane row loads level off near 3 TB/s on this chip) -- and each loaded quad feeds 4 matrix instructions.
+//     up    u4: rows = boundary rows i (b), reduction = own rows j (s -> s4)                 W[i][j]
+//     down  d4: rows = own rows j (s), reduction = [own rows t (s -> s4) | boundary rows (b -> b4)]   [Finv | W^T][j][t]
+constexpr int TIER_Q = 2;        // quads per lane and batch; two batches in flight (deeper prefetch: measured slower, the
+                                 // registers spill next to the leaf pipeline)
 
-// acc += sum_{u in [u0, u1)} col[u * stride] * sv4[(u - base) * 4 + q]
-template <int K>
-__device__ __forceinline__ void tier_dot(const float* __restrict__ col, size_t stride, int u0, int u1, const float* sv4, int base, float (&acc)[K]) {
-    float cur[TIER_U], nxt[TIER_U];
+__device__ __forceinline__ void tier_prefetch(const float4* __restrict__ col, size_t rows, int q0, int q1, float4 (&cur)[TIER_Q]) {
 #pragma unroll
-    for (int e = 0; e < TIER_U; ++e) cur[e] = (u0 + e < u1) ? col[(size_t)(u0 + e) * stride] : 0.0f;
-    for (int u = u0; u < u1; u += TIER_U) {
-#pragma unroll
-        for (int e = 0; e < TIER_U; ++e) nxt[e] = (u + TIER_U + e < u1) ? col[(size_t)(u + TIER_U + e) * stride] : 0.0f;
-#pragma unroll
-        for (int e = 0; e < TIER_U; ++e) {
-            if (u + e < u1) {
-#pragma unroll
-                for (int q = 0; q < K; ++q) acc[q] = fmaf(cur[e], sv4[(u + e - base) * 4 + q], acc[q]);
-            }
+    for (int e = 0; e < TIER_Q; ++e) cur[e] = (q0 + e < q1) ? col[(size_t)(q0 + e) * rows] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// acc[m] += sum over the quads [q0, q1) of col[q * rows] (4 entries each) times the vector sv4[(4 q - base) * 4 + m];
+// cur = the first batch, already requested. The vector is read as registers of 16 entries starting at the batch.
+__device__ __forceinline__ void tier_dot(const float4* __restrict__ col, size_t rows, int q0, int q1, const float* sv4, int base,
+                                         float4 (&cur)[TIER_Q], f32x4& acc) {
+    float4 nxt[TIER_Q];
+    for (int q = q0; q < q1; q += TIER_Q) {
+        const float v16 = sv4[(4 * q - base) * 4 + (threadIdx.x & 63)];
+        tier_prefetch(col, rows, q + TIER_Q, q1, nxt);
+        acc = mv_step<0>(v16, cur[0].x, acc); acc = mv_step<1>(v16, cur[0].y, acc);
+        acc = mv_step<2>(v16, cur[0].z, acc); acc = mv_step<3>(v16, cur[0].w, acc);
+        if (q + 1 < q1) {
+            acc = mv_step<4>(v16, cur[1].x, acc); acc = mv_step<5>(v16, cur[1].y, acc);
+            acc = mv_step<6>(v16, cur[1].z, acc); acc = mv_step<7>(v16, cur[1].w, acc);
         }
 #pragma unroll
-        for (int e = 0; e < TIER_U; ++e) cur[e] = nxt[e];
+        for (int e = 0; e < TIER_Q; ++e) cur[e] = nxt[e];
     }
 }
 
 template <int K>
-__device__ __forceinline__ void node_up_finish(const TierArgs& a, const NodeD& n, int i, const float (&acc)[K]) {
+__device__ __forceinline__ void node_up_finish(const TierArgs& a, const TierItem& n, int i, const float (&acc)[K]) {
     if (i >= n.b || n.pfront_off < 0) return;
     float pass[K];
 #pragma unroll
@@ -238,22 +424,57 @@ __device__ __forceinline__ void node_up_finish(const TierArgs& a, const NodeD& n
     for (int q = 0; q < K; ++q) a.slots[dst + q] = acc[q] + pass[q];
 }
 
-// up: b'_j for the item's reduction range (stored by the row0 == 0 items), partial upd_i = sum_j W[i][j] b'_j
+// What a dense item can request BEFORE the barrier that ends the previous phase (nothing here depends on that phase):
+// the first batches of its matrix stream and static index / vector loads. The wave's first item of a phase gets this
+// treatment; the round trips that remain behind the barrier are the children's slots (up) / the parent's x (down).
 template <int K>
-__device__ __forceinline__ void node_up(const TierArgs& a, const NodeD& n, const TierItem& it, const float* __restrict__ b_in,
-                                        float* region, float* pbuf) {
-    const int lane = threadIdx.x & 63, s = n.s, b = n.b;
+struct DensePre {
+    float4 cur[TIER_Q];    // first batch of the matrix stream
+    float v[K];            // down: b' of reduction entry r0 + lane (if it is an own row)
+    int idx;               // up: parent position of this lane's boundary row; down: the caller's id of this lane's own row
+};
+
+template <int K>
+__device__ __forceinline__ void node_up_pre(const TierArgs& a, const TierItem& it, DensePre<K>& P) {
+    const int lane = threadIdx.x & 63, i = it.row0 + lane;
+    const bool row = i < it.b;
+    const float4* col = reinterpret_cast<const float4*>(a.u4 + it.w_off) + (row ? i : 0);
+    tier_prefetch(col, (size_t)it.b, it.r0 >> 2, row ? it.r1 >> 2 : it.r0 >> 2, P.cur);
+    P.idx = (it.nparts == 1 && row && it.pfront_off >= 0) ? a.ppos[it.bnd_off + i] : 0;
+}
+
+// up: b'_j for the item's reduction range (stored by the row0 == 0 items), partial upd_i = sum_j W[i][j] b'_j.
+// braw: the right-hand side of the tier's dense rows in the tree's numbering (gathered at kernel start, see k_nd_tier).
+template <int K>
+__device__ __forceinline__ void node_up(const TierArgs& a, const TierItem& it, DensePre<K>& P, const float* __restrict__ b_in, float* region, float* pbuf) {
+    const int lane = threadIdx.x & 63, b = it.b;
     const int i = it.row0 + lane;
     const bool row = i < b;
     float* sv4 = region;
-    for (int j = it.r0 + lane; j < it.r1; j += 64) {
-        const size_t g = (size_t)a.perm[n.own_start + j];
-        float v[K];
+    const float4* __restrict__ col = reinterpret_cast<const float4*>(a.u4 + it.w_off) + (row ? i : 0);
+    float pass[K];
 #pragma unroll
-        for (int q = 0; q < K; ++q) v[q] = b_in[g * K + q];
-        if (!(n.flags & NODE_LEAF)) {
+    for (int q = 0; q < K; ++q) pass[q] = 0.0f;
+    const bool fin = it.nparts == 1 && row && it.pfront_off >= 0;
+    if (fin && !(it.flags & NODE_LEAF)) pull_slots<K>(a.slots, a.mask, (size_t)(it.front_off + it.s + i), a.arity, pass);
+    for (int j = it.r0 + lane; j < it.r1; j += 64) {
+        float v[K];
+        if (j >= it.s) {                              // padding of the reduction to a multiple of 4
+#pragma unroll
+            for (int q = 0; q < K; ++q) sv4[(j - it.r0) * 4 + q] = 0.0f;
+            continue;
+        }
+        if (it.flags & NODE_LEAF) {                   // a dense node on the leaf level (phase 0: nothing was gathered for it)
+            const size_t g = (size_t)a.perm[it.own_start + j];
+#pragma unroll
+            for (int q = 0; q < K; ++q) v[q] = b_in[g * K + q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < K; ++q) v[q] = a.braw[(size_t)(it.own_start + j) * K + q];        // gathered at kernel start
+        }
+        if (!(it.flags & NODE_LEAF)) {
             float u[K];
-            pull_slots<K>(a.slots, a.mask, (size_t)(n.front_off + j), a.arity, u);
+            pull_slots<K>(a.slots, a.mask, (size_t)(it.front_off + j), a.arity, u);
 #pragma unroll
             for (int q = 0; q < K; ++q) v[q] -= u[q];
         }
@@ -261,76 +482,97 @@ __device__ __forceinline__ void node_up(const TierArgs& a, const NodeD& n, const
         for (int q = 0; q < K; ++q) sv4[(j - it.r0) * 4 + q] = v[q];
         if (it.row0 == 0) {
 #pragma unroll
-            for (int q = 0; q < K; ++q) a.bprime[(size_t)(n.own_start + j) * K + q] = v[q];
+            for (int q = 0; q < K; ++q) a.bprime[(size_t)(it.own_start + j) * K + q] = v[q];
         }
     }
     wave_lds_sync();
+    f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+    tier_dot(col, (size_t)b, it.r0 >> 2, it.r1 >> 2, sv4, it.r0, P.cur, a4);   // every lane takes part (matrix instruction)
     float acc[K];
 #pragma unroll
-    for (int q = 0; q < K; ++q) acc[q] = 0.0f;
-    if (row) tier_dot<K>(a.wf + n.w_off + i, (size_t)b, it.r0, it.r1, sv4, it.r0, acc);
-    if (it.nparts == 1) node_up_finish<K>(a, n, i, acc);
-    else {
+    for (int q = 0; q < K; ++q) acc[q] = a4[q];
+    if (it.nparts == 1) {
+        if (fin) {
+            const size_t dst = ((size_t)(it.pfront_off + P.idx) * a.arity + it.cix) * K;
+#pragma unroll
+            for (int q = 0; q < K; ++q) a.slots[dst + q] = acc[q] + pass[q];
+        }
+    } else {
 #pragma unroll
         for (int q = 0; q < K; ++q) pbuf[lane * 4 + q] = acc[q];
     }
     wave_lds_sync();
-    (void)s;
 }
 
 template <int K>
-__device__ __forceinline__ void node_down_finish(const TierArgs& a, const NodeD& n, const TierItem& it, float* __restrict__ x_out,
-                                                 const float (&acc)[K]) {
+__device__ __forceinline__ void node_down_finish(const TierArgs& a, const TierItem& it, int g_pre, float* __restrict__ x_out, const float (&acc)[K]) {
     const int lane = threadIdx.x & 63;
     const int j = it.row0 + lane;
-    const bool inner = !(n.flags & NODE_LEAF);
-    if (j < n.s) {
-        const size_t g = (size_t)a.perm[n.own_start + j];
+    const bool inner = !(it.flags & NODE_LEAF);
+    if (j < it.s) {
+        const size_t g = (size_t)(g_pre >= 0 ? g_pre : a.perm[it.own_start + j]);
 #pragma unroll
         for (int q = 0; q < K; ++q) x_out[g * K + q] = acc[q];
-        if (inner) push_down<K>(a.push_tgt, a.push_ptr[n.front_off + j], a.push_ptr[n.front_off + j + 1], a.xb, acc);
+        if (inner) push_down<K>(a.push_tgt, a.push_ptr[it.front_off + j], a.push_ptr[it.front_off + j + 1], a.xb, acc);
     }
     if (inner && it.row0 == 0) {          // the boundary rows hand x down too
-        for (int i = lane; i < n.b; i += 64) {
-            const size_t f = (size_t)(n.front_off + n.s + i);
+        for (int i = lane; i < it.b; i += 64) {
+            const size_t f = (size_t)(it.front_off + it.s + i);
             float v[K];
 #pragma unroll
-            for (int q = 0; q < K; ++q) v[q] = a.xb[(size_t)(n.bnd_off + i) * K + q];
+            for (int q = 0; q < K; ++q) v[q] = a.xb[(size_t)(it.bnd_off + i) * K + q];
             push_down<K>(a.push_tgt, a.push_ptr[f], a.push_ptr[f + 1], a.xb, v);
         }
     }
 }
 
+template <int K>
+__device__ __forceinline__ void node_down_pre(const TierArgs& a, const TierItem& it, DensePre<K>& P) {
+    const int lane = threadIdx.x & 63, s = it.s, j = it.row0 + lane;
+    const bool row = j < s;
+    tier_prefetch(reinterpret_cast<const float4*>(a.d4 + it.finv_off) + (row ? j : 0), (size_t)s, it.r0 >> 2, row ? it.r1 >> 2 : it.r0 >> 2, P.cur);
+    const int t = it.r0 + lane;
+#pragma unroll
+    for (int q = 0; q < K; ++q) P.v[q] = (t < it.r1 && t < s) ? a.bprime[(size_t)(it.own_start + t) * K + q] : 0.0f;
+    P.idx = row ? a.perm[it.own_start + j] : 0;
+}
+
 // down: partial x_j = sum_{t in [r0, r1)} [Finv | -W^T][j][t] * [b' | x_bnd][t]
 template <int K>
-__device__ __forceinline__ void node_down(const TierArgs& a, const NodeD& n, const TierItem& it, float* __restrict__ x_out,
-                                          float* region, float* pbuf) {
-    const int lane = threadIdx.x & 63, s = n.s;
+__device__ __forceinline__ void node_down(const TierArgs& a, const TierItem& it, DensePre<K>& P, float* __restrict__ x_out, float* region, float* pbuf) {
+    const int lane = threadIdx.x & 63, s = it.s;
     const int j = it.row0 + lane;
     const bool row = j < s;
     float* sv4 = region;
+    const float4* __restrict__ col = reinterpret_cast<const float4*>(a.d4 + it.finv_off) + (row ? j : 0);
+    const int s4 = (s + 3) & ~3;                  // reduction index space: [0, s4) own rows (padded), [s4, ..) boundary rows (padded)
     for (int t = it.r0 + lane; t < it.r1; t += 64) {
         float v[K];
         if (t < s) {
+            if (t == it.r0 + lane) {
 #pragma unroll
-            for (int q = 0; q < K; ++q) v[q] = a.bprime[(size_t)(n.own_start + t) * K + q];
+                for (int q = 0; q < K; ++q) v[q] = P.v[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < K; ++q) v[q] = a.bprime[(size_t)(it.own_start + t) * K + q];
+            }
+        } else if (t >= s4 && t - s4 < it.b) {
+#pragma unroll
+            for (int q = 0; q < K; ++q) v[q] = -a.xb[(size_t)(it.bnd_off + t - s4) * K + q];
         } else {
 #pragma unroll
-            for (int q = 0; q < K; ++q) v[q] = -a.xb[(size_t)(n.bnd_off + t - s) * K + q];
+            for (int q = 0; q < K; ++q) v[q] = 0.0f;
         }
 #pragma unroll
         for (int q = 0; q < K; ++q) sv4[(t - it.r0) * 4 + q] = v[q];
     }
     wave_lds_sync();
+    f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+    tier_dot(col, (size_t)s, it.r0 >> 2, it.r1 >> 2, sv4, it.r0, P.cur, a4);
     float acc[K];
 #pragma unroll
-    for (int q = 0; q < K; ++q) acc[q] = 0.0f;
-    if (row) {
-        const int f0 = min(it.r0, s), f1 = min(it.r1, s), g0 = max(it.r0, s), g1 = max(it.r1, s);
-        tier_dot<K>(a.finv + n.finv_off + j, (size_t)s, f0, f1, sv4, it.r0, acc);
-        tier_dot<K>(a.wb + n.w_off + j - (size_t)s * s, (size_t)s, g0, g1, sv4, it.r0, acc);     // row t of wb is boundary row t - s
-    }
-    if (it.nparts == 1) node_down_finish<K>(a, n, it, x_out, acc);
+    for (int q = 0; q < K; ++q) acc[q] = a4[q];
+    if (it.nparts == 1) node_down_finish<K>(a, it, P.idx, x_out, acc);
     else {
 #pragma unroll
         for (int q = 0; q < K; ++q) pbuf[lane * 4 + q] = acc[q];
@@ -340,48 +582,101 @@ __device__ __forceinline__ void node_down(const TierArgs& a, const NodeD& n, con
 
 // One workgroup per subtree. UP: phases run leaves -> tier root. DOWN: tier root -> leaves.
 template <int K, bool UP>
-__global__ __launch_bounds__(64 * TIER_WAVES) void k_nd_tier(TierArgs a, const float* __restrict__ b_in, float* __restrict__ x_out,
+__global__ __launch_bounds__(64 * TIER_WAVES, 4) void k_nd_tier(TierArgs a, const float* __restrict__ b_in, float* __restrict__ x_out,
                                                               int tri_floats) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     float* region = sm + (size_t)wave * a.region_floats;
-    const TierWG& g = a.wgs[blockIdx.x];
-    const int* off = UP ? g.up_off : g.down_off;
-    const unsigned split = UP ? g.up_split : g.down_split;
+    // workgroup header: up_off[7] | down_off[7] | up_split down_split up_leaf down_leaf | n_dense pad | dense_rng[12]
+    const int hdr = lane < 32 ? reinterpret_cast<const int*>(a.wgs + blockIdx.x)[lane] : 0;
+    const int obase = UP ? 0 : TIER_MAX_H + 1;
+    const unsigned split = (unsigned)rl(hdr, UP ? 14 : 15), leafy = (unsigned)rl(hdr, UP ? 16 : 17);
+    tier_stamp(a, 0);
+    if (UP) {
+        // right-hand side of the tier's inner-node rows, gathered once into the tree's numbering (braw): the dense items
+        // read it from a static address instead of walking perm -> b behind a barrier
+        const int n_dense = rl(hdr, 18);
+        for (int r = threadIdx.x; r < n_dense; r += blockDim.x) {
+            // the dense rows of a subtree are one range per level; ranges are listed as (start, count) pairs
+            int o = r, start = 0;
+#pragma unroll
+            for (int t = 0; t < TIER_MAX_H; ++t) {
+                const int cnt = rl(hdr, 20 + 2 * t + 1);
+                const bool here = o >= 0 && o < cnt;
+                start = here ? rl(hdr, 20 + 2 * t) + o : start;
+                o = here ? -1 : o - cnt;
+            }
+            const size_t g = (size_t)a.perm[start];
+#pragma unroll
+            for (int q = 0; q < K; ++q) a.braw[(size_t)start * K + q] = b_in[g * K + q];
+        }
+    }
+    DensePre<K> pre;
+#pragma unroll
+    for (int e = 0; e < TIER_Q; ++e) pre.cur[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < K; ++q) pre.v[q] = 0.0f;
+    pre.idx = 0;
+    TierItem it_pre = rec_unpack(0);
+    bool pre_valid = false;
     for (int ph = 0; ph < a.phases; ++ph) {
-        const int i0 = off[ph], i1 = off[ph + 1];
-        for (int k = i0 + wave; k < i1; k += TIER_WAVES) {
-            const TierItem it = a.items[k];
-            const NodeD n = a.nodes[it.node];
-            float* pbuf = region + a.vec_floats + ((k - i0) / TIER_WAVES) * 256;
-            if (n.flags & NODE_SPARSE) {
-                if (UP) leaf_up<K>(a, n, b_in, region, tri_floats);
-                else leaf_down<K>(a, n, x_out, region, tri_floats);
-            } else {
-                if (UP) node_up<K>(a, n, it, b_in, region, pbuf);
-                else node_down<K>(a, n, it, x_out, region, pbuf);
-            }
+        const int i0 = rl(hdr, obase + ph), i1 = rl(hdr, obase + ph + 1);
+        // the record of this wave's first item of the NEXT phase: requested now, used before this phase's barrier
+        int rec_nx = 0;
+        bool has_nx = false;
+        if (ph + 1 < a.phases && !((leafy >> (ph + 1)) & 1u)) {
+            const int j0 = rl(hdr, obase + ph + 1) + wave;
+            has_nx = j0 < rl(hdr, obase + ph + 2);
+            if (has_nx) rec_nx = rec_load(a.items, j0, lane);
         }
-        if ((split >> ph) & 1u) {
-            __syncthreads();
+        if ((leafy >> ph) & 1u) {
+            if (!(a.ablate & 8)) leaf_phase<K, UP>(a, i0 + wave, i1, b_in, x_out, region, tri_floats);
+        } else if (!(a.ablate & 4)) {
+            int rec = (!pre_valid && i0 + wave < i1) ? rec_load(a.items, i0 + wave, lane) : 0;
             for (int k = i0 + wave; k < i1; k += TIER_WAVES) {
-                const TierItem it = a.items[k];
-                if (it.nparts == 1 || it.part != 0) continue;
-                const NodeD n = a.nodes[it.node];
-                float acc[K];
+                const int rec_next = k + TIER_WAVES < i1 ? rec_load(a.items, k + TIER_WAVES, lane) : 0;
+                const bool first = k == i0 + wave && pre_valid;
+                const TierItem it = first ? it_pre : rec_unpack(rec);
+                rec = rec_next;
+                float* pbuf = region + a.vec_floats + ((k - i0) / TIER_WAVES) * 256;
+                if (!first) { if (UP) node_up_pre<K>(a, it, pre); else node_down_pre<K>(a, it, pre); }
+                if (UP) node_up<K>(a, it, pre, b_in, region, pbuf);
+                else node_down<K>(a, it, pre, x_out, region, pbuf);
+            }
+            if ((split >> ph) & 1u) {
+                __syncthreads();
+                for (int k = i0 + wave; k < i1; k += TIER_WAVES) {
+                    const TierItem it = rec_unpack(rec_load(a.items, k, lane));
+                    if (it.nparts == 1 || it.part != 0) continue;
+                    float acc[K];
 #pragma unroll
-                for (int q = 0; q < K; ++q) acc[q] = 0.0f;
-                for (int p = 0; p < it.nparts; ++p) {          // parts are consecutive items: fixed order of the sum
-                    const int kp = k + p - i0;
-                    const float* pb = sm + (size_t)(kp % TIER_WAVES) * a.region_floats + a.vec_floats + (kp / TIER_WAVES) * 256;
+                    for (int q = 0; q < K; ++q) acc[q] = 0.0f;
+                    for (int p = 0; p < it.nparts; ++p) {          // parts are consecutive items: fixed order of the sum
+                        const int kp = k + p - i0;
+                        const float* pb = sm + (size_t)(kp % TIER_WAVES) * a.region_floats + a.vec_floats + (kp / TIER_WAVES) * 256;
 #pragma unroll
-                    for (int q = 0; q < K; ++q) acc[q] += pb[lane * 4 + q];
+                        for (int q = 0; q < K; ++q) acc[q] += pb[lane * 4 + q];
+                    }
+                    if (UP) node_up_finish<K>(a, it, it.row0 + lane, acc);
+                    else node_down_finish<K>(a, it, -1, x_out, acc);
                 }
-                if (UP) node_up_finish<K>(a, n, it.row0 + lane, acc);
-                else node_down_finish<K>(a, n, it, x_out, acc);
             }
         }
+        // every field of `pre` is rewritten here on every path: nothing of it stays live across a leaf phase
+        pre_valid = has_nx && !(a.ablate & 4);
+        it_pre = rec_unpack(rec_nx);
+        if (pre_valid) {
+            if (UP) node_up_pre<K>(a, it_pre, pre); else node_down_pre<K>(a, it_pre, pre);
+        } else {
+#pragma unroll
+            for (int e = 0; e < TIER_Q; ++e) pre.cur[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < K; ++q) pre.v[q] = 0.0f;
+            pre.idx = 0;
+        }
+        tier_stamp(a, 1 + 2 * ph);
         __syncthreads();      // workgroup-scope release/acquire of the slots / boundary vectors written above (same CU)
+        tier_stamp(a, 2 + 2 * ph);
     }
 }
 

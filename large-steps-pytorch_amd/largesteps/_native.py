@@ -55,8 +55,7 @@ _SIGNATURES = {
     "ls_solver_poll": (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(SolveInfo), c_void_p]),
     "ls_gather_rows": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_int, c_void_p]),
     "ls_solver_destroy": (c_int, [c_void_p]),
-    "ls_direct_create": (c_int, [c_i64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p,
-                                 c_void_p, c_void_p, c_int, c_void_p, ctypes.POINTER(c_void_p)]),
+    "ls_direct_create": (c_int, [c_void_p, c_int, c_void_p, ctypes.POINTER(c_void_p)]),
     "ls_direct_destroy": (c_int, [c_void_p]),
     "ls_direct_solve": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ls_direct_set": (c_int, [c_void_p, ctypes.c_char_p, c_int]),
@@ -68,6 +67,7 @@ _SIGNATURES = {
                                   c_void_p, c_size_t, c_int, c_void_p]),
     "ls_vertex_normals_backward": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "ls_direct_tier_stamps": (c_int, [c_void_p, c_void_p, c_i64]),
     "ls_direct_info": (c_int, [c_void_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_int), ctypes.POINTER(c_double * 3)]),
     "ls_solver_solve": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double, c_double, c_int,
                                 ctypes.POINTER(SolveInfo), c_void_p]),

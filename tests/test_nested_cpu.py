@@ -124,7 +124,9 @@ def test_torch_factorisation_matches_statement(name, kw, arity):
     r, rowptr, c, val = csr_of(v, f, **kw)
     p = NDPlan.build(rowptr, c, v, leaf_size=10, arity=arity)
     finv, w = nd_factor(p, rowptr, c, val)
-    finv_t, wf_t, wb_t = factorize(p, rowptr, c, torch.from_numpy(val), torch.device("cpu"))
+    fac = factorize(p, rowptr, c, torch.from_numpy(val), torch.device("cpu"), sparse_leaves=False)
+    finv_t, wf_t, wb_t = fac.finv, fac.wf, fac.wb
+    assert np.array_equal(fac.finv_off, p.finv_off) and np.array_equal(fac.w_off, p.w_off) and not fac.sparse.any()
     scale = np.abs(finv).max()
     assert np.abs(finv_t.numpy()[:p.finv_size] - finv).max() <= 2e-7 * scale
     assert np.abs(wb_t.numpy()[:p.w_size] - w).max() <= 2e-7 * max(np.abs(w).max(), 1e-30)
@@ -139,6 +141,64 @@ def test_torch_factorisation_matches_statement(name, kw, arity):
     x = nd_solve(p, finv_t.numpy()[:p.finv_size].astype(np.float64), wb_t.numpy()[:p.w_size].astype(np.float64), b)
     x64 = osv.from_differential(r, c, val, b)
     assert np.abs(x - x64).max() <= 1e-5 * np.abs(x64).max()
+
+
+@pytest.mark.parametrize("name,kw", [("plane30", dict(lambda_=30.0)), ("ico10", dict(lambda_=0.0, alpha=0.9, cotan=True)), ("soup0", dict(lambda_=3.0))])
+@pytest.mark.parametrize("arity", [2, 4])
+def test_sparse_leaf_format(name, kw, arity):
+    """Leaves in the tier kernel's format (csrc/nd_tier.h): one packed triangle of F_ss^-1 and the matrix block A_bs as
+    two CSR lists. The tables must reproduce the dense statement: tri == tril(Finv), A_bs Finv == W, and the sweeps
+    written with them (y = Finv b, upd = A_bs y; x = y - Finv A_sb x_bnd) give the dense sweeps' result."""
+    from largesteps.direct import factorize
+    v, f = MESHES[name]()
+    r, rowptr, c, val = csr_of(v, f, **kw)
+    p = NDPlan.build(rowptr, c, v, leaf_size=10, arity=arity)
+    finv, w = nd_factor(p, rowptr, c, val)
+    fac = factorize(p, rowptr, c, torch.from_numpy(val), torch.device("cpu"), sparse_leaves=True, tier_levels=2)
+    leaves = p.level_nodes(p.levels - 1)
+    assert fac.sparse[leaves].sum() == ((p.s[leaves] >= 1) & (p.s[leaves] <= 64)).sum() > 0 and not fac.sparse[:leaves[0]].any()
+    tri, ptr = fac.tri.numpy(), fac.sp_ptr.numpy()
+    ent = fac.sp_ent.numpy().view(np.dtype([("val", np.float32), ("idx", np.int32)]))
+    dense_words = 0
+    for i in range(1, p.n_nodes + 1):
+        s, b = int(p.s[i]), int(p.b[i])
+        Fi = finv[p.finv_off[i]:p.finv_off[i] + s * s].reshape(s, s)
+        W = w[p.w_off[i]:p.w_off[i] + b * s].reshape(b, s)
+        if fac.quad[i]:                       # quad-interleaved streams of a dense tier node
+            assert fac.tri_off[i] < 0 and p.level_of[i] >= p.levels - 2
+            s4, b4 = (s + 3) & ~3, (b + 3) & ~3
+            u4 = fac.u4.numpy()[fac.w_off_all[i]:fac.w_off_all[i] + s4 * b].reshape(s4 // 4, b, 4)
+            got_w = u4.transpose(1, 0, 2).reshape(b, s4)
+            assert np.abs(got_w[:, :s] - W).max(initial=0) <= 2e-7 * max(np.abs(W).max(initial=0), 1e-30) and not got_w[:, s:].any()
+            d4 = fac.d4.numpy()[fac.finv_off_all[i]:fac.finv_off_all[i] + (s4 + b4) * s].reshape((s4 + b4) // 4, s, 4)
+            got_d = d4.transpose(1, 0, 2).reshape(s, s4 + b4)
+            assert np.abs(got_d[:, :s] - Fi).max(initial=0) <= 2e-7 * max(np.abs(Fi).max(initial=0), 1e-30)
+            assert np.abs(got_d[:, s4:s4 + b] - W.T).max(initial=0) <= 2e-7 * max(np.abs(W).max(initial=0), 1e-30)
+            assert not got_d[:, s:s4].any() and not got_d[:, s4 + b:].any()
+            dense_words += 1
+            continue
+        if not fac.sparse[i]:
+            assert fac.tri_off[i] < 0
+            got = fac.finv.numpy()[fac.finv_off[i]:fac.finv_off[i] + s * s].reshape(s, s)
+            assert np.abs(got - Fi).max(initial=0) <= 2e-7 * max(np.abs(Fi).max(initial=0), 1e-30)
+            dense_words += s * s + 2 * s * b
+            continue
+        o = int(fac.tri_off[i])
+        assert o % 4 == 0
+        for rr in range(s):
+            np.testing.assert_allclose(tri[o + rr * (rr + 1) // 2:o + rr * (rr + 1) // 2 + rr + 1], Fi[rr, :rr + 1], rtol=0, atol=2e-7 * np.abs(Fi).max())
+        A_bs = np.zeros((b, s))
+        for ib in range(b):
+            e = ent[ptr[fac.spb_off[i] + ib]:ptr[fac.spb_off[i] + ib + 1]]
+            assert (np.diff(e["idx"]) > 0).all()
+            A_bs[ib, e["idx"]] = e["val"]
+        A_sb = np.zeros((s, b))
+        for js in range(s):
+            e = ent[ptr[fac.sps_off[i] + js]:ptr[fac.sps_off[i] + js + 1]]
+            A_sb[js, e["idx"]] = e["val"]
+        assert np.array_equal(A_sb, A_bs.T)
+        np.testing.assert_allclose(A_bs @ Fi, W, rtol=0, atol=1e-6 * max(np.abs(W).max(initial=0), 1e-30))
+    assert dense_words > 0 or p.levels == 1
 
 
 def test_smoothed_positions_give_thin_separators():

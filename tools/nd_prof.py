@@ -1,6 +1,7 @@
 """one-mesh driver for profiling the nested-dissection re-solve: python tools/nd_prof.py [cfg] [leaf] [solves]"""
 import os, sys, time
-sys.path[:0] = [os.getcwd(), os.path.join(os.getcwd(), "large-steps-pytorch_amd")]
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [_R, os.path.join(_R, "large-steps-pytorch_amd")]
 import torch
 from largesteps import synthetic
 from largesteps.geometry import compute_matrix

@@ -2,8 +2,16 @@
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k_nd_" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# a solve starts with the first k_nd_up after a k_nd_down
-starts = [i for i, r in enumerate(rows) if "k_nd_up" in r["Kernel_Name"] and (i == 0 or "k_nd_down" in rows[i - 1]["Kernel_Name"])]
+def is_up(n):
+    return "k_nd_up" in n or ("k_nd_tier" in n and "true" in n)
+
+
+def is_down(n):
+    return "k_nd_down" in n or ("k_nd_tier" in n and "false" in n)
+
+
+# a solve starts with the first up-sweep kernel after a down-sweep kernel
+starts = [i for i, r in enumerate(rows) if is_up(r["Kernel_Name"]) and (i == 0 or is_down(rows[i - 1]["Kernel_Name"]))]
 last = rows[starts[-1]:]
 t0 = int(last[0]["Start_Timestamp"])
 for r in last:
