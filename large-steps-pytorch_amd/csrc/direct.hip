@@ -36,6 +36,22 @@ struct alignas(64) Tile {
     long long finv_off, w_off;
 };
 
+// A tile record is fetched with ONE vector load (lane i takes dword i) and unpacked with v_readlane: a scalar load at the
+// head of a workgroup queues behind the streaming vector traffic of its neighbours (~3 us next to a loaded CU).
+static_assert(sizeof(Tile) == 64, "Tile layout");
+__device__ __forceinline__ Tile load_tile(const Tile* __restrict__ tiles, int idx) {
+    const int lane = threadIdx.x & 63;
+    const int w = lane < 16 ? reinterpret_cast<const int*>(tiles)[(size_t)idx * 16 + lane] : 0;
+    Tile t;
+    t.store = __builtin_amdgcn_readlane(w, 0); t.row0 = __builtin_amdgcn_readlane(w, 1); t.s = __builtin_amdgcn_readlane(w, 2);
+    t.b = __builtin_amdgcn_readlane(w, 3); t.own_start = __builtin_amdgcn_readlane(w, 4); t.bnd_off = __builtin_amdgcn_readlane(w, 5);
+    t.front_off = __builtin_amdgcn_readlane(w, 6); t.leaf = __builtin_amdgcn_readlane(w, 7); t.pfront_off = __builtin_amdgcn_readlane(w, 8);
+    t.cix = __builtin_amdgcn_readlane(w, 9); t.forward = __builtin_amdgcn_readlane(w, 10); t.arity = __builtin_amdgcn_readlane(w, 11);
+    t.finv_off = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(w, 13) << 32) | (unsigned)__builtin_amdgcn_readlane(w, 12));
+    t.w_off = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(w, 15) << 32) | (unsigned)__builtin_amdgcn_readlane(w, 14));
+    return t;
+}
+
 #ifndef LS_ND_UNROLL
 #define LS_ND_UNROLL 8
 #endif
@@ -213,7 +229,7 @@ __global__ __launch_bounds__(1024) void k_nd_up(const Tile* __restrict__ tiles, 
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sb = sm;
     float* red = sm + (size_t)s_cap * K;
-    const Tile t = tiles[blockIdx.x];
+    const Tile t = load_tile(tiles, blockIdx.x);
     if (t.store == 2) { store_bprime<K>(t, perm, mask, slots, b_in, bprime); return; }
     const int nw = blockDim.x >> 6, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i = t.row0 + lane, s = t.s, b = t.b;
@@ -270,7 +286,7 @@ __global__ __launch_bounds__(1024) void k_nd_down(const Tile* __restrict__ tiles
     float* sb = sm;
     float* sx = sm + (size_t)s_cap * K;
     float* red = sx + (size_t)b_cap * K;
-    const Tile t = tiles[blockIdx.x];
+    const Tile t = load_tile(tiles, blockIdx.x);
     if (t.forward) { forward_rows<K>(t, push_ptr, push_tgt, xb); return; }
     const int nw = blockDim.x >> 6, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int s = t.s, b = t.b, L = s + b;
@@ -330,39 +346,47 @@ __device__ __forceinline__ float wave_sum63(float v) {
     return v;
 }
 
-// One batch = ND_E x 64 reduction steps of the wave's ND_ROWS rows (row r at base + r * stride_rows): every load of a
-// batch is independent and 256 B contiguous across the wave.
+// One batch = ND_E x 256 reduction steps of the wave's ND_ROWS rows (row r at base + r * stride_rows): every lane loads
+// 16 bytes = 4 consecutive steps per request (1 KB contiguous per wave and request; rows are only 4-byte aligned, which
+// global_load_dwordx4 accepts), all requests of a batch are independent.
 #ifndef LS_ND_E
-#define LS_ND_E 8
+#define LS_ND_E 2
 #endif
 constexpr int ND_E = LS_ND_E;
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 __device__ __forceinline__ void rows_load(const float* __restrict__ base, size_t stride_rows, int nrows, int len, int t0,
-                                          float (&a)[ND_ROWS][ND_E]) {
+                                          f4u (&a)[ND_ROWS][ND_E]) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int r = 0; r < ND_ROWS; ++r) {
 #pragma unroll
         for (int e = 0; e < ND_E; ++e) {
-            const int t = t0 + e * 64 + lane;
-            a[r][e] = (r < nrows && t < len) ? base[(size_t)r * stride_rows + t] : 0.0f;
+            const int t = t0 + (e * 64 + lane) * 4;        // (the last quad of a row may reach 12 bytes into the next row /
+            f4u z = {0.f, 0.f, 0.f, 0.f};                  //  the array's slack: those components are never used)
+            a[r][e] = (r < nrows && t < len) ? *reinterpret_cast<const f4u*>(base + (size_t)r * stride_rows + t) : z;
         }
     }
 }
 template <int K>
-__device__ __forceinline__ void rows_fma(const float (&a)[ND_ROWS][ND_E], int len, int t0, const float* __restrict__ sv,
+__device__ __forceinline__ void rows_fma(const f4u (&a)[ND_ROWS][ND_E], int len, int t0, const float* __restrict__ sv,
                                          float (&acc)[ND_ROWS][K]) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int e = 0; e < ND_E; ++e) {
-        const int t = t0 + e * 64 + lane;
+        const int t = t0 + (e * 64 + lane) * 4;
         if (t < len) {
-            float v[K];
+            float v[4 * K];
 #pragma unroll
-            for (int q = 0; q < K; ++q) v[q] = sv[t * K + q];
+            for (int q = 0; q < 4 * K; ++q) v[q] = (t + q / K < len) ? sv[t * K + q] : 0.0f;
 #pragma unroll
-            for (int r = 0; r < ND_ROWS; ++r) {
+            for (int c = 0; c < 4; ++c) {
+                if (t + c < len) {
 #pragma unroll
-                for (int q = 0; q < K; ++q) acc[r][q] = fmaf(a[r][e], v[q], acc[r][q]);
+                    for (int r = 0; r < ND_ROWS; ++r) {
+#pragma unroll
+                        for (int q = 0; q < K; ++q) acc[r][q] = fmaf(a[r][e][c], v[c * K + q], acc[r][q]);
+                    }
+                }
             }
         }
     }
@@ -370,10 +394,10 @@ __device__ __forceinline__ void rows_fma(const float (&a)[ND_ROWS][ND_E], int le
 // acc[r][q] += sum_t row_r[t] * sv[t*K+q]; `first` holds the already loaded batch t0 = 0
 template <int K>
 __device__ __forceinline__ void dot_rows(const float* __restrict__ base, size_t stride_rows, int nrows, int len,
-                                         const float* __restrict__ sv, const float (&first)[ND_ROWS][ND_E], float (&acc)[ND_ROWS][K]) {
+                                         const float* __restrict__ sv, const f4u (&first)[ND_ROWS][ND_E], float (&acc)[ND_ROWS][K]) {
     rows_fma<K>(first, len, 0, sv, acc);
-    for (int t0 = 64 * ND_E; t0 < len; t0 += 64 * ND_E) {
-        float a[ND_ROWS][ND_E];
+    for (int t0 = 256 * ND_E; t0 < len; t0 += 256 * ND_E) {
+        f4u a[ND_ROWS][ND_E];
         rows_load(base, stride_rows, nrows, len, t0, a);
         rows_fma<K>(a, len, t0, sv, acc);
     }
@@ -400,14 +424,14 @@ __global__ __launch_bounds__(64 * ND_BW) void k_nd_up_b(const Tile* __restrict__
                                                         float* __restrict__ bprime, float* slots, int s_cap, int chunks) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sb = sm;
-    const Tile t = tiles[blockIdx.x];
+    const Tile t = load_tile(tiles, blockIdx.x);
     if (t.store == 2) { store_bprime<K>(t, perm, mask, slots, b_in, bprime); return; }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int s = t.s, b = t.b;
     const int iw = t.row0 + w * ND_ROWS * chunks;              // this wave's rows iw .. iw + ND_ROWS * chunks
     const int wrows = max(0, min(ND_ROWS * chunks, b - iw));
     const float* __restrict__ wrow = wb + t.w_off + (size_t)iw * s;
-    float first[ND_ROWS][ND_E];
+    f4u first[ND_ROWS][ND_E];
     rows_load(wrow, (size_t)s, min(wrows, ND_ROWS), s, 0, first);   // in flight while b' is assembled
     // per-row epilogue data (lane r of the wave serves row iw + r), requested before anything else
     int pp = 0;
@@ -453,7 +477,7 @@ __global__ __launch_bounds__(64 * ND_BW) void k_nd_down_b(const Tile* __restrict
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sb = sm;
     float* sx = sm + (size_t)s_cap * K;
-    const Tile t = tiles[blockIdx.x];
+    const Tile t = load_tile(tiles, blockIdx.x);
     if (t.forward) { forward_rows<K>(t, push_ptr, push_tgt, xb); return; }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int s = t.s, b = t.b;
@@ -461,7 +485,7 @@ __global__ __launch_bounds__(64 * ND_BW) void k_nd_down_b(const Tile* __restrict
     const int wrows = max(0, min(ND_ROWS * chunks, s - jw));
     const float* __restrict__ frow = finv + t.finv_off + (size_t)jw * s;
     const float* __restrict__ wrow = wf + t.w_off + (size_t)jw * b;
-    float first_f[ND_ROWS][ND_E], first_w[ND_ROWS][ND_E];
+    f4u first_f[ND_ROWS][ND_E], first_w[ND_ROWS][ND_E];
     rows_load(frow, (size_t)s, min(wrows, ND_ROWS), s, 0, first_f);          // in flight while the vectors are staged
     rows_load(wrow, (size_t)b, min(wrows, ND_ROWS), b, 0, first_w);
     int p0 = 0, p1 = 0;
@@ -529,7 +553,7 @@ __global__ __launch_bounds__(256) void k_nd_up_s(const Tile* __restrict__ tiles,
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sb = sm;                                  // s_cap * K
     float* mw = sm + (size_t)s_cap * K;              // s * b: W^T, mw[j * b + i]
-    const Tile t = tiles[blockIdx.x];
+    const Tile t = load_tile(tiles, blockIdx.x);
     const int s = t.s, b = t.b, i = threadIdx.x;
     stage_block(wf + t.w_off, s * b, mw);
     int pp = 0;
@@ -568,7 +592,7 @@ __global__ __launch_bounds__(256) void k_nd_down_s(const Tile* __restrict__ tile
     float* sb = sm;                                  // s_cap * K
     float* sx = sm + (size_t)s_cap * K;              // b_cap * K
     float* mf = sx + (size_t)b_cap * K;              // s * s: Finv, mf[t * s + j]
-    const Tile t = tiles[blockIdx.x];
+    const Tile t = load_tile(tiles, blockIdx.x);
     if (t.forward) { forward_rows<K>(t, push_ptr, push_tgt, xb); return; }
     const int s = t.s, b = t.b, j = threadIdx.x;
     float* mw = mf + (size_t)s * s;                  // b * s: W, mw[i * s + j]
@@ -1042,8 +1066,8 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
         p.up_b = red_up >= long_up; p.down_b = red_down >= long_red;
         p.up_nw = p.up_b ? ND_BW : pick_nw(red_up, true); p.down_nw = p.down_b ? ND_BW : pick_nw(red_down);
         // *_b kernels: a wave keeps about ND_INFLIGHT row loads in flight -> short rows come in several chunks of ND_ROWS
-        const int inflight = env_int("LS_ND_INFLIGHT", 24);
-        const int lpr_up = div_up(std::max(p.s_cap, 1), WAVE), lpr_down = lpr_up + div_up(std::max(p.b_cap, 1), WAVE);
+        const int inflight = env_int("LS_ND_INFLIGHT", 6);       // 16-byte requests per lane
+        const int lpr_up = div_up(std::max(p.s_cap, 1), 4 * WAVE), lpr_down = lpr_up + div_up(std::max(p.b_cap, 1), 4 * WAVE);   // 16-byte requests per row and lane
         p.up_chunks = std::min(4, std::max(1, div_up(inflight, ND_ROWS * lpr_up)));
         p.down_chunks = std::min(4, std::max(1, div_up(inflight, ND_ROWS * lpr_down)));
         const int up_rows = p.up_b ? ND_ROWS * ND_BW * p.up_chunks : WAVE, down_rows = p.down_b ? ND_ROWS * ND_BW * p.down_chunks : WAVE;
