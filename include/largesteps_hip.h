@@ -216,6 +216,20 @@ int ls_gather_rows(const float* src, const int32_t* idx, int64_t n, int k, float
  * b is read and x written in the caller's numbering. No atomics: bitwise reproducible. A handle owns one workspace:
  * solves issued on different streams are serialised on the device (event wait), concurrent host threads must not
  * share a handle. ls_direct_create is SYNC (copies the host tables). */
+/* Symbolic analysis alone, on the HOST (no device is touched): the elimination tree and everything static of the solver above
+ * for the CSR pattern (h_rowptr, h_col; structurally symmetric) of a V x V matrix. h_positions: (V, 3) vertex positions the
+ * geometric bisection runs on (only their spatial order matters), or NULL: graph-distance pseudo-positions are derived from
+ * the pattern. smooth: neighbour-averaging passes applied to the positions first (4 is the solver's default). */
+typedef struct ls_nd_plan ls_nd_plan;
+int ls_nd_plan_create(int64_t V, const int32_t* h_rowptr, const int32_t* h_col, const float* h_positions, int leaf_size,
+                      int arity, int smooth, ls_nd_plan** out);
+int ls_nd_plan_destroy(ls_nd_plan* p);
+int ls_nd_plan_info(const ls_nd_plan* p, int* levels, int* arity, int* n_nodes, int64_t* n_bnd, int64_t* n_front, double* seconds);
+/* copies out: perm (V), s / b / own_start / parent (n_nodes + 1 each, node ids are 1-based), bnd / ppos / push_tgt (n_bnd),
+ * push_ptr (n_front + 1); any pointer may be NULL */
+int ls_nd_plan_arrays(const ls_nd_plan* p, int32_t* perm, int32_t* s, int32_t* b, int32_t* own_start, int32_t* parent,
+                      int32_t* bnd, int32_t* ppos, int32_t* push_ptr, int32_t* push_tgt);
+
 typedef struct ls_direct ls_direct;
 /* The plan and the factor of one matrix, as plain arrays. h_* live on the host and are copied; d_* are DEVICE arrays
  * owned by the caller and kept alive for the handle's lifetime.

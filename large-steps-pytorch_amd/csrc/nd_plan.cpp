@@ -1,0 +1,356 @@
+// nd_plan.cpp -- see nd_plan.h. Integer / geometric work only, parallel over vertices or tree nodes with a few host threads.
+#include "nd_plan.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <functional>
+#include <numeric>
+#include <thread>
+
+namespace ls {
+namespace {
+
+int n_threads() {
+    static const int n = [] {
+        const char* e = getenv("LS_PLAN_THREADS");
+        const int want = e ? atoi(e) : 16;
+        const int hw = (int)std::thread::hardware_concurrency();
+        return std::max(1, std::min(want, hw > 0 ? hw : 1));
+    }();
+    return n;
+}
+
+// body(begin, end) over [0, n) in contiguous chunks
+void parallel_for(int64_t n, int64_t grain, const std::function<void(int64_t, int64_t)>& body) {
+    const int T = (int)std::min<int64_t>(n_threads(), std::max<int64_t>(1, n / std::max<int64_t>(grain, 1)));
+    if (T <= 1) { body(0, n); return; }
+    std::vector<std::thread> th;
+    const int64_t step = (n + T - 1) / T;
+    for (int t = 0; t < T; ++t) {
+        const int64_t lo = t * step, hi = std::min(n, lo + step);
+        if (lo >= hi) break;
+        th.emplace_back([=, &body] { body(lo, hi); });
+    }
+    for (auto& x : th) x.join();
+}
+
+// level-synchronous BFS; dist < 0 = unreached. Returns the last vertex reached.
+int bfs(int64_t V, const int32_t* rowptr, const int32_t* col, int start, std::vector<float>& dist) {
+    std::vector<int> frontier{start}, next;
+    dist[start] = 0.0f;
+    int last = start;
+    float d = 0.0f;
+    while (!frontier.empty()) {
+        last = frontier[0];
+        next.clear();
+        d += 1.0f;
+        for (int u : frontier)
+            for (int p = rowptr[u]; p < rowptr[u + 1]; ++p) {
+                const int w = col[p];
+                if (dist[w] < 0.0f) { dist[w] = d; next.push_back(w); }
+            }
+        frontier.swap(next);
+    }
+    return last;
+}
+
+// Pseudo-positions for a matrix that comes without vertex positions: graph distances from three mutually far landmarks
+// (double-sweep BFS) per connected component, components laid out side by side. Level sets of a graph distance are
+// separators as thin as the mesh allows; only the ORDER these coordinates induce matters.
+void graph_embedding(int64_t V, const int32_t* rowptr, const int32_t* col, std::vector<double>& pos) {
+    pos.assign((size_t)V * 3, 0.0);
+    std::vector<char> done((size_t)V, 0);
+    std::vector<float> d0((size_t)V), d1((size_t)V), d2((size_t)V), d3((size_t)V);
+    double offset = 0.0;
+    int64_t remaining = V, seed = 0;
+    while (remaining > 0) {
+        while (done[seed]) ++seed;
+        std::fill(d0.begin(), d0.end(), -1.0f);
+        const int p1 = bfs(V, rowptr, col, (int)seed, d0);
+        std::fill(d1.begin(), d1.end(), -1.0f);
+        const int p2 = bfs(V, rowptr, col, p1, d1);
+        std::fill(d2.begin(), d2.end(), -1.0f);
+        bfs(V, rowptr, col, p2, d2);
+        int p3 = (int)seed;
+        float best = -1.0f;
+        for (int64_t v = 0; v < V; ++v)
+            if (d0[v] >= 0.0f) { const float m = std::min(d1[v], d2[v]); if (m > best) { best = m; p3 = (int)v; } }
+        std::fill(d3.begin(), d3.end(), -1.0f);
+        bfs(V, rowptr, col, p3, d3);
+        int64_t comp = 0;
+        float dmax = 0.0f;
+        for (int64_t v = 0; v < V; ++v)
+            if (d0[v] >= 0.0f) {
+                pos[3 * v] = d1[v] + offset; pos[3 * v + 1] = d2[v]; pos[3 * v + 2] = d3[v];
+                done[v] = 1; ++comp; dmax = std::max(dmax, d1[v]);
+            }
+        offset += dmax + 2.0;
+        remaining -= comp;
+        if (comp <= 2 && remaining > 4096) {        // a swarm of isolated vertices: lay the rest out in index order
+            for (int64_t v = 0; v < V; ++v)
+                if (!done[v]) { pos[3 * v] = offset; offset += 1.0; done[v] = 1; }
+            remaining = 0;
+        }
+    }
+}
+
+}  // namespace
+
+std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, const float* pos_in, int leaf_size, int arity,
+                          int smooth, NdPlan& P) {
+    const auto t_start = std::chrono::steady_clock::now();
+    if (V <= 0 || V >= INT32_MAX) return "nd_plan_build: bad vertex count";
+    if (arity != 2 && arity != 4 && arity != 8) return "nd_plan_build: arity must be 2, 4 or 8";
+    if (leaf_size < 1) return "nd_plan_build: leaf_size must be positive";
+    const int m = arity == 2 ? 1 : arity == 4 ? 2 : 3;
+    int D = 0;
+    while ((V >> D) > leaf_size) ++D;
+    D = (D + m - 1) / m * m;
+    if (D > 40) return "nd_plan_build: tree too deep";
+    // ---- positions (averaged `smooth` times over the matrix neighbours: a rough surface bisects badly otherwise) ----
+    std::vector<double> pos((size_t)V * 3);
+    if (pos_in) {
+        for (int64_t i = 0; i < 3 * V; ++i) pos[i] = pos_in[i];
+        bool all_rows = true;
+        for (int64_t v = 0; v < V && all_rows; ++v) all_rows = rowptr[v + 1] > rowptr[v];
+        if (smooth > 0 && all_rows) {
+            std::vector<double> nxt((size_t)V * 3);
+            for (int it = 0; it < smooth; ++it) {
+                parallel_for(V, 4096, [&](int64_t lo, int64_t hi) {
+                    for (int64_t v = lo; v < hi; ++v) {
+                        double a = 0, b = 0, c = 0;
+                        for (int p = rowptr[v]; p < rowptr[v + 1]; ++p) { const int w = col[p]; a += pos[3 * (size_t)w]; b += pos[3 * (size_t)w + 1]; c += pos[3 * (size_t)w + 2]; }
+                        const double inv = 1.0 / (rowptr[v + 1] - rowptr[v]);
+                        nxt[3 * v] = a * inv; nxt[3 * v + 1] = b * inv; nxt[3 * v + 2] = c * inv;
+                    }
+                });
+                pos.swap(nxt);
+            }
+        }
+    } else {
+        graph_embedding(V, rowptr, col, pos);
+    }
+    // ---- D rounds of bisection ------------------------------------------------------------------------------------------
+    std::vector<int64_t> node((size_t)V, 1);          // binary heap id of the domain a vertex lives in / became a separator of
+    std::vector<char> fixed((size_t)V, 0), side((size_t)V, 0), endp((size_t)V, 0);
+    std::vector<int> live((size_t)V);                 // live vertices grouped by domain
+    std::iota(live.begin(), live.end(), 0);
+    int64_t n_live = V;
+    std::vector<int64_t> seg_start;
+    std::vector<int> tmp((size_t)V);
+    for (int r = 0; r < D; ++r) {
+        const int64_t n_dom = (int64_t)1 << r, base = n_dom;
+        // group the live vertices by domain (counting sort, stable in vertex id)
+        seg_start.assign((size_t)n_dom + 1, 0);
+        for (int64_t i = 0; i < n_live; ++i) ++seg_start[(size_t)(node[live[i]] - base) + 1];
+        for (int64_t d = 0; d < n_dom; ++d) seg_start[d + 1] += seg_start[d];
+        {
+            std::vector<int64_t> cur(seg_start.begin(), seg_start.end() - 1);
+            for (int64_t i = 0; i < n_live; ++i) tmp[(size_t)cur[(size_t)(node[live[i]] - base)]++] = live[i];
+            std::copy(tmp.begin(), tmp.begin() + n_live, live.begin());
+        }
+        // median split of every domain along the longest axis of its bounding box
+        parallel_for(n_dom, 1, [&](int64_t lo, int64_t hi) {
+            for (int64_t d = lo; d < hi; ++d) {
+                const int64_t a = seg_start[d], e = seg_start[d + 1], cnt = e - a;
+                if (cnt <= 0) continue;
+                double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+                for (int64_t i = a; i < e; ++i)
+                    for (int k = 0; k < 3; ++k) { const double x = pos[3 * (size_t)live[i] + k]; mn[k] = std::min(mn[k], x); mx[k] = std::max(mx[k], x); }
+                int ax = 0;
+                for (int k = 1; k < 3; ++k) if (mx[k] - mn[k] > mx[ax] - mn[ax]) ax = k;
+                const int64_t half = cnt / 2;
+                auto less = [&](int u, int w) { const double x = pos[3 * (size_t)u + ax], y = pos[3 * (size_t)w + ax]; return x < y || (x == y && u < w); };
+                std::nth_element(live.begin() + a, live.begin() + a + half, live.begin() + e, less);
+                for (int64_t i = a; i < e; ++i) side[live[i]] = i - a >= half;
+            }
+        });
+        // end points of the cut edges, per side
+        std::vector<std::atomic<int>> cnt0((size_t)n_dom), cnt1((size_t)n_dom);
+        for (int64_t d = 0; d < n_dom; ++d) { cnt0[d] = 0; cnt1[d] = 0; }
+        parallel_for(n_live, 4096, [&](int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; ++i) {
+                const int u = live[i];
+                bool cut = false;
+                for (int p = rowptr[u]; p < rowptr[u + 1] && !cut; ++p) {
+                    const int w = col[p];
+                    cut = !fixed[w] && node[w] == node[u] && side[w] != side[u];
+                }
+                endp[u] = cut;
+                if (cut) { if (side[u]) ++cnt1[(size_t)(node[u] - base)]; else ++cnt0[(size_t)(node[u] - base)]; }
+            }
+        });
+        // the smaller end-point set of a domain is its separator; everything else moves down
+        int64_t kept = 0;
+        for (int64_t i = 0; i < n_live; ++i) {
+            const int u = live[i];
+            const int64_t d = node[u] - base;
+            const bool use1 = cnt1[d].load() < cnt0[d].load();
+            if (endp[u] && (side[u] != 0) == use1) fixed[u] = 1;
+            else { node[u] = 2 * node[u] + side[u]; live[kept++] = u; }
+        }
+        n_live = kept;
+    }
+    // ---- merged tree: log2(arity) bisection rounds per level, the leaf domains are the last level -------------------------
+    const int levels = D / m + 1;
+    P = NdPlan();
+    P.V = V; P.levels = levels; P.arity = arity; P.rounds = D;
+    P.level_off.resize((size_t)levels + 1);
+    {
+        int64_t off = 1, cnt = 1;
+        for (int l = 0; l <= levels; ++l) { P.level_off[l] = off; off += cnt; cnt *= arity; if (off > ((int64_t)1 << 30)) return "nd_plan_build: tree too large"; }
+    }
+    const int n_nodes = (int)(P.level_off[levels] - 1);
+    P.n_nodes = n_nodes;
+    P.parent.assign((size_t)n_nodes + 1, 0); P.level_of.assign((size_t)n_nodes + 1, 0); P.child_ix.assign((size_t)n_nodes + 1, 0);
+    for (int l = 0; l < levels; ++l)
+        for (int64_t i = P.level_off[l]; i < P.level_off[l + 1]; ++i) {
+            P.level_of[i] = l;
+            if (l) { P.parent[i] = (int)(P.level_off[l - 1] + (i - P.level_off[l]) / arity); P.child_ix[i] = (int)((i - P.level_off[l]) % arity); }
+        }
+    std::vector<int> node_id((size_t)V);
+    parallel_for(V, 65536, [&](int64_t lo, int64_t hi) {
+        for (int64_t v = lo; v < hi; ++v) {
+            const int64_t h = node[v];
+            int lb = 0;
+            while ((h >> (lb + 1)) != 0) ++lb;
+            const int lvl = lb == D ? D / m : lb / m;
+            const int64_t anc = lb == D ? h : h >> (lb - m * (lb / m));
+            node_id[v] = (int)(P.level_off[lvl] + (anc - ((int64_t)1 << (m * lvl))));
+        }
+    });
+    // ---- ordering: deepest level first, node by node, original id inside a node ----------------------------------------------
+    P.s.assign((size_t)n_nodes + 1, 0); P.b.assign((size_t)n_nodes + 1, 0); P.own_start.assign((size_t)n_nodes + 1, 0);
+    for (int64_t v = 0; v < V; ++v) ++P.s[node_id[v]];
+    {
+        int64_t off = 0;
+        for (int l = levels - 1; l >= 0; --l)
+            for (int64_t i = P.level_off[l]; i < P.level_off[l + 1]; ++i) { P.own_start[i] = (int)off; off += P.s[i]; }
+    }
+    P.perm.resize((size_t)V); P.inv.resize((size_t)V); P.node_of_new.resize((size_t)V);
+    {
+        std::vector<int> cur(P.own_start);
+        for (int64_t v = 0; v < V; ++v) { const int nw = cur[node_id[v]]++; P.perm[nw] = (int)v; P.inv[v] = nw; P.node_of_new[nw] = node_id[v]; }
+    }
+    // ---- boundary sets, deepest level first (a node's set needs its children's) ------------------------------------------------
+    std::vector<std::vector<int>> bset((size_t)n_nodes + 1);
+    std::atomic<bool> bad(false);
+    for (int l = levels - 1; l >= 1; --l) {
+        const int64_t first = P.level_off[l], cnt = P.level_off[l + 1] - first;
+        parallel_for(cnt, 1, [&](int64_t lo, int64_t hi) {
+            for (int64_t k = lo; k < hi; ++k) {
+                const int64_t i = first + k;
+                std::vector<int>& B = bset[i];
+                const int o = P.own_start[i], oe = o + P.s[i];
+                for (int nw = o; nw < oe; ++nw) {
+                    const int v = P.perm[nw];
+                    for (int p = rowptr[v]; p < rowptr[v + 1]; ++p) { const int c = P.inv[col[p]]; if (c >= oe) B.push_back(c); }
+                }
+                if (l + 1 < levels)
+                    for (int c = 0; c < arity; ++c) {
+                        const int64_t ch = P.level_off[l + 1] + (i - first) * arity + c;
+                        for (int w : bset[ch]) if (w >= oe) B.push_back(w);
+                    }
+                std::sort(B.begin(), B.end());
+                B.erase(std::unique(B.begin(), B.end()), B.end());
+            }
+        });
+    }
+    P.bnd_off.assign((size_t)n_nodes + 2, 0); P.front_off.assign((size_t)n_nodes + 2, 0);
+    for (int i = 1; i <= n_nodes; ++i) {
+        P.b[i] = (int)bset[i].size();
+        P.bnd_off[i + 1] = P.bnd_off[i] + P.b[i];
+        P.front_off[i + 1] = P.front_off[i] + P.s[i] + P.b[i];
+    }
+    P.bnd_off[1] = 0; P.front_off[1] = 0;
+    P.n_bnd = P.bnd_off[n_nodes + 1]; P.n_front = P.front_off[n_nodes + 1];
+    if (P.n_bnd >= INT32_MAX || P.n_front * arity >= INT32_MAX) return "nd_plan_build: plan exceeds int32 offsets";
+    P.bnd.resize((size_t)P.n_bnd); P.ppos.assign((size_t)P.n_bnd, 0);
+    // position of every boundary vertex in its parent's front [own | boundary]
+    parallel_for(n_nodes, 64, [&](int64_t lo, int64_t hi) {
+        for (int64_t k = lo; k < hi; ++k) {
+            const int64_t i = k + 1;
+            if (i < 2) continue;
+            const int par = P.parent[i];
+            const int po = P.own_start[par], pe = po + P.s[par];
+            const std::vector<int>& PB = bset[par];
+            for (int k = 0; k < P.b[i]; ++k) {
+                const int w = bset[i][k];
+                P.bnd[(size_t)P.bnd_off[i] + k] = w;
+                int pp;
+                if (w < pe) { if (w < po) bad = true; pp = w - po; }
+                else {
+                    const auto it = std::lower_bound(PB.begin(), PB.end(), w);
+                    if (it == PB.end() || *it != w) { bad = true; pp = 0; } else pp = P.s[par] + (int)(it - PB.begin());
+                }
+                P.ppos[(size_t)P.bnd_off[i] + k] = pp;
+            }
+        }
+    });
+    if (bad) return "nd_plan_build: separator property violated (the matrix pattern is not symmetric?)";
+    if (P.b[1] != 0) return "nd_plan_build: the root has a boundary";
+    // ---- push lists of the down sweep: front position -> boundary entries of the children that are this vertex -------------
+    P.push_ptr.assign((size_t)P.n_front + 1, 0);
+    P.push_tgt.resize((size_t)P.n_bnd);
+    for (int i = 2; i <= n_nodes; ++i) {
+        const int64_t pf = P.front_off[P.parent[i]];
+        for (int k = 0; k < P.b[i]; ++k) ++P.push_ptr[(size_t)(pf + P.ppos[(size_t)P.bnd_off[i] + k]) + 1];
+    }
+    for (int64_t f = 0; f < P.n_front; ++f) P.push_ptr[f + 1] += P.push_ptr[f];
+    {
+        std::vector<int> cur(P.push_ptr.begin(), P.push_ptr.end() - 1);
+        for (int i = 2; i <= n_nodes; ++i) {
+            const int64_t pf = P.front_off[P.parent[i]];
+            for (int k = 0; k < P.b[i]; ++k) P.push_tgt[(size_t)cur[(size_t)(pf + P.ppos[(size_t)P.bnd_off[i] + k])]++] = (int)(P.bnd_off[i] + k);
+        }
+    }
+    P.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    return "";
+}
+
+}  // namespace ls
+
+// ---- host-only C entry points (no device needed: the CPU tests check the plan's invariants through these) ---------------------
+#include "../../include/largesteps_hip.h"
+
+namespace ls { void set_error(const char* fmt, ...); }
+
+struct ls_nd_plan { ls::NdPlan p; };
+
+extern "C" int ls_nd_plan_create(int64_t V, const int32_t* h_rowptr, const int32_t* h_col, const float* h_positions, int leaf_size,
+                                 int arity, int smooth, ls_nd_plan** out) {
+    if (!out || !h_rowptr || !h_col) { ls::set_error("ls_nd_plan_create: null argument"); return LS_E_INVALID; }
+    *out = nullptr;
+    ls_nd_plan* h = new ls_nd_plan();
+    const std::string err = ls::nd_plan_build(V, h_rowptr, h_col, h_positions, leaf_size, arity, smooth, h->p);
+    if (!err.empty()) { delete h; ls::set_error("%s", err.c_str()); return LS_E_INVALID; }
+    *out = h;
+    return LS_OK;
+}
+
+extern "C" int ls_nd_plan_destroy(ls_nd_plan* h) { delete h; return LS_OK; }
+
+extern "C" int ls_nd_plan_info(const ls_nd_plan* h, int* levels, int* arity, int* n_nodes, int64_t* n_bnd, int64_t* n_front, double* seconds) {
+    if (!h) { ls::set_error("ls_nd_plan_info: null handle"); return LS_E_INVALID; }
+    if (levels) *levels = h->p.levels;
+    if (arity) *arity = h->p.arity;
+    if (n_nodes) *n_nodes = h->p.n_nodes;
+    if (n_bnd) *n_bnd = h->p.n_bnd;
+    if (n_front) *n_front = h->p.n_front;
+    if (seconds) *seconds = h->p.seconds;
+    return LS_OK;
+}
+
+// copies: perm (V), s / b / own_start / parent (n_nodes + 1 each), bnd / ppos / push_tgt (n_bnd), push_ptr (n_front + 1); any pointer may be NULL
+extern "C" int ls_nd_plan_arrays(const ls_nd_plan* h, int32_t* perm, int32_t* s, int32_t* b, int32_t* own_start, int32_t* parent,
+                                 int32_t* bnd, int32_t* ppos, int32_t* push_ptr, int32_t* push_tgt) {
+    if (!h) { ls::set_error("ls_nd_plan_arrays: null handle"); return LS_E_INVALID; }
+    const ls::NdPlan& p = h->p;
+    auto cp = [](int32_t* dst, const std::vector<int>& src) { if (dst) std::copy(src.begin(), src.end(), dst); };
+    cp(perm, p.perm); cp(s, p.s); cp(b, p.b); cp(own_start, p.own_start); cp(parent, p.parent);
+    cp(bnd, p.bnd); cp(ppos, p.ppos); cp(push_ptr, p.push_ptr); cp(push_tgt, p.push_tgt);
+    return LS_OK;
+}

@@ -68,6 +68,11 @@ _SIGNATURES = {
     "ls_vertex_normals_backward": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "ls_direct_tier_stamps": (c_int, [c_void_p, c_void_p, c_i64]),
+    "ls_nd_plan_create": (c_int, [c_i64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "ls_nd_plan_destroy": (c_int, [c_void_p]),
+    "ls_nd_plan_info": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_i64),
+                                ctypes.POINTER(c_i64), ctypes.POINTER(c_double)]),
+    "ls_nd_plan_arrays": (c_int, [c_void_p] + [c_void_p] * 9),
     "ls_direct_info": (c_int, [c_void_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_int), ctypes.POINTER(c_double * 3)]),
     "ls_solver_solve": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double, c_double, c_int,
                                 ctypes.POINTER(SolveInfo), c_void_p]),

@@ -273,3 +273,33 @@ def test_extreme_meshes(shape):
         assert int((p.s + p.b).max()) <= 80 and p.factor_entries <= 80 * v.shape[0]
         finv, w = nd_factor(p, rowptr, c, val)
         assert np.abs(nd_solve(p, finv, w, b) - x64).max() <= 1e-10 * np.abs(x64).max()
+
+
+@pytest.mark.parametrize("name,kw", [("plane30", dict(lambda_=30.0)), ("ico10", dict(lambda_=0.0, alpha=0.9, cotan=True)),
+                                      ("soup0", dict(lambda_=3.0)), ("soup1", dict(lambda_=0.0, alpha=0.5)), ("tiny", dict(lambda_=1.0))])
+@pytest.mark.parametrize("arity,leaf", [(2, 12), (4, 12), (8, 12), (4, 3)])
+@pytest.mark.parametrize("with_pos", [True, False])
+def test_native_plan_solves_the_system(name, kw, arity, leaf, with_pos):
+    """The C++ symbolic analysis (csrc/nd_plan.cpp, through the host-only C entry points ls_nd_plan_*): its plan, fed to the
+    numpy statements of the factorisation and of the two sweeps, solves the system -- which exercises every array of it
+    (ordering, fronts, parent positions, push lists). With and without vertex positions (graph-distance embedding)."""
+    from native_plan import native_plan
+    v, f = MESHES[name]()
+    if kw.get("cotan"):
+        v = synthetic.perturb(v, radial=0.05, tangential=0.1, edge=0.1, seed=1)
+    r, rowptr, c, val = csr_of(v, f, **kw)
+    p = native_plan(rowptr, c, v if with_pos else None, leaf_size=leaf, arity=arity)
+    V = v.shape[0]
+    assert sorted(p.perm.tolist()) == list(range(V)) and p.b[1] == 0 and int(p.s.sum()) == V
+    # ordering: deepest level first, every node one contiguous range; boundary lists ascending and above the own block
+    for i in range(1, p.n_nodes + 1):
+        bi = p.bnd[p.bnd_off[i]:p.bnd_off[i] + p.b[i]]
+        assert (np.diff(bi) > 0).all() and (bi >= p.own_start[i] + p.s[i]).all()
+    finv, w = nd_factor(p, rowptr, c, val)
+    b = np.random.default_rng(0).standard_normal((V, 3))
+    x = nd_solve(p, finv, w, b)
+    x64 = osv.from_differential(r, c, val, b)
+    assert np.abs(x - x64).max() <= 1e-10 * np.abs(x64).max()
+    if with_pos and name in ("plane30", "ico10"):            # same quality as the numpy statement's plan
+        q = NDPlan.build(rowptr, c, v, leaf_size=leaf, arity=arity)
+        assert p.levels == q.levels and abs(p.factor_entries - q.factor_entries) <= 0.02 * q.factor_entries
