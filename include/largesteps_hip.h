@@ -270,6 +270,24 @@ typedef struct ls_direct_arrays {
     int64_t n_sp_ptr, n_sp_ent;    /* lengths of the two sparse-leaf arrays (accounting only) */
 } ls_direct_arrays;
 int ls_direct_create(const ls_direct_arrays* arrays, int device, void* stream, ls_direct** out);
+/* Matrix in, solver out: symbolic analysis (host threads), numeric multifrontal factorisation in fp64 on the device with
+ * hand-written kernels (csrc/nd_factor.hip), fp32 factor in the solve kernels' layouts, handle. This one call is the
+ * constructor of the reference's default solver (largesteps/solvers.py:34, CholeskySolverF(n, ii, jj, x, MatrixType.COO)).
+ * d_rowptr / d_col / d_val: CSR of the symmetric positive definite matrix (DEVICE, original numbering, column-sorted rows);
+ * d_positions: (V, 3) fp32 vertex positions (DEVICE) or NULL (graph-distance pseudo-positions); leaf_size 64 and arity 4 are
+ * the tuned defaults; tier_levels deepest levels go into the tier layouts (3; 0 = none), sparse_leaves != 0 stores the leaves
+ * as packed triangle + sparse block. SYNC. Errors: LS_E_INVALID (not symmetric / not positive definite / bad arguments),
+ * LS_E_WORKSPACE (fronts or factor beyond the solver's limits, or the tier does not fit LDS: retry with fewer tier_levels). */
+int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, const float* d_val, int64_t V, int64_t nnz,
+                     const float* d_positions, int leaf_size, int arity, int tier_levels, int sparse_leaves, int device,
+                     void* stream, ls_direct** out);
+/* tree levels, arity, levels run by the tier kernels and their workgroup count (any pointer may be NULL) */
+int ls_direct_shape(const ls_direct* d, int* h_levels, int* h_arity, int* h_tier_levels, int* h_tier_workgroups);
+/* seconds of the three constructor stages of a handle made by ls_direct_factor: symbolic analysis, layout tables, numeric */
+int ls_direct_factor_seconds(const ls_direct* d, double* h_s3);
+/* SYNC: *h_symmetric = 1 iff every stored entry (r, c, v) has a stored mirror (c, r, v') with |v - v'| <= tol */
+int ls_csr_is_symmetric(const int32_t* d_rowptr, const int32_t* d_col, const float* d_val, int64_t V, int64_t nnz, float tol,
+                        int* h_symmetric, int device, void* stream);
 int ls_direct_destroy(ls_direct* d);
 /* x = M^-1 b for k <= 4 interleaved columns ((V, k) row-major, b != x) */
 int ls_direct_solve(ls_direct* d, const float* b, float* x, int k, void* stream);

@@ -824,6 +824,8 @@ struct ls_direct {
     hipEvent_t busy = nullptr;          // recorded after every solve: a solve on another stream waits for it (one workspace)
     hipStream_t last_stream = nullptr;
     bool used = false;
+    std::vector<void*> owned;           // device arrays adopted from ls_direct_factor (freed with the handle)
+    double factor_s[3] = {0, 0, 0};     // ls_direct_factor: symbolic analysis, layout / sparse tables, numeric factorisation
     std::vector<LevelPlan> plan;
     int64_t factor_entries = 0;
     int profile = 0;
@@ -841,6 +843,8 @@ static int pick_nw(int len, bool up_sweep = false) {
     while (nw < 16 && len > nw * target) nw *= 2;
     return nw;
 }
+
+int ls_direct_adopt(ls_direct* d, void* const* owned, int n_owned, const double* seconds3);
 
 static int env_int0(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
@@ -1197,6 +1201,7 @@ extern "C" int ls_direct_destroy(ls_direct* d) {
     (void)hipFree(d->mask); (void)hipFree(d->bp); (void)hipFree(d->braw); (void)hipFree(d->slots); (void)hipFree(d->xb);
     (void)hipFree(d->d_items); (void)hipFree(d->d_wgs); (void)hipFree(d->dbg);
     if (d->busy) (void)hipEventDestroy(d->busy);
+    for (void* p : d->owned) (void)hipFree(p);
     for (hipEvent_t e : d->ev) (void)hipEventDestroy(e);
     delete d;
     return LS_OK;
@@ -1303,6 +1308,27 @@ extern "C" int ls_direct_set(ls_direct* d, const char* name, int value) {
     }
     set_error("ls_direct_set: unknown option '%s'", name);
     return LS_E_INVALID;
+}
+
+int ls_direct_adopt(ls_direct* d, void* const* owned, int n_owned, const double* seconds3) {
+    d->owned.assign(owned, owned + n_owned);
+    for (int i = 0; i < 3; ++i) d->factor_s[i] = seconds3[i];
+    return LS_OK;
+}
+
+extern "C" int ls_direct_shape(const ls_direct* d, int* h_levels, int* h_arity, int* h_tier_levels, int* h_tier_workgroups) {
+    LS_REQUIRE(d, LS_E_INVALID, "ls_direct_shape: bad argument");
+    if (h_levels) *h_levels = d->levels;
+    if (h_arity) *h_arity = d->arity;
+    if (h_tier_levels) *h_tier_levels = d->tier_phases;
+    if (h_tier_workgroups) *h_tier_workgroups = d->tier_wgs;
+    return LS_OK;
+}
+
+extern "C" int ls_direct_factor_seconds(const ls_direct* d, double* h_s3) {
+    LS_REQUIRE(d && h_s3, LS_E_INVALID, "ls_direct_factor_seconds: bad argument");
+    for (int i = 0; i < 3; ++i) h_s3[i] = d->factor_s[i];
+    return LS_OK;
 }
 
 extern "C" int ls_direct_tier_stamps(const ls_direct* d, long long* h_out, int64_t n) {

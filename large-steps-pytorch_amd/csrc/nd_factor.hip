@@ -1,0 +1,589 @@
+// nd_factor.hip -- numeric multifrontal factorisation of the nested-dissection plan on the MI355X, and ls_direct_factor:
+// matrix in, solver handle out, entirely behind the C ABI.
+//
+// Replaces the constructor of the reference's default solver (largesteps/solvers.py:26-34: cholespy / CHOLMOD analyse +
+// factorise). Per tree level, deepest first, every node i with front F = [own | boundary] (fp64, s + b rows):
+//     F      = A[front, front] (entries with a row or column in own_i)  +  the children's Schur complements (extend-add)
+//     Finv   = F_ss^-1                       recursive 2 x 2 Schur inversion: only matrix products + a <= 64 x 64 in-LDS inverse
+//     W      = F_bs Finv
+//     U      = F_bb - W F_sb                 stays in the front's storage for the parent
+// All nodes of a level go through the same launches (batched: grid.y = node). The fp64 results are written once, as fp32, in
+// the layouts the solve kernels read (csrc/direct.hip: finv / wf / wb; csrc/nd_tier.h: quad-interleaved u4 / d4, packed
+// triangles + sparse blocks of the leaves). Everything dense here is hand-written: a tiled fp64 batched GEMM with per-batch
+// descriptors, the small SPD inverse, assembly / extend-add / conversion kernels. No rocSOLVER / rocBLAS / torch.
+#include "common.h"
+#include "nd_plan.h"
+#include <algorithm>
+#include <chrono>
+#include <string.h>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace ls {
+
+struct SpEnt { float val; int idx; };      // same layout as csrc/nd_tier.h
+
+// ---- batched fp64 GEMM: C = alpha * op(A) op(B) + beta * C, row-major, per-batch descriptor ------------------------------------
+struct GemmDesc {
+    const double* A; const double* B; double* C;
+    int M, N, K, lda, ldb, ldc, ta, tb;          // ta / tb: the operand is stored transposed (op(A)[m][k] = A[k * lda + m])
+    double alpha, beta;
+};
+
+constexpr int GT = 64, GK = 16;                  // 64 x 64 output tile per workgroup, 16-deep slices
+
+__global__ __launch_bounds__(256) void k_gemm_batched(const GemmDesc* __restrict__ descs) {
+    const GemmDesc d = descs[blockIdx.y];
+    const int tiles_n = (d.N + GT - 1) / GT, tiles_m = (d.M + GT - 1) / GT;
+    if ((int)blockIdx.x >= tiles_m * tiles_n || d.M <= 0 || d.N <= 0) return;
+    const int tm = (blockIdx.x / tiles_n) * GT, tn = (blockIdx.x % tiles_n) * GT;
+    __shared__ double sa[GK][GT + 1], sb[GK][GT + 1];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;       // thread -> 4 x 4 outputs at (ty * 4, tx * 4)
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    for (int k0 = 0; k0 < d.K; k0 += GK) {
+        for (int e = threadIdx.x; e < GK * GT; e += 256) {
+            // A slice: (m, k); B slice: (k, n). Index order chosen per storage order so that consecutive threads read consecutive memory.
+            int m, k;
+            if (d.ta) { m = e % GT; k = e / GT; } else { k = e % GK; m = e / GK; }
+            const int gm = tm + m, gk = k0 + k;
+            sa[k][m] = (gm < d.M && gk < d.K) ? (d.ta ? d.A[(size_t)gk * d.lda + gm] : d.A[(size_t)gm * d.lda + gk]) : 0.0;
+            int n, kk;
+            if (d.tb) { kk = e % GK; n = e / GK; } else { n = e % GT; kk = e / GT; }
+            const int gn = tn + n, gk2 = k0 + kk;
+            sb[kk][n] = (gn < d.N && gk2 < d.K) ? (d.tb ? d.B[(size_t)gn * d.ldb + gk2] : d.B[(size_t)gk2 * d.ldb + gn]) : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < GK; ++k) {
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = sa[k][ty * 4 + i]; b[i] = sb[k][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gm = tm + ty * 4 + i;
+        if (gm >= d.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gn = tn + tx * 4 + j;
+            if (gn >= d.N) continue;
+            double* c = d.C + (size_t)gm * d.ldc + gn;
+            *c = d.alpha * acc[i][j] + (d.beta != 0.0 ? d.beta * *c : 0.0);
+        }
+    }
+}
+
+// ---- X = M^-1 for SPD M, n <= 64, one workgroup per matrix in LDS (Cholesky, triangular inverse, product) ------------------------
+struct InvDesc { const double* M; double* X; int n, ldm, ldx, pad; };
+
+constexpr int INV_N = 64;
+
+__global__ __launch_bounds__(256) void k_spd_inverse_small(const InvDesc* __restrict__ descs, int* __restrict__ flag) {
+    const InvDesc d = descs[blockIdx.x];
+    const int n = d.n;
+    if (n <= 0) return;
+    extern __shared__ __attribute__((aligned(16))) double inv_sm[];
+    double (*a)[INV_N + 1] = reinterpret_cast<double (*)[INV_N + 1]>(inv_sm);
+    double (*li)[INV_N + 1] = reinterpret_cast<double (*)[INV_N + 1]>(inv_sm + INV_N * (INV_N + 1));
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    for (int e = threadIdx.x; e < n * n; e += 256) a[e / n][e % n] = d.M[(size_t)(e / n) * d.ldm + e % n];
+    __syncthreads();
+    // right-looking Cholesky, lower triangle in place
+    for (int k = 0; k < n; ++k) {
+        if (threadIdx.x == 0) {
+            const double p = a[k][k];
+            if (!(p > 0.0)) { bad = 1; a[k][k] = 1.0; } else a[k][k] = sqrt(p);
+        }
+        __syncthreads();
+        const double dk = a[k][k];
+        for (int i = k + 1 + threadIdx.x; i < n; i += 256) a[i][k] /= dk;
+        __syncthreads();
+        const int rem = n - k - 1;
+        for (int e = threadIdx.x; e < rem * rem; e += 256) {
+            const int i = k + 1 + e / rem, j = k + 1 + e % rem;
+            if (j <= i) a[i][j] -= a[i][k] * a[j][k];
+        }
+        __syncthreads();
+    }
+    // Linv: column j by forward substitution, a thread per column
+    for (int j = threadIdx.x; j < n; j += 256) {
+        for (int i = 0; i < n; ++i) {
+            double v = (i == j) ? 1.0 : 0.0;
+            for (int k = j; k < i; ++k) v -= a[i][k] * li[k][j];
+            li[i][j] = i < j ? 0.0 : v / a[i][i];
+        }
+    }
+    __syncthreads();
+    // X = Linv^T Linv
+    for (int e = threadIdx.x; e < n * n; e += 256) {
+        const int i = e / n, j = e % n;
+        double v = 0.0;
+        for (int k = max(i, j); k < n; ++k) v = fma(li[k][i], li[k][j], v);
+        d.X[(size_t)i * d.ldx + j] = v;
+    }
+    if (threadIdx.x == 0 && bad) atomicExch(flag, 1);
+}
+
+// ---- assembly -------------------------------------------------------------------------------------------------------------------
+struct FactorNode {              // device copy of what the assembly / conversion kernels need per node
+    int s, b, own_start, parent;
+    long long bnd_off, f_off, x_off, w_off;      // offsets into bnd / fronts (fp64) / Finv storage (fp64) / W storage (fp64)
+    long long o_finv, o_w, o_tri;                // fp32 output offsets (plain: finv, wf/wb; quad: d4, u4; sparse leaf: tri)
+    int layout, pad;                             // 0 plain, 1 quad, 2 sparse leaf
+};
+
+// every stored matrix entry whose row lives in node n and whose column is in the front of n
+__global__ void k_assemble(int64_t nnz, const int* __restrict__ rowidx, const int* __restrict__ col, const float* __restrict__ val,
+                           const int* __restrict__ inv, const int* __restrict__ node_of_new, const FactorNode* __restrict__ nodes,
+                           const int* __restrict__ bnd, double* __restrict__ fronts, int* __restrict__ flag) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    const int r = inv[rowidx[e]], c = inv[col[e]];
+    const int n = node_of_new[r];
+    const FactorNode nd = nodes[n];
+    if (c < nd.own_start) return;                          // column in a descendant: the mirrored entry is assembled there
+    const int m = nd.s + nd.b, rl = r - nd.own_start;
+    double* F = fronts + nd.f_off;
+    const double v = (double)val[e];
+    if (c < nd.own_start + nd.s) { F[(size_t)rl * m + (c - nd.own_start)] = v; return; }
+    const int* B = bnd + nd.bnd_off;
+    int lo = 0, hi = nd.b;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (B[mid] < c) lo = mid + 1; else hi = mid; }
+    if (lo >= nd.b || B[lo] != c) { atomicExch(flag, 2); return; }
+    F[(size_t)rl * m + nd.s + lo] = v;
+    F[(size_t)(nd.s + lo) * m + rl] = v;
+}
+
+// parent front += Schur complement of the children with sibling index cix (one launch per cix: no two writers per entry)
+__global__ void k_extend_add(const int* __restrict__ kids, int n_kids, const FactorNode* __restrict__ nodes, const int* __restrict__ ppos,
+                             double* __restrict__ fronts) {
+    const int ch = kids[blockIdx.y];
+    const FactorNode c = nodes[ch];
+    const FactorNode p = nodes[c.parent];
+    const int b = c.b, mc = c.s + c.b, mp = p.s + p.b;
+    const int* pp = ppos + c.bnd_off;
+    const double* U = fronts + c.f_off + (size_t)c.s * mc + c.s;
+    double* F = fronts + p.f_off;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < (int64_t)b * b; e += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e / b), j = (int)(e % b);
+        F[(size_t)pp[i] * mp + pp[j]] += U[(size_t)i * mc + j];
+    }
+}
+
+// fp64 results -> the fp32 arrays of the solve kernels
+__global__ void k_convert(const int* __restrict__ ids, const FactorNode* __restrict__ nodes, const double* __restrict__ xs,
+                          const double* __restrict__ ws, float* __restrict__ finv, float* __restrict__ wf, float* __restrict__ wb,
+                          float* __restrict__ u4, float* __restrict__ d4, float* __restrict__ tri) {
+    const FactorNode nd = nodes[ids[blockIdx.y]];
+    const int s = nd.s, b = nd.b;
+    const double* X = xs + nd.x_off;
+    const double* W = ws + nd.w_off;                         // (b, s) row-major
+    const int s4 = (s + 3) & ~3;
+    const int64_t total = (int64_t)s * s + (int64_t)b * s;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        if (e < (int64_t)s * s) {
+            const int j = (int)(e / s), t = (int)(e % s);
+            const float v = (float)(0.5 * (X[(size_t)j * s + t] + X[(size_t)t * s + j]));
+            if (nd.layout == 0) finv[nd.o_finv + (size_t)t * s + j] = v;
+            else if (nd.layout == 1) d4[nd.o_finv + ((size_t)(t >> 2) * s + j) * 4 + (t & 3)] = v;
+            else if (t <= j) tri[nd.o_tri + (size_t)j * (j + 1) / 2 + t] = v;
+        } else if (nd.layout != 2) {
+            const int64_t f = e - (int64_t)s * s;
+            const int i = (int)(f / s), j = (int)(f % s);
+            const float v = (float)W[(size_t)i * s + j];
+            if (nd.layout == 0) { wb[nd.o_w + (size_t)i * s + j] = v; wf[nd.o_w + (size_t)j * b + i] = v; }
+            else {
+                u4[nd.o_w + ((size_t)(j >> 2) * b + i) * 4 + (j & 3)] = v;
+                const int t = s4 + i;
+                d4[nd.o_finv + ((size_t)(t >> 2) * s + j) * 4 + (t & 3)] = v;
+            }
+        }
+    }
+}
+
+}  // namespace ls
+
+using namespace ls;
+
+// ---- host driver -------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Blk { double* M; double* X; double* ws; int n, ldm, ldx; };
+
+struct FactorCtx {
+    hipStream_t st;
+    GemmDesc* d_gemm = nullptr; InvDesc* d_inv = nullptr;   // descriptor staging on the device
+    size_t cap_gemm = 0, cap_inv = 0;
+    int* d_flag = nullptr;
+    hipError_t err = hipSuccess;
+    int launches = 0;
+};
+
+void gemm_batched(FactorCtx& c, std::vector<GemmDesc>& v) {
+    if (c.err != hipSuccess) return;
+    std::vector<GemmDesc> live;
+    int tiles = 0;
+    for (const GemmDesc& d : v)
+        if (d.M > 0 && d.N > 0) { live.push_back(d); tiles = std::max(tiles, div_up(d.M, GT) * div_up(d.N, GT)); }
+    v.clear();
+    if (live.empty()) return;
+    if (live.size() > c.cap_gemm) {
+        (void)hipFree(c.d_gemm);
+        c.cap_gemm = live.size() * 2;
+        if ((c.err = hipMalloc((void**)&c.d_gemm, c.cap_gemm * sizeof(GemmDesc))) != hipSuccess) return;
+    }
+    // (pageable source: the copy is staged before the call returns, the vector may go out of scope)
+    if ((c.err = hipMemcpyAsync(c.d_gemm, live.data(), live.size() * sizeof(GemmDesc), hipMemcpyHostToDevice, c.st)) != hipSuccess) return;
+    for (size_t b0 = 0; b0 < live.size(); b0 += 65535) {
+        const int nb = (int)std::min<size_t>(65535, live.size() - b0);
+        hipLaunchKernelGGL(k_gemm_batched, dim3(tiles, nb), dim3(256), 0, c.st, c.d_gemm + b0);
+    }
+    ++c.launches;
+}
+
+void inverse_small(FactorCtx& c, const std::vector<Blk>& v) {
+    if (c.err != hipSuccess) return;
+    std::vector<InvDesc> live;
+    for (const Blk& b : v) if (b.n > 0) live.push_back(InvDesc{b.M, b.X, b.n, b.ldm, b.ldx, 0});
+    if (live.empty()) return;
+    if (live.size() > c.cap_inv) {
+        (void)hipFree(c.d_inv);
+        c.cap_inv = live.size() * 2;
+        if ((c.err = hipMalloc((void**)&c.d_inv, c.cap_inv * sizeof(InvDesc))) != hipSuccess) return;
+    }
+    if ((c.err = hipMemcpyAsync(c.d_inv, live.data(), live.size() * sizeof(InvDesc), hipMemcpyHostToDevice, c.st)) != hipSuccess) return;
+    const size_t lds = 2 * INV_N * (INV_N + 1) * sizeof(double);
+    (void)hipFuncSetAttribute((const void*)k_spd_inverse_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_spd_inverse_small, dim3((unsigned)live.size()), dim3(256), lds, c.st, c.d_inv, c.d_flag);
+    ++c.launches;
+}
+
+// X = M^-1 for every block (SPD, any size): 2 x 2 Schur recursion `depth` times, then the in-LDS inverse. M is overwritten.
+void inverse_rec(FactorCtx& c, const std::vector<Blk>& v, int depth) {
+    if (depth == 0) { inverse_small(c, v); return; }
+    const size_t N = v.size();
+    std::vector<Blk> A(N), S(N);
+    std::vector<GemmDesc> g;
+    for (size_t i = 0; i < N; ++i) {
+        const Blk& b = v[i];
+        const int n1 = (b.n + 1) / 2, n2 = b.n - n1;
+        A[i] = Blk{b.M, b.X, b.ws + (size_t)n2 * n1, n1, b.ldm, b.ldx};
+        S[i] = Blk{b.M + (size_t)n1 * b.ldm + n1, b.X + (size_t)n1 * b.ldx + n1, b.ws + (size_t)n2 * n1, n2, b.ldm, b.ldx};
+    }
+    inverse_rec(c, A, depth - 1);                                     // X11 = A^-1
+    for (size_t i = 0; i < N; ++i) {                                  // T = B X11
+        const Blk& b = v[i]; const int n1 = A[i].n, n2 = S[i].n;
+        g.push_back(GemmDesc{b.M + (size_t)n1 * b.ldm, b.X, b.ws, n2, n1, n1, b.ldm, b.ldx, n1, 0, 0, 1.0, 0.0});
+    }
+    gemm_batched(c, g);
+    for (size_t i = 0; i < N; ++i) {                                  // S = C - T B^T (in place)
+        const Blk& b = v[i]; const int n1 = A[i].n, n2 = S[i].n;
+        g.push_back(GemmDesc{b.ws, b.M + (size_t)n1 * b.ldm, S[i].M, n2, n2, n1, n1, b.ldm, b.ldm, 0, 1, -1.0, 1.0});
+    }
+    gemm_batched(c, g);
+    inverse_rec(c, S, depth - 1);                                     // X22 = S^-1
+    for (size_t i = 0; i < N; ++i) {                                  // X21 = -X22 T
+        const Blk& b = v[i]; const int n1 = A[i].n, n2 = S[i].n;
+        g.push_back(GemmDesc{S[i].X, b.ws, b.X + (size_t)n1 * b.ldx, n2, n1, n2, b.ldx, n1, b.ldx, 0, 0, -1.0, 0.0});
+    }
+    gemm_batched(c, g);
+    for (size_t i = 0; i < N; ++i) {                                  // X12 = -T^T X22 ; X11 -= T^T X21
+        const Blk& b = v[i]; const int n1 = A[i].n, n2 = S[i].n;
+        g.push_back(GemmDesc{b.ws, S[i].X, b.X + n1, n1, n2, n2, n1, b.ldx, b.ldx, 1, 0, -1.0, 0.0});
+        g.push_back(GemmDesc{b.ws, b.X + (size_t)n1 * b.ldx, b.X, n1, n1, n2, n1, b.ldx, b.ldx, 1, 0, -1.0, 1.0});
+    }
+    gemm_batched(c, g);
+}
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+}  // namespace
+
+// defined in direct.hip: builds the handle from plan + factor arrays and takes ownership of the device arrays
+extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* stream, ls_direct** out);
+int ls_direct_adopt(ls_direct* d, void* const* owned, int n_owned, const double* seconds3);
+
+extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, const float* d_val, int64_t V, int64_t nnz,
+                                const float* d_positions, int leaf_size, int arity, int tier_levels, int sparse_leaves, int device,
+                                void* stream, ls_direct** out) {
+    LS_REQUIRE(out && d_rowptr && d_col && d_val && V > 0 && nnz > 0 && nnz < INT32_MAX, LS_E_INVALID, "ls_direct_factor: bad argument");
+    *out = nullptr;
+    DeviceGuard g(device);
+    LS_HIP(g.err);
+    hipStream_t st = (hipStream_t)stream;
+    const double t0 = now_s();
+    // ---- symbolic analysis on the host -------------------------------------------------------------------------------------------
+    std::vector<int32_t> rowptr((size_t)V + 1), col((size_t)nnz);
+    std::vector<float> val((size_t)nnz), pos;
+    LS_HIP(hipMemcpyAsync(rowptr.data(), d_rowptr, sizeof(int32_t) * (V + 1), hipMemcpyDeviceToHost, st));
+    LS_HIP(hipMemcpyAsync(col.data(), d_col, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost, st));
+    LS_HIP(hipMemcpyAsync(val.data(), d_val, sizeof(float) * nnz, hipMemcpyDeviceToHost, st));
+    if (d_positions) { pos.resize((size_t)V * 3); LS_HIP(hipMemcpyAsync(pos.data(), d_positions, sizeof(float) * 3 * V, hipMemcpyDeviceToHost, st)); }
+    LS_HIP(hipStreamSynchronize(st));
+    LS_REQUIRE(rowptr[0] == 0 && rowptr[V] == nnz, LS_E_INVALID, "ls_direct_factor: rowptr does not match nnz");
+    NdPlan P;
+    {
+        const std::string err = nd_plan_build(V, rowptr.data(), col.data(), d_positions ? pos.data() : nullptr, leaf_size, arity, 4, P);
+        LS_REQUIRE(err.empty(), LS_E_INVALID, "%s", err.c_str());
+    }
+    const double t1 = now_s();
+    const int n_nodes = P.n_nodes, levels = P.levels;
+    int max_front = 0;
+    for (int i = 1; i <= n_nodes; ++i) max_front = std::max(max_front, P.s[i] + P.b[i]);
+    LS_REQUIRE(max_front <= 8000, LS_E_WORKSPACE, "ls_direct_factor: a front of %d rows exceeds the solver's limit (the mesh does not dissect)", max_front);
+    // ---- layouts -------------------------------------------------------------------------------------------------------------------
+    tier_levels = std::max(0, std::min(std::min(tier_levels, levels), 6));
+    const int tier_root = levels - tier_levels;
+    bool leaves_ok = tier_levels > 0 && sparse_leaves;
+    for (int64_t i = P.level_off[levels - 1]; i < P.level_off[levels] && leaves_ok; ++i) leaves_ok = P.s[i] <= 64;
+    std::vector<FactorNode> fn((size_t)n_nodes + 1);
+    memset(fn.data(), 0, fn.size() * sizeof(FactorNode));
+    std::vector<int64_t> hn((size_t)(n_nodes + 1) * LS_DIRECT_NODE_COLS, 0);
+    int64_t f_tot = 0, x_tot = 0, w_tot = 0, o_finv = 0, o_w = 0, o_d4 = 0, o_u4 = 0, o_tri = 0;
+    for (int i = 1; i <= n_nodes; ++i) {
+        FactorNode& n = fn[i];
+        const int s = P.s[i], b = P.b[i], lv = P.level_of[i];
+        n.s = s; n.b = b; n.own_start = P.own_start[i]; n.parent = P.parent[i]; n.bnd_off = P.bnd_off[i];
+        n.f_off = f_tot; f_tot += (int64_t)(s + b) * (s + b);
+        n.x_off = x_tot; x_tot += (int64_t)s * s;
+        n.w_off = w_tot; w_tot += (int64_t)s * b;
+        const bool sparse = leaves_ok && lv == levels - 1 && s >= 1;
+        const bool quad = !sparse && lv >= tier_root;
+        n.layout = sparse ? 2 : quad ? 1 : 0;
+        int64_t* r = hn.data() + (size_t)i * LS_DIRECT_NODE_COLS;
+        r[0] = s; r[1] = b; r[2] = P.own_start[i]; r[3] = P.bnd_off[i]; r[4] = P.front_off[i]; r[7] = P.parent[i];
+        r[8] = -1; r[9] = -1; r[10] = -1; r[11] = quad;
+        const int64_t s4 = (s + 3) & ~3, b4 = (b + 3) & ~3;
+        if (sparse) { n.o_tri = o_tri; r[8] = o_tri; o_tri += ((int64_t)s * (s + 1) / 2 + 3) & ~(int64_t)3; }
+        else if (quad) { n.o_finv = o_d4; n.o_w = o_u4; r[5] = o_d4; r[6] = o_u4; o_d4 += (s4 + b4) * s; o_u4 += s4 * b; }
+        else { n.o_finv = o_finv; n.o_w = o_w; r[5] = o_finv; r[6] = o_w; o_finv += (int64_t)s * s; o_w += (int64_t)s * b; }
+    }
+    LS_REQUIRE(o_finv + 2 * o_w + o_d4 + o_u4 + 2 * o_tri < (int64_t)3000000000, LS_E_WORKSPACE, "ls_direct_factor: the factor is too large");
+    // ---- sparse leaves: the off-diagonal block A_bs as two CSR lists (host) ----------------------------------------------------------
+    std::vector<int32_t> sp_ptr;
+    std::vector<SpEnt> sp_ent;
+    if (leaves_ok) {
+        const int64_t l0 = P.level_off[levels - 1], l1 = P.level_off[levels];
+        std::vector<std::vector<std::pair<int, SpEnt>>> rows_b((size_t)(l1 - l0)), rows_s((size_t)(l1 - l0));   // (row, {val, other index})
+        // one pass per leaf, a few threads
+        const int T = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t)
+            th.emplace_back([&, t] {
+                for (int64_t i = l0 + t; i < l1; i += T) {
+                    const int s = P.s[i], b = P.b[i], o = P.own_start[i];
+                    if (s < 1) continue;
+                    const int* B = P.bnd.data() + P.bnd_off[i];
+                    auto& rb = rows_b[(size_t)(i - l0)];
+                    auto& rs = rows_s[(size_t)(i - l0)];
+                    for (int j = 0; j < s; ++j) {
+                        const int v = P.perm[o + j];
+                        for (int p = rowptr[v]; p < rowptr[v + 1]; ++p) {
+                            const int c = P.inv[col[p]];
+                            if (c < o + s) continue;
+                            const int k = (int)(std::lower_bound(B, B + b, c) - B);
+                            rs.push_back({j, SpEnt{val[p], k}});
+                            rb.push_back({k, SpEnt{val[p], j}});
+                        }
+                    }
+                    auto by_row = [](const std::pair<int, SpEnt>& a, const std::pair<int, SpEnt>& c) { return a.first < c.first || (a.first == c.first && a.second.idx < c.second.idx); };
+                    std::sort(rb.begin(), rb.end(), by_row);
+                    std::sort(rs.begin(), rs.end(), by_row);
+                }
+            });
+        for (auto& x : th) x.join();
+        for (int pass = 0; pass < 2; ++pass)                 // boundary rows of all leaves first, then own rows
+            for (int64_t i = l0; i < l1; ++i) {
+                const int s = P.s[i], b = P.b[i];
+                if (s < 1) continue;
+                const auto& R = pass == 0 ? rows_b[(size_t)(i - l0)] : rows_s[(size_t)(i - l0)];
+                const int nr = pass == 0 ? b : s;
+                hn[(size_t)i * LS_DIRECT_NODE_COLS + (pass == 0 ? 9 : 10)] = (int64_t)sp_ptr.size();
+                size_t k = 0;
+                for (int r = 0; r <= nr; ++r) {
+                    sp_ptr.push_back((int32_t)sp_ent.size());
+                    if (r < nr) while (k < R.size() && R[k].first == r) sp_ent.push_back(R[k++].second);
+                }
+            }
+    }
+    const double t2 = now_s();
+    // ---- device storage ---------------------------------------------------------------------------------------------------------------
+    std::vector<void*> owned, scratch;
+    int rc = LS_OK;
+    auto dalloc = [&](void** p, size_t bytes, bool keep, bool zero) -> bool {
+        hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 16) + 16);
+        if (e == hipSuccess && zero) e = hipMemsetAsync(*p, 0, std::max<size_t>(bytes, 16) + 16, st);
+        if (e != hipSuccess) { rc = hip_fail(e, "ls_direct_factor allocation", __FILE__, __LINE__); *p = nullptr; return false; }
+        (keep ? owned : scratch).push_back(*p);
+        return true;
+    };
+    float *finv = nullptr, *wf = nullptr, *wb = nullptr, *u4 = nullptr, *d4 = nullptr, *tri = nullptr;
+    int32_t* d_sp_ptr = nullptr; SpEnt* d_sp_ent = nullptr;
+    double *fronts = nullptr, *xs = nullptr, *ws = nullptr, *work = nullptr;
+    int *d_inv = nullptr, *d_non = nullptr, *d_bnd = nullptr, *d_ppos = nullptr, *d_rowidx = nullptr, *d_ids = nullptr;
+    FactorNode* d_nodes = nullptr;
+    FactorCtx ctx; ctx.st = st;
+    int64_t work_tot = 0;
+    for (int i = 1; i <= n_nodes; ++i) work_tot += ((int64_t)P.s[i] * P.s[i] + 1) / 2 + 64;
+    bool ok = dalloc((void**)&finv, sizeof(float) * o_finv, true, false) && dalloc((void**)&wf, sizeof(float) * o_w, true, false) &&
+              dalloc((void**)&wb, sizeof(float) * o_w, true, false) && dalloc((void**)&u4, sizeof(float) * o_u4, true, true) &&
+              dalloc((void**)&d4, sizeof(float) * o_d4, true, true) && dalloc((void**)&tri, sizeof(float) * o_tri, true, true) &&
+              dalloc((void**)&d_sp_ptr, sizeof(int32_t) * sp_ptr.size(), true, false) && dalloc((void**)&d_sp_ent, sizeof(SpEnt) * sp_ent.size(), true, true) &&
+              dalloc((void**)&fronts, sizeof(double) * f_tot, false, true) && dalloc((void**)&xs, sizeof(double) * x_tot, false, false) &&
+              dalloc((void**)&ws, sizeof(double) * w_tot, false, false) && dalloc((void**)&work, sizeof(double) * work_tot, false, false) &&
+              dalloc((void**)&d_inv, sizeof(int) * V, false, false) && dalloc((void**)&d_non, sizeof(int) * V, false, false) &&
+              dalloc((void**)&d_bnd, sizeof(int) * P.n_bnd, false, false) && dalloc((void**)&d_ppos, sizeof(int) * P.n_bnd, false, false) &&
+              dalloc((void**)&d_rowidx, sizeof(int) * nnz, false, false) && dalloc((void**)&d_ids, sizeof(int) * (n_nodes + 1), false, false) &&
+              dalloc((void**)&d_nodes, sizeof(FactorNode) * (n_nodes + 1), false, false) && dalloc((void**)&ctx.d_flag, sizeof(int), false, true);
+    auto cleanup = [&](bool all) {
+        (void)hipStreamSynchronize(st);
+        for (void* p : scratch) (void)hipFree(p);
+        (void)hipFree(ctx.d_gemm); (void)hipFree(ctx.d_inv);
+        if (all) for (void* p : owned) (void)hipFree(p);
+    };
+    if (!ok) { cleanup(true); return rc; }
+    std::vector<int> rowidx((size_t)nnz);
+    for (int64_t v = 0; v < V; ++v) for (int p = rowptr[v]; p < rowptr[v + 1]; ++p) rowidx[p] = (int)v;
+    hipError_t e = hipSuccess;
+    auto h2d = [&](void* dst, const void* src, size_t bytes) { if (e == hipSuccess && bytes) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st); };
+    h2d(d_inv, P.inv.data(), sizeof(int) * V); h2d(d_non, P.node_of_new.data(), sizeof(int) * V);
+    h2d(d_bnd, P.bnd.data(), sizeof(int) * P.n_bnd); h2d(d_ppos, P.ppos.data(), sizeof(int) * P.n_bnd);
+    h2d(d_rowidx, rowidx.data(), sizeof(int) * nnz); h2d(d_nodes, fn.data(), sizeof(FactorNode) * (n_nodes + 1));
+    h2d(d_sp_ptr, sp_ptr.data(), sizeof(int32_t) * sp_ptr.size()); h2d(d_sp_ent, sp_ent.data(), sizeof(SpEnt) * sp_ent.size());
+    if (e != hipSuccess) { cleanup(true); return hip_fail(e, "ls_direct_factor uploads", __FILE__, __LINE__); }
+    // ---- numeric factorisation -------------------------------------------------------------------------------------------------------
+    hipLaunchKernelGGL(k_assemble, dim3((unsigned)div_up(nnz, 256)), dim3(256), 0, st, nnz, d_rowidx, d_col, d_val, d_inv, d_non, d_nodes, d_bnd,
+                       fronts, ctx.d_flag);
+    std::vector<int> ids;
+    std::vector<int64_t> work_off((size_t)n_nodes + 1, 0);
+    { int64_t o = 0; for (int i = 1; i <= n_nodes; ++i) { work_off[i] = o; o += ((int64_t)P.s[i] * P.s[i] + 1) / 2 + 64; } }
+    for (int lv = levels - 1; lv >= 0 && ctx.err == hipSuccess && e == hipSuccess; --lv) {
+        const int64_t first = P.level_off[lv], last = P.level_off[lv + 1];
+        if (lv + 1 < levels) {                                      // children's Schur complements, one sibling index per launch
+            for (int c = 0; c < arity; ++c) {
+                ids.clear();
+                int bmax = 0;
+                for (int64_t ch = P.level_off[lv + 1] + c; ch < P.level_off[lv + 2]; ch += arity)
+                    if (P.b[ch] > 0) { ids.push_back((int)ch); bmax = std::max(bmax, P.b[ch]); }
+                if (ids.empty()) continue;
+                h2d(d_ids, ids.data(), sizeof(int) * ids.size());
+                for (size_t b0 = 0; b0 < ids.size(); b0 += 65535) {
+                    const int nb = (int)std::min<size_t>(65535, ids.size() - b0);
+                    hipLaunchKernelGGL(k_extend_add, dim3(std::min(64, div_up((int64_t)bmax * bmax, 256)), nb), dim3(256), 0, st, d_ids + b0, nb,
+                                       d_nodes, d_ppos, fronts);
+                }
+                e = e == hipSuccess ? hipStreamSynchronize(st) : e;       // ids is reused by the next launch
+            }
+        }
+        int smax = 0;
+        for (int64_t i = first; i < last; ++i) smax = std::max(smax, P.s[i]);
+        int depth = 0;
+        while (((smax + (1 << depth) - 1) >> depth) > INV_N) ++depth;
+        std::vector<Blk> blocks;
+        ids.clear();
+        for (int64_t i = first; i < last; ++i) {
+            if (P.s[i] == 0) continue;
+            const int m = P.s[i] + P.b[i];
+            blocks.push_back(Blk{fronts + fn[i].f_off, xs + fn[i].x_off, work + work_off[i], P.s[i], m, P.s[i]});
+            ids.push_back((int)i);
+        }
+        inverse_rec(ctx, blocks, depth);
+        std::vector<GemmDesc> gd;
+        for (int64_t i = first; i < last; ++i) {                    // W = F_bs Finv
+            const int s = P.s[i], b = P.b[i], m = s + b;
+            if (s && b) gd.push_back(GemmDesc{fronts + fn[i].f_off + (size_t)s * m, xs + fn[i].x_off, ws + fn[i].w_off, b, s, s, m, s, s, 0, 0, 1.0, 0.0});
+        }
+        gemm_batched(ctx, gd);
+        for (int64_t i = first; i < last; ++i) {                    // U = F_bb - W F_sb  (F_sb = F_bs^T)
+            const int s = P.s[i], b = P.b[i], m = s + b;
+            if (s && b) gd.push_back(GemmDesc{ws + fn[i].w_off, fronts + fn[i].f_off + (size_t)s * m, fronts + fn[i].f_off + (size_t)s * m + s,
+                                              b, b, s, s, m, m, 0, 1, -1.0, 1.0});
+        }
+        gemm_batched(ctx, gd);
+        if (!ids.empty()) {
+            h2d(d_ids, ids.data(), sizeof(int) * ids.size());
+            int64_t emax = 0;
+            for (int i : ids) emax = std::max(emax, (int64_t)P.s[i] * (P.s[i] + P.b[i]));
+            for (size_t b0 = 0; b0 < ids.size(); b0 += 65535) {
+                const int nb = (int)std::min<size_t>(65535, ids.size() - b0);
+                hipLaunchKernelGGL(k_convert, dim3(std::min(256, div_up(emax, 256)), nb), dim3(256), 0, st, d_ids + b0, d_nodes, xs, ws, finv, wf, wb, u4,
+                                   d4, tri);
+            }
+            e = e == hipSuccess ? hipStreamSynchronize(st) : e;
+        }
+    }
+    int flag = 0;
+    if (e == hipSuccess && ctx.err == hipSuccess) e = hipMemcpyAsync(&flag, ctx.d_flag, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess || ctx.err != hipSuccess) { cleanup(true); return hip_fail(e != hipSuccess ? e : ctx.err, "ls_direct_factor kernels", __FILE__, __LINE__); }
+    cleanup(false);
+    if (flag) {
+        for (void* p : owned) (void)hipFree(p);
+        set_error(flag == 2 ? "ls_direct_factor: the matrix pattern is not symmetric" : "ls_direct_factor: a front is not positive definite");
+        return LS_E_INVALID;
+    }
+    const double t3 = now_s();
+    // ---- the solver handle ---------------------------------------------------------------------------------------------------------------
+    ls_direct_arrays A;
+    memset(&A, 0, sizeof(A));
+    A.V = V; A.levels = levels; A.arity = arity; A.h_nodes = hn.data(); A.h_perm = P.perm.data(); A.h_ppos = P.ppos.data(); A.n_bnd = P.n_bnd;
+    A.h_push_ptr = P.push_ptr.data(); A.h_push_tgt = P.push_tgt.data(); A.n_front = P.n_front;
+    A.d_finv = finv; A.d_wf = wf; A.d_wb = wb; A.d_u4 = u4; A.d_d4 = d4; A.d_tri = tri; A.d_sp_ptr = d_sp_ptr; A.d_sp_ent = d_sp_ent;
+    A.n_sp_ptr = (int64_t)sp_ptr.size(); A.n_sp_ent = (int64_t)sp_ent.size();
+    rc = ls_direct_create(&A, device, stream, out);
+    if (rc != LS_OK) { for (void* p : owned) (void)hipFree(p); return rc; }
+    const double secs[3] = {t1 - t0, t2 - t1, t3 - t2};
+    return ls_direct_adopt(*out, owned.data(), (int)owned.size(), secs);
+}
+
+// ---- is a CSR matrix symmetric (pattern and values)? Replaces a sort-based check on the host side of the solver -------------------
+namespace ls {
+__global__ void k_csr_symmetric(int64_t nnz, const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
+                                const int* __restrict__ rowidx_or_null, int64_t V, float tol, int* __restrict__ flag) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    int r;
+    {   // row of entry e: binary search in rowptr
+        int64_t lo = 0, hi = V;
+        while (lo + 1 < hi) { const int64_t mid = (lo + hi) >> 1; if (rowptr[mid] <= e) lo = mid; else hi = mid; }
+        r = (int)lo;
+    }
+    const int c = col[e];
+    int lo = rowptr[c], hi = rowptr[c + 1];
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (col[mid] < r) lo = mid + 1; else hi = mid; }
+    if (lo >= rowptr[c + 1] || col[lo] != r || fabsf(val[lo] - val[e]) > tol) atomicExch(flag, 1);
+}
+}  // namespace ls
+
+extern "C" int ls_csr_is_symmetric(const int32_t* d_rowptr, const int32_t* d_col, const float* d_val, int64_t V, int64_t nnz, float tol,
+                                   int* h_symmetric, int device, void* stream) {
+    LS_REQUIRE(d_rowptr && d_col && d_val && h_symmetric && V > 0 && nnz >= 0, LS_E_INVALID, "ls_csr_is_symmetric: bad argument");
+    DeviceGuard g(device);
+    LS_HIP(g.err);
+    hipStream_t st = (hipStream_t)stream;
+    int* d_flag = nullptr;
+    LS_HIP(hipMalloc((void**)&d_flag, sizeof(int)));
+    hipError_t e = hipMemsetAsync(d_flag, 0, sizeof(int), st);
+    if (e == hipSuccess && nnz) hipLaunchKernelGGL(k_csr_symmetric, dim3((unsigned)div_up(nnz, 256)), dim3(256), 0, st, nnz, d_rowptr, d_col, d_val,
+                                                  (const int*)nullptr, V, tol, d_flag);
+    int flag = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_flag);
+    LS_HIP(e);
+    *h_symmetric = flag ? 0 : 1;
+    return LS_OK;
+}

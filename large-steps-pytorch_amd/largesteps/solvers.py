@@ -244,37 +244,101 @@ class IterativeCholeskySolver(PCGSolver):
                          patch_columns=patch_columns)
 
 
+class _NativeDirect:
+    """Owner of a native ls_direct handle built by ls_direct_factor (symbolic analysis + numeric factorisation behind the C ABI)."""
+
+    def __init__(self, csr, leaf_size, arity, tier_levels, sparse_leaves):
+        self.device = csr.device
+        self._h = ctypes.c_void_p(None)
+        pos = csr.positions
+        if pos is not None:
+            pos = pos.detach().to(torch.float32).contiguous()
+        dev = csr.device
+        with torch.cuda.device(dev):
+            _native.check(_native.lib().ls_direct_factor(_native.ptr(csr.rowptr), _native.ptr(csr.col), _native.ptr(csr.val), csr.V, csr.nnz,
+                                                         _native.ptr(pos), int(leaf_size), int(arity), int(tier_levels), int(bool(sparse_leaves)),
+                                                         dev.index, _native.stream_of(dev), ctypes.byref(self._h)))
+        s3 = (ctypes.c_double * 3)()
+        _native.check(_native.lib().ls_direct_factor_seconds(self._h, ctypes.byref(s3)))
+        self.timings = dict(plan_seconds=s3[0], table_seconds=s3[1], factor_seconds=s3[2])
+        self.tier_levels = int(tier_levels)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                _native.lib().ls_direct_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def solve(self, b, x):
+        with torch.cuda.device(self.device):
+            _native.check(_native.lib().ls_direct_solve(self._h, _native.ptr(b), _native.ptr(x), b.shape[1], _native.stream_of(self.device)))
+
+    def set_option(self, name, value):
+        _native.check(_native.lib().ls_direct_set(self._h, name.encode(), int(value)))
+
+    def info(self):
+        fe, nl = ctypes.c_int64(0), ctypes.c_int(0)
+        ms = (ctypes.c_double * 3)()
+        _native.check(_native.lib().ls_direct_info(self._h, ctypes.byref(fe), ctypes.byref(nl), ms))
+        lv, ar, th, tw = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        _native.check(_native.lib().ls_direct_shape(self._h, ctypes.byref(lv), ctypes.byref(ar), ctypes.byref(th), ctypes.byref(tw)))
+        return dict(factor_entries=fe.value, launches=nl.value, up_ms=ms[0], down_ms=ms[1], levels=lv.value, arity=ar.value,
+                    tier_levels=th.value, tier_workgroups=tw.value)
+
+
 class NestedDissectionSolver(Solver):
     """
     Factor-once / re-solve direct solver (what the reference's default method does through cholespy / CHOLMOD,
-    solvers.py:26-39), MI355X-native: geometric nested dissection of the mesh (largesteps/nested.py), multifrontal
-    numeric factorisation on the device in fp64 (largesteps/direct.py), and a re-solve made of one hand-written HIP
-    launch per tree level and sweep (csrc/direct.hip). The result is a function of b only and bitwise reproducible.
+    solvers.py:26-39), MI355X-native and entirely behind the C ABI (`ls_direct_factor`): geometric nested dissection of
+    the mesh on host threads (csrc/nd_plan.cpp), multifrontal numeric factorisation in fp64 on the device with
+    hand-written kernels (csrc/nd_factor.hip), and a re-solve of one launch per upper tree level and sweep plus one
+    launch per sweep for the deepest levels (csrc/direct.hip, csrc/nd_tier.h). The result is a function of b only and
+    bitwise reproducible.
 
     The dissection uses the vertex positions the matrix was assembled from (`compute_matrix`); a symmetric matrix built
-    elsewhere gets graph-distance pseudo-positions instead. Raises ValueError when the matrix is not symmetric or the
-    mesh does not dissect into fronts that fit the kernels.
+    elsewhere gets graph-distance pseudo-positions instead. Raises ValueError when the matrix is not symmetric or not
+    positive definite, RuntimeError when the mesh does not dissect into fronts that fit the kernels.
     """
 
     def __init__(self, M, leaf_size=64, arity=4):
-        from . import direct
         import time
         csr = _native.csr_of(M)
         self._csr = csr
         self.last_info = None
         if csr.symmetric is None:          # a matrix that was not built by compute_matrix: the factorisation needs M = M^T
-            idx, val, V = M.indices(), M.values(), M.shape[0]
-            k1, k2 = idx[0] * V + idx[1], idx[1] * V + idx[0]
-            order = torch.argsort(k2)
-            csr.symmetric = bool(torch.equal(k2[order], k1)) and bool(
-                (val[order] - val).abs().max() <= 1e-6 * val.abs().max()) if val.numel() else True
+            ok = ctypes.c_int(0)
+            tol = 1e-6 * float(csr.val.abs().max()) if csr.nnz else 0.0
+            with torch.cuda.device(csr.device):
+                _native.check(_native.lib().ls_csr_is_symmetric(_native.ptr(csr.rowptr), _native.ptr(csr.col), _native.ptr(csr.val), csr.V,
+                                                                csr.nnz, tol, ctypes.byref(ok), csr.device.index,
+                                                                _native.stream_of(csr.device)))
+            csr.symmetric = bool(ok.value)
+        if not csr.symmetric:
+            raise ValueError("NestedDissectionSolver: the matrix is not symmetric")
         t0 = time.perf_counter()
-        self._direct = direct.build(csr, leaf_size=leaf_size, arity=arity)
+        tier = max(0, min(6, int(os.environ.get("LS_ND_TIER_H", "3"))))
+        sparse = not os.environ.get("LS_ND_DENSE_LEAVES")
+        if os.environ.get("LS_ND_PYTHON_FACTOR"):          # A/B: numpy plan + torch factorisation (the statement of the native code)
+            from . import direct
+            self._direct = direct.build(csr, leaf_size=leaf_size, arity=arity)
+            if self._direct is None:
+                raise ValueError("NestedDissectionSolver: the fronts exceed the solver's limits")
+        else:
+            while True:
+                try:
+                    self._direct = _NativeDirect(csr, leaf_size, arity, tier, sparse)
+                    break
+                except RuntimeError as e:      # a tier whose subtrees need more LDS than a workgroup has: one level less
+                    if tier == 0 or "does not fit" not in str(e):
+                        raise
+                    tier -= 1
         torch.cuda.synchronize(csr.device)
         self.build_seconds = time.perf_counter() - t0
-        if self._direct is None:
-            raise ValueError("NestedDissectionSolver: the matrix is not symmetric, or its fronts exceed the solver's limits")
-        self.plan = self._direct.plan
+        self.plan = getattr(self._direct, "plan", None)
+        self.timings = self._direct.timings
 
     def solve(self, b, backward=False):
         _native.require_device(b, "b")

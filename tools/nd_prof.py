@@ -21,9 +21,6 @@ for _ in range(3): x = s.solve(u)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(n): x = s.solve(u)
 torch.cuda.synchronize()
-print(f"{cfg_name} leaf {leaf} arity {arity}: {(time.perf_counter() - t0) / n * 1e3:.3f} ms/solve, err {float((x - tv).abs().max()):.2e}, levels={s.plan.levels}, entries/V={s.plan.factor_entries / v.shape[0]:.1f}, build {s.build_seconds:.1f}s")
-print("constructor:", {k: round(v, 2) for k, v in s._direct.timings.items()})
-p = s.plan
-for lv in range(p.levels):
-    nd = p.level_nodes(lv)
-    print("level", lv, "nodes", nd.shape[0], "s", int(p.s[nd].max()), "b", int(p.b[nd].max()), "entries", int((p.s[nd] ** 2 + 2 * p.s[nd] * p.b[nd]).sum()))
+inf = s.info()
+print(f"{cfg_name} leaf {leaf} arity {arity}: {(time.perf_counter() - t0) / n * 1e3:.3f} ms/solve, err {float((x - tv).abs().max()):.2e}, levels={inf.get('levels')}, words/V={inf['factor_entries'] / v.shape[0]:.1f}, launches={inf['launches']}, build {s.build_seconds:.2f}s")
+print("constructor:", {k: round(v, 3) for k, v in s.timings.items()})

@@ -18,7 +18,7 @@ for _ in range(3): s.solve(u)
 s.set_option("profile", 2)
 s.solve(u)
 h = s._direct._h
-n_wg = int(s.plan.arity ** max(0, s.plan.levels - int(os.environ.get("LS_ND_TIER_H", "3"))))
+n_wg = s.info()["tier_workgroups"]
 n = 2 * n_wg * 4 * 32
 buf = np.zeros(n, dtype=np.int64)
 _native.check(_native.lib().ls_direct_tier_stamps(h, buf.ctypes.data_as(ctypes.c_void_p), n))
