@@ -8,7 +8,8 @@ bench.py -- from_differential solves/sec on the 1M-vertex plane (BASELINE.json m
 
 One "step" = one from_differential solve  M x = u  (M = I + 50 L_uniform of the 1000x1000 plane, u = M v,
 k = 3 right-hand sides, cold start x0 = 0, stop at ||r|| <= 1e-6 ||b|| per column), inputs resident in HBM.
-N = 1: the public API path (largesteps.parameterize.from_differential -> C ABI -> HIP PCG).
+N = 1: the public API path (largesteps.parameterize.from_differential -> CholeskySolver -> C ABI: ls_direct_factor once,
+       ls_direct_solve per step -- the nested-dissection direct solver; --iterative / --pcg time the iterative paths).
 N > 1 (one rank per GPU, RCCL; largesteps.distributed), strong scaling (total work fixed), two modes (--shard):
   columns (default): the 3 right-hand-side columns are independent systems -> rank r solves column r on its GPU with
                      the single-GPU kernels, one all-gather of the solution per solve, nothing per iteration;
@@ -17,10 +18,12 @@ N > 1 (one rank per GPU, RCCL; largesteps.distributed), strong scaling (total wo
   replicas         : every rank solves its own copy of the system (independent meshes), weak scaling, no communication.
 
 Prints ONE JSON line on rank 0 (contract: see the task description): metric/value/unit/... plus
-  "roofline":     HBM roofline of the dominant kernel (K1: SpMV + p.Ap), timed with HIP events on the solve's
-                  own stream in an extra profiled pass right after the timed region (same workload)
+  "roofline":     HBM roofline of the dominant kernel group (the down sweep of the direct solver: its algorithmic bytes /
+                  its duration from HIP events on the solve's own stream, in an extra profiled pass right after the timed
+                  region, same workload)
   "cpu_baseline": the oracle's CPU "factor once / re-solve" direct solver (scipy SuperLU, fp64, 1 thread) on
-                  the same 1M-vertex system, rank 0 at N = 1 only (bounded: 1 factorisation + 3 solves)
+                  the same 1M-vertex system, rank 0 at N = 1 only (bounded: 1 factorisation + 3 solves); "extra": the
+                  reference's CG algorithm on the host (70k config) and in stock torch ops on the device (B2 / B3)
 """
 import argparse
 import json
@@ -62,9 +65,9 @@ def algorithmic_bytes(V, nnz, k, iters, method="pcg", implicit_values=False):
 
 
 def pmc_traffic(kernel_prefix, workload):
-    """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/r01_pmc_traffic.json: separate
+    """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/r02_pmc_traffic.json: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 correction applied), or None."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     try:
         with open(path) as fh:
             d = json.load(fh)
@@ -244,11 +247,65 @@ def run_single(args):
     print(json.dumps(out), flush=True)
 
 
+def extra_baselines(args):
+    """SURVEY 8(d) baselines B2 / B3, outside any timed region of the product:
+      B2  the reference's own ConjugateGradientSolver algorithm (largesteps/solvers.py:58-126; oracle.solve.reference_cg, fp32,
+          column by column, stop at ||r|| <= 1e-5, no preconditioner) on the host at config 2 (70k vertices);
+      B3  the same algorithm written with stock torch ops on the HIP device ("naive ROCm port": torch.sparse.mm + torch
+          reductions, one column at a time like the reference) on the benchmark's own system."""
+    from oracle import laplacian as ol, solve as osv
+    from largesteps import synthetic
+    out = {}
+    v2, f2, c2 = synthetic.config_mesh("cfg2_bunny70k")
+    r, c, val = ol.compute_matrix(v2, f2, c2["lambda_"], alpha=c2["alpha"], cotan=c2["cotan"])
+    u2 = osv.to_differential(r, c, val, v2).astype(np.float32)
+    t0 = time.perf_counter()
+    x2, its = osv.reference_cg(r, c, val, u2)
+    t = time.perf_counter() - t0
+    out["B2_reference_cg_cpu_cfg2"] = dict(solves_per_s=1.0 / t, ms_per_solve=t * 1e3, iterations_per_column=[int(i) for i in its], cores=1,
+                                           max_abs_err_vs_v=float(np.abs(x2 - v2).max()),
+                                           note="reference CG algorithm, numpy/scipy fp32 on the host, 70k-vertex config")
+    dev = torch.device("cuda", 0)
+    v, f, cfg = synthetic.config_mesh(args.workload)
+    r, c, val = ol.compute_matrix(v, f, cfg["lambda_"] if cfg["lambda_"] is not None else 0.0, alpha=cfg["alpha"], cotan=cfg["cotan"])
+    V = v.shape[0]
+    Mt = torch.sparse_coo_tensor(torch.from_numpy(np.stack([r, c])).to(dev), torch.from_numpy(val.astype(np.float32)).to(dev), (V, V)).coalesce()
+    tv = torch.from_numpy(v).to(dev)
+    b = torch.sparse.mm(Mt, tv)
+
+    def torch_cg(bcol):          # solvers.py:58-84, stock torch ops
+        x = torch.zeros_like(bcol)
+        rr = -bcol.clone()
+        p = -rr
+        rn = torch.norm(rr)
+        k = 0
+        while float(rn) > 1e-5 and k < 20000:
+            Ap = torch.sparse.mm(Mt, p.unsqueeze(1)).squeeze(1)
+            r2 = rn * rn
+            alpha = r2 / (p * Ap).sum()
+            x = x + alpha * p
+            rr = rr + alpha * Ap
+            rn = torch.norm(rr)
+            p = -rr + (rn * rn / r2) * p
+            k += 1
+        return x, k
+    torch_cg(b[:, 0].contiguous())             # warm-up (allocator, kernel load)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    cols = [torch_cg(b[:, j].contiguous()) for j in range(3)]
+    torch.cuda.synchronize()
+    t = time.perf_counter() - t0
+    xs = torch.stack([c_[0] for c_ in cols], 1)
+    out["B3_torch_cg_hip_device"] = dict(solves_per_s=1.0 / t, ms_per_solve=t * 1e3, iterations_per_column=[int(c_[1]) for c_ in cols],
+                                         max_abs_err_vs_v=float((xs - tv).abs().max()),
+                                         note=f"reference CG algorithm in stock torch ops on the MI355X, {args.workload}")
+    return out
+
+
 def report_direct(args, solver, M, u, x, tv, v, f, cfg, ms, t_assemble):
     """JSON line for the factor-once / re-solve direct solver (largesteps.solvers.NestedDissectionSolver)."""
     from largesteps.parameterize import to_differential
     V, nnz, k = v.shape[0], M._nnz(), 3
-    plan = solver.plan
     # profiled pass right after the timed region: HIP events around the up sweep and the down sweep (solve's stream)
     solver.set_option("profile", 1)
     n_prof = max(1, min(args.steps, 5))
@@ -259,39 +316,42 @@ def report_direct(args, solver, M, u, x, tv, v, f, cfg, ms, t_assemble):
         up_ms += inf["up_ms"] / n_prof
         down_ms += inf["down_ms"] / n_prof
     solver.set_option("profile", 0)
-    lv_s = [int(plan.s[plan.level_nodes(lv)].sum()) for lv in range(plan.D + 1)]
-    n_down = sum(1 for t in lv_s if t)
-    n_up = inf["launches"] - n_down
-    n_bnd = int(plan.b.sum())
-    # algorithmic bytes (fp32 factor: Finv once, W in both sweeps; vectors once per sweep)
-    up_bytes = 4 * plan.w_size + 4 * k * (2 * V + 3 * n_bnd) + 4 * V
-    down_bytes = 4 * (plan.w_size + plan.finv_size) + 4 * k * (2 * V + 3 * n_bnd) + 4 * V
+    n_up = n_down = inf["launches"] // 2
+    n_bnd = inf["n_bnd"]
+    # algorithmic bytes: the fp32 factor data each sweep reads (dense nodes: W in both sweeps, Finv in the down sweep; leaves:
+    # one packed triangle per sweep + their sparse block) + the vectors once per sweep (b / b' / x rows, boundary vectors)
+    up_bytes = 4 * inf["words_up"] + 4 * k * (2 * V + 3 * n_bnd) + 4 * V
+    down_bytes = 4 * inf["words_down"] + 4 * k * (2 * V + 3 * n_bnd) + 4 * V
     solve_bytes = up_bytes + down_bytes
     r = to_differential(M, x) - u
     rel_res = [float(a / b) for a, b in zip(r.norm(dim=0).tolist(), u.norm(dim=0).tolist())]
     down_gbs = down_bytes / (down_ms * 1e-3) / 1e9
+    tm = solver.timings
     out = dict(
         metric="from_differential_solves_per_sec", value=1e3 / ms, unit="solves/s", n_gpus=1, steps=args.steps,
         warmup=args.warmup, ms_per_step=ms, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32",
         data="synthetic",
         config=dict(workload=describe(args.workload, cfg, V, nnz) + ", factor once (not timed), re-solve timed",
-                    solver=(f"HIP nested-dissection multifrontal direct solver: {plan.D + 1} tree levels, fp64 factorisation on "
-                            f"the device (once), fp32 factor {plan.factor_entries / 1e6:.1f} M numbers; re-solve = "
-                            f"{inf['launches']} launches (one per level and sweep), no atomics"),
+                    solver=(f"HIP nested-dissection multifrontal direct solver behind ls_direct_factor: {inf['levels']} tree levels, "
+                            f"symbolic analysis on host threads, fp64 factorisation with hand-written kernels (once), fp32 factor "
+                            f"{inf['factor_entries'] / 1e6:.1f} M words per solve; re-solve = {inf['launches']} launches (one per upper "
+                            f"level and sweep, one per sweep for the deepest {inf['tier_levels']} levels), no atomics"),
                     method="nested-dissection", iterations=0, converged=True, rel_residual=rel_res,
                     max_abs_err_vs_v=float((x - tv).abs().max()), assemble_ms=t_assemble * 1e3,
                     factor_seconds=getattr(solver, "build_seconds", None),
+                    factor_stages_seconds=dict(symbolic_host=tm["plan_seconds"], tables_host=tm["table_seconds"], numeric_device=tm["factor_seconds"]),
                     solve_bytes=solve_bytes, solve_gbs=solve_bytes / (ms * 1e-3) / 1e9,
                     solve_frac_of_8tbs=solve_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     kernel_us=dict(up_sweep=up_ms * 1e3, down_sweep=down_ms * 1e3, up_launches=n_up, down_launches=n_down),
                     device=torch.cuda.get_device_name(0)),
-        roofline=dict(bound="hbm", kernel=f"down sweep: k_nd_down_b<3> / k_nd_down<3>, {n_down} launches (x_s = Finv b'_s - W^T x_bnd per tree level)",
+        roofline=dict(bound="hbm", kernel=f"down sweep: k_nd_down_b<3> x {n_down - 1} + k_nd_tier<3, false> ({n_down} launches: x_s = Finv b'_s - W^T x_bnd "
+                                          f"per upper tree level, then the deepest {inf['tier_levels']} levels in one launch)",
                       achieved=down_gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=down_gbs / HBM_PEAK_GBS,
                       frac_of_achievable=down_gbs / HBM_ACHIEVABLE_GBS, bytes_per_launch=down_bytes / n_down,
                       avg_launch_us=down_ms * 1e3 / n_down, launches_timed=n_down * n_prof,
-                      traffic=pmc_traffic("ls::k_nd_down", args.workload),
-                      note="the sweeps are latency bound, not bandwidth bound: every tree level is one dependent launch "
-                           "(~8 us of launch + memory round trips), only the leaf levels stream enough bytes to matter"),
+                      traffic=pmc_traffic("ls::k_nd_", args.workload),
+                      note="latency bound, not bandwidth bound: every upper tree level is one dependent launch (~10 us of launch + "
+                           "dependent memory round trips), the tier kernels are bound by dependent round trips and instruction issue"),
     )
     if not args.no_cpu_baseline:
         base, x_oracle = cpu_baseline(v, f, cfg, u.cpu().numpy())
@@ -299,6 +359,8 @@ def report_direct(args, solver, M, u, x, tv, v, f, cfg, ms, t_assemble):
         # parity of the timed solve's result with the oracle's fp64 solution of the same system (tolerance: 1e-4 relative)
         out["config"]["max_abs_err_vs_oracle"] = float(np.abs(x.cpu().numpy() - x_oracle).max())
         out["config"]["max_abs_oracle"] = float(np.abs(x_oracle).max())
+        if not args.no_extra_baselines:
+            out["cpu_baseline"]["extra"] = extra_baselines(args)
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out), flush=True)
@@ -359,6 +421,7 @@ def main():
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--check-every", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-baselines", action="store_true", help="skip the B2 / B3 legs (reference CG on the host / in stock torch ops)")
     ap.add_argument("--pcg", action="store_true", help="time the Jacobi-PCG instead of the default (Chebyshev) solver")
     ap.add_argument("--iterative", action="store_true",
                     help="'Cholesky' through the Chebyshev-Jacobi iteration instead of the nested-dissection direct solver (A/B)")

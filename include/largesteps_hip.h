@@ -281,8 +281,10 @@ int ls_direct_create(const ls_direct_arrays* arrays, int device, void* stream, l
 int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, const float* d_val, int64_t V, int64_t nnz,
                      const float* d_positions, int leaf_size, int arity, int tier_levels, int sparse_leaves, int device,
                      void* stream, ls_direct** out);
-/* tree levels, arity, levels run by the tier kernels and their workgroup count (any pointer may be NULL) */
-int ls_direct_shape(const ls_direct* d, int* h_levels, int* h_arity, int* h_tier_levels, int* h_tier_workgroups);
+/* tree levels, arity, levels run by the tier kernels and their workgroup count, 4-byte words of factor data the up / the
+ * down sweep reads, total boundary entries (any pointer may be NULL) */
+int ls_direct_shape(const ls_direct* d, int* h_levels, int* h_arity, int* h_tier_levels, int* h_tier_workgroups,
+                    int64_t* h_words_up, int64_t* h_words_down, int64_t* h_n_bnd);
 /* seconds of the three constructor stages of a handle made by ls_direct_factor: symbolic analysis, layout tables, numeric */
 int ls_direct_factor_seconds(const ls_direct* d, double* h_s3);
 /* SYNC: *h_symmetric = 1 iff every stored entry (r, c, v) has a stored mirror (c, r, v') with |v - v'| <= tol */

@@ -827,7 +827,7 @@ struct ls_direct {
     std::vector<void*> owned;           // device arrays adopted from ls_direct_factor (freed with the handle)
     double factor_s[3] = {0, 0, 0};     // ls_direct_factor: symbolic analysis, layout / sparse tables, numeric factorisation
     std::vector<LevelPlan> plan;
-    int64_t factor_entries = 0;
+    int64_t factor_entries = 0, words_up = 0, words_down = 0;    // 4-byte words of factor data per solve / per sweep
     int profile = 0;
     std::vector<hipEvent_t> ev;
     double prof_ms[3] = {0, 0, 0};     // up sweep, down sweep, 0 (last profiled solve)
@@ -960,7 +960,7 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
     std::vector<NodeDesc> nodes((size_t)n_nodes + 1);
     std::vector<NodeD> nd((size_t)n_nodes + 1);
     memset(nd.data(), 0, nd.size() * sizeof(NodeD));
-    int64_t fe = 0;
+    int64_t fe = 0, fe_up = 0, fe_down = 0;
     for (int i = 1; i <= n_nodes; ++i) {
         const int64_t* r = h_nodes + (size_t)i * LS_DIRECT_NODE_COLS;
         NodeDesc& n = nodes[i];
@@ -975,12 +975,14 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
             set_error("ls_direct_create: node %d of the plan is inconsistent", i);
             return LS_E_INVALID;
         }
-        const int64_t s4 = (n.s + 3) & ~3, b4 = (n.b + 3) & ~3;
-        fe += sparse ? 2 * (((int64_t)n.s * (n.s + 1) / 2 + 3) & ~(int64_t)3)
-                     : quad ? s4 * n.b + (s4 + b4) * n.s : (int64_t)n.s * n.s + 2 * (int64_t)n.s * n.b;
+        const int64_t s4 = (n.s + 3) & ~3, b4 = (n.b + 3) & ~3, tri_w = ((int64_t)n.s * (n.s + 1) / 2 + 3) & ~(int64_t)3;
+        const int64_t up_w = sparse ? tri_w : quad ? s4 * n.b : (int64_t)n.s * n.b;
+        const int64_t down_w = sparse ? tri_w : quad ? (s4 + b4) * n.s : (int64_t)n.s * n.s + (int64_t)n.s * n.b;
+        fe += up_w + down_w; fe_up += up_w; fe_down += down_w;
     }
-    fe += 2 * A->n_sp_ent + A->n_sp_ptr;
-    d->factor_entries = fe;
+    fe += 2 * A->n_sp_ent + A->n_sp_ptr;        // each CSR list is read by one sweep (8-byte entries, 4-byte pointers)
+    fe_up += A->n_sp_ent + A->n_sp_ptr / 2; fe_down += A->n_sp_ent + A->n_sp_ptr - A->n_sp_ptr / 2;
+    d->factor_entries = fe; d->words_up = fe_up; d->words_down = fe_down;
     for (int lv = 0; lv < levels; ++lv)
         for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i) {
             const NodeDesc& n = nodes[i];
@@ -1316,8 +1318,12 @@ int ls_direct_adopt(ls_direct* d, void* const* owned, int n_owned, const double*
     return LS_OK;
 }
 
-extern "C" int ls_direct_shape(const ls_direct* d, int* h_levels, int* h_arity, int* h_tier_levels, int* h_tier_workgroups) {
+extern "C" int ls_direct_shape(const ls_direct* d, int* h_levels, int* h_arity, int* h_tier_levels, int* h_tier_workgroups,
+                               int64_t* h_words_up, int64_t* h_words_down, int64_t* h_n_bnd) {
     LS_REQUIRE(d, LS_E_INVALID, "ls_direct_shape: bad argument");
+    if (h_words_up) *h_words_up = d->words_up;
+    if (h_words_down) *h_words_down = d->words_down;
+    if (h_n_bnd) *h_n_bnd = d->n_bnd;
     if (h_levels) *h_levels = d->levels;
     if (h_arity) *h_arity = d->arity;
     if (h_tier_levels) *h_tier_levels = d->tier_phases;

@@ -562,7 +562,7 @@ def bench_sharded(workload, device, steps, warmup, shard="auto"):
     out = dict(V=v.shape[0], nnz=int(M._nnz()), ms_per_step=float(elapsed.item()) / steps * 1e3, err=float(err.item()), shard=shard)
     if shard == "replicas":
         out.update(iterations=0, converged=True, halo=0, method=local.method, depth=0, rows_per_rank=v.shape[0], replicas=world,
-                   solve_bytes=(int(world * 4 * local.plan.factor_entries) if local.method == "nested-dissection" else None),
+                   solve_bytes=(int(world * 4 * local.info()["factor_entries"]) if local.method == "nested-dissection" else None),
                    solver=f"{world} independent replicas of the single-GPU solver ({local.method}), one full system per rank, no communication")
         return out
     if shard == "columns":
@@ -573,7 +573,7 @@ def bench_sharded(workload, device, steps, warmup, shard="auto"):
         if local.method == "nested-dissection":
             what = (f"HIP nested-dissection direct solver (factor once per rank, {local.info()['launches']} launches per re-solve)")
             # every active rank reads the whole factor for its column(s)
-            out["solve_bytes"] = int(active * 4 * local.plan.factor_entries + 4 * k * 4 * v.shape[0])
+            out["solve_bytes"] = int(active * 4 * local.info()["factor_entries"] + 4 * k * 4 * v.shape[0])
         else:
             what = "HIP Chebyshev-Jacobi / Jacobi-PCG iteration"
             out["solve_bytes"] = None

@@ -284,9 +284,11 @@ class _NativeDirect:
         ms = (ctypes.c_double * 3)()
         _native.check(_native.lib().ls_direct_info(self._h, ctypes.byref(fe), ctypes.byref(nl), ms))
         lv, ar, th, tw = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
-        _native.check(_native.lib().ls_direct_shape(self._h, ctypes.byref(lv), ctypes.byref(ar), ctypes.byref(th), ctypes.byref(tw)))
+        wu, wd, nb = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        _native.check(_native.lib().ls_direct_shape(self._h, ctypes.byref(lv), ctypes.byref(ar), ctypes.byref(th), ctypes.byref(tw),
+                                                    ctypes.byref(wu), ctypes.byref(wd), ctypes.byref(nb)))
         return dict(factor_entries=fe.value, launches=nl.value, up_ms=ms[0], down_ms=ms[1], levels=lv.value, arity=ar.value,
-                    tier_levels=th.value, tier_workgroups=tw.value)
+                    tier_levels=th.value, tier_workgroups=tw.value, words_up=wu.value, words_down=wd.value, n_bnd=nb.value)
 
 
 class NestedDissectionSolver(Solver):
@@ -321,23 +323,16 @@ class NestedDissectionSolver(Solver):
         t0 = time.perf_counter()
         tier = max(0, min(6, int(os.environ.get("LS_ND_TIER_H", "3"))))
         sparse = not os.environ.get("LS_ND_DENSE_LEAVES")
-        if os.environ.get("LS_ND_PYTHON_FACTOR"):          # A/B: numpy plan + torch factorisation (the statement of the native code)
-            from . import direct
-            self._direct = direct.build(csr, leaf_size=leaf_size, arity=arity)
-            if self._direct is None:
-                raise ValueError("NestedDissectionSolver: the fronts exceed the solver's limits")
-        else:
-            while True:
-                try:
-                    self._direct = _NativeDirect(csr, leaf_size, arity, tier, sparse)
-                    break
-                except RuntimeError as e:      # a tier whose subtrees need more LDS than a workgroup has: one level less
-                    if tier == 0 or "does not fit" not in str(e):
-                        raise
-                    tier -= 1
+        while True:
+            try:
+                self._direct = _NativeDirect(csr, leaf_size, arity, tier, sparse)
+                break
+            except RuntimeError as e:      # a tier whose subtrees need more LDS than a workgroup has: one level less
+                if tier == 0 or "does not fit" not in str(e):
+                    raise
+                tier -= 1
         torch.cuda.synchronize(csr.device)
         self.build_seconds = time.perf_counter() - t0
-        self.plan = getattr(self._direct, "plan", None)
         self.timings = self._direct.timings
 
     def solve(self, b, backward=False):

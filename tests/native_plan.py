@@ -6,7 +6,7 @@ import ctypes
 import numpy as np
 
 from largesteps import _native
-from largesteps.nested import NDPlan
+from nd_plan_statement import NDPlan
 
 
 def native_plan(rowptr, col, positions, leaf_size=64, arity=4, smooth=4):

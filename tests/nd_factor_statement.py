@@ -1,6 +1,8 @@
 """
-Factor-once / re-solve direct solver on the MI355X: numeric multifrontal factorisation of a nested-dissection plan
-(largesteps/nested.py) and the handle of the native re-solve kernels (csrc/direct.hip, C ABI ls_direct_*).
+TEST CODE -- torch statement of the numeric factorisation the product does with hand-written kernels
+(csrc/nd_factor.hip), and a handle built from PYTHON arrays through ls_direct_create (the array-level entry of the C ABI):
+numeric multifrontal factorisation of a nested-dissection plan (tests/nd_plan_statement.py) in the layouts of the native
+re-solve kernels (csrc/direct.hip, csrc/nd_tier.h).
 
 Replaces: largesteps/solvers.py:26-39 of the reference (CholeskySolver: cholespy / CHOLMOD factorisation in the
 constructor, two triangular solves per call). Here the constructor
@@ -17,8 +19,8 @@ import os
 import numpy as np
 import torch
 
-from . import _native
-from .nested import NDPlan, _row_index, graph_embedding
+from largesteps import _native
+from nd_plan_statement import NDPlan, _row_index, graph_embedding
 
 
 def _level_tables(plan, lv):

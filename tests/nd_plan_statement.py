@@ -1,6 +1,6 @@
 """
-Nested-dissection plan of the factor-once / re-solve direct solver (csrc/direct.hip) -- host-side symbolic analysis,
-numpy only. This is the MI355X answer to the reference's default method (solvers.py:26-39: cholespy / CHOLMOD
+TEST CODE -- numpy statement of the symbolic analysis the product does in C++ (csrc/nd_plan.cpp): nested-dissection plan
+of the factor-once / re-solve direct solver (csrc/direct.hip). This is the MI355X answer to the reference's default method (solvers.py:26-39: cholespy / CHOLMOD
 factorisation, then two sparse triangular solves per call).
 
 Why not a level-scheduled sparse triangular solve: its dependency chains are thousands of levels long on a mesh. A

@@ -7,7 +7,7 @@ never imports this module.
 """
 import numpy as np
 
-from largesteps.nested import _row_index
+from nd_plan_statement import _row_index
 
 
 # ---- nested-dissection direct solver: numeric factorisation and the two sweeps (dense per node) ----------------

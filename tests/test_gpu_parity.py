@@ -384,6 +384,66 @@ def test_direct_solver_all_golden_meshes(golden, dev, name, case):
     assert np.abs(x - x64).max() <= tol * max(np.abs(x64).max(), 1e-30)
 
 
+@pytest.mark.parametrize("name", ["octahedron", "tetra", "quad", "unreferenced", "nonmanifold", "ico3", "plane12", "ico6"])
+def test_factor_and_solve_through_the_c_abi_only(golden, dev, name):
+    """What a non-Python consumer of liblargesteps_hip.so does (SURVEY 8c G1-G7 meshes): CSR in, ls_direct_factor, ls_direct_solve,
+    ls_direct_destroy -- raw ctypes calls, no solver class, and none of the Python statements of the plan / factorisation loaded."""
+    import ctypes
+    import sys
+    from largesteps import _native
+    from largesteps.geometry import compute_matrix
+    v, f = golden[f"{name}/verts"], golden[f"{name}/faces"]
+    M = compute_matrix(_t(v, dev), _t(f, dev), **golden.params["uni_l10"])
+    idx, val = M.indices().cpu().numpy(), M.values().cpu().numpy()
+    csr = _native.csr_of(M)
+    lib = _native.lib()
+    V = v.shape[0]
+    b = _t(np.random.default_rng(3).standard_normal((V, 3)).astype(np.float32), dev)
+    x = torch.empty_like(b)
+    for positions in (_t(v, dev).contiguous(), None):              # with vertex positions, and with the graph-distance embedding
+        h = ctypes.c_void_p()
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        rc = lib.ls_direct_factor(ctypes.c_void_p(csr.rowptr.data_ptr()), ctypes.c_void_p(csr.col.data_ptr()), ctypes.c_void_p(csr.val.data_ptr()),
+                                  V, csr.nnz, ctypes.c_void_p(positions.data_ptr()) if positions is not None else None, 64, 4, 3, 1,
+                                  dev.index, st, ctypes.byref(h))
+        assert rc == 0, _native.last_error()
+        assert lib.ls_direct_solve(h, ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(x.data_ptr()), 3, st) == 0, _native.last_error()
+        torch.cuda.synchronize()
+        x64 = osv.from_differential(idx[0], idx[1], val, b.cpu().numpy())
+        assert np.abs(x.cpu().numpy() - x64).max() <= 2e-5 * np.abs(x64).max()
+        assert lib.ls_direct_destroy(h) == 0
+    assert not any(m in sys.modules for m in ("largesteps.nested", "largesteps.direct"))
+    # a matrix that is not positive definite is refused by the factorisation, not solved wrongly
+    bad = csr.val.clone()
+    bad[csr.rowptr[:-1].long()] = -1.0                              # first stored entry of every row
+    h = ctypes.c_void_p()
+    rc = lib.ls_direct_factor(ctypes.c_void_p(csr.rowptr.data_ptr()), ctypes.c_void_p(csr.col.data_ptr()), ctypes.c_void_p(bad.data_ptr()), V,
+                              csr.nnz, None, 64, 4, 3, 1, dev.index, st, ctypes.byref(h))
+    assert rc != 0 and not h.value
+
+
+def test_python_array_handle_matches_native_factorisation(dev):
+    """ls_direct_create (plan and factor handed over as arrays: here the numpy plan + torch factorisation STATEMENTS of
+    tests/) and ls_direct_factor (everything native) solve the same system to the same accuracy."""
+    import nd_factor_statement
+    from largesteps import _native, synthetic
+    from largesteps.geometry import compute_matrix
+    from largesteps.solvers import NestedDissectionSolver
+    v, f = synthetic.icosphere(24)
+    v = synthetic.perturb(v, radial=0.05, tangential=0.1, edge=0.05, seed=4)
+    M = compute_matrix(_t(v, dev), _t(f, dev), 0.0, alpha=0.9, cotan=True)
+    idx, val = M.indices().cpu().numpy(), M.values().cpu().numpy()
+    b = np.random.default_rng(2).standard_normal((v.shape[0], 3)).astype(np.float32)
+    x64 = osv.from_differential(idx[0], idx[1], val, b)
+    native = NestedDissectionSolver(M).solve(_t(b, dev)).cpu().numpy()
+    for sparse in (True, False):
+        h = nd_factor_statement.build(_native.csr_of(M), sparse_leaves=sparse)
+        x = torch.empty_like(_t(b, dev))
+        h.solve(_t(b, dev), x)
+        assert np.abs(x.cpu().numpy() - x64).max() <= 2e-5 * np.abs(x64).max()
+        assert np.abs(x.cpu().numpy() - native).max() <= 2e-5 * np.abs(x64).max()
+
+
 @pytest.mark.parametrize("k", [1, 2, 3, 4, 7])
 @pytest.mark.parametrize("leaf,arity", [(8, 2), (8, 4), (64, 4), (16, 8)])
 def test_direct_solver_widths_and_trees(dev, k, leaf, arity):

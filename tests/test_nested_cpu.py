@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from largesteps import synthetic
-from largesteps.nested import NDPlan
+from nd_plan_statement import NDPlan
 from statements import nd_factor, nd_solve
 from oracle import laplacian as ol
 from oracle import solve as osv
@@ -119,7 +119,7 @@ def test_numpy_statement_vs_oracle(name, kw, arity):
 def test_torch_factorisation_matches_statement(name, kw, arity):
     """largesteps.direct.factorize (what runs on the MI355X, here on CPU tensors): padded level batches, extend-add by
     index arithmetic, packing into the three flat fp32 arrays of the C ABI."""
-    from largesteps.direct import factorize
+    from nd_factor_statement import factorize
     v, f = MESHES[name]()
     r, rowptr, c, val = csr_of(v, f, **kw)
     p = NDPlan.build(rowptr, c, v, leaf_size=10, arity=arity)
@@ -149,7 +149,7 @@ def test_sparse_leaf_format(name, kw, arity):
     """Leaves in the tier kernel's format (csrc/nd_tier.h): one packed triangle of F_ss^-1 and the matrix block A_bs as
     two CSR lists. The tables must reproduce the dense statement: tri == tril(Finv), A_bs Finv == W, and the sweeps
     written with them (y = Finv b, upd = A_bs y; x = y - Finv A_sb x_bnd) give the dense sweeps' result."""
-    from largesteps.direct import factorize
+    from nd_factor_statement import factorize
     v, f = MESHES[name]()
     r, rowptr, c, val = csr_of(v, f, **kw)
     p = NDPlan.build(rowptr, c, v, leaf_size=10, arity=arity)
@@ -224,7 +224,7 @@ def test_smoothed_positions_give_thin_separators():
 def test_graph_embedding_replaces_positions():
     """No positions (a matrix built elsewhere): graph distances from three far landmarks order the vertices well enough
     for thin separators; disconnected components and isolated vertices are laid out side by side."""
-    from largesteps.nested import graph_embedding
+    from nd_plan_statement import graph_embedding
     v, f = synthetic.plane(60)
     r, rowptr, c, val = csr_of(v, f, lambda_=5.0)
     pos = graph_embedding(rowptr, c, v.shape[0])
@@ -254,7 +254,7 @@ def test_graph_embedding_replaces_positions():
 def test_extreme_meshes(shape):
     """A hub of valence 3000 and a 2 x 6000 strip: the separators stay tiny (the hub itself / two vertices), with the
     real positions and with graph-distance pseudo-positions."""
-    from largesteps.nested import graph_embedding
+    from nd_plan_statement import graph_embedding
     if shape == "fan":
         n = 3000
         ang = np.linspace(0, 2 * np.pi, n, endpoint=False)

@@ -1,0 +1,24 @@
+#!/bin/bash
+# full GPU pass (round 2): parity tests, smoke, bench (direct solver; iterative and PCG A/B), rocprofv3 kernel stats + per-level
+# trace + FETCH_SIZE / WRITE_SIZE passes of the bench command, constructor profile
+set -u
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/full2; rm -rf $O; mkdir -p $O/pmc
+export TMPDIR=/tmp
+( timeout 1500 python -m pytest tests -m gpu -q --timeout 900 2>&1 | tail -30 ) > $O/pytest.log 2>&1
+( timeout 200 python -c "import __graft_entry__ as g; g.smoke()" ) > $O/smoke.log 2>&1
+( timeout 600 python bench.py --steps 50 --warmup 3 ) > $O/bench.json 2> $O/bench.err
+( timeout 400 python bench.py --steps 20 --warmup 3 --iterative --no-cpu-baseline ) > $O/bench_iterative.json 2> $O/bench_iterative.err
+( timeout 400 python bench.py --steps 20 --warmup 3 --pcg --no-cpu-baseline ) > $O/bench_pcg.json 2> $O/bench_pcg.err
+for w in cfg2_bunny70k cfg3_dragon250k cfg5_plane4m; do ( timeout 400 python bench.py --steps 50 --warmup 3 --workload $w --no-extra-baselines $( [ $w = cfg5_plane4m ] && echo --no-cpu-baseline ) ) > $O/bench_$w.json 2> $O/bench_$w.err; done
+( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 2 --no-cpu-baseline ) > $O/rocprof.log 2>&1
+for C in FETCH_SIZE WRITE_SIZE; do
+  ( cd /tmp && timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc/bench_$C -o out -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline ) > $O/pmc/bench_$C.log 2>&1
+done
+python tools/pmc_summary.py $O/pmc/bench_FETCH_SIZE $O/pmc/bench_WRITE_SIZE cfg4_plane1m $O/pmc_traffic.json > $O/pmc_summary.log 2>&1
+python tools/nd_trace.py $(find $O/prof -name "*kernel_trace.csv" | head -1) > $O/nd_levels.txt 2>&1
+cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
+rm -rf $O/prof; find $O/pmc -name "*.csv" -size +1M -delete
+tail -4 $O/pytest.log; tail -2 $O/smoke.log; cat $O/bench.json; for w in cfg2_bunny70k cfg3_dragon250k cfg5_plane4m; do cut -c1-300 $O/bench_$w.json; echo; done
+cut -c1-300 $O/bench_iterative.json; echo; cut -c1-300 $O/bench_pcg.json; echo; tail -3 $O/bench.err
+head -12 $O/kernel_stats.csv | cut -c1-160; cat $O/pmc_summary.log | head -30; cat $O/nd_levels.txt
