@@ -10,11 +10,11 @@ One "step" = one from_differential solve  M x = u  (M = I + 50 L_uniform of the 
 k = 3 right-hand sides, cold start x0 = 0, stop at ||r|| <= 1e-6 ||b|| per column), inputs resident in HBM.
 N = 1: the public API path (largesteps.parameterize.from_differential -> CholeskySolver -> C ABI: ls_direct_factor once,
        ls_direct_solve per step -- the nested-dissection direct solver; --iterative / --pcg time the iterative paths).
-N > 1 (one rank per GPU, RCCL; largesteps.distributed), strong scaling (total work fixed), two modes (--shard):
-  columns (default): the 3 right-hand-side columns are independent systems -> rank r solves column r on its GPU with
-                     the single-GPU kernels, one all-gather of the solution per solve, nothing per iteration;
-  vertex           : N contiguous vertex blocks, Chebyshev with depth-s ghost layers (a neighbour exchange every s
-                     iterations) -- the mode for meshes that do not fit one GPU; at 1M vertices it cannot beat 1 GPU.
+N > 1 (one rank per GPU, RCCL; largesteps.distributed), strong scaling (total work fixed), modes (--shard):
+  vertex (default) : vertex blocks = subtrees of the direct solver's elimination tree: rank r runs its share of the subtrees
+                     below the cut level, every rank the few levels above it; ONE all-reduce (sum) of a few hundred KB per solve;
+  columns          : the 3 right-hand-side columns are independent systems -> rank r solves column r, one all-gather per solve;
+  halo             : N contiguous vertex blocks of the Chebyshev / PCG iteration with ghost layers (neighbour exchanges);
   replicas         : every rank solves its own copy of the system (independent meshes), weak scaling, no communication.
 
 Prints ONE JSON line on rank 0 (contract: see the task description): metric/value/unit/... plus
@@ -425,9 +425,9 @@ def main():
     ap.add_argument("--pcg", action="store_true", help="time the Jacobi-PCG instead of the default (Chebyshev) solver")
     ap.add_argument("--iterative", action="store_true",
                     help="'Cholesky' through the Chebyshev-Jacobi iteration instead of the nested-dissection direct solver (A/B)")
-    ap.add_argument("--shard", default="auto", choices=["auto", "columns", "vertex", "replicas"],
-                    help="N > 1: right-hand-side columns across ranks (default; no per-iteration communication), vertex blocks, "
-                         "or independent replicas (one whole system per rank: weak scaling)")
+    ap.add_argument("--shard", default="auto", choices=["auto", "vertex", "columns", "halo", "replicas"],
+                    help="N > 1: vertex blocks = subtrees of the direct solver's elimination tree (default), right-hand-side columns across "
+                         "ranks, vertex blocks of the iteration with halo exchange, or independent replicas (weak scaling)")
     args = ap.parse_args()
     if args.iterative:
         os.environ["LARGESTEPS_NO_DIRECT"] = "1"

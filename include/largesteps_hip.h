@@ -268,6 +268,7 @@ typedef struct ls_direct_arrays {
     const int32_t* d_sp_ptr;
     const void* d_sp_ent;          /* {float value; int32 index} pairs */
     int64_t n_sp_ptr, n_sp_ent;    /* lengths of the two sparse-leaf arrays (accounting only) */
+    int32_t shard_rank, shard_count;   /* subtree sharding over `shard_count` processes (0 or 1: none), see ls_direct_solve_part */
 } ls_direct_arrays;
 int ls_direct_create(const ls_direct_arrays* arrays, int device, void* stream, ls_direct** out);
 /* Matrix in, solver out: symbolic analysis (host threads), numeric multifrontal factorisation in fp64 on the device with
@@ -276,11 +277,12 @@ int ls_direct_create(const ls_direct_arrays* arrays, int device, void* stream, l
  * d_rowptr / d_col / d_val: CSR of the symmetric positive definite matrix (DEVICE, original numbering, column-sorted rows);
  * d_positions: (V, 3) fp32 vertex positions (DEVICE) or NULL (graph-distance pseudo-positions); leaf_size 64 and arity 4 are
  * the tuned defaults; tier_levels deepest levels go into the tier layouts (3; 0 = none), sparse_leaves != 0 stores the leaves
- * as packed triangle + sparse block. SYNC. Errors: LS_E_INVALID (not symmetric / not positive definite / bad arguments),
+ * as packed triangle + sparse block; shard_rank / shard_count: subtree sharding (0 / 1: none; every rank factorises the whole
+ * matrix, the re-solve is sharded, see ls_direct_solve_part). SYNC. Errors: LS_E_INVALID (not symmetric / not positive definite / bad arguments),
  * LS_E_WORKSPACE (fronts or factor beyond the solver's limits, or the tier does not fit LDS: retry with fewer tier_levels). */
 int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, const float* d_val, int64_t V, int64_t nnz,
-                     const float* d_positions, int leaf_size, int arity, int tier_levels, int sparse_leaves, int device,
-                     void* stream, ls_direct** out);
+                     const float* d_positions, int leaf_size, int arity, int tier_levels, int sparse_leaves, int shard_rank,
+                     int shard_count, int device, void* stream, ls_direct** out);
 /* tree levels, arity, levels run by the tier kernels and their workgroup count, 4-byte words of factor data the up / the
  * down sweep reads, total boundary entries (any pointer may be NULL) */
 int ls_direct_shape(const ls_direct* d, int* h_levels, int* h_arity, int* h_tier_levels, int* h_tier_workgroups,
@@ -293,6 +295,19 @@ int ls_csr_is_symmetric(const int32_t* d_rowptr, const int32_t* d_col, const flo
 int ls_direct_destroy(ls_direct* d);
 /* x = M^-1 b for k <= 4 interleaved columns ((V, k) row-major, b != x) */
 int ls_direct_solve(ls_direct* d, const float* b, float* x, int k, void* stream);
+/* Subtree sharding, one process per GPU (largesteps/distributed.py ShardedDirect): a handle created with shard_count = N > 1
+ * runs the subtrees of the first tree level that has >= N of them ("cut" level; rank r takes a contiguous share) and,
+ * replicated on every rank, the levels above the cut. One solve =
+ *     part 0   this rank's subtrees upwards; their updates for level cut - 1 land in `exchange` (floats_per_column x k floats,
+ *              zero where another rank's subtree contributes)
+ *     the caller SUMS `exchange` over the ranks (one all-reduce of a few hundred KB; every entry has exactly one non-zero
+ *     contributor, so the sum is exact and order independent)
+ *     part 1   the replicated levels up and down, then this rank's subtrees downwards: x rows of the rank's subtrees and of
+ *              the replicated levels are written, other rows of x are left untouched.
+ * h_owned_rows (V bytes, may be NULL): 1 where this rank is the designated owner of the row (replicated levels: rank 0). */
+int ls_direct_solve_part(ls_direct* d, const float* b, float* x, int k, int part, float* exchange, void* stream);
+int ls_direct_shard_info(const ls_direct* d, int* h_rank, int* h_count, int* h_cut_level, int64_t* h_exchange_floats_per_column,
+                         unsigned char* h_owned_rows);
 /* knobs: "profile" (1: the next solves time the up sweep and the down sweep with HIP events and synchronise; 2: the
  * tier kernels also record shader-clock stamps per wave, read back by ls_direct_tier_stamps) */
 int ls_direct_set(ls_direct* d, const char* name, int value);

@@ -819,12 +819,18 @@ struct ls_direct {
     // bottom tier: levels [tier_root, levels) run as one launch per sweep, one workgroup per subtree (nd_tier.h)
     int tier_root = 0, tier_phases = 0, tier_wgs = 0, tier_region = 0, tier_vec = 0, tier_tri = 0;
     TierItem* d_items = nullptr;
+    int* pull = nullptr;                // tier up sweep: (front position, child) -> child boundary entry (n_front x arity)
     TierWG* d_wgs = nullptr;
     long long* dbg = nullptr;           // profile = 2: per-wave clock stamps of the tier kernels (2 x tier_wgs x TIER_WAVES x 32)
     hipEvent_t busy = nullptr;          // recorded after every solve: a solve on another stream waits for it (one workspace)
     hipStream_t last_stream = nullptr;
     bool used = false;
     std::vector<void*> owned;           // device arrays adopted from ls_direct_factor (freed with the handle)
+    // subtree sharding (one process per GPU): this handle runs the subtrees [sub_lo, sub_hi) of level `cut` and, replicated on
+    // every rank, the levels above; the ranks meet once per solve in a sum over the slots of level cut - 1 (exch_f0 .. exch_f1)
+    int shard_rank = 0, shard_count = 1, cut = 0;
+    int64_t exch_f0 = 0, exch_f1 = 0;
+    std::vector<unsigned char> owned_rows;    // caller's numbering: 1 = this rank is the designated owner of the row's x
     double factor_s[3] = {0, 0, 0};     // ls_direct_factor: symbolic analysis, layout / sparse tables, numeric factorisation
     std::vector<LevelPlan> plan;
     int64_t factor_entries = 0, words_up = 0, words_down = 0;    // 4-byte words of factor data per solve / per sweep
@@ -850,17 +856,16 @@ static int env_int0(const char* name, int dflt) { const char* e = getenv(name); 
 
 // Bottom tier (nd_tier.h): cut the subtrees rooted at level `root` into wave-sized items. Returns the LDS floats a wave
 // needs (0 = the tier does not fit), fills items / wgs.
-static size_t plan_tier(const std::vector<NodeD>& nd, const std::vector<int64_t>& level_off, int levels, int arity, int root,
-                        std::vector<TierItem>& items, std::vector<TierWG>& wgs, int& vec_floats, int& tri_floats) {
+static size_t plan_tier(const std::vector<NodeD>& nd, const std::vector<int64_t>& level_off, int levels, int arity, int root, int64_t q_lo,
+                        int64_t q_hi, std::vector<TierItem>& items, std::vector<TierWG>& wgs, int& vec_floats, int& tri_floats) {
     const int H = levels - root;
-    const int64_t n_wg = level_off[root + 1] - level_off[root];
-    items.clear(); wgs.assign((size_t)n_wg, TierWG());
+    items.clear(); wgs.assign((size_t)(q_hi - q_lo), TierWG());
     int vec_need = 0, pbuf_need = 0, leaf_need = 0, tri_cap = 0;
     for (int64_t i = level_off[levels - 1]; i < level_off[levels]; ++i)
         if (nd[i].flags & NODE_SPARSE) tri_cap = std::max(tri_cap, (nd[i].s * (nd[i].s + 1) / 2 + 3) & ~3);
     tri_floats = tri_cap;
-    for (int64_t q = 0; q < n_wg; ++q) {
-        TierWG& g = wgs[(size_t)q];
+    for (int64_t q = q_lo; q < q_hi; ++q) {
+        TierWG& g = wgs[(size_t)(q - q_lo)];
         g.up_split = g.down_split = g.up_leaf = g.down_leaf = 0;
         g.n_dense = 0; g.pad = 0;
         for (int t = 0; t < 2 * TIER_MAX_H; ++t) g.dense_rng[t] = 0;
@@ -897,7 +902,7 @@ static size_t plan_tier(const std::vector<NodeD>& nd, const std::vector<int64_t>
                     TierItem it;
                     memset(&it, 0, sizeof(it));
                     it.s = n.s; it.b = n.b; it.own_start = n.own_start; it.bnd_off = n.bnd_off; it.front_off = n.front_off;
-                    it.pfront_off = n.pfront_off; it.cix = n.cix; it.flags = n.flags; it.finv_off = n.finv_off; it.w_off = n.w_off;
+                    it.pfront_off = n.pfront_off; it.cix = n.cix; it.flags = n.flags | (lv > root ? NODE_UPC : 0); it.finv_off = n.finv_off; it.w_off = n.w_off;
                     it.spb_off = n.spb_off; it.sps_off = n.sps_off; it.nparts = 1;
                     if (n.flags & NODE_SPARSE) {
                         items.push_back(it);
@@ -957,6 +962,20 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
     d->finv = A->d_finv; d->wf = A->d_wf; d->wb = A->d_wb;
     d->u4 = A->d_u4; d->d4 = A->d_d4;
     d->tri = A->d_tri; d->sp_ptr = A->d_sp_ptr; d->sp_ent = (const SpEnt*)A->d_sp_ent;
+    // subtree sharding: the cut level is the first one with at least `count` subtrees; rank r takes a contiguous share of them
+    const int n_ranks = std::max(1, (int)A->shard_count), rank = std::min(std::max(0, (int)A->shard_rank), n_ranks - 1);
+    int cut = 0;
+    while (cut + 1 < levels && level_off[cut + 1] - level_off[cut] < n_ranks) ++cut;
+    if (n_ranks == 1) cut = 0;
+    const int64_t n_sub = level_off[cut + 1] - level_off[cut];
+    const int64_t sub_lo = n_sub * rank / n_ranks, sub_hi = n_sub * (rank + 1) / n_ranks;
+    auto active = [&](int64_t i, int lv) -> bool {
+        if (lv < cut) return true;
+        int64_t q = i - level_off[lv];
+        for (int t = cut; t < lv; ++t) q /= arity;
+        return q >= sub_lo && q < sub_hi;
+    };
+    d->shard_rank = rank; d->shard_count = n_ranks; d->cut = cut;
     std::vector<NodeDesc> nodes((size_t)n_nodes + 1);
     std::vector<NodeD> nd((size_t)n_nodes + 1);
     memset(nd.data(), 0, nd.size() * sizeof(NodeD));
@@ -1035,7 +1054,10 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
         d->tier_root = levels;
         if (root < levels) {
             const int H = levels - root;
-            size_t region = H <= TIER_MAX_H ? plan_tier(nd, level_off, levels, arity, root, items, wgs, d->tier_vec, d->tier_tri) : 0;
+            if (cut > root) { delete d; set_error("ls_direct_create: %d ranks need a cut below the tier's root level (tree too small)", n_ranks); return LS_E_INVALID; }
+            int64_t span = 1;
+            for (int t = cut; t < root; ++t) span *= arity;
+            size_t region = H <= TIER_MAX_H ? plan_tier(nd, level_off, levels, arity, root, sub_lo * span, sub_hi * span, items, wgs, d->tier_vec, d->tier_tri) : 0;
             if (!region || region * sizeof(float) * TIER_WAVES > 150 * 1024) {
                 delete d;
                 set_error("ls_direct_create: a tier of %d levels does not fit the kernel (LDS per wave: %zu floats)", H, region);
@@ -1043,6 +1065,17 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
             }
             d->tier_root = root; d->tier_phases = H; d->tier_wgs = (int)wgs.size(); d->tier_region = (int)((region + 3) & ~(size_t)3);
         }
+    }
+    std::vector<int> pull;
+    if (d->tier_root < levels) {
+        pull.assign((size_t)n_front * arity, -1);
+        for (int lv = d->tier_root + 1; lv < levels; ++lv)
+            for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i) {
+                const NodeDesc& n = nodes[i];
+                const int cix = (int)((i - level_off[lv]) % arity);
+                const int64_t pf = nodes[n.parent].front_off;
+                for (int k = 0; k < n.b; ++k) pull[(size_t)(pf + h_ppos[n.bnd_off + k]) * arity + cix] = n.bnd_off + k;
+            }
     }
     // tiles of the upper levels: a range of rows of one node each
     std::vector<Tile> tiles;
@@ -1063,8 +1096,11 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
     const int long_up = env_int("LS_ND_LONG_UP", long_red);     // up sweep (reduction s)
     for (int lv = 0; lv < d->tier_root; ++lv) {
         LevelPlan& p = d->plan[lv];
+        // this rank's nodes of the level: one contiguous range (all of them above the cut)
+        int64_t a0 = level_off[lv], a1 = level_off[lv + 1];
+        if (lv >= cut) { int64_t span = 1; for (int t = cut; t < lv; ++t) span *= arity; a0 = level_off[lv] + sub_lo * span; a1 = level_off[lv] + sub_hi * span; }
         int red_up = 0, red_down = 0;
-        for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i) {
+        for (int64_t i = a0; i < a1; ++i) {
             p.s_cap = std::max(p.s_cap, nodes[i].s); p.b_cap = std::max(p.b_cap, nodes[i].b);
             red_up = std::max(red_up, nodes[i].s); red_down = std::max(red_down, nodes[i].s + nodes[i].b);
         }
@@ -1097,13 +1133,13 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
         auto pack_level = [&](bool up_sweep, int& first, int& count, int& lds_rows_s, int& lds_rows_b) {
             first = (int)ptiles.size();
             lds_rows_s = lds_rows_b = 0;
-            int64_t i = level_off[lv];
-            while (i < level_off[lv + 1]) {
+            int64_t i = a0;
+            while (i < a1) {
                 PackedTile t;
                 memset(&t, 0, sizeof(t));
                 t.leaf = lv + 1 >= levels; t.arity = arity;
                 int rows = 0;
-                while (i < level_off[lv + 1] && t.n < ND_PACK) {
+                while (i < a1 && t.n < ND_PACK) {
                     const NodeDesc& nd = nodes[i];
                     const int r = up_sweep ? nd.b : nd.s;
                     if (t.n && rows + r > WAVE) break;
@@ -1127,7 +1163,7 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
         if (p.down_p) { pack_level(false, p.down_p_first, p.down_p_tiles, p.down_p_s, p.down_p_lds); p.down_s = 0; p.down_b = 0; }
         p.up_first = (int)tiles.size();
         const int up_threads = WAVE * p.up_nw;
-        for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i) {
+        for (int64_t i = a0; i < a1; ++i) {
             // b' of the own rows is kept for the down sweep: by the first compute tile (small nodes, or nodes whose only
             // tile exists for that purpose), or by store-only tiles of blockDim rows each (large nodes: the one tile
             // would walk s / blockDim dependent load chains)
@@ -1142,10 +1178,10 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
         }
         p.up_tiles = (int)tiles.size() - p.up_first;
         p.down_first = (int)tiles.size();
-        for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i)
+        for (int64_t i = a0; i < a1; ++i)
             for (int r = 0; r < nodes[i].s; r += (p.down_s ? 1 << 30 : down_rows)) tiles.push_back(tile_of(i, r, lv, 0));
         if (lv + 1 < levels)      // forward tiles: boundary rows of every node (staged kernel: only of nodes without own rows)
-            for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i)
+            for (int64_t i = a0; i < a1; ++i)
                 if (!p.down_s || !nodes[i].s)
                     for (int r = 0; r < nodes[i].b; r += WAVE * p.down_nw) tiles.push_back(tile_of(i, r, lv, 1));
         p.down_tiles = (int)tiles.size() - p.down_first;
@@ -1155,6 +1191,17 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
         delete d;
         set_error("ls_direct_create: a front needs %zu bytes of LDS (separator too large for this kernel)", lds_max);
         return LS_E_INVALID;
+    }
+    if (n_ranks > 1 && cut >= 1) {
+        d->exch_f0 = nodes[level_off[cut - 1]].front_off;
+        d->exch_f1 = nodes[level_off[cut]].front_off;
+    }
+    if (n_ranks > 1) {        // designated owner of every row of x: the rank that runs the row's subtree, rank 0 for the replicated levels
+        d->owned_rows.assign((size_t)V, 0);
+        for (int lv = 0; lv < levels; ++lv)
+            for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i)
+                if (lv < cut ? rank == 0 : active(i, lv))
+                    for (int r = 0; r < nodes[i].s; ++r) d->owned_rows[(size_t)h_perm[nodes[i].own_start + r]] = 1;
     }
     int rc = LS_OK;
     auto up = [&](auto** dst, const auto* src, size_t n) -> int {
@@ -1166,7 +1213,7 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
         !(rc = up(&d->perm, h_perm, (size_t)V)) &&
         !(rc = up(&d->ppos, h_ppos, (size_t)n_bnd)) && !(rc = up(&d->push_ptr, h_push_ptr, (size_t)n_front + 1)) &&
         !(rc = up(&d->push_tgt, h_push_tgt, (size_t)n_bnd)) && !(rc = up(&d->mask, mask.data(), mask.size())) &&
-        !(rc = up(&d->d_items, items.data(), items.size())) &&
+        !(rc = up(&d->d_items, items.data(), items.size())) && !(rc = up(&d->pull, pull.data(), pull.size())) &&
         !(rc = up(&d->d_wgs, wgs.data(), wgs.size()))) {
         hipError_t e = hipMalloc((void**)&d->bp, sizeof(float) * (size_t)V * d->kmax);
         if (e == hipSuccess) e = hipMalloc((void**)&d->braw, sizeof(float) * (size_t)V * d->kmax);
@@ -1201,7 +1248,7 @@ extern "C" int ls_direct_destroy(ls_direct* d) {
     DeviceGuard g(d->device);
     (void)hipFree(d->tiles); (void)hipFree(d->ptiles); (void)hipFree(d->perm); (void)hipFree(d->ppos); (void)hipFree(d->push_ptr); (void)hipFree(d->push_tgt);
     (void)hipFree(d->mask); (void)hipFree(d->bp); (void)hipFree(d->braw); (void)hipFree(d->slots); (void)hipFree(d->xb);
-    (void)hipFree(d->d_items); (void)hipFree(d->d_wgs); (void)hipFree(d->dbg);
+    (void)hipFree(d->d_items); (void)hipFree(d->d_wgs); (void)hipFree(d->dbg); (void)hipFree(d->pull);
     if (d->busy) (void)hipEventDestroy(d->busy);
     for (void* p : d->owned) (void)hipFree(p);
     for (hipEvent_t e : d->ev) (void)hipEventDestroy(e);
@@ -1209,21 +1256,28 @@ extern "C" int ls_direct_destroy(ls_direct* d) {
     return LS_OK;
 }
 
+// part: -1 the whole solve; sharded handles: 0 = this rank's subtrees upwards, level cut - 1's slots -> exchange buffer;
+//       1 = exchange buffer (summed over the ranks by the caller) -> slots, the replicated levels, everything downwards
 template <int K>
-static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st) {
+static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st, int part, float* exchange) {
     const int top = d->tier_root - 1;            // levels [0, tier_root) are one launch each, the rest is the bottom tier
     TierArgs ta;
     ta.items = d->d_items; ta.wgs = d->d_wgs; ta.perm = d->perm; ta.mask = d->mask; ta.ppos = d->ppos;
-    ta.push_ptr = d->push_ptr; ta.push_tgt = d->push_tgt; ta.u4 = d->u4; ta.d4 = d->d4; ta.tri = d->tri;
+    ta.pull = d->pull; ta.push_ptr = d->push_ptr; ta.push_tgt = d->push_tgt; ta.u4 = d->u4; ta.d4 = d->d4; ta.tri = d->tri;
     ta.sp_ptr = d->sp_ptr; ta.sp_ent = d->sp_ent; ta.bprime = d->bp; ta.braw = d->braw; ta.slots = d->slots; ta.xb = d->xb;
     ta.arity = d->arity; ta.phases = d->tier_phases; ta.region_floats = d->tier_region; ta.vec_floats = d->tier_vec;
     ta.dbg = d->profile == 2 ? d->dbg : nullptr;
     ta.ablate = env_int0("LS_ND_ABLATE", 0);
     const size_t tier_lds = (size_t)d->tier_region * TIER_WAVES * sizeof(float);
+    const size_t exch_off = (size_t)d->exch_f0 * d->arity * K, exch_n = (size_t)(d->exch_f1 - d->exch_f0) * d->arity * K;
+    if (part != 1) {
     if (d->profile) LS_HIP(hipEventRecord(d->ev[0], st));
+    if (part == 0 && exch_n) LS_HIP(hipMemsetAsync(d->slots + exch_off, 0, exch_n * sizeof(float), st));
     if (d->tier_wgs)
         hipLaunchKernelGGL((k_nd_tier<K, true>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
-    for (int lv = top; lv >= 0; --lv) {
+    }
+    if (part == 1 && exch_n) LS_HIP(hipMemcpyAsync(d->slots + exch_off, exchange, exch_n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    for (int lv = (part == 1 ? std::min(top, d->cut - 1) : top); lv >= (part == 0 ? d->cut : 0); --lv) {
         const LevelPlan& p = d->plan[lv];
         if (!(p.up_p ? p.up_p_tiles : p.up_tiles)) continue;
         if (p.up_p)
@@ -1238,6 +1292,11 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
         else
             hipLaunchKernelGGL(k_nd_up<K>, dim3(p.up_tiles), dim3(WAVE * p.up_nw), ((size_t)p.s_cap + (size_t)(p.up_nw - 1) * WAVE) * K * sizeof(float),
                                st, d->tiles + p.up_first, d->perm, d->mask, d->ppos, d->wf, b, d->bp, d->slots, p.s_cap);
+    }
+    if (part == 0) {
+        if (exch_n) LS_HIP(hipMemcpyAsync(exchange, d->slots + exch_off, exch_n * sizeof(float), hipMemcpyDeviceToDevice, st));
+        LS_HIP(hipGetLastError());
+        return LS_OK;
     }
     if (d->profile) LS_HIP(hipEventRecord(d->ev[1], st));
     for (int lv = 0; lv <= top; ++lv) {
@@ -1286,13 +1345,39 @@ extern "C" int ls_direct_solve(ls_direct* d, const float* b, float* x, int k, vo
     if (d->used && st != d->last_stream) LS_HIP(hipStreamWaitEvent(st, d->busy, 0));
     int rc;
     switch (k) {
-        case 1: rc = direct_solve_k<1>(d, b, x, st); break;
-        case 2: rc = direct_solve_k<2>(d, b, x, st); break;
-        case 3: rc = direct_solve_k<3>(d, b, x, st); break;
-        default: rc = direct_solve_k<4>(d, b, x, st); break;
+        case 1: rc = direct_solve_k<1>(d, b, x, st, -1, nullptr); break;
+        case 2: rc = direct_solve_k<2>(d, b, x, st, -1, nullptr); break;
+        case 3: rc = direct_solve_k<3>(d, b, x, st, -1, nullptr); break;
+        default: rc = direct_solve_k<4>(d, b, x, st, -1, nullptr); break;
     }
     if (rc == LS_OK) { LS_HIP(hipEventRecord(d->busy, st)); d->last_stream = st; d->used = true; }
     return rc;
+}
+
+extern "C" int ls_direct_solve_part(ls_direct* d, const float* b, float* x, int k, int part, float* exchange, void* stream) {
+    LS_REQUIRE(d && b && x && k >= 1 && k <= d->kmax && (part == 0 || part == 1), LS_E_INVALID, "ls_direct_solve_part: bad argument");
+    LS_REQUIRE(b != x, LS_E_INVALID, "ls_direct_solve_part: b and x must not alias");
+    LS_REQUIRE(exchange || d->exch_f1 == d->exch_f0, LS_E_INVALID, "ls_direct_solve_part: the exchange buffer is missing");
+    DeviceGuard g(d->device);
+    LS_HIP(g.err);
+    hipStream_t st = (hipStream_t)stream;
+    switch (k) {
+        case 1: return direct_solve_k<1>(d, b, x, st, part, exchange);
+        case 2: return direct_solve_k<2>(d, b, x, st, part, exchange);
+        case 3: return direct_solve_k<3>(d, b, x, st, part, exchange);
+        default: return direct_solve_k<4>(d, b, x, st, part, exchange);
+    }
+}
+
+extern "C" int ls_direct_shard_info(const ls_direct* d, int* h_rank, int* h_count, int* h_cut_level, int64_t* h_exchange_floats_per_column,
+                                    unsigned char* h_owned_rows) {
+    LS_REQUIRE(d, LS_E_INVALID, "ls_direct_shard_info: bad argument");
+    if (h_rank) *h_rank = d->shard_rank;
+    if (h_count) *h_count = d->shard_count;
+    if (h_cut_level) *h_cut_level = d->cut;
+    if (h_exchange_floats_per_column) *h_exchange_floats_per_column = (d->exch_f1 - d->exch_f0) * d->arity;
+    if (h_owned_rows) { if (d->owned_rows.empty()) memset(h_owned_rows, 1, (size_t)d->V); else memcpy(h_owned_rows, d->owned_rows.data(), (size_t)d->V); }
+    return LS_OK;
 }
 
 extern "C" int ls_direct_set(ls_direct* d, const char* name, int value) {

@@ -316,8 +316,8 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
 int ls_direct_adopt(ls_direct* d, void* const* owned, int n_owned, const double* seconds3);
 
 extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, const float* d_val, int64_t V, int64_t nnz,
-                                const float* d_positions, int leaf_size, int arity, int tier_levels, int sparse_leaves, int device,
-                                void* stream, ls_direct** out) {
+                                const float* d_positions, int leaf_size, int arity, int tier_levels, int sparse_leaves, int shard_rank,
+                                int shard_count, int device, void* stream, ls_direct** out) {
     LS_REQUIRE(out && d_rowptr && d_col && d_val && V > 0 && nnz > 0 && nnz < INT32_MAX, LS_E_INVALID, "ls_direct_factor: bad argument");
     *out = nullptr;
     DeviceGuard g(device);
@@ -543,6 +543,7 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     A.h_push_ptr = P.push_ptr.data(); A.h_push_tgt = P.push_tgt.data(); A.n_front = P.n_front;
     A.d_finv = finv; A.d_wf = wf; A.d_wb = wb; A.d_u4 = u4; A.d_d4 = d4; A.d_tri = tri; A.d_sp_ptr = d_sp_ptr; A.d_sp_ent = d_sp_ent;
     A.n_sp_ptr = (int64_t)sp_ptr.size(); A.n_sp_ent = (int64_t)sp_ent.size();
+    A.shard_rank = shard_rank; A.shard_count = shard_count;
     rc = ls_direct_create(&A, device, stream, out);
     if (rc != LS_OK) { for (void* p : owned) (void)hipFree(p); return rc; }
     const double secs[3] = {t1 - t0, t2 - t1, t3 - t2};

@@ -32,7 +32,7 @@ constexpr int TIER_WAVES = 4;            // waves per tier workgroup
 constexpr int TIER_TRI4 = 9;             // 16-byte loads per lane that hold a leaf triangle (s <= 64: 2080 floats = 520 float4)
 constexpr int TIER_SPE = 4;              // sparse entries per row prefetched to registers (longer rows: loop)
 
-enum : int { NODE_LEAF = 1, NODE_SPARSE = 2, NODE_QUAD = 4 };
+enum : int { NODE_LEAF = 1, NODE_SPARSE = 2, NODE_QUAD = 4, NODE_UPC = 8 };   // UPC: the parent is in the tier too (compact update hand-off)
 
 struct SpEnt { float val; int idx; };
 
@@ -67,6 +67,7 @@ struct TierArgs {
     const int* perm;
     const unsigned char* mask;
     const int* ppos;
+    const int* pull;                                 // up sweep inside the tier: (front position, child) -> index of the child's boundary entry, -1 = none
     const int* push_ptr;
     const int* push_tgt;
     const float* u4;                                 // dense tier nodes, up sweep stream (quad-interleaved, see tier_dot)
@@ -118,6 +119,24 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 __device__ __forceinline__ float bcast_lane(float v, int c) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), c));
+}
+
+// Up-sweep hand-off INSIDE the tier: a child stores its update vector contiguously (entry i of its boundary list at
+// upd[(bnd_off + i) * K], in the array the down sweep later uses for x_bnd) and the parent gathers per front position through
+// a static pull list -- the slot scheme of the upper levels (arity x K floats per position, 12-byte pieces written by
+// different workgroup phases) moved ~80 MB of partial cache lines per sweep at 1M vertices.
+template <int K>
+__device__ __forceinline__ void pull_compact(const TierArgs& a, size_t f, float (&v)[K]) {
+#pragma unroll
+    for (int q = 0; q < K; ++q) v[q] = 0.0f;
+    const int* pl = a.pull + f * a.arity;
+    for (int c = 0; c < a.arity; ++c) {
+        const int idx = pl[c];
+        if (idx >= 0) {
+#pragma unroll
+            for (int q = 0; q < K; ++q) v[q] += a.xb[(size_t)idx * K + q];
+        }
+    }
 }
 
 // ---- sparse leaves --------------------------------------------------------------------------------------------------
@@ -274,12 +293,14 @@ __device__ __forceinline__ void leaf_up_compute(const TierArgs& a, const TierIte
     }
     wave_lds_sync();
     if (n.pfront_off >= 0 && !(a.ablate & 2)) {
+        const bool upc = n.flags & NODE_UPC;
         if (lane < b) {
             float u[K];
             sparse_row<K>(a, ix, e, yv, u);
-            const size_t dst = ((size_t)(n.pfront_off + ix.pp) * a.arity + n.cix) * K;
+            const size_t dst = upc ? (size_t)(n.bnd_off + lane) * K : ((size_t)(n.pfront_off + ix.pp) * a.arity + n.cix) * K;
+            float* out = upc ? a.xb : a.slots;
 #pragma unroll
-            for (int q = 0; q < K; ++q) a.slots[dst + q] = u[q];
+            for (int q = 0; q < K; ++q) out[dst + q] = u[q];
         }
         for (int i = lane + 64; i < b; i += 64) {          // leaves with more than 64 boundary rows: no prefetch
             const int p0 = a.sp_ptr[n.spb_off + i], p1 = a.sp_ptr[n.spb_off + i + 1], pp = a.ppos[n.bnd_off + i];
@@ -291,9 +312,10 @@ __device__ __forceinline__ void leaf_up_compute(const TierArgs& a, const TierIte
 #pragma unroll
                 for (int q = 0; q < K; ++q) u[q] = fmaf(z.val, yv[z.idx * 4 + q], u[q]);
             }
-            const size_t dst = ((size_t)(n.pfront_off + pp) * a.arity + n.cix) * K;
+            const size_t dst = upc ? (size_t)(n.bnd_off + i) * K : ((size_t)(n.pfront_off + pp) * a.arity + n.cix) * K;
+            float* out = upc ? a.xb : a.slots;
 #pragma unroll
-            for (int q = 0; q < K; ++q) a.slots[dst + q] = u[q];
+            for (int q = 0; q < K; ++q) out[dst + q] = u[q];
         }
     }
     wave_lds_sync();
@@ -417,7 +439,12 @@ __device__ __forceinline__ void node_up_finish(const TierArgs& a, const TierItem
     float pass[K];
 #pragma unroll
     for (int q = 0; q < K; ++q) pass[q] = 0.0f;
-    if (!(n.flags & NODE_LEAF)) pull_slots<K>(a.slots, a.mask, (size_t)(n.front_off + n.s + i), a.arity, pass);
+    if (!(n.flags & NODE_LEAF)) pull_compact<K>(a, (size_t)(n.front_off + n.s + i), pass);
+    if (n.flags & NODE_UPC) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) a.xb[(size_t)(n.bnd_off + i) * K + q] = acc[q] + pass[q];
+        return;
+    }
     const int pp = a.ppos[n.bnd_off + i];
     const size_t dst = ((size_t)(n.pfront_off + pp) * a.arity + n.cix) * K;
 #pragma unroll
@@ -456,7 +483,7 @@ __device__ __forceinline__ void node_up(const TierArgs& a, const TierItem& it, D
 #pragma unroll
     for (int q = 0; q < K; ++q) pass[q] = 0.0f;
     const bool fin = it.nparts == 1 && row && it.pfront_off >= 0;
-    if (fin && !(it.flags & NODE_LEAF)) pull_slots<K>(a.slots, a.mask, (size_t)(it.front_off + it.s + i), a.arity, pass);
+    if (fin && !(it.flags & NODE_LEAF)) pull_compact<K>(a, (size_t)(it.front_off + it.s + i), pass);
     for (int j = it.r0 + lane; j < it.r1; j += 64) {
         float v[K];
         if (j >= it.s) {                              // padding of the reduction to a multiple of 4
@@ -474,7 +501,7 @@ __device__ __forceinline__ void node_up(const TierArgs& a, const TierItem& it, D
         }
         if (!(it.flags & NODE_LEAF)) {
             float u[K];
-            pull_slots<K>(a.slots, a.mask, (size_t)(it.front_off + j), a.arity, u);
+            pull_compact<K>(a, (size_t)(it.front_off + j), u);
 #pragma unroll
             for (int q = 0; q < K; ++q) v[q] -= u[q];
         }
@@ -493,9 +520,11 @@ __device__ __forceinline__ void node_up(const TierArgs& a, const TierItem& it, D
     for (int q = 0; q < K; ++q) acc[q] = a4[q];
     if (it.nparts == 1) {
         if (fin) {
-            const size_t dst = ((size_t)(it.pfront_off + P.idx) * a.arity + it.cix) * K;
+            const bool upc = it.flags & NODE_UPC;
+            const size_t dst = upc ? (size_t)(it.bnd_off + i) * K : ((size_t)(it.pfront_off + P.idx) * a.arity + it.cix) * K;
+            float* out = upc ? a.xb : a.slots;
 #pragma unroll
-            for (int q = 0; q < K; ++q) a.slots[dst + q] = acc[q] + pass[q];
+            for (int q = 0; q < K; ++q) out[dst + q] = acc[q] + pass[q];
         }
     } else {
 #pragma unroll

@@ -68,8 +68,11 @@ _SIGNATURES = {
     "ls_vertex_normals_backward": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "ls_direct_tier_stamps": (c_int, [c_void_p, c_void_p, c_i64]),
-    "ls_direct_factor": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
-                                 ctypes.POINTER(c_void_p)]),
+    "ls_direct_factor": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                 c_void_p, ctypes.POINTER(c_void_p)]),
+    "ls_direct_solve_part": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "ls_direct_shard_info": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_i64),
+                                     c_void_p]),
     "ls_direct_shape": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int),
                                 ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "ls_direct_factor_seconds": (c_int, [c_void_p, ctypes.POINTER(c_double * 3)]),

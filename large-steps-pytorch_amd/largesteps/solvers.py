@@ -247,7 +247,7 @@ class IterativeCholeskySolver(PCGSolver):
 class _NativeDirect:
     """Owner of a native ls_direct handle built by ls_direct_factor (symbolic analysis + numeric factorisation behind the C ABI)."""
 
-    def __init__(self, csr, leaf_size, arity, tier_levels, sparse_leaves):
+    def __init__(self, csr, leaf_size, arity, tier_levels, sparse_leaves, shard=(0, 1)):
         self.device = csr.device
         self._h = ctypes.c_void_p(None)
         pos = csr.positions
@@ -257,7 +257,7 @@ class _NativeDirect:
         with torch.cuda.device(dev):
             _native.check(_native.lib().ls_direct_factor(_native.ptr(csr.rowptr), _native.ptr(csr.col), _native.ptr(csr.val), csr.V, csr.nnz,
                                                          _native.ptr(pos), int(leaf_size), int(arity), int(tier_levels), int(bool(sparse_leaves)),
-                                                         dev.index, _native.stream_of(dev), ctypes.byref(self._h)))
+                                                         int(shard[0]), int(shard[1]), dev.index, _native.stream_of(dev), ctypes.byref(self._h)))
         s3 = (ctypes.c_double * 3)()
         _native.check(_native.lib().ls_direct_factor_seconds(self._h, ctypes.byref(s3)))
         self.timings = dict(plan_seconds=s3[0], table_seconds=s3[1], factor_seconds=s3[2])
@@ -305,7 +305,7 @@ class NestedDissectionSolver(Solver):
     positive definite, RuntimeError when the mesh does not dissect into fronts that fit the kernels.
     """
 
-    def __init__(self, M, leaf_size=64, arity=4):
+    def __init__(self, M, leaf_size=64, arity=4, shard=(0, 1)):
         import time
         csr = _native.csr_of(M)
         self._csr = csr
@@ -325,7 +325,7 @@ class NestedDissectionSolver(Solver):
         sparse = not os.environ.get("LS_ND_DENSE_LEAVES")
         while True:
             try:
-                self._direct = _NativeDirect(csr, leaf_size, arity, tier, sparse)
+                self._direct = _NativeDirect(csr, leaf_size, arity, tier, sparse, shard=shard)
                 break
             except RuntimeError as e:      # a tier whose subtrees need more LDS than a workgroup has: one level less
                 if tier == 0 or "does not fit" not in str(e):

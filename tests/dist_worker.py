@@ -143,6 +143,13 @@ def test_matrix(name):
     if name == "plane40":
         v, f = synthetic.plane(40)
         lam, alpha, cot = 30.0, None, False
+    elif name == "plane120":
+        v, f = synthetic.plane(120)
+        lam, alpha, cot = 30.0, None, False
+    elif name == "ico24cot":
+        v, f = synthetic.icosphere(24)
+        v = synthetic.perturb(v, radial=0.05, tangential=0.2, edge=0.05, seed=5)
+        lam, alpha, cot = 0.0, 0.9, True
     elif name == "ico12cot":
         v, f = synthetic.icosphere(12)
         v = synthetic.perturb(v, radial=0.05, tangential=0.2, edge=0.1, seed=5)
@@ -176,6 +183,35 @@ def main():
     os.environ["MASTER_PORT"] = str(a.port)
     dist.init_process_group(a.backend, rank=a.rank, world_size=a.world)
     v, rowptr, col, val = test_matrix(a.mesh)
+    if a.solver == "direct":
+        # the nested-dissection direct solver sharded by subtrees: every rank builds the full matrix on cuda:0 (loopback: the
+        # ranks share the one GPU, gloo moves the exchange buffer), solves, and reports the full x after the gather
+        from largesteps.distributed import ShardedDirect
+        from largesteps.geometry import compute_matrix
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda:0")
+        kw = dict(plane40=dict(lambda_=30.0), plane120=dict(lambda_=30.0), ico12cot=dict(lambda_=0.0, alpha=0.9, cotan=True),
+                  ico24cot=dict(lambda_=0.0, alpha=0.9, cotan=True))[a.mesh]
+        f = synthetic.plane(int(a.mesh[5:]))[1] if a.mesh.startswith("plane") else synthetic.icosphere(int(a.mesh[3:5]))[1]
+        M = compute_matrix(torch.from_numpy(v).to(dev), torch.from_numpy(f).to(dev), **kw)
+        b_full = (sp.csr_matrix((val.astype(np.float64), col, rowptr)) @ v.astype(np.float64)).astype(np.float32)
+        if a.k != 3:
+            b_full = np.random.default_rng(3).standard_normal((v.shape[0], a.k)).astype(np.float32)
+        sd = ShardedDirect(M)
+        bt = torch.from_numpy(b_full).to(dev)
+        x = sd.solve(bt, gather=True)
+        assert torch.equal(x, sd.solve(bt, gather=True)), "bitwise reproducible"
+        mine = sd.solve(bt)                                   # without the gather: this rank's rows only
+        assert torch.equal(mine[sd.owned], x[sd.owned])
+        own = torch.zeros(v.shape[0], dtype=torch.int32)
+        own[sd.owned.cpu()] = 1
+        dist.all_reduce(own)
+        assert bool((own == 1).all()), "every row has exactly one owner"
+        np.save(os.path.join(a.out, f"x_{a.rank}.npy"), x.cpu().numpy())
+        np.save(os.path.join(a.out, f"it_{a.rank}.npy"), np.array([sd.cut_level, sd.exchange_floats_per_column, int(sd.owned.sum())]))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     plan = ShardPlan.build(rowptr, col, val, v.shape[0], a.world, a.rank, depth=a.depth)
     rng = np.random.default_rng(3)
     b_full = (sp.csr_matrix((val.astype(np.float64), col, rowptr)) @ v.astype(np.float64)).astype(np.float32)

@@ -90,7 +90,7 @@ def run_world(tmp_path, world, mesh, k=3, ops="numpy", backend="gloo", timeout=3
     for r, p in enumerate(procs):
         assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-3000:]}"
     xs = [np.load(os.path.join(tmp_path, f"x_{r}.npy")) for r in range(world)]
-    x = xs if solver == "cols" else np.concatenate(xs)
+    x = xs if solver in ("cols", "direct") else np.concatenate(xs)
     its = [np.load(os.path.join(tmp_path, f"it_{r}.npy")) for r in range(world)]
     return x, its
 

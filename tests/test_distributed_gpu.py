@@ -73,3 +73,37 @@ def test_shard_from_matrix_single_rank():
     assert cheb.last_info["method"] == "chebyshev" and cheb.last_info["converged"]
     # (the single-GPU path reads implicit uniform values, the shard the stored ones: same iterate up to rounding)
     assert float((xc - ref_c).abs().max()) <= 1e-5 * float(ref_c.abs().max())
+
+
+@pytest.mark.parametrize("mesh,world,k", [("plane120", 1, 3), ("plane120", 2, 3), ("plane120", 4, 3), ("ico24cot", 2, 3), ("ico24cot", 4, 2),
+                                          ("plane40", 3, 1)])
+def test_sharded_direct_solver(tmp_path, mesh, world, k):
+    """The nested-dissection direct solver sharded by subtrees over `world` processes that share the one GPU (gloo loopback):
+    the HIP kernels on every rank's subtrees, ONE summed exchange per solve. Every rank ends with the same full x, equal to
+    the fp64 oracle to the single-GPU solver's tolerance; ownership partitions the rows."""
+    x64 = reference_solution(mesh, k)
+    xs, info = run_world(tmp_path, world, mesh, k=k, ops="hip", timeout=600, solver="direct")
+    for x in xs:
+        assert np.array_equal(x, xs[0])
+        assert np.abs(x - x64).max() <= 2e-5 * np.abs(x64).max()
+    assert sum(int(i[2]) for i in info) == x64.shape[0]
+    if world > 1:
+        assert all(int(i[0]) >= 1 and int(i[1]) > 0 for i in info)
+
+
+def test_rccl_process_group_initialises():
+    """backend 'nccl' (= RCCL on ROCm) with world size 1 on the real device: the branch bench.py --gpus N takes, executed once
+    on hardware (one all-reduce through RCCL)."""
+    import subprocess
+    code = ("import os, torch, torch.distributed as dist\n"
+            "os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')\n"
+            "dev = torch.device('cuda', 0); torch.cuda.set_device(dev)\n"
+            "dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)\n"
+            "t = torch.arange(8, dtype=torch.float32, device=dev)\n"
+            "dist.all_reduce(t); torch.cuda.synchronize()\n"
+            "assert float(t.sum()) == 28.0\n"
+            "dist.barrier(); dist.destroy_process_group(); print('rccl ok')\n")
+    from test_distributed_cpu import free_port
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "rccl ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

@@ -404,7 +404,7 @@ def test_factor_and_solve_through_the_c_abi_only(golden, dev, name):
         h = ctypes.c_void_p()
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         rc = lib.ls_direct_factor(ctypes.c_void_p(csr.rowptr.data_ptr()), ctypes.c_void_p(csr.col.data_ptr()), ctypes.c_void_p(csr.val.data_ptr()),
-                                  V, csr.nnz, ctypes.c_void_p(positions.data_ptr()) if positions is not None else None, 64, 4, 3, 1,
+                                  V, csr.nnz, ctypes.c_void_p(positions.data_ptr()) if positions is not None else None, 64, 4, 3, 1, 0, 1,
                                   dev.index, st, ctypes.byref(h))
         assert rc == 0, _native.last_error()
         assert lib.ls_direct_solve(h, ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(x.data_ptr()), 3, st) == 0, _native.last_error()
@@ -418,7 +418,7 @@ def test_factor_and_solve_through_the_c_abi_only(golden, dev, name):
     bad[csr.rowptr[:-1].long()] = -1.0                              # first stored entry of every row
     h = ctypes.c_void_p()
     rc = lib.ls_direct_factor(ctypes.c_void_p(csr.rowptr.data_ptr()), ctypes.c_void_p(csr.col.data_ptr()), ctypes.c_void_p(bad.data_ptr()), V,
-                              csr.nnz, None, 64, 4, 3, 1, dev.index, st, ctypes.byref(h))
+                              csr.nnz, None, 64, 4, 3, 1, 0, 1, dev.index, st, ctypes.byref(h))
     assert rc != 0 and not h.value
 
 
