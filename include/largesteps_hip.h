@@ -319,6 +319,17 @@ int ls_direct_info(const ls_direct* d, int64_t* h_factor_entries, int* h_launche
  * [16 + r] the wave's r-th leaf done. h_out: n int64 values, n <= 2 x workgroups x 4 x 32. */
 int ls_direct_tier_stamps(const ls_direct* d, long long* h_out, int64_t n);
 
+/* ---- remove_duplicates (reference scripts/geometry.py:3-11) --------------------------------------
+ * unique_verts = the distinct rows of verts ((V, 3) fp32) in lexicographic order of their VALUES (-0.0 == 0.0), exactly what
+ * torch.unique(v, dim=0, return_inverse=True) returns; inverse (V) int64: verts[i] == unique_verts[inverse[i]];
+ * new_faces (F, 3) int64 = inverse[faces] (faces int32 / int64 by idx_bytes; F may be 0). unique_verts needs room for V rows;
+ * *h_n_unique receives the number of rows written. Hand-written stable LSD radix sort (no library sort). SYNC.
+ * A face index outside [0, V) -> LS_E_INDEX. */
+int ls_remove_duplicates_workspace_bytes(int64_t V, size_t* h_bytes);
+int ls_remove_duplicates(const float* verts, int64_t V, const void* faces, int idx_bytes, int64_t F, float* unique_verts,
+                         int64_t* inverse, int64_t* new_faces, int64_t* h_n_unique, void* workspace, size_t ws_bytes, int device,
+                         void* stream);
+
 /* ---- normals ----------------------------------------------------------------------
  * faces: (F, 3) int32 or int64 (idx_bytes 4 / 8), verts (V, 3) fp32. Face normals are (3, F) like the reference returns
  * them. Semantics of scripts/geometry.py kept to the letter: a degenerate face / an unreferenced vertex gives NaN, and

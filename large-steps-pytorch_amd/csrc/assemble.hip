@@ -487,3 +487,164 @@ extern "C" int ls_csr_from_coo(const int64_t* coo_rows, const int64_t* coo_cols,
     LS_REQUIRE(!dinv || h[2] == 0, LS_E_INVALID, "matrix has a missing or non-positive diagonal entry: not SPD");
     return LS_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// remove_duplicates (reference: scripts/geometry.py:3-11): unique vertex rows in lexicographic order of their VALUES
+// (what torch.unique(v, dim=0) returns), the inverse map, and the faces re-indexed through it. Done once per remesh.
+// Stable LSD radix sort of the row ids over the 12 key bytes (z low byte first, x high byte last), hand-written:
+// per pass a histogram kernel, the scan above, and a scatter kernel in which ONE wave walks its chunk in order and ranks
+// equal digits inside every 64-element tile with ballots (stable by construction, no atomics in the scatter).
+// ------------------------------------------------------------------------------------------------
+namespace ls {
+
+constexpr int RS_CHUNK = 4096;      // elements per workgroup (histogram: 256 threads; scatter: one wave)
+
+// order-preserving map of a float to uint32; -0.0 is folded into +0.0 first (torch compares values)
+__device__ __forceinline__ unsigned key_of(float x) {
+    unsigned u = __float_as_uint(x);
+    if (u == 0x80000000u) u = 0u;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ unsigned digit_of(const float* __restrict__ verts, int row, int pass) {
+    return (key_of(verts[3 * (size_t)row + (2 - pass / 4)]) >> (8 * (pass & 3))) & 255u;
+}
+
+__global__ __launch_bounds__(256) void k_rs_hist(const float* __restrict__ verts, const int* __restrict__ order, int64_t n, int pass,
+                                                 int nblocks, int* __restrict__ hist /* [256][nblocks] */) {
+    __shared__ int h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RS_CHUNK;
+    for (int e = threadIdx.x; e < RS_CHUNK && base + e < n; e += 256) atomicAdd(&h[digit_of(verts, order ? order[base + e] : (int)(base + e), pass)], 1);
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(64) void k_rs_scatter(const float* __restrict__ verts, const int* __restrict__ order, int64_t n, int pass,
+                                                   int nblocks, const int* __restrict__ offs /* scanned hist */, int* __restrict__ out) {
+    __shared__ int run[256];
+    const int lane = threadIdx.x;
+    for (int d = lane; d < 256; d += 64) run[d] = offs[(size_t)d * nblocks + blockIdx.x];
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RS_CHUNK;
+    const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+    for (int t = 0; t < RS_CHUNK && base + t < n; t += 64) {
+        const int64_t e = base + t + lane;
+        const bool ok = e < n;
+        const int row = ok ? (order ? order[e] : (int)e) : 0;
+        const unsigned dg = ok ? digit_of(verts, row, pass) : 0u;
+        unsigned long long peers = __ballot(ok);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const unsigned long long b = __ballot((dg >> bit) & 1u);
+            peers &= ((dg >> bit) & 1u) ? b : ~b;
+        }
+        const int rank = __popcll(peers & lt), cnt = __popcll(peers);
+        const int start = ok ? run[dg] : 0;
+        __syncthreads();                       // one wave: orders the reads of run[] before the updates below
+        if (ok) {
+            out[start + rank] = row;
+            if (rank == cnt - 1) run[dg] = start + cnt;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dedup_flags(const float* __restrict__ verts, const int* __restrict__ order, int64_t n, int* __restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int f = 1;
+    if (i) {
+        const int a = order[i], b = order[i - 1];
+        f = key_of(verts[3 * (size_t)a]) != key_of(verts[3 * (size_t)b]) || key_of(verts[3 * (size_t)a + 1]) != key_of(verts[3 * (size_t)b + 1]) ||
+            key_of(verts[3 * (size_t)a + 2]) != key_of(verts[3 * (size_t)b + 2]);
+    }
+    flag[i] = f;
+}
+
+// uid[i] = exclusive scan of flag -> unique id of sorted position i is uid[i + 1] - 1
+__global__ __launch_bounds__(256) void k_dedup_emit(const float* __restrict__ verts, const int* __restrict__ order, int64_t n, const int* __restrict__ flag,
+                                                    const int* __restrict__ uid, float* __restrict__ unique_verts, int64_t* __restrict__ inverse) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int row = order[i], u = uid[i + 1] - 1;
+    inverse[row] = u;
+    if (flag[i]) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) unique_verts[3 * (size_t)u + c] = verts[3 * (size_t)row + c];
+    }
+}
+
+template <typename IdxT>
+__global__ __launch_bounds__(256) void k_dedup_faces(const IdxT* __restrict__ faces, int64_t m, int64_t V, const int64_t* __restrict__ inverse,
+                                                     int64_t* __restrict__ out, int* __restrict__ bad) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const int64_t v = (int64_t)faces[i];
+    if (v < 0 || v >= V) { *bad = 1; out[i] = 0; return; }
+    out[i] = inverse[v];
+}
+
+}  // namespace ls
+
+extern "C" int ls_remove_duplicates_workspace_bytes(int64_t V, size_t* h_bytes) {
+    LS_REQUIRE(h_bytes && V >= 0, LS_E_INVALID, "ls_remove_duplicates_workspace_bytes: bad argument");
+    const size_t nb = (size_t)div_up(std::max<int64_t>(V, 1), RS_CHUNK);
+    // order a / b, flags, uid (V + 1), histogram + its scan (256 nb + 1 each), scan block sums
+    *h_bytes = sizeof(int) * ((size_t)V * 4 + 16 + 2 * (256 * nb + 16) + (size_t)div_up(std::max<int64_t>(std::max<int64_t>(V, 256 * (int64_t)nb), 1), SCAN_CHUNK) + 64) + 256;
+    return LS_OK;
+}
+
+extern "C" int ls_remove_duplicates(const float* verts, int64_t V, const void* faces, int idx_bytes, int64_t F, float* unique_verts,
+                                    int64_t* inverse, int64_t* new_faces, int64_t* h_n_unique, void* workspace, size_t ws_bytes, int device,
+                                    void* stream) {
+    LS_REQUIRE(h_n_unique && V >= 0 && F >= 0 && V < INT32_MAX && (V == 0 || (verts && unique_verts && inverse)) &&
+               (F == 0 || (faces && new_faces && (idx_bytes == 4 || idx_bytes == 8))), LS_E_INVALID, "ls_remove_duplicates: bad argument");
+    size_t need = 0;
+    ls_remove_duplicates_workspace_bytes(V, &need);
+    LS_REQUIRE(workspace && ws_bytes >= need, LS_E_WORKSPACE, "ls_remove_duplicates: workspace too small (%zu < %zu bytes)", ws_bytes, need);
+    *h_n_unique = 0;
+    DeviceGuard g(device);
+    LS_HIP(g.err);
+    hipStream_t st = (hipStream_t)stream;
+    if (V == 0) { LS_REQUIRE(F == 0, LS_E_INDEX, "ls_remove_duplicates: faces without vertices"); return LS_OK; }
+    const int nb = div_up(V, RS_CHUNK);
+    int* w = (int*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    int* ord_a = w;
+    int* ord_b = ord_a + V;
+    int* flag = ord_b + V;
+    int* uid = flag + V;                       // V + 1
+    int* hist = uid + V + 16;                  // 256 nb
+    int* offs = hist + 256 * (size_t)nb + 16;  // 256 nb + 1
+    int* bsum = offs + 256 * (size_t)nb + 16;
+    const int* src = nullptr;                  // pass 0 reads the identity order
+    int* dst = ord_a;
+    for (int pass = 0; pass < 12; ++pass) {
+        hipLaunchKernelGGL(k_rs_hist, dim3(nb), dim3(256), 0, st, verts, src, V, pass, nb, hist);
+        int rc = exclusive_scan(hist, 256 * (int64_t)nb, offs, bsum, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_rs_scatter, dim3(nb), dim3(64), 0, st, verts, src, V, pass, nb, (const int*)offs, dst);
+        src = dst;
+        dst = (dst == ord_a) ? ord_b : ord_a;
+    }
+    const int vg = div_up(V, 256);
+    hipLaunchKernelGGL(k_dedup_flags, dim3(vg), dim3(256), 0, st, verts, src, V, flag);
+    int rc = exclusive_scan(flag, V, uid, bsum, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_dedup_emit, dim3(vg), dim3(256), 0, st, verts, src, V, (const int*)flag, (const int*)uid, unique_verts, inverse);
+    int* bad = flag;                           // flags are consumed: reuse one word as the range-check flag
+    if (F) {
+        LS_HIP(hipMemsetAsync(bad, 0, sizeof(int), st));
+        const int64_t m = 3 * F;
+        if (idx_bytes == 4) hipLaunchKernelGGL(k_dedup_faces<int32_t>, dim3(div_up(m, 256)), dim3(256), 0, st, (const int32_t*)faces, m, V, (const int64_t*)inverse, new_faces, bad);
+        else hipLaunchKernelGGL(k_dedup_faces<int64_t>, dim3(div_up(m, 256)), dim3(256), 0, st, (const int64_t*)faces, m, V, (const int64_t*)inverse, new_faces, bad);
+    }
+    LS_HIP(hipGetLastError());
+    int h[2] = {0, 0};
+    LS_HIP(hipMemcpyAsync(&h[0], uid + V, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (F) LS_HIP(hipMemcpyAsync(&h[1], bad, sizeof(int), hipMemcpyDeviceToHost, st));
+    LS_HIP(hipStreamSynchronize(st));
+    LS_REQUIRE(h[1] == 0, LS_E_INDEX, "a face index is outside [0, %lld)", (long long)V);
+    *h_n_unique = h[0];
+    return LS_OK;
+}

@@ -59,6 +59,9 @@ _SIGNATURES = {
     "ls_direct_destroy": (c_int, [c_void_p]),
     "ls_direct_solve": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ls_direct_set": (c_int, [c_void_p, ctypes.c_char_p, c_int]),
+    "ls_remove_duplicates_workspace_bytes": (c_int, [c_i64, ctypes.POINTER(c_size_t)]),
+    "ls_remove_duplicates": (c_int, [c_void_p, c_i64, c_void_p, c_int, c_i64, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_i64), c_void_p,
+                                     c_size_t, c_int, c_void_p]),
     "ls_normals_workspace_bytes": (c_int, [c_i64, c_i64, ctypes.POINTER(c_size_t)]),
     "ls_face_normals": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_i64, c_void_p, c_int, c_void_p]),
     "ls_face_normals_backward": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

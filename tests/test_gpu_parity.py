@@ -783,3 +783,41 @@ def test_adam_uniform(golden, dev):
         # fp32 elementwise update: 2e-6 relative (bias-correction reciprocal rounding differs from torch)
         np.testing.assert_allclose(p.detach().cpu().numpy(), golden["adam/traj"][step], rtol=2e-6, atol=2e-7)
     assert set(opt.state[p].keys()) == {"step", "g1", "g2"}
+
+
+# ---------------------------------------------------------------------------------------------------
+# row f4: remove_duplicates, re-factorisation at a remesh, batched small meshes
+# ---------------------------------------------------------------------------------------------------
+def test_remove_duplicates_vs_reference_fixture(dev):
+    """largesteps.meshops.remove_duplicates (HIP radix sort + compaction) against the outputs of the reference's own function
+    (tests/golden/reference_dedup.npz): unique vertices, faces and inverse map exactly equal, int64 like torch's."""
+    import os
+    from largesteps.meshops import remove_duplicates
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_dedup.npz"))
+    for n in sorted({k.split("/")[0] for k in d.files}):
+        uv, nf, inv = remove_duplicates(_t(d[f"{n}/v"], dev), _t(d[f"{n}/f"], dev))
+        assert nf.dtype == torch.int64 and inv.dtype == torch.int64
+        assert np.array_equal(uv.cpu().numpy(), d[f"{n}/unique"]), n
+        assert np.array_equal(nf.cpu().numpy(), d[f"{n}/new_faces"]) and np.array_equal(inv.cpu().numpy(), d[f"{n}/inverse"]), n
+    with pytest.raises(IndexError):
+        remove_duplicates(_t(d["plane12_unique/v"], dev), _t(d["plane12_unique/f"] + 1000, dev))
+
+
+def test_remove_duplicates_large_vs_oracle(dev):
+    """a 1.2M-row triangle soup (every face its own vertices, shuffled) against the oracle (np.unique(axis=0)); sortedness
+    and v == unique[inverse] as size-independent properties."""
+    from oracle import meshops
+    from largesteps import synthetic
+    from largesteps.meshops import remove_duplicates
+    v, f = synthetic.plane(450)
+    sv = v[f.reshape(-1)]
+    p = np.random.default_rng(0).permutation(sv.shape[0])
+    sv = sv[p].copy()
+    inv_p = np.empty_like(p)
+    inv_p[p] = np.arange(p.shape[0])
+    sf = inv_p[np.arange(f.size).reshape(-1, 3)]
+    uv, nf, inv = remove_duplicates(_t(sv, dev), _t(sf, dev))
+    ouv, onf, oinv = meshops.remove_duplicates(sv, sf)
+    assert uv.shape[0] == v.shape[0] == ouv.shape[0]
+    assert np.array_equal(uv.cpu().numpy(), ouv) and np.array_equal(inv.cpu().numpy(), oinv) and np.array_equal(nf.cpu().numpy(), onf)
+    assert torch.equal(uv[inv], _t(sv, dev))

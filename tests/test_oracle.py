@@ -192,3 +192,18 @@ def test_properties_random_mesh():
     # SPD with lambda_min >= 1
     M = _dense(*ol.compute_matrix(v, f, 5.0, cotan=True), V)
     assert np.linalg.eigvalsh(M).min() >= 1 - 1e-4
+
+
+def test_remove_duplicates_oracle_equals_reference_fixture():
+    """oracle.meshops.remove_duplicates (np.unique(axis=0)) == the reference's scripts/geometry.py:3-11 outputs
+    (tests/golden/reference_dedup.npz, generated by executing the reference): unique rows, re-indexed faces, inverse map."""
+    import os
+    from oracle import meshops
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_dedup.npz"))
+    names = sorted({k.split("/")[0] for k in d.files})
+    assert len(names) >= 6
+    for n in names:
+        uv, nf, inv = meshops.remove_duplicates(d[f"{n}/v"], d[f"{n}/f"])
+        assert np.array_equal(uv, d[f"{n}/unique"]) and np.array_equal(nf, d[f"{n}/new_faces"]) and np.array_equal(inv, d[f"{n}/inverse"])
+        assert inv.dtype == np.int64 and nf.dtype == np.int64
+        assert np.array_equal(uv[inv], d[f"{n}/v"])
