@@ -2,7 +2,8 @@
    v = from_differential(M, u) -> face / vertex normals -> loss -> backward (normals, then the adjoint solve) -> AdamUniform.
    python tools/bench_step.py [workload] [steps]"""
 import os, sys, time
-sys.path[:0] = [os.getcwd(), os.path.join(os.getcwd(), "large-steps-pytorch_amd")]
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [_R, os.path.join(_R, "large-steps-pytorch_amd")]
 import torch
 from largesteps import synthetic
 from largesteps.geometry import compute_matrix
