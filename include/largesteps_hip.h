@@ -330,6 +330,18 @@ int ls_remove_duplicates(const float* verts, int64_t V, const void* faces, int i
                          int64_t* inverse, int64_t* new_faces, int64_t* h_n_unique, void* workspace, size_t ws_bytes, int device,
                          void* stream);
 
+/* CSR of the transpose (rows of M^T sorted by column = original row), for the backward pass of to_differential on a matrix
+ * that is not symmetric. Hand-written radix sort of the entry ids by column. SYNC (range check of the column indices). */
+int ls_csr_transpose_workspace_bytes(int64_t V, int64_t nnz, size_t* h_bytes);
+int ls_csr_transpose(const int32_t* rowptr, const int32_t* col, const float* val, int64_t V, int64_t nnz, int32_t* t_rowptr,
+                     int32_t* t_col, float* t_val, void* workspace, size_t ws_bytes, int device, void* stream);
+/* Vertex-major ranking of the 3 F face corners (see the normals below): vptr (V + 1) = first rank of every vertex, cpos (3 F) =
+ * rank of corner 3 f + i; the corners of a vertex are ranked in ascending corner id. A face index outside [0, V) -> LS_E_INDEX.
+ * SYNC. */
+int ls_corner_ranks_workspace_bytes(int64_t F, int64_t V, size_t* h_bytes);
+int ls_corner_ranks(const void* faces, int idx_bytes, int64_t F, int64_t V, int32_t* vptr, int32_t* cpos, void* workspace,
+                    size_t ws_bytes, int device, void* stream);
+
 /* ---- normals ----------------------------------------------------------------------
  * faces: (F, 3) int32 or int64 (idx_bytes 4 / 8), verts (V, 3) fp32. Face normals are (3, F) like the reference returns
  * them. Semantics of scripts/geometry.py kept to the letter: a degenerate face / an unreferenced vertex gives NaN, and
@@ -356,11 +368,6 @@ int ls_vertex_normals_backward(const float* verts, const void* faces, int idx_by
 
 int ls_adam_uniform_step(float* param, const float* grad, float* g1, float* g2, int64_t n, float lr,
                          float beta1, float beta2, int step, void* scratch, int device, void* stream);
-
-/* A/B kernels used to choose the production kernels' structure (csrc/experiments.hip, tools/ubench.py); not
- * part of the product path. */
-int ls_experiment(int which, int bs, int grid, int64_t V, const float* dinv, const float* r, float* p,
-                  const double* part, const int32_t* slice_ptr, const void* cv, void* stream);
 
 #ifdef __cplusplus
 }

@@ -505,22 +505,30 @@ __device__ __forceinline__ unsigned key_of(float x) {
     if (u == 0x80000000u) u = 0u;
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
-__device__ __forceinline__ unsigned digit_of(const float* __restrict__ verts, int row, int pass) {
-    return (key_of(verts[3 * (size_t)row + (2 - pass / 4)]) >> (8 * (pass & 3))) & 255u;
-}
+// key policies of the radix sort: the 12 bytes of a vertex row (x most significant) / the 4 bytes of an int32 key
+struct KeyVerts {
+    const float* verts;
+    __device__ __forceinline__ unsigned digit(int row, int pass) const { return (key_of(verts[3 * (size_t)row + (2 - pass / 4)]) >> (8 * (pass & 3))) & 255u; }
+};
+struct KeyInt {
+    const int* keys;
+    __device__ __forceinline__ unsigned digit(int row, int pass) const { return ((unsigned)keys[row] >> (8 * pass)) & 255u; }
+};
 
-__global__ __launch_bounds__(256) void k_rs_hist(const float* __restrict__ verts, const int* __restrict__ order, int64_t n, int pass,
+template <typename Key>
+__global__ __launch_bounds__(256) void k_rs_hist(Key key, const int* __restrict__ order, int64_t n, int pass,
                                                  int nblocks, int* __restrict__ hist /* [256][nblocks] */) {
     __shared__ int h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * RS_CHUNK;
-    for (int e = threadIdx.x; e < RS_CHUNK && base + e < n; e += 256) atomicAdd(&h[digit_of(verts, order ? order[base + e] : (int)(base + e), pass)], 1);
+    for (int e = threadIdx.x; e < RS_CHUNK && base + e < n; e += 256) atomicAdd(&h[key.digit(order ? order[base + e] : (int)(base + e), pass)], 1);
     __syncthreads();
     hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
-__global__ __launch_bounds__(64) void k_rs_scatter(const float* __restrict__ verts, const int* __restrict__ order, int64_t n, int pass,
+template <typename Key>
+__global__ __launch_bounds__(64) void k_rs_scatter(Key key, const int* __restrict__ order, int64_t n, int pass,
                                                    int nblocks, const int* __restrict__ offs /* scanned hist */, int* __restrict__ out) {
     __shared__ int run[256];
     const int lane = threadIdx.x;
@@ -532,7 +540,7 @@ __global__ __launch_bounds__(64) void k_rs_scatter(const float* __restrict__ ver
         const int64_t e = base + t + lane;
         const bool ok = e < n;
         const int row = ok ? (order ? order[e] : (int)e) : 0;
-        const unsigned dg = ok ? digit_of(verts, row, pass) : 0u;
+        const unsigned dg = ok ? key.digit(row, pass) : 0u;
         unsigned long long peers = __ballot(ok);
 #pragma unroll
         for (int bit = 0; bit < 8; ++bit) {
@@ -587,6 +595,24 @@ __global__ __launch_bounds__(256) void k_dedup_faces(const IdxT* __restrict__ fa
 
 }  // namespace ls
 
+// order = the ids 0..n-1 sorted stably by `passes` key bytes; tmp: n ints; hist / offs: 256 nb + 16 ints each; returns where the result is
+template <typename Key>
+static int radix_argsort(Key key, int64_t n, int passes, int* ord_a, int* ord_b, int* hist, int* offs, int* bsum, hipStream_t st, const int** result) {
+    const int nb = div_up(n, RS_CHUNK);
+    const int* src = nullptr;                  // pass 0 reads the identity order
+    int* dst = ord_a;
+    for (int pass = 0; pass < passes; ++pass) {
+        hipLaunchKernelGGL(k_rs_hist<Key>, dim3(nb), dim3(256), 0, st, key, src, n, pass, nb, hist);
+        int rc = exclusive_scan(hist, 256 * (int64_t)nb, offs, bsum, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_rs_scatter<Key>, dim3(nb), dim3(64), 0, st, key, src, n, pass, nb, (const int*)offs, dst);
+        src = dst;
+        dst = (dst == ord_a) ? ord_b : ord_a;
+    }
+    *result = src;
+    return LS_OK;
+}
+
 extern "C" int ls_remove_duplicates_workspace_bytes(int64_t V, size_t* h_bytes) {
     LS_REQUIRE(h_bytes && V >= 0, LS_E_INVALID, "ls_remove_duplicates_workspace_bytes: bad argument");
     const size_t nb = (size_t)div_up(std::max<int64_t>(V, 1), RS_CHUNK);
@@ -617,15 +643,11 @@ extern "C" int ls_remove_duplicates(const float* verts, int64_t V, const void* f
     int* hist = uid + V + 16;                  // 256 nb
     int* offs = hist + 256 * (size_t)nb + 16;  // 256 nb + 1
     int* bsum = offs + 256 * (size_t)nb + 16;
-    const int* src = nullptr;                  // pass 0 reads the identity order
-    int* dst = ord_a;
-    for (int pass = 0; pass < 12; ++pass) {
-        hipLaunchKernelGGL(k_rs_hist, dim3(nb), dim3(256), 0, st, verts, src, V, pass, nb, hist);
-        int rc = exclusive_scan(hist, 256 * (int64_t)nb, offs, bsum, st);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_rs_scatter, dim3(nb), dim3(64), 0, st, verts, src, V, pass, nb, (const int*)offs, dst);
-        src = dst;
-        dst = (dst == ord_a) ? ord_b : ord_a;
+    const int* src = nullptr;
+    {
+        KeyVerts key{verts};
+        const int rc0 = radix_argsort(key, V, 12, ord_a, ord_b, hist, offs, bsum, st, &src);
+        if (rc0) return rc0;
     }
     const int vg = div_up(V, 256);
     hipLaunchKernelGGL(k_dedup_flags, dim3(vg), dim3(256), 0, st, verts, src, V, flag);
@@ -646,5 +668,131 @@ extern "C" int ls_remove_duplicates(const float* verts, int64_t V, const void* f
     LS_HIP(hipStreamSynchronize(st));
     LS_REQUIRE(h[1] == 0, LS_E_INDEX, "a face index is outside [0, %lld)", (long long)V);
     *h_n_unique = h[0];
+    return LS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Two more users of the radix sort (both replace stock-torch sorts that sat next to the product path):
+//   ls_csr_transpose   CSR of M^T (for the backward pass of to_differential on an unsymmetric foreign matrix)
+//   ls_corner_ranks    vertex-major ranking of the 3 F face corners (normals: corners of a vertex summed in ascending corner id)
+// ------------------------------------------------------------------------------------------------
+namespace ls {
+__global__ __launch_bounds__(256) void k_count_keys(const int* __restrict__ keys, int64_t n, int64_t nkeys, int* __restrict__ cnt, int* __restrict__ bad) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int k = keys[i];
+    if (k < 0 || k >= nkeys) { *bad = 1; return; }
+    atomicAdd(&cnt[k], 1);
+}
+__global__ __launch_bounds__(256) void k_transpose_emit(const int* __restrict__ order, int64_t nnz, const int* __restrict__ rowptr, int64_t V,
+                                                        const float* __restrict__ val, int* __restrict__ t_col, float* __restrict__ t_val) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nnz) return;
+    const int e = order[i];
+    int64_t lo = 0, hi = V;                     // row of entry e
+    while (lo + 1 < hi) { const int64_t mid = (lo + hi) >> 1; if (rowptr[mid] <= e) lo = mid; else hi = mid; }
+    t_col[i] = (int)lo;
+    t_val[i] = val[e];
+}
+template <typename IdxT>
+__global__ __launch_bounds__(256) void k_faces_to_i32(const IdxT* __restrict__ f, int64_t m, int* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < m) out[i] = (int)f[i];
+}
+__global__ __launch_bounds__(256) void k_invert_order(const int* __restrict__ order, int64_t n, int* __restrict__ rank) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) rank[order[i]] = (int)i;
+}
+}  // namespace ls
+
+static size_t argsort_ws_ints(int64_t n, int64_t nkeys) {
+    const size_t nb = (size_t)div_up(std::max<int64_t>(n, 1), RS_CHUNK);
+    return (size_t)n * 3 + (size_t)nkeys + 64 + 2 * (256 * nb + 16) + (size_t)div_up(std::max<int64_t>(std::max<int64_t>(std::max<int64_t>(n, nkeys), 256 * (int64_t)nb), 1), SCAN_CHUNK) + 64;
+}
+
+extern "C" int ls_csr_transpose_workspace_bytes(int64_t V, int64_t nnz, size_t* h_bytes) {
+    LS_REQUIRE(h_bytes && V >= 0 && nnz >= 0, LS_E_INVALID, "ls_csr_transpose_workspace_bytes: bad argument");
+    *h_bytes = sizeof(int) * argsort_ws_ints(nnz, V + 1) + 256;
+    return LS_OK;
+}
+
+extern "C" int ls_csr_transpose(const int32_t* rowptr, const int32_t* col, const float* val, int64_t V, int64_t nnz, int32_t* t_rowptr,
+                                int32_t* t_col, float* t_val, void* workspace, size_t ws_bytes, int device, void* stream) {
+    LS_REQUIRE(rowptr && t_rowptr && V > 0 && nnz >= 0 && nnz < INT32_MAX && (nnz == 0 || (col && val && t_col && t_val)), LS_E_INVALID, "ls_csr_transpose: bad argument");
+    size_t need = 0;
+    ls_csr_transpose_workspace_bytes(V, nnz, &need);
+    LS_REQUIRE(workspace && ws_bytes >= need, LS_E_WORKSPACE, "ls_csr_transpose: workspace too small (%zu < %zu bytes)", ws_bytes, need);
+    DeviceGuard g(device);
+    LS_HIP(g.err);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nb = (size_t)div_up(std::max<int64_t>(nnz, 1), RS_CHUNK);
+    int* w = (int*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    int *ord_a = w, *ord_b = ord_a + nnz, *cnt = ord_b + nnz;          // cnt: V + 1 (last = range flag)
+    int *hist = cnt + V + 16 + nnz, *offs = hist + 256 * nb + 16, *bsum = offs + 256 * nb + 16;
+    LS_HIP(hipMemsetAsync(cnt, 0, sizeof(int) * (V + 1), st));
+    if (nnz) hipLaunchKernelGGL(k_count_keys, dim3(div_up(nnz, 256)), dim3(256), 0, st, (const int*)col, nnz, V, cnt, cnt + V);
+    int rc = exclusive_scan(cnt, V, t_rowptr, bsum, st);
+    if (rc) return rc;
+    if (nnz) {
+        const int* src = nullptr;
+        int passes = 1;
+        while (passes < 4 && (V - 1) >> (8 * passes)) ++passes;
+        KeyInt key{(const int*)col};
+        rc = radix_argsort(key, nnz, passes, ord_a, ord_b, hist, offs, bsum, st, &src);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_transpose_emit, dim3(div_up(nnz, 256)), dim3(256), 0, st, src, nnz, (const int*)rowptr, V, val, (int*)t_col, t_val);
+    }
+    int bad = 0;
+    LS_HIP(hipMemcpyAsync(&bad, cnt + V, sizeof(int), hipMemcpyDeviceToHost, st));
+    LS_HIP(hipStreamSynchronize(st));
+    LS_HIP(hipGetLastError());
+    LS_REQUIRE(!bad, LS_E_INDEX, "ls_csr_transpose: a column index is outside [0, %lld)", (long long)V);
+    return LS_OK;
+}
+
+extern "C" int ls_corner_ranks_workspace_bytes(int64_t F, int64_t V, size_t* h_bytes) {
+    LS_REQUIRE(h_bytes && F >= 0 && V >= 0, LS_E_INVALID, "ls_corner_ranks_workspace_bytes: bad argument");
+    *h_bytes = sizeof(int) * (argsort_ws_ints(3 * F, V + 1) + (size_t)3 * F) + 256;
+    return LS_OK;
+}
+
+extern "C" int ls_corner_ranks(const void* faces, int idx_bytes, int64_t F, int64_t V, int32_t* vptr, int32_t* cpos, void* workspace,
+                               size_t ws_bytes, int device, void* stream) {
+    LS_REQUIRE(vptr && V >= 0 && F >= 0 && 3 * F < INT32_MAX && (F == 0 || (faces && cpos && (idx_bytes == 4 || idx_bytes == 8))), LS_E_INVALID,
+               "ls_corner_ranks: bad argument");
+    size_t need = 0;
+    ls_corner_ranks_workspace_bytes(F, V, &need);
+    LS_REQUIRE(workspace && ws_bytes >= need, LS_E_WORKSPACE, "ls_corner_ranks: workspace too small (%zu < %zu bytes)", ws_bytes, need);
+    DeviceGuard g(device);
+    LS_HIP(g.err);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = 3 * F;
+    const size_t nb = (size_t)div_up(std::max<int64_t>(n, 1), RS_CHUNK);
+    int* w = (int*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    int *ord_a = w, *ord_b = ord_a + n, *cnt = ord_b + n;
+    int *hist = cnt + V + 16 + n, *offs = hist + 256 * nb + 16, *bsum = offs + 256 * nb + 16;
+    int* keys = bsum + div_up(std::max<int64_t>(std::max<int64_t>(std::max<int64_t>(n, V + 1), 256 * (int64_t)nb), 1), SCAN_CHUNK) + 64;
+    LS_HIP(hipMemsetAsync(cnt, 0, sizeof(int) * (V + 1), st));
+    if (n) {
+        if (idx_bytes == 4) hipLaunchKernelGGL(k_faces_to_i32<int32_t>, dim3(div_up(n, 256)), dim3(256), 0, st, (const int32_t*)faces, n, keys);
+        else hipLaunchKernelGGL(k_faces_to_i32<int64_t>, dim3(div_up(n, 256)), dim3(256), 0, st, (const int64_t*)faces, n, keys);
+        hipLaunchKernelGGL(k_count_keys, dim3(div_up(n, 256)), dim3(256), 0, st, (const int*)keys, n, V, cnt, cnt + V);
+    }
+    int rc = exclusive_scan(cnt, V, (int*)vptr, bsum, st);
+    if (rc) return rc;
+    int bad = 0;
+    LS_HIP(hipMemcpyAsync(&bad, cnt + V, sizeof(int), hipMemcpyDeviceToHost, st));
+    LS_HIP(hipStreamSynchronize(st));
+    LS_REQUIRE(!bad, LS_E_INDEX, "face index out of range for %lld vertices", (long long)V);
+    if (n) {
+        const int* src = nullptr;
+        int passes = 1;
+        while (passes < 4 && (std::max<int64_t>(V, 1) - 1) >> (8 * passes)) ++passes;
+        KeyInt key{(const int*)keys};
+        rc = radix_argsort(key, n, passes, ord_a, ord_b, hist, offs, bsum, st, &src);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_invert_order, dim3(div_up(n, 256)), dim3(256), 0, st, src, n, (int*)cpos);
+    }
+    LS_HIP(hipGetLastError());
     return LS_OK;
 }

@@ -62,6 +62,10 @@ _SIGNATURES = {
     "ls_remove_duplicates_workspace_bytes": (c_int, [c_i64, ctypes.POINTER(c_size_t)]),
     "ls_remove_duplicates": (c_int, [c_void_p, c_i64, c_void_p, c_int, c_i64, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_i64), c_void_p,
                                      c_size_t, c_int, c_void_p]),
+    "ls_csr_transpose_workspace_bytes": (c_int, [c_i64, c_i64, ctypes.POINTER(c_size_t)]),
+    "ls_csr_transpose": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "ls_corner_ranks_workspace_bytes": (c_int, [c_i64, c_i64, ctypes.POINTER(c_size_t)]),
+    "ls_corner_ranks": (c_int, [c_void_p, c_int, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "ls_normals_workspace_bytes": (c_int, [c_i64, c_i64, ctypes.POINTER(c_size_t)]),
     "ls_face_normals": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_i64, c_void_p, c_int, c_void_p]),
     "ls_face_normals_backward": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -99,7 +103,6 @@ _SIGNATURES = {
                                           ctypes.POINTER(SolveInfo), c_void_p]),
     "ls_solver_profile": (c_int, [c_void_p, ctypes.POINTER(c_double * 3), ctypes.POINTER(c_int)]),
     "ls_solver_sell": (c_int, [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_i64)]),
-    "ls_experiment": (c_int, [c_int, c_int, c_int, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ls_solver_workspace_bytes": (c_int, [c_void_p, ctypes.POINTER(c_size_t)]),
     "ls_adam_uniform_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_float, c_float, c_float, c_int,
                                      c_void_p, c_int, c_void_p]),
@@ -182,7 +185,7 @@ def ptr(t):
 class CsrMatrix:
     """int32 CSR (rowptr, col) + fp32 val of a (V,V) matrix on one HIP device. `val` is the very tensor
     that backs M.values() (same order: row-major sorted COO == CSR order), so no value copy exists."""
-    __slots__ = ("V", "nnz", "rowptr", "col", "val", "device", "symmetric", "a_min", "uniform", "positions", "__weakref__")
+    __slots__ = ("V", "nnz", "rowptr", "col", "val", "device", "symmetric", "a_min", "uniform", "positions", "_transposed", "__weakref__")
 
     def __init__(self, V, rowptr, col, val, symmetric, a_min=None, uniform=None, positions=None):
         self.V, self.nnz = int(V), int(col.shape[0])
@@ -196,6 +199,7 @@ class CsrMatrix:
         # (V,3) vertex positions the matrix was assembled from (detached; only their spatial order is used, to cut
         # the mesh into compact patches for the LDS-resident solver kernel)
         self.positions = positions
+        self._transposed = None
 
 
 # (id(M)) -> (CsrMatrix, weakref(M)). Mirrors the reference's solver cache (parameterize.py:5-17): keyed by
@@ -259,3 +263,23 @@ def spmv(csr, x, variant=0):
     check(lib().ls_spmv(ptr(csr.rowptr), ptr(csr.col), ptr(csr.val), csr.V, csr.nnz, ptr(x), ptr(y), x.shape[1], variant,
                         dev.index, stream_of(dev)))
     return y
+
+
+def csr_transposed(csr):
+    """CSR side car of M^T (cached on the side car of M): native radix sort of the entries by column, no torch sort."""
+    t = getattr(csr, "_transposed", None)
+    if t is not None:
+        return t
+    dev = csr.device
+    n = c_size_t(0)
+    check(lib().ls_csr_transpose_workspace_bytes(csr.V, csr.nnz, ctypes.byref(n)))
+    ws = torch.empty(n.value, dtype=torch.uint8, device=dev)
+    rowptr = torch.empty(csr.V + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(max(csr.nnz, 1), dtype=torch.int32, device=dev)[: csr.nnz]
+    val = torch.empty(max(csr.nnz, 1), dtype=torch.float32, device=dev)[: csr.nnz]
+    with torch.cuda.device(dev):
+        check(lib().ls_csr_transpose(ptr(csr.rowptr), ptr(csr.col), ptr(csr.val), csr.V, csr.nnz, ptr(rowptr), ptr(col), ptr(val), ptr(ws),
+                                     ws.numel(), dev.index, stream_of(dev)))
+    t = CsrMatrix(csr.V, rowptr, col, val, symmetric=csr.symmetric)
+    csr._transposed = t
+    return t

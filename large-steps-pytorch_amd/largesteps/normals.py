@@ -19,7 +19,7 @@ from . import _native
 
 
 # Per face TENSOR OBJECT: range check of the indices (syncs the host once) and the vertex-major ranking of the corners.
-# One-off integer plumbing per mesh connectivity: a stable sort of the 3 F corner vertex ids groups the corners by
+# One-off integer plumbing per mesh connectivity (ls_corner_ranks: native radix sort): the 3 F corners grouped by
 # vertex, in ascending corner id (deterministic sums); cpos is the inverse permutation (corner -> rank), vptr the ranks
 # each vertex owns. An entry is valid only for the very tensor it was built from (weak reference + version counter):
 # a storage address is recycled by the caching allocator as soon as a face tensor dies, so it cannot be the identity.
@@ -35,15 +35,15 @@ def _plan(f, V):
                 and v_count == V:
             return plan
         del _plans[key]
-    if f.shape[0] and (int(f.min()) < 0 or int(f.max()) >= V):
-        raise IndexError(f"face index out of range for {V} vertices")
-    flat = f.reshape(-1).long()
-    order = torch.argsort(flat, stable=True)
-    vcorner = torch.empty(flat.numel(), dtype=torch.int32, device=f.device)       # corner -> rank ("cpos" of the C ABI)
-    vcorner[order] = torch.arange(flat.numel(), dtype=torch.int32, device=f.device)
-    vptr = torch.zeros(V + 1, dtype=torch.int32, device=f.device)
-    if flat.numel():
-        vptr[1:] = torch.cumsum(torch.bincount(flat, minlength=V), 0).to(torch.int32)
+    F = f.shape[0]
+    n = ctypes.c_size_t(0)
+    _native.check(_native.lib().ls_corner_ranks_workspace_bytes(F, V, ctypes.byref(n)))
+    ws = torch.empty(n.value, dtype=torch.uint8, device=f.device)
+    vcorner = torch.empty(max(3 * F, 1), dtype=torch.int32, device=f.device)[: 3 * F]     # corner -> rank ("cpos" of the C ABI)
+    vptr = torch.empty(V + 1, dtype=torch.int32, device=f.device)
+    with torch.cuda.device(f.device):                  # range check + counting + stable radix sort by vertex id, all native
+        _native.check(_native.lib().ls_corner_ranks(_native.ptr(f), f.element_size(), F, V, _native.ptr(vptr), _native.ptr(vcorner), _native.ptr(ws),
+                                                    ws.numel(), f.device.index, _native.stream_of(f.device)))
     for k in [k for k, h in _plans.items() if h[0]() is None]:      # entries of dead tensors
         del _plans[k]
     if len(_plans) >= 8:

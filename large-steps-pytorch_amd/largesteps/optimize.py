@@ -20,10 +20,9 @@ def _scratch_for(dev):
 
 class AdamUniform(torch.optim.Optimizer):
     """
-    Variant of Adam with uniform scaling by the second moment.
-
-    Instead of dividing each component by the square root of its second moment,
-    we divide all of them by the max.
+    Adam with one global step scale (reference: optimize.py:3-41): the first moment is divided by the LARGEST root second
+    moment of the whole parameter instead of element by element, so every coordinate of a vertex (and every vertex) moves
+    on the same scale. Constructor arguments and state keys ("step", "g1", "g2") are the reference's.
     """
     def __init__(self, params, lr=0.1, betas=(0.9, 0.999)):
         defaults = dict(lr=lr, betas=betas)

@@ -1,6 +1,7 @@
 """
-to_differential / from_differential with the reference's API and cache semantics
-(reference: largesteps/parameterize.py:5-61).
+The differential parameterization (reference: largesteps/parameterize.py:5-61), same function names, arguments and caching
+behaviour, on the MI355X:  u = L v  is one LDS-staged CSR SpMV (csrc/spmv.hip),  v = L^-1 u  goes through a solver object that
+is built on first use per (matrix, method) and lives exactly as long as the matrix does.
 """
 import weakref
 
@@ -9,49 +10,53 @@ import torch
 from . import _native
 from .solvers import CholeskySolver, ConjugateGradientSolver, solve
 
-# Cache for the system solvers: (id(L), method) -> (solver, weakref(L)); same keying and eviction as the
-# reference (parameterize.py:5-17). No solver of this package keeps a strong reference to L, so the entry
-# (and the native handle) really goes away with the matrix -- the reference's 'CG' entry never did.
+# (id(L), method) -> (solver, weak reference to L). The key is the matrix OBJECT, as in the reference (parameterize.py:5-17);
+# the weak reference's callback removes the entry when the matrix dies. Unlike the reference's 'CG' solver, nothing stored here
+# holds a strong reference to L, so the entry -- and the native handle behind it -- really goes away with the matrix.
 _cache = {}
 
 
 def cache_put(key, value, A):
-    # Called when 'A' is garbage collected
-    def cleanup_callback(wr):
+    def forget(_ref, key=key):          # runs when A is garbage collected
         _cache.pop(key, None)
 
-    wr = weakref.ref(A, cleanup_callback)
-    _cache[key] = (value, wr)
+    _cache[key] = (value, weakref.ref(A, forget))
 
 
 class _SpMV(torch.autograd.Function):
-    """u = L v with the HIP CSR SpMV; d/dv = L^T g."""
+    """u = L v with the HIP CSR SpMV; the gradient with respect to v is L^T g: the same kernel on the transposed side car
+    (identical to L's for the symmetric matrices compute_matrix builds)."""
 
     @staticmethod
-    def forward(ctx, L, csr, v):
-        ctx.L, ctx.csr = L, csr
+    def forward(ctx, csr, v):
+        ctx.csr = csr
         return _native.spmv(csr, v)
 
     @staticmethod
     def backward(ctx, g):
-        if not ctx.needs_input_grad[2]:
-            return None, None, None
-        g = g.contiguous()
-        if ctx.csr.symmetric:
-            return None, None, _native.spmv(ctx.csr, g)
-        return None, None, torch.sparse.mm(ctx.L.t(), g)   # foreign, possibly unsymmetric matrix
+        if not ctx.needs_input_grad[1]:
+            return None, None
+        csr = ctx.csr
+        if csr.symmetric is None:           # a foreign matrix: find out once whether L^T = L
+            import ctypes
+            ok = ctypes.c_int(0)
+            with torch.cuda.device(csr.device):
+                _native.check(_native.lib().ls_csr_is_symmetric(_native.ptr(csr.rowptr), _native.ptr(csr.col), _native.ptr(csr.val), csr.V, csr.nnz,
+                                                                0.0, ctypes.byref(ok), csr.device.index, _native.stream_of(csr.device)))
+            csr.symmetric = bool(ok.value)
+        return None, _native.spmv(csr if csr.symmetric else _native.csr_transposed(csr), g.contiguous())
 
 
 def to_differential(L, v):
     """
-    Convert vertex coordinates to the differential parameterization:  u = L @ v.
+    Differential coordinates of v:  u = L @ v.
 
     Parameters
     ----------
     L : torch.sparse.Tensor
-        (I + l*L) matrix
+        The system matrix (I + lambda * Laplacian), as returned by `compute_matrix`
     v : torch.Tensor
-        Vertex coordinates
+        Vertex coordinates, (V, k) or (V,), float32 on the matrix's device
     """
     _native.require_device(v, "v")
     csr = _native.csr_of(L)
@@ -65,39 +70,39 @@ def to_differential(L, v):
     v2 = (v.unsqueeze(1) if squeeze else v).contiguous()
     if v2.shape[1] == 0 or v2.shape[1] > 64:
         raise ValueError(f"to_differential supports 1..64 columns, got {v2.shape[1]}")
-    u = _SpMV.apply(L, csr, v2)
+    u = _SpMV.apply(csr, v2)
     return u.squeeze(1) if squeeze else u
 
 
 def from_differential(L, u, method='Cholesky'):
     """
-    Convert differential coordinates back to Cartesian:  solve L v = u.
+    Vertex coordinates from differential coordinates:  the solution v of  L v = u.
 
-    If this is the first time we call this function on a given matrix L, the
-    solver is cached. It will be destroyed once the matrix is garbage collected.
+    The solver for (L, method) is constructed on the first call and reused afterwards; it is dropped when L is garbage
+    collected.
 
     Parameters
     ----------
     L : torch.sparse.Tensor
-        (I + l*L) matrix
+        The system matrix (I + lambda * Laplacian)
     u : torch.Tensor
         Differential coordinates
     method : {'Cholesky', 'CG'}
-        Solver to use. Both run the HIP Jacobi-PCG: 'Cholesky' to a relative residual of 1e-6 from a cold
-        start (the accuracy class of the reference's fp32 Cholesky solve), 'CG' with the reference's own
-        stopping rule (||r|| <= 1e-5, warm-started from the previous solution).
+        'Cholesky' (default): factor once / re-solve -- the nested-dissection direct solver (the constructor factorises,
+        every call is a re-solve whose result depends on u only); matrices it cannot factorise fall back to a cold-started
+        Chebyshev / PCG iteration run to a residual reduction of 1e-6. 'CG': the reference's conjugate-gradient contract
+        (stop at ||r||_2 <= 1e-5, warm start from the previous forward / backward solution) on the HIP iteration kernels.
     """
     key = (id(L), method)
-    if key not in _cache.keys():
+    hit = _cache.get(key)
+    if hit is None:
         if method == 'Cholesky':
             solver = CholeskySolver(L)
         elif method == 'CG':
             solver = ConjugateGradientSolver(L)
         else:
             raise ValueError(f"Unknown solver type '{method}'.")
-
         cache_put(key, solver, L)
     else:
-        solver = _cache[key][0]
-
+        solver = hit[0]
     return solve(solver, u)

@@ -23,21 +23,22 @@ _KMAX = 4   # right-hand-side columns one native solve handles; wider b is solve
 
 class Solver:
     """
-    Sparse linear system solver base class.
+    What `solve()` below expects of a solver object (reference: solvers.py:6-24): a constructor that takes the matrix and a
+    `solve(b, backward)` method. Subclass it to plug in any other linear solver.
     """
     def __init__(self, M):
         pass
 
     def solve(self, b, backward=False):
         """
-        Solve the linear system.
+        Return x with M x = b.
 
         Parameters
         ----------
         b : torch.Tensor
-            The right hand side of the system Lx=b
+            Right-hand side(s), one column per system
         backward : bool (optional)
-            Whether this is the backward or forward solve
+            True when called for the gradient (solvers that warm start keep the two directions apart)
         """
         raise NotImplementedError()
 
@@ -430,10 +431,8 @@ class ConjugateGradientSolver(PCGSolver):
 
 class DifferentiableSolve(Function):
     """
-    Differentiable function to solve the linear system.
-
-    This simply calls the solve methods implemented by the Solver classes; the backward pass is the same
-    solve applied to the incoming gradient (M is symmetric). Reference: solvers.py:128-145.
+    x = M^-1 b as an autograd node (reference: solvers.py:128-145). M is symmetric, so the gradient with respect to b is the
+    same solve applied to the incoming gradient; the solver object itself gets no gradient.
     """
     @staticmethod
     def forward(ctx, solver, b):
@@ -442,12 +441,9 @@ class DifferentiableSolve(Function):
 
     @staticmethod
     def backward(ctx, grad_output):
-        solver_grad = None  # We have to return a gradient per input argument in forward
-        b_grad = None
-        if ctx.needs_input_grad[1]:
-            b_grad = ctx.solver.solve(grad_output.contiguous(), backward=True)
-        return (solver_grad, b_grad)
+        grad_b = ctx.solver.solve(grad_output.contiguous(), backward=True) if ctx.needs_input_grad[1] else None
+        return None, grad_b
 
 
-# Alias for DifferentiableSolve function
+# functional form, as in the reference (solvers.py:148)
 solve = DifferentiableSolve.apply

@@ -130,3 +130,30 @@ def test_hip_large_mesh_vs_oracle_and_errors(dev):
         compute_vertex_normals(tv, tf, fn[:, :-1])
     with pytest.raises(TypeError):
         compute_face_normals(tv, tf.to(torch.int16))
+
+
+@pytest.mark.gpu
+def test_plan_cache_is_tied_to_the_face_tensor():
+    """Two different connectivities of identical shape, the first freed before the second is created (the caching allocator
+    hands the second the same address): the corner ranking must be rebuilt, not reused."""
+    import gc
+    import torch
+    from largesteps import synthetic
+    from largesteps.normals import compute_face_normals, compute_vertex_normals
+    from oracle import normals as on
+    dev = torch.device("cuda:0")
+    v, f = synthetic.icosphere(6)
+    rng = np.random.default_rng(0)
+    tv = torch.from_numpy(v).to(dev)
+    outs = []
+    for trial in range(3):
+        fp = f[rng.permutation(f.shape[0])][:, rng.permutation(3)] if trial else f
+        # keep the orientation: a cyclic shift only
+        fp = np.roll(f[rng.permutation(f.shape[0])], trial, axis=1)
+        tf = torch.from_numpy(fp).to(dev)
+        n = compute_vertex_normals(tv, tf, compute_face_normals(tv, tf)).cpu().numpy()
+        ref = on.vertex_normals(v.astype(np.float64), fp, on.face_normals(v.astype(np.float64), fp))
+        assert np.abs(n - ref).max() <= 1e-5
+        outs.append(tf.data_ptr())
+        del tf
+        gc.collect()

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""Micro A/B of kernel structures (csrc/experiments.hip) on the 1M-vertex plane. Prints us/launch and GB/s."""
+"""Micro A/B of kernel structures (tools/ubench/experiments.hip -- NOT part of the product library) on the 1M-vertex plane.
+Build the side library first:  make -C tools/ubench      Prints us/launch and GB/s."""
 import ctypes
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "large-steps-pytorch_amd")]
 import torch  # noqa: E402
 from largesteps.geometry import compute_matrix  # noqa: E402
@@ -18,6 +19,9 @@ tv, tf = torch.from_numpy(v).to(dev), torch.from_numpy(f).to(dev)
 M = compute_matrix(tv, tf, c["lambda_"] or 0.0, alpha=c["alpha"], cotan=c["cotan"])
 s = PCGSolver(M)
 lib = _native.lib()
+xlib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "build", "libls_ubench.so"))
+xlib.ls_experiment.restype = ctypes.c_int
+xlib.ls_experiment.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64] + [ctypes.c_void_p] * 7
 sp, cv, ne = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int64()
 _native.check(lib.ls_solver_sell(s._handle, ctypes.byref(sp), ctypes.byref(cv), ctypes.byref(ne)))
 V, nnz = v.shape[0], M._nnz()
@@ -30,7 +34,7 @@ st = _native.stream_of(dev)
 
 def run(which, bs, grid, reps=200):
     def launch():
-        _native.check(lib.ls_experiment(which, bs, grid, V, _native.ptr(dinv), _native.ptr(r), _native.ptr(p), _native.ptr(part), sp, cv, st))
+        _native.check(xlib.ls_experiment(which, bs, grid, V, _native.ptr(dinv), _native.ptr(r), _native.ptr(p), _native.ptr(part), sp, cv, st))
     for _ in range(5):
         launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
