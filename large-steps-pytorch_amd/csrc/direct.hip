@@ -919,7 +919,7 @@ static size_t plan_tier(const std::vector<NodeD>& nd, const std::vector<int64_t>
                             it.row0 = r; it.r0 = (int)((int64_t)(L / 4) * pt / nparts) * 4; it.r1 = (int)((int64_t)(L / 4) * (pt + 1) / nparts) * 4;
                             it.part = pt; it.nparts = nparts;
                             items.push_back(it);
-                            vec_need = std::max(vec_need, 4 * (it.r1 - it.r0 + 16));             // read as registers of 16 entries
+                            vec_need = std::max(vec_need, 4 * (it.r1 - it.r0 + 32));             // read as registers of 16 entries (two per batch of 8 quads)
                         }
                     if (nparts > 1) { if (up) g.up_split |= 1u << ph; else g.down_split |= 1u << ph; }
                 }
@@ -1268,6 +1268,7 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
     ta.arity = d->arity; ta.phases = d->tier_phases; ta.region_floats = d->tier_region; ta.vec_floats = d->tier_vec;
     ta.dbg = d->profile == 2 ? d->dbg : nullptr;
     ta.ablate = env_int0("LS_ND_ABLATE", 0);
+    ta.stagger = env_int0("LS_ND_STAGGER", 0);
     const size_t tier_lds = (size_t)d->tier_region * TIER_WAVES * sizeof(float);
     const size_t exch_off = (size_t)d->exch_f0 * d->arity * K, exch_n = (size_t)(d->exch_f1 - d->exch_f0) * d->arity * K;
     if (part != 1) {

@@ -81,6 +81,7 @@ struct TierArgs {
     float* xb;
     int arity, phases, region_floats, vec_floats;    // LDS per wave: [vec_floats | partial sums: rounds x 64 x 4]
     long long* dbg;                                  // profile = 2: shader-clock stamps, 32 per wave (see k_nd_tier)
+    int stagger;                                     // LS_ND_STAGGER: half of the workgroups start this many x ~4 us (at 2 GHz) late
     int ablate;                                      // LS_ND_ABLATE (timing experiments only, WRONG results): 1 no leaf mat-vec, 2 no sparse product,
                                                      // 4 no dense phases, 8 no leaf phase, 16 no triangle loads
 };
@@ -227,16 +228,29 @@ template <int T>
 __device__ __forceinline__ void tri_chunk(const float* stage, const float* vec4, int s, int lane, int j, int tj, f32x4& a0, f32x4& a1) {
     if (16 * T >= s) return;
     const float v16 = vec4[64 * T + lane];
-#define LS_TRI_STEP(E)                                                                      \
-    if (16 * T + E < s) {                                                                   \
-        constexpr int c = 16 * T + E;                                                       \
-        const float lo = stage[tj + c], hi = stage[c * (c + 1) / 2 + j];                    \
-        const float m = lane >= c ? lo : hi;                                                \
-        if (E & 1) a1 = mv_step<E>(v16, m, a1); else a0 = mv_step<E>(v16, m, a0);           \
+    // all 32 LDS reads of the chunk are requested before the first matrix instruction (no branch per column: a branch ends
+    // the basic block and with it the scheduler's freedom to hoist the reads).
+    float m[16];
+    if (16 * T + 16 <= s) {            // a full chunk: both addresses are a per-lane base + a COMPILE-TIME offset (no address arithmetic)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            constexpr int c0 = 16 * T;
+            const int c = c0 + e;
+            const float lo = stage[tj + c], hi = stage[c * (c + 1) / 2 + j];
+            m[e] = lane >= c ? lo : hi;
+        }
+    } else {                           // the last, partial chunk: columns c >= s read a clamped address and meet a zero vector entry
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int c = 16 * T + e, cc = min(c, s - 1);
+            const float lo = stage[tj + cc], hi = stage[cc * (cc + 1) / 2 + j];
+            m[e] = lane >= cc ? lo : hi;
+        }
     }
-    LS_TRI_STEP(0) LS_TRI_STEP(1) LS_TRI_STEP(2) LS_TRI_STEP(3) LS_TRI_STEP(4) LS_TRI_STEP(5) LS_TRI_STEP(6) LS_TRI_STEP(7)
-    LS_TRI_STEP(8) LS_TRI_STEP(9) LS_TRI_STEP(10) LS_TRI_STEP(11) LS_TRI_STEP(12) LS_TRI_STEP(13) LS_TRI_STEP(14) LS_TRI_STEP(15)
-#undef LS_TRI_STEP
+    a0 = mv_step<0>(v16, m[0], a0);   a1 = mv_step<1>(v16, m[1], a1);   a0 = mv_step<2>(v16, m[2], a0);   a1 = mv_step<3>(v16, m[3], a1);
+    a0 = mv_step<4>(v16, m[4], a0);   a1 = mv_step<5>(v16, m[5], a1);   a0 = mv_step<6>(v16, m[6], a0);   a1 = mv_step<7>(v16, m[7], a1);
+    a0 = mv_step<8>(v16, m[8], a0);   a1 = mv_step<9>(v16, m[9], a1);   a0 = mv_step<10>(v16, m[10], a0); a1 = mv_step<11>(v16, m[11], a1);
+    a0 = mv_step<12>(v16, m[12], a0); a1 = mv_step<13>(v16, m[13], a1); a0 = mv_step<14>(v16, m[14], a0); a1 = mv_step<15>(v16, m[15], a1);
 }
 template <int K>
 __device__ __forceinline__ void tri_matvec(const float* stage, const float* vec4, int s, int lane, float (&acc)[K]) {
@@ -356,8 +370,10 @@ __device__ __forceinline__ void leaf_down_compute(const TierArgs& a, const TierI
     wave_lds_sync();
 }
 
-// the leaves of this wave in one phase: items k0, k0 + stride, ... < k1. Software pipeline per leaf r:
-//   record (r + 3) requested | data (r + 1): triangle, right-hand side, sparse entries | indices (r + 2) | multiply (r)
+// The leaves of this wave in one phase: items k0, k0 + stride, ... < k1, one after the other. Only the small loads of the NEXT
+// leaf are requested ahead (its item record and the index lists that depend on it: 5 registers). A full software pipeline
+// (next leaf's triangle in flight during the multiply, 36 more registers) was measured slower: it spilled, and the leaf
+// phase is bound by its dependent steps, not by bytes in flight.
 template <int K, bool UP>
 __device__ __forceinline__ void leaf_phase(const TierArgs& a, int k0, int k1, const float* __restrict__ b_in, float* __restrict__ x_out,
                                            float* region, int tri_floats) {
@@ -365,36 +381,32 @@ __device__ __forceinline__ void leaf_phase(const TierArgs& a, int k0, int k1, co
     if (k0 >= k1) return;
     constexpr int S = TIER_WAVES;
     tier_stamp(a, 24);
+    TierItem it = rec_unpack(rec_load(a.items, k0, lane));
     int rec_n = k0 + S < k1 ? rec_load(a.items, k0 + S, lane) : 0;
-    int rec_nn = k0 + 2 * S < k1 ? rec_load(a.items, k0 + 2 * S, lane) : 0;
-    TierItem it_c = rec_unpack(rec_load(a.items, k0, lane)), it_n = it_c;
-    LeafIdx ix_c, ix_n;
-    LeafDat<K> d;
-    leaf_idx<UP>(a, it_c, lane, ix_c);
-    ix_n = ix_c;
-    if (k0 + S < k1) { it_n = rec_unpack(rec_n); leaf_idx<UP>(a, it_n, lane, ix_n); }
-    leaf_dat<K, UP>(a, it_c, ix_c, b_in, lane, d);
+    LeafIdx ix;
+    leaf_idx<UP>(a, it, lane, ix);
     for (int k = k0; k < k1; k += S) {
-        // the current leaf's loads -> LDS / a few registers; its big registers are free for the next leaf
-        tri_stage<K>(d, it_c.s, lane, region);
         float v[K], xv[K];
         SpEnt e[TIER_SPE];
+        {
+            LeafDat<K> d;
+            leaf_dat<K, UP>(a, it, ix, b_in, lane, d);
+            tri_stage<K>(d, it.s, lane, region);
 #pragma unroll
-        for (int q = 0; q < K; ++q) { v[q] = d.v[q]; xv[q] = UP ? 0.0f : d.xv[q]; }
+            for (int q = 0; q < K; ++q) { v[q] = d.v[q]; xv[q] = UP ? 0.0f : d.xv[q]; }
 #pragma unroll
-        for (int t = 0; t < TIER_SPE; ++t) e[t] = d.e[t];
+            for (int t = 0; t < TIER_SPE; ++t) e[t] = d.e[t];
+        }
         wave_lds_sync();
-        if (k == k0) tier_stamp(a, 27);
-        const bool more = k + S < k1, more2 = k + 2 * S < k1;
-        const int rec_3 = k + 3 * S < k1 ? rec_load(a.items, k + 3 * S, lane) : 0;   // record of leaf r + 3
-        if (more) leaf_dat<K, UP>(a, it_n, ix_n, b_in, lane, d);                       // data of leaf r + 1
-        TierItem it_nn = it_n;
-        LeafIdx ix_nn = ix_n;
-        if (more2) { it_nn = rec_unpack(rec_nn); leaf_idx<UP>(a, it_nn, lane, ix_nn); }   // indices of leaf r + 2 (record asked for an iteration ago)
-        if (k == k0) tier_stamp(a, 28);
-        if (UP) leaf_up_compute<K>(a, it_c, ix_c, v, e, region, tri_floats);
-        else leaf_down_compute<K>(a, it_c, ix_c, v, xv, e, x_out, region, tri_floats);
-        it_c = it_n; ix_c = ix_n; it_n = it_nn; ix_n = ix_nn; rec_nn = rec_3;
+        // the next leaf's record has arrived by now: its index loads go out before this leaf is multiplied
+        const bool more = k + S < k1;
+        TierItem it_n = it;
+        LeafIdx ix_n = ix;
+        if (more) { it_n = rec_unpack(rec_n); leaf_idx<UP>(a, it_n, lane, ix_n); }
+        rec_n = k + 2 * S < k1 ? rec_load(a.items, k + 2 * S, lane) : 0;
+        if (UP) leaf_up_compute<K>(a, it, ix, v, e, region, tri_floats);
+        else leaf_down_compute<K>(a, it, ix, v, xv, e, x_out, region, tri_floats);
+        it = it_n; ix = ix_n;
         tier_stamp(a, 16 + min(7, (k - k0) / S));
     }
 }
@@ -406,12 +418,22 @@ __device__ __forceinline__ void leaf_phase(const TierArgs& a, int k0, int k1, co
 // wants (4-byte-per-lane row loads level off near 3 TB/s on this chip) -- and each loaded quad feeds 4 matrix instructions.
 //     up    u4: rows = boundary rows i (b), reduction = own rows j (s -> s4)                 W[i][j]
 //     down  d4: rows = own rows j (s), reduction = [own rows t (s -> s4) | boundary rows (b -> b4)]   [Finv | W^T][j][t]
-constexpr int TIER_Q = 2;        // quads per lane and batch; two batches in flight (deeper prefetch: measured slower, the
-                                 // registers spill next to the leaf pipeline)
+#ifndef LS_TIER_Q
+#define LS_TIER_Q 4
+#endif
+constexpr int TIER_Q = LS_TIER_Q;   // quads per lane and batch; two batches in flight
 
 __device__ __forceinline__ void tier_prefetch(const float4* __restrict__ col, size_t rows, int q0, int q1, float4 (&cur)[TIER_Q]) {
 #pragma unroll
     for (int e = 0; e < TIER_Q; ++e) cur[e] = (q0 + e < q1) ? col[(size_t)(q0 + e) * rows] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// 4 quads (16 reduction entries) against one vector register; n = quads that exist
+__device__ __forceinline__ void tier_mv16(float v16, const float4& a, const float4& b, const float4& c, const float4& d, int n, f32x4& acc) {
+    acc = mv_step<0>(v16, a.x, acc); acc = mv_step<1>(v16, a.y, acc); acc = mv_step<2>(v16, a.z, acc); acc = mv_step<3>(v16, a.w, acc);
+    if (n > 1) { acc = mv_step<4>(v16, b.x, acc); acc = mv_step<5>(v16, b.y, acc); acc = mv_step<6>(v16, b.z, acc); acc = mv_step<7>(v16, b.w, acc); }
+    if (n > 2) { acc = mv_step<8>(v16, c.x, acc); acc = mv_step<9>(v16, c.y, acc); acc = mv_step<10>(v16, c.z, acc); acc = mv_step<11>(v16, c.w, acc); }
+    if (n > 3) { acc = mv_step<12>(v16, d.x, acc); acc = mv_step<13>(v16, d.y, acc); acc = mv_step<14>(v16, d.z, acc); acc = mv_step<15>(v16, d.w, acc); }
 }
 
 // acc[m] += sum over the quads [q0, q1) of col[q * rows] (4 entries each) times the vector sv4[(4 q - base) * 4 + m];
@@ -419,15 +441,14 @@ __device__ __forceinline__ void tier_prefetch(const float4* __restrict__ col, si
 __device__ __forceinline__ void tier_dot(const float4* __restrict__ col, size_t rows, int q0, int q1, const float* sv4, int base,
                                          float4 (&cur)[TIER_Q], f32x4& acc) {
     float4 nxt[TIER_Q];
+    const int lane = threadIdx.x & 63;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int q = q0; q < q1; q += TIER_Q) {
-        const float v16 = sv4[(4 * q - base) * 4 + (threadIdx.x & 63)];
         tier_prefetch(col, rows, q + TIER_Q, q1, nxt);
-        acc = mv_step<0>(v16, cur[0].x, acc); acc = mv_step<1>(v16, cur[0].y, acc);
-        acc = mv_step<2>(v16, cur[0].z, acc); acc = mv_step<3>(v16, cur[0].w, acc);
-        if (q + 1 < q1) {
-            acc = mv_step<4>(v16, cur[1].x, acc); acc = mv_step<5>(v16, cur[1].y, acc);
-            acc = mv_step<6>(v16, cur[1].z, acc); acc = mv_step<7>(v16, cur[1].w, acc);
-        }
+        if (TIER_Q == 2) tier_mv16(sv4[(4 * q - base) * 4 + lane], cur[0], cur[1], z, z, min(2, q1 - q), acc);
+        if (TIER_Q >= 4) tier_mv16(sv4[(4 * q - base) * 4 + lane], cur[0], cur[1], cur[TIER_Q >= 4 ? 2 : 0], cur[TIER_Q >= 4 ? 3 : 0], q1 - q, acc);
+        if (TIER_Q >= 8 && q + 4 < q1) tier_mv16(sv4[(4 * q + 16 - base) * 4 + lane], cur[TIER_Q >= 8 ? 4 : 0], cur[TIER_Q >= 8 ? 5 : 0],
+                                                 cur[TIER_Q >= 8 ? 6 : 0], cur[TIER_Q >= 8 ? 7 : 0], q1 - q - 4, acc);
 #pragma unroll
         for (int e = 0; e < TIER_Q; ++e) cur[e] = nxt[e];
     }
@@ -621,6 +642,9 @@ __global__ __launch_bounds__(64 * TIER_WAVES, 4) void k_nd_tier(TierArgs a, cons
     const int obase = UP ? 0 : TIER_MAX_H + 1;
     const unsigned split = (unsigned)rl(hdr, UP ? 14 : 15), leafy = (unsigned)rl(hdr, UP ? 16 : 17);
     tier_stamp(a, 0);
+    if (a.stagger > 0 && (blockIdx.x & 8)) {            // phase shift for every other group of 8 workgroups (one per XCD)
+        for (int t = 0; t < a.stagger; ++t) __builtin_amdgcn_s_sleep(127);
+    }
     if (UP) {
         // right-hand side of the tier's inner-node rows, gathered once into the tree's numbering (braw): the dense items
         // read it from a static address instead of walking perm -> b behind a barrier
@@ -659,7 +683,7 @@ __global__ __launch_bounds__(64 * TIER_WAVES, 4) void k_nd_tier(TierArgs a, cons
             if (has_nx) rec_nx = rec_load(a.items, j0, lane);
         }
         if ((leafy >> ph) & 1u) {
-            if (!(a.ablate & 8)) leaf_phase<K, UP>(a, i0 + wave, i1, b_in, x_out, region, tri_floats);
+            if (!(a.ablate & 8)) leaf_phase<K, UP>(a, i0 + wave, (a.ablate & 32) ? min(i1, i0 + TIER_WAVES) : (a.ablate & 64) ? min(i1, i0 + 2 * TIER_WAVES) : i1, b_in, x_out, region, tri_floats);
         } else if (!(a.ablate & 4)) {
             int rec = (!pre_valid && i0 + wave < i1) ? rec_load(a.items, i0 + wave, lane) : 0;
             for (int k = i0 + wave; k < i1; k += TIER_WAVES) {
