@@ -60,7 +60,10 @@ constexpr int ND_UNROLL = LS_ND_UNROLL;   // independent matrix loads in flight 
 #define LS_ND_ROWS 2
 #endif
 constexpr int ND_ROWS = LS_ND_ROWS;     // rows a wave processes together (lanes-along-the-reduction kernels)
-constexpr int ND_BW = 4;       // waves per workgroup of the *_b kernels -> ND_ROWS * ND_BW rows per tile
+#ifndef LS_ND_BW
+#define LS_ND_BW 4
+#endif
+constexpr int ND_BW = LS_ND_BW;       // waves per workgroup of the *_b kernels -> ND_ROWS * ND_BW rows per tile
 
 // Sum of the valid child slots of front position f: slots[(f * A + c) * K + q], valid iff bit c of m. All A slots are
 // loaded unconditionally (contiguous; never-written ones hold garbage and are masked out): no load waits for the mask.

@@ -5,6 +5,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <functional>
 #include <numeric>
@@ -16,7 +17,7 @@ namespace {
 int n_threads() {
     static const int n = [] {
         const char* e = getenv("LS_PLAN_THREADS");
-        const int want = e ? atoi(e) : 16;
+        const int want = e ? atoi(e) : 32;
         const int hw = (int)std::thread::hardware_concurrency();
         return std::max(1, std::min(want, hw > 0 ? hw : 1));
     }();
@@ -102,6 +103,8 @@ void graph_embedding(int64_t V, const int32_t* rowptr, const int32_t* col, std::
 std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, const float* pos_in, int leaf_size, int arity,
                           int smooth, NdPlan& P) {
     const auto t_start = std::chrono::steady_clock::now();
+    const bool timing = getenv("LS_PLAN_TIMING") != nullptr;
+    auto lap = [&](const char* what) { if (timing) fprintf(stderr, "[nd_plan] %-28s %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count()); };
     if (V <= 0 || V >= INT32_MAX) return "nd_plan_build: bad vertex count";
     if (arity != 2 && arity != 4 && arity != 8) return "nd_plan_build: arity must be 2, 4 or 8";
     if (leaf_size < 1) return "nd_plan_build: leaf_size must be positive";
@@ -133,25 +136,26 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
     } else {
         graph_embedding(V, rowptr, col, pos);
     }
+    lap("positions");
     // ---- D rounds of bisection ------------------------------------------------------------------------------------------
     std::vector<int64_t> node((size_t)V, 1);          // binary heap id of the domain a vertex lives in / became a separator of
     std::vector<char> fixed((size_t)V, 0), side((size_t)V, 0), endp((size_t)V, 0);
+    // (domain << 2 | side << 1 | fixed) of every vertex in ONE word: the cut detection touches one cache line per neighbour
+    std::vector<int64_t> state((size_t)V, 4);
     std::vector<int> live((size_t)V);                 // live vertices grouped by domain
     std::iota(live.begin(), live.end(), 0);
     int64_t n_live = V;
     std::vector<int64_t> seg_start;
     std::vector<int> tmp((size_t)V);
+    // `live` holds the live vertices grouped by domain: domain d of the round owns live[seg_start[d] .. seg_start[d + 1]).
+    // A median split partitions the segment in place, so the next round's grouping is the two halves minus the separator
+    // vertices -- compacted per half with per-domain counts: every pass of a round is parallel over domains or vertices.
+    seg_start.assign(2, 0);
+    seg_start[1] = V;
+    std::vector<int64_t> next_start, keep_cnt;
+    std::vector<int> cnt0, cnt1;
     for (int r = 0; r < D; ++r) {
         const int64_t n_dom = (int64_t)1 << r, base = n_dom;
-        // group the live vertices by domain (counting sort, stable in vertex id)
-        seg_start.assign((size_t)n_dom + 1, 0);
-        for (int64_t i = 0; i < n_live; ++i) ++seg_start[(size_t)(node[live[i]] - base) + 1];
-        for (int64_t d = 0; d < n_dom; ++d) seg_start[d + 1] += seg_start[d];
-        {
-            std::vector<int64_t> cur(seg_start.begin(), seg_start.end() - 1);
-            for (int64_t i = 0; i < n_live; ++i) tmp[(size_t)cur[(size_t)(node[live[i]] - base)]++] = live[i];
-            std::copy(tmp.begin(), tmp.begin() + n_live, live.begin());
-        }
         // median split of every domain along the longest axis of its bounding box
         parallel_for(n_dom, 1, [&](int64_t lo, int64_t hi) {
             for (int64_t d = lo; d < hi; ++d) {
@@ -163,37 +167,64 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
                 int ax = 0;
                 for (int k = 1; k < 3; ++k) if (mx[k] - mn[k] > mx[ax] - mn[ax]) ax = k;
                 const int64_t half = cnt / 2;
-                auto less = [&](int u, int w) { const double x = pos[3 * (size_t)u + ax], y = pos[3 * (size_t)w + ax]; return x < y || (x == y && u < w); };
-                std::nth_element(live.begin() + a, live.begin() + a + half, live.begin() + e, less);
-                for (int64_t i = a; i < e; ++i) side[live[i]] = i - a >= half;
+                // selection on contiguous (key, id) pairs: the comparator must not chase pos[] through the index array
+                std::vector<std::pair<double, int>> kv((size_t)cnt);
+                for (int64_t i = a; i < e; ++i) kv[(size_t)(i - a)] = {pos[3 * (size_t)live[i] + ax], live[i]};
+                std::nth_element(kv.begin(), kv.begin() + half, kv.end());
+                for (int64_t i = a; i < e; ++i) {
+                    const int u = kv[(size_t)(i - a)].second;
+                    live[i] = u; side[u] = i - a >= half;
+                    state[u] = (node[u] << 2) | ((int64_t)side[u] << 1);
+                }
             }
         });
-        // end points of the cut edges, per side
-        std::vector<std::atomic<int>> cnt0((size_t)n_dom), cnt1((size_t)n_dom);
-        for (int64_t d = 0; d < n_dom; ++d) { cnt0[d] = 0; cnt1[d] = 0; }
+        // end points of the cut edges
         parallel_for(n_live, 4096, [&](int64_t lo, int64_t hi) {
             for (int64_t i = lo; i < hi; ++i) {
                 const int u = live[i];
                 bool cut = false;
-                for (int p = rowptr[u]; p < rowptr[u + 1] && !cut; ++p) {
-                    const int w = col[p];
-                    cut = !fixed[w] && node[w] == node[u] && side[w] != side[u];
-                }
+                const int64_t mine = state[u];          // live vertex of domain node[u] on side side[u]
+                for (int p = rowptr[u]; p < rowptr[u + 1] && !cut; ++p) cut = (state[col[p]] ^ mine) == 2;   // same domain, live, other side
                 endp[u] = cut;
-                if (cut) { if (side[u]) ++cnt1[(size_t)(node[u] - base)]; else ++cnt0[(size_t)(node[u] - base)]; }
             }
         });
-        // the smaller end-point set of a domain is its separator; everything else moves down
-        int64_t kept = 0;
-        for (int64_t i = 0; i < n_live; ++i) {
-            const int u = live[i];
-            const int64_t d = node[u] - base;
-            const bool use1 = cnt1[d].load() < cnt0[d].load();
-            if (endp[u] && (side[u] != 0) == use1) fixed[u] = 1;
-            else { node[u] = 2 * node[u] + side[u]; live[kept++] = u; }
-        }
-        n_live = kept;
+        // per domain: the smaller end-point set is the separator; count what stays in either half
+        cnt0.assign((size_t)n_dom, 0); cnt1.assign((size_t)n_dom, 0);
+        keep_cnt.assign((size_t)2 * n_dom, 0);
+        parallel_for(n_dom, 1, [&](int64_t lo, int64_t hi) {
+            for (int64_t d = lo; d < hi; ++d) {
+                const int64_t a = seg_start[d], e = seg_start[d + 1], half = (e - a) / 2;
+                int c0 = 0, c1 = 0;
+                for (int64_t i = a; i < e; ++i) if (endp[live[i]]) { if (i - a >= half) ++c1; else ++c0; }
+                cnt0[d] = c0; cnt1[d] = c1;
+                const bool use1 = c1 < c0;
+                keep_cnt[2 * d] = half - (use1 ? 0 : c0);
+                keep_cnt[2 * d + 1] = (e - a - half) - (use1 ? c1 : 0);
+            }
+        });
+        next_start.assign((size_t)2 * n_dom + 1, 0);
+        for (int64_t h = 0; h < 2 * n_dom; ++h) next_start[h + 1] = next_start[h] + keep_cnt[h];
+        parallel_for(n_dom, 1, [&](int64_t lo, int64_t hi) {
+            for (int64_t d = lo; d < hi; ++d) {
+                const int64_t a = seg_start[d], e = seg_start[d + 1], half = (e - a) / 2;
+                const bool use1 = cnt1[d] < cnt0[d];
+                int64_t w0 = next_start[2 * d], w1 = next_start[2 * d + 1];
+                for (int64_t i = a; i < e; ++i) {
+                    const int u = live[i];
+                    const bool s1 = i - a >= half;
+                    if (endp[u] && s1 == use1) { fixed[u] = 1; state[u] |= 1; continue; }      // node[u] stays: the domain it separates
+                    tmp[(size_t)(s1 ? w1++ : w0++)] = u;
+                }
+            }
+        });
+        n_live = next_start[2 * n_dom];
+        parallel_for(n_live, 65536, [&](int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; ++i) { const int u = tmp[i]; live[i] = u; node[u] = 2 * node[u] + side[u]; }
+        });
+        seg_start.swap(next_start);
+        (void)base;
     }
+    lap("bisection");
     // ---- merged tree: log2(arity) bisection rounds per level, the leaf domains are the last level -------------------------
     const int levels = D / m + 1;
     P = NdPlan();
@@ -235,6 +266,7 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
         std::vector<int> cur(P.own_start);
         for (int64_t v = 0; v < V; ++v) { const int nw = cur[node_id[v]]++; P.perm[nw] = (int)v; P.inv[v] = nw; P.node_of_new[nw] = node_id[v]; }
     }
+    lap("ordering");
     // ---- boundary sets, deepest level first (a node's set needs its children's) ------------------------------------------------
     std::vector<std::vector<int>> bset((size_t)n_nodes + 1);
     std::atomic<bool> bad(false);
@@ -259,6 +291,7 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
             }
         });
     }
+    lap("boundary sets");
     P.bnd_off.assign((size_t)n_nodes + 2, 0); P.front_off.assign((size_t)n_nodes + 2, 0);
     for (int i = 1; i <= n_nodes; ++i) {
         P.b[i] = (int)bset[i].size();
@@ -292,6 +325,7 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
     });
     if (bad) return "nd_plan_build: separator property violated (the matrix pattern is not symmetric?)";
     if (P.b[1] != 0) return "nd_plan_build: the root has a boundary";
+    lap("parent positions");
     // ---- push lists of the down sweep: front position -> boundary entries of the children that are this vertex -------------
     P.push_ptr.assign((size_t)P.n_front + 1, 0);
     P.push_tgt.resize((size_t)P.n_bnd);
@@ -307,6 +341,7 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
             for (int k = 0; k < P.b[i]; ++k) P.push_tgt[(size_t)cur[(size_t)(pf + P.ppos[(size_t)P.bnd_off[i] + k])]++] = (int)(P.bnd_off[i] + k);
         }
     }
+    lap("push lists");
     P.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     return "";
 }
