@@ -316,7 +316,8 @@ def report_direct(args, solver, M, u, x, tv, v, f, cfg, ms, t_assemble):
         up_ms += inf["up_ms"] / n_prof
         down_ms += inf["down_ms"] / n_prof
     solver.set_option("profile", 0)
-    n_up = n_down = inf["launches"] // 2
+    n_down = (inf["launches"] + 1) // 2          # the root has no up-sweep launch of its own (its down tiles form b')
+    n_up = inf["launches"] - n_down
     n_bnd = inf["n_bnd"]
     # algorithmic bytes: the fp32 factor data each sweep reads (dense nodes: W in both sweeps, Finv in the down sweep; leaves:
     # one packed triangle per sweep + their sparse block) + the vectors once per sweep (b / b' / x rows, boundary vectors)

@@ -104,7 +104,7 @@ __device__ __forceinline__ void fill_rows(const Tile& t, int j_lo, int j_hi, con
         for (int r = 0; r < R; ++r) {
             const int j = jb + r * blockDim.x;
             const bool ok = j < j_hi;
-            g[r] = ok ? (size_t)perm[t.own_start + j] : 0;
+            g[r] = !ok ? 0 : perm ? (size_t)perm[t.own_start + j] : (size_t)(t.own_start + j);   // perm == nullptr: b_in is already in the tree's numbering
             m[r] = (ok && !t.leaf) ? mask[t.front_off + j] : 0u;
             if (ok && !t.leaf) load_slots<K, A>(slots, (size_t)(t.front_off + j), raw[r]);
         }
@@ -157,6 +157,16 @@ __device__ __forceinline__ void store_bprime(const Tile& t, const int* __restric
     if (t.arity == 4) fill_rows<K, 4, 1>(t, t.row0, hi, perm, mask, slots, b_in, bprime, nullptr);
     else if (t.arity == 2) fill_rows<K, 2, 1>(t, t.row0, hi, perm, mask, slots, b_in, bprime, nullptr);
     else fill_rows<K, 8, 1>(t, t.row0, hi, perm, mask, slots, b_in, bprime, nullptr);
+}
+
+// The root's up-sweep step is only  b'_s = b_s - (slots at own positions): the root's down-sweep tiles can form it themselves
+// (rf.slots != nullptr) and the root needs no up-sweep launch at all.
+struct RootFill { const int* perm; const unsigned char* mask; const float* slots; const float* b_in; };
+template <int K>
+__device__ __forceinline__ void root_bprime(const Tile& t, const RootFill& rf, float* __restrict__ sb) {
+    if (t.arity == 4) fill_rows<K, 4, 4>(t, 0, t.s, rf.perm, rf.mask, rf.slots, rf.b_in, nullptr, sb);
+    else if (t.arity == 2) fill_rows<K, 2, 4>(t, 0, t.s, rf.perm, rf.mask, rf.slots, rf.b_in, nullptr, sb);
+    else fill_rows<K, 8, 2>(t, 0, t.s, rf.perm, rf.mask, rf.slots, rf.b_in, nullptr, sb);
 }
 
 // hand x of a front position down: xb[target] = v for every child boundary entry that is this vertex
@@ -284,7 +294,7 @@ __global__ __launch_bounds__(1024) void k_nd_down(const Tile* __restrict__ tiles
                                                   const int* __restrict__ push_ptr, const int* __restrict__ push_tgt,
                                                   const float* __restrict__ finv, const float* __restrict__ wb,
                                                   const float* __restrict__ bprime, float* xb, float* __restrict__ x_out,
-                                                  int s_cap, int b_cap) {   // xb: own rows read, children's rows written
+                                                  int s_cap, int b_cap, RootFill rf) {   // xb: own rows read, children's rows written
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sb = sm;
     float* sx = sm + (size_t)s_cap * K;
@@ -308,6 +318,8 @@ __global__ __launch_bounds__(1024) void k_nd_down(const Tile* __restrict__ tiles
         g = (size_t)perm[t.own_start + j];
         if (!t.leaf) { p0 = push_ptr[t.front_off + j]; p1 = push_ptr[t.front_off + j + 1]; }
     }
+    if (rf.slots && t.pfront_off < 0) root_bprime<K>(t, rf, sb);
+    else
     for (int u = threadIdx.x; u < s; u += blockDim.x) {
 #pragma unroll
         for (int q = 0; q < K; ++q) sb[u * K + q] = bprime[(size_t)(t.own_start + u) * K + q];
@@ -476,7 +488,7 @@ __global__ __launch_bounds__(64 * ND_BW) void k_nd_down_b(const Tile* __restrict
                                                           const int* __restrict__ push_ptr, const int* __restrict__ push_tgt,
                                                           const float* __restrict__ finv, const float* __restrict__ wf,
                                                           const float* __restrict__ bprime, float* xb, float* __restrict__ x_out,
-                                                          int s_cap, int b_cap, int chunks) {
+                                                          int s_cap, int b_cap, int chunks, RootFill rf) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sb = sm;
     float* sx = sm + (size_t)s_cap * K;
@@ -497,6 +509,8 @@ __global__ __launch_bounds__(64 * ND_BW) void k_nd_down_b(const Tile* __restrict
         g = (size_t)perm[t.own_start + jw + lane];
         if (!t.leaf) { p0 = push_ptr[t.front_off + jw + lane]; p1 = push_ptr[t.front_off + jw + lane + 1]; }
     }
+    if (rf.slots && t.pfront_off < 0) root_bprime<K>(t, rf, sb);
+    else
     for (int u = threadIdx.x; u < s; u += blockDim.x) {
 #pragma unroll
         for (int q = 0; q < K; ++q) sb[u * K + q] = bprime[(size_t)(t.own_start + u) * K + q];
@@ -679,7 +693,7 @@ __device__ __forceinline__ void packed_fill(const PackedTile& t, const int* __re
     for (int r = threadIdx.x; r < S; r += blockDim.x) {
         const int h = find_group(t.sb0, t.n, r);
         const int j = r - t.sb0[h];
-        const size_t g = (size_t)perm[first + r];            // own ranges of consecutive nodes are consecutive
+        const size_t g = perm ? (size_t)perm[first + r] : (size_t)(first + r);            // own ranges of consecutive nodes are consecutive
         float v[K];
 #pragma unroll
         for (int q = 0; q < K; ++q) v[q] = b_in[g * K + q];
@@ -820,6 +834,8 @@ struct ls_direct {
     float* braw = nullptr;                                       // tier kernels: gathered right-hand side of the inner-node rows (V, k)
     float *bp = nullptr, *slots = nullptr, *xb = nullptr;        // b' (V, k); up-sweep slots (n_front, arity, k); x at boundaries (n_bnd, k)
     // bottom tier: levels [tier_root, levels) run as one launch per sweep, one workgroup per subtree (nd_tier.h)
+    bool fuse_root = true;              // LS_ND_NO_FUSE_ROOT: the root keeps its up-sweep launch
+    int upper_lo = 0;                   // rows [upper_lo, V) of the tree's numbering belong to the levels above the tier
     int tier_root = 0, tier_phases = 0, tier_wgs = 0, tier_region = 0, tier_vec = 0, tier_tri = 0;
     TierItem* d_items = nullptr;
     int* pull = nullptr;                // tier up sweep: (front position, child) -> child boundary entry (n_front x arity)
@@ -1069,6 +1085,8 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
             d->tier_root = root; d->tier_phases = H; d->tier_wgs = (int)wgs.size(); d->tier_region = (int)((region + 3) & ~(size_t)3);
         }
     }
+    d->fuse_root = getenv("LS_ND_NO_FUSE_ROOT") == nullptr;
+    d->upper_lo = (d->tier_root < levels && d->tier_root > 0) ? nodes[level_off[d->tier_root - 1]].own_start : (int)V;
     std::vector<int> pull;
     if (d->tier_root < levels) {
         pull.assign((size_t)n_front * arity, -1);
@@ -1270,6 +1288,7 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
     ta.sp_ptr = d->sp_ptr; ta.sp_ent = d->sp_ent; ta.bprime = d->bp; ta.braw = d->braw; ta.slots = d->slots; ta.xb = d->xb;
     ta.arity = d->arity; ta.phases = d->tier_phases; ta.region_floats = d->tier_region; ta.vec_floats = d->tier_vec;
     ta.dbg = d->profile == 2 ? d->dbg : nullptr;
+    ta.upper_lo = d->upper_lo; ta.upper_hi = (int)d->V;
     ta.ablate = env_int0("LS_ND_ABLATE", 0);
     ta.stagger = env_int0("LS_ND_STAGGER", 0);
     const size_t tier_lds = (size_t)d->tier_region * TIER_WAVES * sizeof(float);
@@ -1281,21 +1300,28 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
         hipLaunchKernelGGL((k_nd_tier<K, true>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
     }
     if (part == 1 && exch_n) LS_HIP(hipMemcpyAsync(d->slots + exch_off, exchange, exch_n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    // the tier's up-sweep launch gathers b of the upper levels' rows into the tree's numbering (braw): their kernels skip perm -> b
+    const int* up_perm = d->tier_wgs ? nullptr : d->perm;
+    const float* up_b = d->tier_wgs ? d->braw : b;
+    // the root (level 0, when it is a level of its own launches): b' is formed by its down-sweep tiles, no up-sweep launch
+    const bool fuse_root = top >= 0 && d->fuse_root && !d->plan[0].down_p && !d->plan[0].down_s;
+    const RootFill rf = fuse_root ? RootFill{up_perm, d->mask, d->slots, up_b} : RootFill{nullptr, nullptr, nullptr, nullptr};
     for (int lv = (part == 1 ? std::min(top, d->cut - 1) : top); lv >= (part == 0 ? d->cut : 0); --lv) {
         const LevelPlan& p = d->plan[lv];
         if (!(p.up_p ? p.up_p_tiles : p.up_tiles)) continue;
+        if (lv == 0 && fuse_root) continue;
         if (p.up_p)
             hipLaunchKernelGGL(k_nd_up_p<K>, dim3(p.up_p_tiles), dim3(WAVE), (size_t)std::max(p.up_p_lds, 1) * K * sizeof(float), st,
-                               d->ptiles + p.up_p_first, d->perm, d->mask, d->ppos, d->wf, b, d->bp, d->slots);
+                               d->ptiles + p.up_p_first, up_perm, d->mask, d->ppos, d->wf, up_b, d->bp, d->slots);
         else if (p.up_s)
             hipLaunchKernelGGL(k_nd_up_s<K>, dim3(p.up_tiles), dim3(WAVE * p.up_nw), ((size_t)p.s_cap * p.b_cap + (size_t)p.s_cap * K) * sizeof(float), st,
-                               d->tiles + p.up_first, d->perm, d->mask, d->ppos, d->wf, b, d->bp, d->slots, p.s_cap, p.b_cap);
+                               d->tiles + p.up_first, up_perm, d->mask, d->ppos, d->wf, up_b, d->bp, d->slots, p.s_cap, p.b_cap);
         else if (p.up_b)
             hipLaunchKernelGGL(k_nd_up_b<K>, dim3(p.up_tiles), dim3(WAVE * ND_BW), (size_t)p.s_cap * K * sizeof(float), st, d->tiles + p.up_first,
-                               d->perm, d->mask, d->ppos, d->wb, b, d->bp, d->slots, p.s_cap, p.up_chunks);
+                               up_perm, d->mask, d->ppos, d->wb, up_b, d->bp, d->slots, p.s_cap, p.up_chunks);
         else
             hipLaunchKernelGGL(k_nd_up<K>, dim3(p.up_tiles), dim3(WAVE * p.up_nw), ((size_t)p.s_cap + (size_t)(p.up_nw - 1) * WAVE) * K * sizeof(float),
-                               st, d->tiles + p.up_first, d->perm, d->mask, d->ppos, d->wf, b, d->bp, d->slots, p.s_cap);
+                               st, d->tiles + p.up_first, up_perm, d->mask, d->ppos, d->wf, up_b, d->bp, d->slots, p.s_cap);
     }
     if (part == 0) {
         if (exch_n) LS_HIP(hipMemcpyAsync(exchange, d->slots + exch_off, exch_n * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -1317,11 +1343,12 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
         else if (p.down_b)
             hipLaunchKernelGGL(k_nd_down_b<K>, dim3(p.down_tiles), dim3(WAVE * ND_BW), ((size_t)p.s_cap + p.b_cap) * K * sizeof(float), st,
                                d->tiles + p.down_first, d->perm, d->push_ptr, d->push_tgt, d->finv, d->wf, (const float*)d->bp, d->xb, x,
-                               p.s_cap, p.b_cap, p.down_chunks);
+                               p.s_cap, p.b_cap, p.down_chunks, lv == 0 ? rf : RootFill{nullptr, nullptr, nullptr, nullptr});
         else
             hipLaunchKernelGGL(k_nd_down<K>, dim3(p.down_tiles), dim3(WAVE * p.down_nw),
                                ((size_t)p.s_cap + p.b_cap + (size_t)(p.down_nw - 1) * WAVE) * K * sizeof(float), st, d->tiles + p.down_first,
-                               d->perm, d->push_ptr, d->push_tgt, d->finv, d->wb, (const float*)d->bp, d->xb, x, p.s_cap, p.b_cap);
+                               d->perm, d->push_ptr, d->push_tgt, d->finv, d->wb, (const float*)d->bp, d->xb, x, p.s_cap, p.b_cap,
+                               lv == 0 ? rf : RootFill{nullptr, nullptr, nullptr, nullptr});
     }
     if (ta.dbg) ta.dbg += (size_t)d->tier_wgs * TIER_WAVES * 32;
     if (d->tier_wgs)
@@ -1443,7 +1470,8 @@ extern "C" int ls_direct_info(const ls_direct* d, int64_t* h_factor_entries, int
         int n = 0;
         for (int lv = 0; lv < d->levels; ++lv) {
             const LevelPlan& p = d->plan[lv];
-            n += ((p.up_p ? p.up_p_tiles : p.up_tiles) ? 1 : 0) + ((p.down_p ? p.down_p_tiles : p.down_tiles) ? 1 : 0);
+            const bool fused = lv == 0 && d->tier_root > 0 && d->fuse_root && !p.down_p && !p.down_s;     // the root's up step rides in its down tiles
+            n += (((p.up_p ? p.up_p_tiles : p.up_tiles) && !fused) ? 1 : 0) + ((p.down_p ? p.down_p_tiles : p.down_tiles) ? 1 : 0);
         }
         *h_launches = n + (d->tier_wgs ? 2 : 0);
     }

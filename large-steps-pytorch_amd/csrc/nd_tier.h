@@ -76,6 +76,7 @@ struct TierArgs {
     const int* sp_ptr;
     const SpEnt* sp_ent;
     float* bprime;
+    int upper_lo, upper_hi;                          // rows of the levels above the tier (tree numbering): gathered into braw as well
     float* braw;                                     // b of the tier's inner-node rows in the tree's numbering (up sweep scratch)
     float* slots;
     float* xb;
@@ -662,6 +663,12 @@ __global__ __launch_bounds__(64 * TIER_WAVES, 4) void k_nd_tier(TierArgs a, cons
             const size_t g = (size_t)a.perm[start];
 #pragma unroll
             for (int q = 0; q < K; ++q) a.braw[(size_t)start * K + q] = b_in[g * K + q];
+        }
+        // ... and the rows of the levels above the tier (a few per workgroup): their launches start from braw, not from perm -> b
+        for (int r = a.upper_lo + blockIdx.x * blockDim.x + threadIdx.x; r < a.upper_hi; r += gridDim.x * blockDim.x) {
+            const size_t g = (size_t)a.perm[r];
+#pragma unroll
+            for (int q = 0; q < K; ++q) a.braw[(size_t)r * K + q] = b_in[g * K + q];
         }
     }
     DensePre<K> pre;
