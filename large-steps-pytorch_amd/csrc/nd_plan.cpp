@@ -7,35 +7,105 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <numeric>
 #include <thread>
 
 namespace ls {
 namespace {
 
-int n_threads() {
-    static const int n = [] {
-        const char* e = getenv("LS_PLAN_THREADS");
-        const int want = e ? atoi(e) : 32;
-        const int hw = (int)std::thread::hardware_concurrency();
-        return std::max(1, std::min(want, hw > 0 ? hw : 1));
-    }();
-    return n;
+int n_threads() {          // read at every build: tests compare the one-thread and the many-thread paths
+    const char* e = getenv("LS_PLAN_THREADS");
+    const int want = e ? atoi(e) : 32;
+    const int hw = (int)std::thread::hardware_concurrency();
+    return std::max(1, std::min(want, hw > 0 ? hw : 1));
 }
 
-// body(begin, end) over [0, n) in contiguous chunks
-void parallel_for(int64_t n, int64_t grain, const std::function<void(int64_t, int64_t)>& body) {
-    const int T = (int)std::min<int64_t>(n_threads(), std::max<int64_t>(1, n / std::max<int64_t>(grain, 1)));
-    if (T <= 1) { body(0, n); return; }
-    std::vector<std::thread> th;
-    const int64_t step = (n + T - 1) / T;
-    for (int t = 0; t < T; ++t) {
-        const int64_t lo = t * step, hi = std::min(n, lo + step);
-        if (lo >= hi) break;
-        th.emplace_back([=, &body] { body(lo, hi); });
+// A pool of host threads that lives for one nd_plan_build call: a round of the bisection issues a handful of short parallel
+// passes, and creating 32 threads for each of them costs more than the passes themselves.
+class Pool {
+public:
+    explicit Pool(int threads) {
+        for (int t = 1; t < threads; ++t) th_.emplace_back([this] { worker(); });
     }
-    for (auto& x : th) x.join();
+    ~Pool() {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    int size() const { return (int)th_.size() + 1; }
+    // fn(chunk, begin, end) for `chunks` contiguous pieces of [0, n); the calling thread takes part
+    void run(int64_t n, int chunks, const std::function<void(int, int64_t, int64_t)>& fn) {
+        if (n <= 0) return;
+        chunks = (int)std::max<int64_t>(1, std::min<int64_t>(chunks, n));
+        if (chunks == 1 || th_.empty()) {
+            const int64_t step = (n + chunks - 1) / chunks;
+            for (int c = 0; c < chunks; ++c) { const int64_t lo = c * step, hi = std::min(n, lo + step); if (lo < hi) fn(c, lo, hi); }
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fn_ = &fn; n_ = n; chunks_ = chunks; step_ = (n + chunks - 1) / chunks; next_ = 0; pending_ = chunks; ++gen_;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [&] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    void work() {
+        for (;;) {
+            const std::function<void(int, int64_t, int64_t)>* fn;
+            int c;
+            int64_t lo, hi;
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (!fn_ || next_ >= chunks_) return;
+                c = next_++; fn = fn_; lo = c * step_; hi = std::min(n_, lo + step_);
+            }
+            if (lo < hi) (*fn)(c, lo, hi);
+            std::lock_guard<std::mutex> lk(m_);
+            if (--pending_ == 0) done_.notify_all();
+        }
+    }
+    void worker() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+            }
+            work();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int, int64_t, int64_t)>* fn_ = nullptr;
+    int64_t n_ = 0, step_ = 0;
+    int chunks_ = 0, next_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+
+thread_local Pool* g_pool = nullptr;      // the pool of the nd_plan_build call running on this thread
+
+// body(begin, end) over [0, n) in contiguous chunks of at least `grain`
+void parallel_for(int64_t n, int64_t grain, const std::function<void(int64_t, int64_t)>& body) {
+    const int T = (int)std::min<int64_t>(g_pool ? g_pool->size() : 1, std::max<int64_t>(1, n / std::max<int64_t>(grain, 1)));
+    if (T <= 1 || !g_pool) { body(0, n); return; }
+    g_pool->run(n, T, [&](int, int64_t lo, int64_t hi) { body(lo, hi); });
+}
+// fn(chunk, begin, end): the chunk index lets a pass keep per-chunk partial results
+void parallel_chunks(int64_t n, int chunks, const std::function<void(int, int64_t, int64_t)>& fn) {
+    if (!g_pool) { Pool one(1); one.run(n, chunks, fn); return; }
+    g_pool->run(n, chunks, fn);
 }
 
 // level-synchronous BFS; dist < 0 = unreached. Returns the last vertex reached.
@@ -108,6 +178,9 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
     if (V <= 0 || V >= INT32_MAX) return "nd_plan_build: bad vertex count";
     if (arity != 2 && arity != 4 && arity != 8) return "nd_plan_build: arity must be 2, 4 or 8";
     if (leaf_size < 1) return "nd_plan_build: leaf_size must be positive";
+    Pool pool(n_threads());
+    struct PoolScope { PoolScope(Pool* p) { g_pool = p; } ~PoolScope() { g_pool = nullptr; } } pool_scope(&pool);
+    const int T = pool.size();
     const int m = arity == 2 ? 1 : arity == 4 ? 2 : 3;
     int D = 0;
     while ((V >> D) > leaf_size) ++D;
@@ -154,30 +227,110 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
     seg_start[1] = V;
     std::vector<int64_t> next_start, keep_cnt;
     std::vector<int> cnt0, cnt1;
+    // Rounds with fewer domains than threads run their passes parallel INSIDE a domain (the first round is one domain of V
+    // vertices); later rounds run one domain per thread. Both produce the same sets: which vertices land left of the median
+    // is decided by the (key, id) order alone, the arrangement inside `live` is irrelevant.
+    typedef std::pair<double, int> KV;
+    std::vector<KV> kv_a, kv_b;
+    constexpr int NB = 2048;                          // buckets of the parallel selection
+    std::vector<int> hist;
+    struct Piece { int64_t d, lo, hi; int n0, e0, n1, e1; int64_t w0, w1; };
+    std::vector<Piece> pieces;
     for (int r = 0; r < D; ++r) {
-        const int64_t n_dom = (int64_t)1 << r, base = n_dom;
-        // median split of every domain along the longest axis of its bounding box
-        parallel_for(n_dom, 1, [&](int64_t lo, int64_t hi) {
-            for (int64_t d = lo; d < hi; ++d) {
-                const int64_t a = seg_start[d], e = seg_start[d + 1], cnt = e - a;
-                if (cnt <= 0) continue;
+        const int64_t n_dom = (int64_t)1 << r;
+        const bool inside = 4 * n_dom <= T && n_live >= 65536;       // (with a thread for every second domain or more, whole domains per thread win)
+        auto split_serial = [&](int64_t d) {
+            const int64_t a = seg_start[d], e = seg_start[d + 1], cnt = e - a;
+            if (cnt <= 0) return;
+            double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+            for (int64_t i = a; i < e; ++i)
+                for (int k = 0; k < 3; ++k) { const double x = pos[3 * (size_t)live[i] + k]; mn[k] = std::min(mn[k], x); mx[k] = std::max(mx[k], x); }
+            int ax = 0;
+            for (int k = 1; k < 3; ++k) if (mx[k] - mn[k] > mx[ax] - mn[ax]) ax = k;
+            const int64_t half = cnt / 2;
+            // selection on contiguous (key, id) pairs: the comparator must not chase pos[] through the index array
+            std::vector<KV> kv((size_t)cnt);
+            for (int64_t i = a; i < e; ++i) kv[(size_t)(i - a)] = {pos[3 * (size_t)live[i] + ax], live[i]};
+            std::nth_element(kv.begin(), kv.begin() + half, kv.end());
+            for (int64_t i = a; i < e; ++i) {
+                const int u = kv[(size_t)(i - a)].second;
+                live[i] = u; side[u] = i - a >= half;
+                state[u] = (node[u] << 2) | ((int64_t)side[u] << 1);
+            }
+        };
+        auto split_parallel = [&](int64_t d) {
+            const int64_t a = seg_start[d], e = seg_start[d + 1], cnt = e - a;
+            if (cnt < 32768) { split_serial(d); return; }
+            const int C = (int)std::min<int64_t>(T, cnt / 8192);
+            std::vector<double> part((size_t)C * 6);
+            for (int c = 0; c < C; ++c) for (int k = 0; k < 3; ++k) { part[(size_t)c * 6 + k] = 1e300; part[(size_t)c * 6 + 3 + k] = -1e300; }
+            parallel_chunks(cnt, C, [&](int c, int64_t lo, int64_t hi) {
                 double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
-                for (int64_t i = a; i < e; ++i)
+                for (int64_t i = a + lo; i < a + hi; ++i)
                     for (int k = 0; k < 3; ++k) { const double x = pos[3 * (size_t)live[i] + k]; mn[k] = std::min(mn[k], x); mx[k] = std::max(mx[k], x); }
-                int ax = 0;
-                for (int k = 1; k < 3; ++k) if (mx[k] - mn[k] > mx[ax] - mn[ax]) ax = k;
-                const int64_t half = cnt / 2;
-                // selection on contiguous (key, id) pairs: the comparator must not chase pos[] through the index array
-                std::vector<std::pair<double, int>> kv((size_t)cnt);
-                for (int64_t i = a; i < e; ++i) kv[(size_t)(i - a)] = {pos[3 * (size_t)live[i] + ax], live[i]};
-                std::nth_element(kv.begin(), kv.begin() + half, kv.end());
-                for (int64_t i = a; i < e; ++i) {
-                    const int u = kv[(size_t)(i - a)].second;
-                    live[i] = u; side[u] = i - a >= half;
-                    state[u] = (node[u] << 2) | ((int64_t)side[u] << 1);
+                for (int k = 0; k < 3; ++k) { part[(size_t)c * 6 + k] = mn[k]; part[(size_t)c * 6 + 3 + k] = mx[k]; }
+            });
+            double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+            for (int c = 0; c < C; ++c) for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], part[(size_t)c * 6 + k]); mx[k] = std::max(mx[k], part[(size_t)c * 6 + 3 + k]); }
+            int ax = 0;
+            for (int k = 1; k < 3; ++k) if (mx[k] - mn[k] > mx[ax] - mn[ax]) ax = k;
+            const int64_t half = cnt / 2;
+            // bucket = a monotone function of the key: a smaller bucket means a smaller key, so only the median's bucket needs a
+            // real selection
+            const double lo_key = mn[ax], scale = mx[ax] > mn[ax] ? NB / (mx[ax] - mn[ax]) : 0.0;
+            auto bucket = [&](double x) { const int q = (int)((x - lo_key) * scale); return q < 0 ? 0 : q >= NB ? NB - 1 : q; };
+            if ((int64_t)kv_a.size() < cnt) { kv_a.resize((size_t)cnt); kv_b.resize((size_t)cnt); }
+            hist.assign((size_t)C * NB, 0);
+            parallel_chunks(cnt, C, [&](int c, int64_t lo, int64_t hi) {
+                int* h = hist.data() + (size_t)c * NB;
+                for (int64_t i = lo; i < hi; ++i) {
+                    const int u = live[a + i];
+                    const double x = pos[3 * (size_t)u + ax];
+                    kv_a[(size_t)i] = {x, u};
+                    ++h[bucket(x)];
+                }
+            });
+            std::vector<int64_t> total((size_t)NB, 0);
+            for (int c = 0; c < C; ++c) for (int q = 0; q < NB; ++q) total[q] += hist[(size_t)c * NB + q];
+            int bm = 0;
+            int64_t before = 0;
+            while (bm + 1 < NB && before + total[bm] <= half) { before += total[bm]; ++bm; }
+            const int64_t n_left = before, n_mid = total[bm];
+            // write offsets of every chunk's three classes (left of / in / right of the median's bucket)
+            std::vector<int64_t> off((size_t)C * 3);
+            {
+                int64_t wl = 0, wm = n_left, wr = n_left + n_mid;
+                for (int c = 0; c < C; ++c) {
+                    int64_t cl = 0, cr = 0;
+                    const int* h = hist.data() + (size_t)c * NB;
+                    for (int q = 0; q < bm; ++q) cl += h[q];
+                    for (int q = bm + 1; q < NB; ++q) cr += h[q];
+                    off[(size_t)c * 3] = wl; off[(size_t)c * 3 + 1] = wm; off[(size_t)c * 3 + 2] = wr;
+                    wl += cl; wm += h[bm]; wr += cr;
                 }
             }
-        });
+            parallel_chunks(cnt, C, [&](int c, int64_t lo, int64_t hi) {
+                int64_t wl = off[(size_t)c * 3], wm = off[(size_t)c * 3 + 1], wr = off[(size_t)c * 3 + 2];
+                for (int64_t i = lo; i < hi; ++i) {
+                    const KV x = kv_a[(size_t)i];
+                    const int q = bucket(x.first);
+                    kv_b[(size_t)(q < bm ? wl++ : q == bm ? wm++ : wr++)] = x;
+                }
+            });
+            std::nth_element(kv_b.begin() + n_left, kv_b.begin() + half, kv_b.begin() + n_left + n_mid);
+            parallel_chunks(cnt, C, [&](int, int64_t lo, int64_t hi) {
+                for (int64_t i = lo; i < hi; ++i) {
+                    const int u = kv_b[(size_t)i].second;
+                    live[a + i] = u; side[u] = i >= half;
+                    state[u] = (node[u] << 2) | ((int64_t)side[u] << 1);
+                }
+            });
+        };
+        const auto tr0 = std::chrono::steady_clock::now();
+        // median split of every domain along the longest axis of its bounding box
+        if (inside) { for (int64_t d = 0; d < n_dom; ++d) split_parallel(d); }
+        else parallel_for(n_dom, 1, [&](int64_t lo, int64_t hi) { for (int64_t d = lo; d < hi; ++d) split_serial(d); });
+        const auto tr1 = std::chrono::steady_clock::now();
         // end points of the cut edges
         parallel_for(n_live, 4096, [&](int64_t lo, int64_t hi) {
             for (int64_t i = lo; i < hi; ++i) {
@@ -188,28 +341,61 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
                 endp[u] = cut;
             }
         });
-        // per domain: the smaller end-point set is the separator; count what stays in either half
-        cnt0.assign((size_t)n_dom, 0); cnt1.assign((size_t)n_dom, 0);
-        keep_cnt.assign((size_t)2 * n_dom, 0);
-        parallel_for(n_dom, 1, [&](int64_t lo, int64_t hi) {
-            for (int64_t d = lo; d < hi; ++d) {
-                const int64_t a = seg_start[d], e = seg_start[d + 1], half = (e - a) / 2;
-                int c0 = 0, c1 = 0;
-                for (int64_t i = a; i < e; ++i) if (endp[live[i]]) { if (i - a >= half) ++c1; else ++c0; }
-                cnt0[d] = c0; cnt1[d] = c1;
-                const bool use1 = c1 < c0;
-                keep_cnt[2 * d] = half - (use1 ? 0 : c0);
-                keep_cnt[2 * d + 1] = (e - a - half) - (use1 ? c1 : 0);
+        const auto tr2 = std::chrono::steady_clock::now();
+        // per domain: the smaller end-point set is the separator; what stays in either half moves on, in order, to the next
+        // round's grouping. The passes run over pieces of domains (a domain is one piece once there are enough domains).
+        pieces.clear();
+        {
+            const int per_dom = inside ? (int)std::max<int64_t>(1, 2 * T / n_dom) : 1;
+            for (int64_t d = 0; d < n_dom; ++d) {
+                const int64_t a = seg_start[d], e = seg_start[d + 1];
+                const int np = (int)std::max<int64_t>(1, std::min<int64_t>(per_dom, (e - a) / 4096));
+                const int64_t step = (e - a + np - 1) / np;
+                for (int q = 0; q < np; ++q) {
+                    Piece pc{d, a + q * step, std::min(e, a + (q + 1) * step), 0, 0, 0, 0, 0, 0};
+                    if (pc.lo < pc.hi || q == 0) pieces.push_back(pc);
+                }
+            }
+        }
+        const int64_t n_pieces = (int64_t)pieces.size();
+        parallel_for(n_pieces, 1, [&](int64_t lo, int64_t hi) {
+            for (int64_t q = lo; q < hi; ++q) {
+                Piece& pc = pieces[(size_t)q];
+                const int64_t a = seg_start[pc.d], half = (seg_start[pc.d + 1] - a) / 2;
+                int n0 = 0, e0 = 0, n1 = 0, e1 = 0;
+                for (int64_t i = pc.lo; i < pc.hi; ++i) {
+                    const bool ep = endp[live[i]];
+                    if (i - a >= half) { ++n1; e1 += ep; } else { ++n0; e0 += ep; }
+                }
+                pc.n0 = n0; pc.e0 = e0; pc.n1 = n1; pc.e1 = e1;
             }
         });
+        cnt0.assign((size_t)n_dom, 0); cnt1.assign((size_t)n_dom, 0);
+        keep_cnt.assign((size_t)2 * n_dom, 0);
+        for (const Piece& pc : pieces) { cnt0[(size_t)pc.d] += pc.e0; cnt1[(size_t)pc.d] += pc.e1; }
+        for (const Piece& pc : pieces) {
+            const bool use1 = cnt1[(size_t)pc.d] < cnt0[(size_t)pc.d];
+            keep_cnt[2 * (size_t)pc.d] += pc.n0 - (use1 ? 0 : pc.e0);
+            keep_cnt[2 * (size_t)pc.d + 1] += pc.n1 - (use1 ? pc.e1 : 0);
+        }
         next_start.assign((size_t)2 * n_dom + 1, 0);
         for (int64_t h = 0; h < 2 * n_dom; ++h) next_start[h + 1] = next_start[h] + keep_cnt[h];
-        parallel_for(n_dom, 1, [&](int64_t lo, int64_t hi) {
-            for (int64_t d = lo; d < hi; ++d) {
-                const int64_t a = seg_start[d], e = seg_start[d + 1], half = (e - a) / 2;
-                const bool use1 = cnt1[d] < cnt0[d];
-                int64_t w0 = next_start[2 * d], w1 = next_start[2 * d + 1];
-                for (int64_t i = a; i < e; ++i) {
+        {
+            std::vector<int64_t> w(next_start.begin(), next_start.end() - 1);
+            for (Piece& pc : pieces) {
+                const bool use1 = cnt1[(size_t)pc.d] < cnt0[(size_t)pc.d];
+                pc.w0 = w[2 * (size_t)pc.d]; pc.w1 = w[2 * (size_t)pc.d + 1];
+                w[2 * (size_t)pc.d] += pc.n0 - (use1 ? 0 : pc.e0);
+                w[2 * (size_t)pc.d + 1] += pc.n1 - (use1 ? pc.e1 : 0);
+            }
+        }
+        parallel_for(n_pieces, 1, [&](int64_t lo, int64_t hi) {
+            for (int64_t q = lo; q < hi; ++q) {
+                const Piece& pc = pieces[(size_t)q];
+                const int64_t a = seg_start[pc.d], half = (seg_start[pc.d + 1] - a) / 2;
+                const bool use1 = cnt1[(size_t)pc.d] < cnt0[(size_t)pc.d];
+                int64_t w0 = pc.w0, w1 = pc.w1;
+                for (int64_t i = pc.lo; i < pc.hi; ++i) {
                     const int u = live[i];
                     const bool s1 = i - a >= half;
                     if (endp[u] && s1 == use1) { fixed[u] = 1; state[u] |= 1; continue; }      // node[u] stays: the domain it separates
@@ -222,7 +408,12 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
             for (int64_t i = lo; i < hi; ++i) { const int u = tmp[i]; live[i] = u; node[u] = 2 * node[u] + side[u]; }
         });
         seg_start.swap(next_start);
-        (void)base;
+        if (timing) {
+            const auto tr3 = std::chrono::steady_clock::now();
+            auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count() * 1e3; };
+            fprintf(stderr, "[nd_plan]   round %2d (%6lld domains%s): split %.2f ms, cut edges %.2f ms, regroup %.2f ms\n", r, (long long)n_dom, inside ? ", inside" : "",
+                    ms(tr0, tr1), ms(tr1, tr2), ms(tr2, tr3));
+        }
     }
     lap("bisection");
     // ---- merged tree: log2(arity) bisection rounds per level, the leaf domains are the last level -------------------------
@@ -255,16 +446,32 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
     });
     // ---- ordering: deepest level first, node by node, original id inside a node ----------------------------------------------
     P.s.assign((size_t)n_nodes + 1, 0); P.b.assign((size_t)n_nodes + 1, 0); P.own_start.assign((size_t)n_nodes + 1, 0);
-    for (int64_t v = 0; v < V; ++v) ++P.s[node_id[v]];
     {
+        // stable counting sort of the vertices by node id, chunk by chunk: counts per (chunk, node), offsets = the node's start +
+        // what earlier chunks hold of that node
+        const int C = (int)std::max<int64_t>(1, std::min<int64_t>(T, V / 32768));
+        std::vector<int> cnt((size_t)C * (n_nodes + 1), 0);
+        parallel_chunks(V, C, [&](int c, int64_t lo, int64_t hi) {
+            int* h = cnt.data() + (size_t)c * (n_nodes + 1);
+            for (int64_t v = lo; v < hi; ++v) ++h[node_id[v]];
+        });
+        parallel_for(n_nodes + 1, 4096, [&](int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; ++i) { int t = 0; for (int c = 0; c < C; ++c) t += cnt[(size_t)c * (n_nodes + 1) + i]; P.s[i] = t; }
+        });
         int64_t off = 0;
         for (int l = levels - 1; l >= 0; --l)
             for (int64_t i = P.level_off[l]; i < P.level_off[l + 1]; ++i) { P.own_start[i] = (int)off; off += P.s[i]; }
-    }
-    P.perm.resize((size_t)V); P.inv.resize((size_t)V); P.node_of_new.resize((size_t)V);
-    {
-        std::vector<int> cur(P.own_start);
-        for (int64_t v = 0; v < V; ++v) { const int nw = cur[node_id[v]]++; P.perm[nw] = (int)v; P.inv[v] = nw; P.node_of_new[nw] = node_id[v]; }
+        parallel_for(n_nodes + 1, 4096, [&](int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; ++i) {
+                int t = P.own_start[i];
+                for (int c = 0; c < C; ++c) { int& x = cnt[(size_t)c * (n_nodes + 1) + i]; const int n = x; x = t; t += n; }
+            }
+        });
+        P.perm.resize((size_t)V); P.inv.resize((size_t)V); P.node_of_new.resize((size_t)V);
+        parallel_chunks(V, C, [&](int c, int64_t lo, int64_t hi) {
+            int* cur = cnt.data() + (size_t)c * (n_nodes + 1);
+            for (int64_t v = lo; v < hi; ++v) { const int nw = cur[node_id[v]]++; P.perm[nw] = (int)v; P.inv[v] = nw; P.node_of_new[nw] = node_id[v]; }
+        });
     }
     lap("ordering");
     // ---- boundary sets, deepest level first (a node's set needs its children's) ------------------------------------------------
@@ -329,18 +536,28 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
     // ---- push lists of the down sweep: front position -> boundary entries of the children that are this vertex -------------
     P.push_ptr.assign((size_t)P.n_front + 1, 0);
     P.push_tgt.resize((size_t)P.n_bnd);
-    for (int i = 2; i <= n_nodes; ++i) {
-        const int64_t pf = P.front_off[P.parent[i]];
-        for (int k = 0; k < P.b[i]; ++k) ++P.push_ptr[(size_t)(pf + P.ppos[(size_t)P.bnd_off[i] + k]) + 1];
-    }
-    for (int64_t f = 0; f < P.n_front; ++f) P.push_ptr[f + 1] += P.push_ptr[f];
-    {
-        std::vector<int> cur(P.push_ptr.begin(), P.push_ptr.end() - 1);
-        for (int i = 2; i <= n_nodes; ++i) {
-            const int64_t pf = P.front_off[P.parent[i]];
-            for (int k = 0; k < P.b[i]; ++k) P.push_tgt[(size_t)cur[(size_t)(pf + P.ppos[(size_t)P.bnd_off[i] + k])]++] = (int)(P.bnd_off[i] + k);
+    // a parent's front positions receive entries from its own children only: counts and fills run parent by parent
+    const int64_t n_inner = P.level_off[levels - 1] - 1;             // nodes 1 .. n_inner have children
+    auto children = [&](int64_t par, int64_t& first) { const int l = P.level_of[par]; first = P.level_off[l + 1] + (par - P.level_off[l]) * arity; };
+    parallel_for(n_inner, 16, [&](int64_t lo, int64_t hi) {
+        for (int64_t par = lo + 1; par <= hi; ++par) {
+            int64_t first; children(par, first);
+            const int64_t pf = P.front_off[par];
+            for (int64_t i = first; i < first + arity; ++i)
+                for (int k = 0; k < P.b[i]; ++k) ++P.push_ptr[(size_t)(pf + P.ppos[(size_t)P.bnd_off[i] + k]) + 1];
         }
-    }
+    });
+    for (int64_t f = 0; f < P.n_front; ++f) P.push_ptr[f + 1] += P.push_ptr[f];
+    parallel_for(n_inner, 16, [&](int64_t lo, int64_t hi) {
+        std::vector<int> cur;
+        for (int64_t par = lo + 1; par <= hi; ++par) {
+            int64_t first; children(par, first);
+            const int64_t pf = P.front_off[par], fl = P.s[par] + P.b[par];
+            cur.assign(P.push_ptr.begin() + pf, P.push_ptr.begin() + pf + fl);
+            for (int64_t i = first; i < first + arity; ++i)
+                for (int k = 0; k < P.b[i]; ++k) P.push_tgt[(size_t)cur[(size_t)P.ppos[(size_t)P.bnd_off[i] + k]]++] = (int)(P.bnd_off[i] + k);
+        }
+    });
     lap("push lists");
     P.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     return "";

@@ -303,3 +303,24 @@ def test_native_plan_solves_the_system(name, kw, arity, leaf, with_pos):
     if with_pos and name in ("plane30", "ico10"):            # same quality as the numpy statement's plan
         q = NDPlan.build(rowptr, c, v, leaf_size=leaf, arity=arity)
         assert p.levels == q.levels and abs(p.factor_entries - q.factor_entries) <= 0.02 * q.factor_entries
+
+
+@pytest.mark.parametrize("with_pos", [True, False])
+def test_native_plan_is_independent_of_the_thread_count(with_pos, monkeypatch):
+    """Rounds with fewer domains than threads split a domain with a parallel bucket selection (csrc/nd_plan.cpp); the plan must
+    be the one a single thread computes -- every array identical -- on a mesh large enough to take that path (> 65536 vertices,
+    degenerate keys: a plane has 300 distinct x values)."""
+    from native_plan import native_plan
+    v, f = synthetic.plane(300)
+    v = v.copy()
+    v[:, 2] = 0.05 * np.sin(7.0 * v[:, 0]) * np.cos(5.0 * v[:, 1])
+    r, rowptr, c, val = csr_of(v, f, lambda_=5.0)
+    plans = []
+    for threads in ("1", "8", "5"):
+        monkeypatch.setenv("LS_PLAN_THREADS", threads)
+        plans.append(native_plan(rowptr, c, v if with_pos else None, leaf_size=64, arity=4))
+    a = plans[0]
+    assert sorted(a.perm.tolist()) == list(range(v.shape[0]))
+    for q in plans[1:]:
+        for name in ("perm", "s", "b", "own_start", "bnd", "ppos", "push_ptr", "push_tgt"):
+            assert np.array_equal(getattr(a, name), getattr(q, name)), name
