@@ -84,55 +84,41 @@ __global__ __launch_bounds__(256) void k_gemm_batched(const GemmDesc* __restrict
     }
 }
 
-// ---- X = M^-1 for SPD M, n <= 64, one workgroup per matrix in LDS (Cholesky, triangular inverse, product) ------------------------
+// ---- X = M^-1 for SPD M, n <= 64, one workgroup per matrix in LDS ---------------------------------------------------------------
 struct InvDesc { const double* M; double* X; int n, ldm, ldx, pad; };
 
 constexpr int INV_N = 64;
 
+// X = M^-1 for SPD blocks of up to 64 rows, one workgroup per block, the block resident in LDS: Gauss-Jordan sweeps in place
+// (no pivoting: the pivots of an SPD matrix are the diagonal of its Schur complements, all positive). Step k reads column k and
+// row k from a copy, so the whole n x n update is one pass between two barriers; thread (ty, tx) owns column tx of rows ty, ty + 4, ...
 __global__ __launch_bounds__(256) void k_spd_inverse_small(const InvDesc* __restrict__ descs, int* __restrict__ flag) {
     const InvDesc d = descs[blockIdx.x];
     const int n = d.n;
     if (n <= 0) return;
     extern __shared__ __attribute__((aligned(16))) double inv_sm[];
     double (*a)[INV_N + 1] = reinterpret_cast<double (*)[INV_N + 1]>(inv_sm);
-    double (*li)[INV_N + 1] = reinterpret_cast<double (*)[INV_N + 1]>(inv_sm + INV_N * (INV_N + 1));
-    __shared__ int bad;
-    if (threadIdx.x == 0) bad = 0;
-    for (int e = threadIdx.x; e < n * n; e += 256) a[e / n][e % n] = d.M[(size_t)(e / n) * d.ldm + e % n];
+    __shared__ double colk[INV_N], rowk[INV_N];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    if (tx < n)
+        for (int i = ty; i < n; i += 4) a[i][tx] = d.M[(size_t)i * d.ldm + tx];
     __syncthreads();
-    // right-looking Cholesky, lower triangle in place
+    bool bad = false;
     for (int k = 0; k < n; ++k) {
-        if (threadIdx.x == 0) {
-            const double p = a[k][k];
-            if (!(p > 0.0)) { bad = 1; a[k][k] = 1.0; } else a[k][k] = sqrt(p);
-        }
+        if (threadIdx.x < n) { colk[threadIdx.x] = a[threadIdx.x][k]; rowk[threadIdx.x] = a[k][threadIdx.x]; }
         __syncthreads();
-        const double dk = a[k][k];
-        for (int i = k + 1 + threadIdx.x; i < n; i += 256) a[i][k] /= dk;
-        __syncthreads();
-        const int rem = n - k - 1;
-        for (int e = threadIdx.x; e < rem * rem; e += 256) {
-            const int i = k + 1 + e / rem, j = k + 1 + e % rem;
-            if (j <= i) a[i][j] -= a[i][k] * a[j][k];
+        double p = colk[k];
+        if (!(p > 0.0)) { bad = true; p = 1.0; }
+        const double ip = 1.0 / p;
+        if (tx < n) {
+            const double r = rowk[tx] * ip;
+            for (int i = ty; i < n; i += 4)
+                a[i][tx] = i == k ? (tx == k ? ip : r) : (tx == k ? -colk[i] * ip : fma(-colk[i], r, a[i][tx]));
         }
         __syncthreads();
     }
-    // Linv: column j by forward substitution, a thread per column
-    for (int j = threadIdx.x; j < n; j += 256) {
-        for (int i = 0; i < n; ++i) {
-            double v = (i == j) ? 1.0 : 0.0;
-            for (int k = j; k < i; ++k) v -= a[i][k] * li[k][j];
-            li[i][j] = i < j ? 0.0 : v / a[i][i];
-        }
-    }
-    __syncthreads();
-    // X = Linv^T Linv
-    for (int e = threadIdx.x; e < n * n; e += 256) {
-        const int i = e / n, j = e % n;
-        double v = 0.0;
-        for (int k = max(i, j); k < n; ++k) v = fma(li[k][i], li[k][j], v);
-        d.X[(size_t)i * d.ldx + j] = v;
-    }
+    if (tx < n)
+        for (int i = ty; i < n; i += 4) d.X[(size_t)i * d.ldx + tx] = a[i][tx];
     if (threadIdx.x == 0 && bad) atomicExch(flag, 1);
 }
 
@@ -264,8 +250,7 @@ void inverse_small(FactorCtx& c, const std::vector<Blk>& v) {
         if ((c.err = hipMalloc((void**)&c.d_inv, c.cap_inv * sizeof(InvDesc))) != hipSuccess) return;
     }
     if ((c.err = hipMemcpyAsync(c.d_inv, live.data(), live.size() * sizeof(InvDesc), hipMemcpyHostToDevice, c.st)) != hipSuccess) return;
-    const size_t lds = 2 * INV_N * (INV_N + 1) * sizeof(double);
-    (void)hipFuncSetAttribute((const void*)k_spd_inverse_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = INV_N * (INV_N + 1) * sizeof(double);
     hipLaunchKernelGGL(k_spd_inverse_small, dim3((unsigned)live.size()), dim3(256), lds, c.st, c.d_inv, c.d_flag);
     ++c.launches;
 }
