@@ -329,6 +329,9 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     for (int i = 1; i <= n_nodes; ++i) max_front = std::max(max_front, P.s[i] + P.b[i]);
     LS_REQUIRE(max_front <= 8000, LS_E_WORKSPACE, "ls_direct_factor: a front of %d rows exceeds the solver's limit (the mesh does not dissect)", max_front);
     // ---- layouts -------------------------------------------------------------------------------------------------------------------
+    // tier_levels < 0: chosen here -- three levels per tier workgroup once the tree has eight (1024 workgroups at arity 4), two
+    // below that: a tier of three on a smaller tree leaves most CUs without a workgroup (tools/tier_sweep.py, 576 .. 1M vertices)
+    if (tier_levels < 0) tier_levels = levels >= 8 ? 3 : 2;
     tier_levels = std::max(0, std::min(std::min(tier_levels, levels), 6));
     const int tier_root = levels - tier_levels;
     bool leaves_ok = tier_levels > 0 && sparse_leaves;

@@ -322,7 +322,7 @@ class NestedDissectionSolver(Solver):
         if not csr.symmetric:
             raise ValueError("NestedDissectionSolver: the matrix is not symmetric")
         t0 = time.perf_counter()
-        tier = max(0, min(6, int(os.environ.get("LS_ND_TIER_H", "3"))))
+        tier = max(-1, min(6, int(os.environ.get("LS_ND_TIER_H", "-1"))))      # -1: the library picks (2 or 3 by tree depth)
         sparse = not os.environ.get("LS_ND_DENSE_LEAVES")
         while True:
             try:
@@ -331,7 +331,7 @@ class NestedDissectionSolver(Solver):
             except RuntimeError as e:      # a tier whose subtrees need more LDS than a workgroup has: one level less
                 if tier == 0 or "does not fit" not in str(e):
                     raise
-                tier -= 1
+                tier = 2 if tier < 0 or tier > 3 else tier - 1
         torch.cuda.synchronize(csr.device)
         self.build_seconds = time.perf_counter() - t0
         self.timings = self._direct.timings

@@ -471,7 +471,8 @@ def test_direct_solver_widths_and_trees(dev, k, leaf, arity):
 
 @pytest.mark.parametrize("env", [{"LS_ND_NO_SMALL": "1"}, {"LS_ND_NO_PACK": "1"}, {"LS_ND_NO_PACK": "1", "LS_ND_NO_SMALL": "1"}, {"LS_ND_SMALL_DOWN": "1", "LS_ND_SMALL_KB": "150"}, {"LS_ND_LONG": "16"},
                                  {"LS_ND_LONG": "100000", "LS_ND_STEPS": "8"}, {"LS_ND_INFLIGHT": "200", "LS_ND_LONG": "16"},
-                                 {"LS_ND_TIER_H": "1"}, {"LS_ND_TIER_H": "2"}, {"LS_ND_TIER_H": "4"}, {"LS_ND_TIER_H": "6"},
+                                 {"LS_ND_TIER_H": "1"}, {"LS_ND_TIER_H": "2"}, {"LS_ND_TIER_H": "3"}, {"LS_ND_TIER_H": "4"}, {"LS_ND_TIER_H": "6"},
+                                 {"LS_ND_LONG": "256", "LS_ND_LONG_UP": "64"}, {"LS_ND_TIER_H": "3", "LS_ND_LONG": "256"},
                                  {"LS_ND_DENSE_LEAVES": "1"}, {"LS_ND_DENSE_LEAVES": "1", "LS_ND_TIER_H": "0"},
                                  {"LS_ND_DENSE_LEAVES": "1", "LS_ND_TIER_H": "5"}])
 def test_direct_solver_kernel_shapes(dev, monkeypatch, env):
