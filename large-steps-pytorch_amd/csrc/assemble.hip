@@ -119,7 +119,8 @@ __global__ __launch_bounds__(BLOCK) void k_scan_final(const int* __restrict__ in
 }
 
 // out[0..n] = exclusive scan of in[0..n); out[n] = total. `in` and `out` may not alias.
-static int exclusive_scan(const int* in, int64_t n, int* out, int* bsum, hipStream_t st) {
+int exclusive_scan(const int* in, int64_t n, int* out, int* bsum, hipStream_t st) {      // declared in common.h (nd_factor.hip uses it too)
+    if (n <= 0) { LS_HIP(hipMemsetAsync(out, 0, sizeof(int), st)); return LS_OK; }
     const int nb = div_up(n, SCAN_CHUNK);
     hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(BLOCK), 0, st, in, n, bsum);
     hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(BLOCK), 0, st, bsum, nb);

@@ -44,6 +44,9 @@ struct DeviceGuard {  // every entry point pins the device itself: no thread-loc
 };
 
 inline int div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+// assemble.hip: out[0 .. n] = exclusive scan of the int32 in[0 .. n), out[n] = total; bsum: scan_blocks(n) + 1 ints of scratch
+int exclusive_scan(const int* in, int64_t n, int* out, int* bsum, hipStream_t st);
+inline int64_t scan_blocks(int64_t n) { return (n + 2047) / 2048; }
 
 // ---- device side ---------------------------------------------------------------------------------
 #ifdef __HIPCC__

@@ -1114,9 +1114,9 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
     d->plan.resize(levels);
     size_t lds_max = 0;
     // (measured over 576 .. 1M vertices, tools/tier_sweep.py: the down sweep of levels with s + b of 90 .. 250 runs 5-10 % of a
-    //  whole solve faster with the lanes along the reduction; the up sweep of s = 125 nodes loses 2 %)
+    //  whole solve faster with the lanes along the reduction; the up sweep of the s = 125 nodes of an 8-level tree loses 2-3 %)
     const int long_red = env_int("LS_ND_LONG", 64);             // down sweep (reduction s + b)
-    const int long_up = env_int("LS_ND_LONG_UP", 256);          // up sweep (reduction s)
+    const int long_up = env_int("LS_ND_LONG_UP", levels >= 8 ? 256 : 64);   // up sweep (reduction s): small trees gain 1-3 % from 64
     for (int lv = 0; lv < d->tier_root; ++lv) {
         LevelPlan& p = d->plan[lv];
         // this rank's nodes of the level: one contiguous range (all of them above the cut)

@@ -152,6 +152,69 @@ __global__ void k_assemble(int64_t nnz, const int* __restrict__ rowidx, const in
     F[(size_t)(nd.s + lo) * m + rl] = v;
 }
 
+// row index of every stored entry (the caller hands over CSR; the per-entry kernels want COO rows)
+__global__ void k_expand_rows(int64_t V, const int* __restrict__ rowptr, int* __restrict__ rowidx) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    for (int p = rowptr[v]; p < rowptr[v + 1]; ++p) rowidx[p] = (int)v;
+}
+
+// ---- sparse leaves: the off-diagonal block A_bs of every leaf as two CSR lists (by boundary row, by own row) ---------------------
+// One thread per stored matrix entry (row in a sparse-layout leaf, column in its boundary). MODE 0 counts the entries of the
+// two rows an entry belongs to, MODE 1 drops it into both lists (slot order by atomic cursor -- k_leaf_sort then orders every
+// row by its index field, which is unique within a row: the result does not depend on the order of arrival).
+// Own rows of the leaves are the tree's numbering [0, rows_s) (deepest level first); their boundary rows are
+// bnd[bnd0 .. n_bnd).
+template <int MODE>
+__global__ void k_leaf_entries(int64_t nnz, const int* __restrict__ rowidx, const int* __restrict__ col, const float* __restrict__ val,
+                               const int* __restrict__ inv, const int* __restrict__ node_of_new, const FactorNode* __restrict__ nodes,
+                               const int* __restrict__ bnd, long long bnd0, int* __restrict__ cnt_s, int* __restrict__ cnt_b,
+                               const int* __restrict__ ptr_s, const int* __restrict__ ptr_b, SpEnt* __restrict__ ent, int n_ent) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    const int r = inv[rowidx[e]];
+    const FactorNode nd = nodes[node_of_new[r]];
+    if (nd.layout != 2) return;
+    const int c = inv[col[e]];
+    if (c < nd.own_start + nd.s) return;
+    const int* B = bnd + nd.bnd_off;
+    int lo = 0, hi = nd.b;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (B[mid] < c) lo = mid + 1; else hi = mid; }
+    if (lo >= nd.b || B[lo] != c) return;                  // (k_assemble reports the broken pattern)
+    const int j = r - nd.own_start, rs = r;
+    const long long rb = nd.bnd_off - bnd0 + lo;
+    if (MODE == 0) { atomicAdd(cnt_s + rs, 1); atomicAdd(cnt_b + rb, 1); return; }
+    const int pb = ptr_b[rb] + atomicAdd(cnt_b + rb, 1);
+    ent[pb] = SpEnt{val[e], j};
+    const int ps = n_ent + ptr_s[rs] + atomicAdd(cnt_s + rs, 1);
+    ent[ps] = SpEnt{val[e], lo};
+}
+
+__global__ void k_leaf_sort(int64_t rows, const int* __restrict__ ptr, int base, SpEnt* __restrict__ ent) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    SpEnt* a = ent + base + ptr[row];
+    const int n = ptr[row + 1] - ptr[row];
+    for (int i = 1; i < n; ++i) {
+        const SpEnt x = a[i];
+        int k = i - 1;
+        while (k >= 0 && a[k].idx > x.idx) { a[k + 1] = a[k]; --k; }
+        a[k + 1] = x;
+    }
+}
+
+// the pointer lists the tier kernels read: per leaf b + 1 entries for its boundary rows (at off_b[leaf]) and s + 1 for its own
+// rows (at off_s[leaf]); values are absolute offsets into the entry array (boundary-row lists first, then own-row lists)
+__global__ void k_leaf_ptrs(int first_leaf, const FactorNode* __restrict__ nodes, long long bnd0, const int* __restrict__ off_b,
+                            const int* __restrict__ off_s, const int* __restrict__ ptr_b, const int* __restrict__ ptr_s, int n_ent,
+                            int* __restrict__ sp_ptr) {
+    const int leaf = blockIdx.x;
+    if (off_b[leaf] < 0) return;
+    const FactorNode nd = nodes[first_leaf + leaf];
+    for (int r = threadIdx.x; r <= nd.b; r += blockDim.x) sp_ptr[off_b[leaf] + r] = ptr_b[nd.bnd_off - bnd0 + r];
+    for (int r = threadIdx.x; r <= nd.s; r += blockDim.x) sp_ptr[off_s[leaf] + r] = n_ent + ptr_s[nd.own_start + r];
+}
+
 // parent front += Schur complement of the children with sibling index cix (one launch per cix: no two writers per entry)
 __global__ void k_extend_add(const int* __restrict__ kids, int n_kids, const FactorNode* __restrict__ nodes, const int* __restrict__ ppos,
                              double* __restrict__ fronts) {
@@ -309,21 +372,24 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     LS_HIP(g.err);
     hipStream_t st = (hipStream_t)stream;
     const double t0 = now_s();
+    const bool timing = getenv("LS_PLAN_TIMING") != nullptr;
+    auto lap = [&](const char* what) { if (timing) { (void)hipStreamSynchronize(st); fprintf(stderr, "[ls_direct_factor] %-30s %.3f s\n", what, now_s() - t0); } };
     // ---- symbolic analysis on the host -------------------------------------------------------------------------------------------
     std::vector<int32_t> rowptr((size_t)V + 1), col((size_t)nnz);
-    std::vector<float> val((size_t)nnz), pos;
+    std::vector<float> pos;
     LS_HIP(hipMemcpyAsync(rowptr.data(), d_rowptr, sizeof(int32_t) * (V + 1), hipMemcpyDeviceToHost, st));
     LS_HIP(hipMemcpyAsync(col.data(), d_col, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost, st));
-    LS_HIP(hipMemcpyAsync(val.data(), d_val, sizeof(float) * nnz, hipMemcpyDeviceToHost, st));
     if (d_positions) { pos.resize((size_t)V * 3); LS_HIP(hipMemcpyAsync(pos.data(), d_positions, sizeof(float) * 3 * V, hipMemcpyDeviceToHost, st)); }
     LS_HIP(hipStreamSynchronize(st));
     LS_REQUIRE(rowptr[0] == 0 && rowptr[V] == nnz, LS_E_INVALID, "ls_direct_factor: rowptr does not match nnz");
+    lap("matrix to the host");
     NdPlan P;
     {
         const std::string err = nd_plan_build(V, rowptr.data(), col.data(), d_positions ? pos.data() : nullptr, leaf_size, arity, 4, P);
         LS_REQUIRE(err.empty(), LS_E_INVALID, "%s", err.c_str());
     }
     const double t1 = now_s();
+    lap("symbolic analysis");
     const int n_nodes = P.n_nodes, levels = P.levels;
     int max_front = 0;
     for (int i = 1; i <= n_nodes; ++i) max_front = std::max(max_front, P.s[i] + P.b[i]);
@@ -359,51 +425,20 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
         else { n.o_finv = o_finv; n.o_w = o_w; r[5] = o_finv; r[6] = o_w; o_finv += (int64_t)s * s; o_w += (int64_t)s * b; }
     }
     LS_REQUIRE(o_finv + 2 * o_w + o_d4 + o_u4 + 2 * o_tri < (int64_t)3000000000, LS_E_WORKSPACE, "ls_direct_factor: the factor is too large");
-    // ---- sparse leaves: the off-diagonal block A_bs as two CSR lists (host) ----------------------------------------------------------
-    std::vector<int32_t> sp_ptr;
-    std::vector<SpEnt> sp_ent;
+    lap("layouts");
+    // ---- sparse leaves: where every leaf's two pointer lists (A_bs by boundary row / by own row) start; the lists themselves are
+    // built on the device below
+    std::vector<int> off_b, off_s;
+    int64_t n_sp_ptr = 0;
+    const int64_t leaf0 = P.level_off[levels - 1], leaf1 = P.level_off[levels];
     if (leaves_ok) {
-        const int64_t l0 = P.level_off[levels - 1], l1 = P.level_off[levels];
-        std::vector<std::vector<std::pair<int, SpEnt>>> rows_b((size_t)(l1 - l0)), rows_s((size_t)(l1 - l0));   // (row, {val, other index})
-        // one pass per leaf, a few threads
-        const int T = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-        std::vector<std::thread> th;
-        for (int t = 0; t < T; ++t)
-            th.emplace_back([&, t] {
-                for (int64_t i = l0 + t; i < l1; i += T) {
-                    const int s = P.s[i], b = P.b[i], o = P.own_start[i];
-                    if (s < 1) continue;
-                    const int* B = P.bnd.data() + P.bnd_off[i];
-                    auto& rb = rows_b[(size_t)(i - l0)];
-                    auto& rs = rows_s[(size_t)(i - l0)];
-                    for (int j = 0; j < s; ++j) {
-                        const int v = P.perm[o + j];
-                        for (int p = rowptr[v]; p < rowptr[v + 1]; ++p) {
-                            const int c = P.inv[col[p]];
-                            if (c < o + s) continue;
-                            const int k = (int)(std::lower_bound(B, B + b, c) - B);
-                            rs.push_back({j, SpEnt{val[p], k}});
-                            rb.push_back({k, SpEnt{val[p], j}});
-                        }
-                    }
-                    auto by_row = [](const std::pair<int, SpEnt>& a, const std::pair<int, SpEnt>& c) { return a.first < c.first || (a.first == c.first && a.second.idx < c.second.idx); };
-                    std::sort(rb.begin(), rb.end(), by_row);
-                    std::sort(rs.begin(), rs.end(), by_row);
-                }
-            });
-        for (auto& x : th) x.join();
+        off_b.assign((size_t)(leaf1 - leaf0), -1); off_s.assign((size_t)(leaf1 - leaf0), -1);
         for (int pass = 0; pass < 2; ++pass)                 // boundary rows of all leaves first, then own rows
-            for (int64_t i = l0; i < l1; ++i) {
-                const int s = P.s[i], b = P.b[i];
-                if (s < 1) continue;
-                const auto& R = pass == 0 ? rows_b[(size_t)(i - l0)] : rows_s[(size_t)(i - l0)];
-                const int nr = pass == 0 ? b : s;
-                hn[(size_t)i * LS_DIRECT_NODE_COLS + (pass == 0 ? 9 : 10)] = (int64_t)sp_ptr.size();
-                size_t k = 0;
-                for (int r = 0; r <= nr; ++r) {
-                    sp_ptr.push_back((int32_t)sp_ent.size());
-                    if (r < nr) while (k < R.size() && R[k].first == r) sp_ent.push_back(R[k++].second);
-                }
+            for (int64_t i = leaf0; i < leaf1; ++i) {
+                if (P.s[i] < 1) continue;
+                (pass == 0 ? off_b : off_s)[(size_t)(i - leaf0)] = (int)n_sp_ptr;
+                hn[(size_t)i * LS_DIRECT_NODE_COLS + (pass == 0 ? 9 : 10)] = n_sp_ptr;
+                n_sp_ptr += (pass == 0 ? P.b[i] : P.s[i]) + 1;
             }
     }
     const double t2 = now_s();
@@ -428,7 +463,7 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     bool ok = dalloc((void**)&finv, sizeof(float) * o_finv, true, false) && dalloc((void**)&wf, sizeof(float) * o_w, true, false) &&
               dalloc((void**)&wb, sizeof(float) * o_w, true, false) && dalloc((void**)&u4, sizeof(float) * o_u4, true, true) &&
               dalloc((void**)&d4, sizeof(float) * o_d4, true, true) && dalloc((void**)&tri, sizeof(float) * o_tri, true, true) &&
-              dalloc((void**)&d_sp_ptr, sizeof(int32_t) * sp_ptr.size(), true, false) && dalloc((void**)&d_sp_ent, sizeof(SpEnt) * sp_ent.size(), true, true) &&
+              dalloc((void**)&d_sp_ptr, sizeof(int32_t) * n_sp_ptr, true, false) &&
               dalloc((void**)&fronts, sizeof(double) * f_tot, false, true) && dalloc((void**)&xs, sizeof(double) * x_tot, false, false) &&
               dalloc((void**)&ws, sizeof(double) * w_tot, false, false) && dalloc((void**)&work, sizeof(double) * work_tot, false, false) &&
               dalloc((void**)&d_inv, sizeof(int) * V, false, false) && dalloc((void**)&d_non, sizeof(int) * V, false, false) &&
@@ -442,15 +477,47 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
         if (all) for (void* p : owned) (void)hipFree(p);
     };
     if (!ok) { cleanup(true); return rc; }
-    std::vector<int> rowidx((size_t)nnz);
-    for (int64_t v = 0; v < V; ++v) for (int p = rowptr[v]; p < rowptr[v + 1]; ++p) rowidx[p] = (int)v;
+    lap("device allocations");
     hipError_t e = hipSuccess;
     auto h2d = [&](void* dst, const void* src, size_t bytes) { if (e == hipSuccess && bytes) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st); };
     h2d(d_inv, P.inv.data(), sizeof(int) * V); h2d(d_non, P.node_of_new.data(), sizeof(int) * V);
     h2d(d_bnd, P.bnd.data(), sizeof(int) * P.n_bnd); h2d(d_ppos, P.ppos.data(), sizeof(int) * P.n_bnd);
-    h2d(d_rowidx, rowidx.data(), sizeof(int) * nnz); h2d(d_nodes, fn.data(), sizeof(FactorNode) * (n_nodes + 1));
-    h2d(d_sp_ptr, sp_ptr.data(), sizeof(int32_t) * sp_ptr.size()); h2d(d_sp_ent, sp_ent.data(), sizeof(SpEnt) * sp_ent.size());
+    h2d(d_nodes, fn.data(), sizeof(FactorNode) * (n_nodes + 1));
     if (e != hipSuccess) { cleanup(true); return hip_fail(e, "ls_direct_factor uploads", __FILE__, __LINE__); }
+    hipLaunchKernelGGL(k_expand_rows, dim3((unsigned)div_up(V, 256)), dim3(256), 0, st, V, d_rowptr, d_rowidx);
+    int64_t n_ent = 0;
+    if (leaves_ok) {
+        // own rows of the leaves: the tree's numbering [0, rows_s); boundary rows: bnd[bnd0, n_bnd)
+        const int64_t rows_s = levels > 1 ? P.own_start[P.level_off[levels - 2]] : V, bnd0 = P.bnd_off[leaf0], rows_b = P.n_bnd - bnd0;
+        int *cnt_s = nullptr, *cnt_b = nullptr, *ptr_s = nullptr, *ptr_b = nullptr, *bsum = nullptr, *d_off_b = nullptr, *d_off_s = nullptr;
+        ok = dalloc((void**)&cnt_s, sizeof(int) * (rows_s + 1), false, true) && dalloc((void**)&cnt_b, sizeof(int) * (rows_b + 1), false, true) &&
+             dalloc((void**)&ptr_s, sizeof(int) * (rows_s + 1), false, false) && dalloc((void**)&ptr_b, sizeof(int) * (rows_b + 1), false, false) &&
+             dalloc((void**)&bsum, sizeof(int) * (scan_blocks(std::max(rows_s, rows_b)) + 2), false, false) &&
+             dalloc((void**)&d_off_b, sizeof(int) * off_b.size(), false, false) && dalloc((void**)&d_off_s, sizeof(int) * off_s.size(), false, false);
+        if (!ok) { cleanup(true); return rc; }
+        h2d(d_off_b, off_b.data(), sizeof(int) * off_b.size()); h2d(d_off_s, off_s.data(), sizeof(int) * off_s.size());
+        const unsigned eg = (unsigned)div_up(nnz, 256);
+        hipLaunchKernelGGL(k_leaf_entries<0>, dim3(eg), dim3(256), 0, st, nnz, d_rowidx, d_col, d_val, d_inv, d_non, d_nodes, d_bnd, (long long)bnd0, cnt_s,
+                           cnt_b, (const int*)nullptr, (const int*)nullptr, (SpEnt*)nullptr, 0);
+        int tot[2] = {0, 0};
+        if (exclusive_scan(cnt_s, rows_s, ptr_s, bsum, st) != LS_OK || exclusive_scan(cnt_b, rows_b, ptr_b, bsum, st) != LS_OK) { cleanup(true); return LS_E_INVALID; }
+        if (e == hipSuccess) e = hipMemcpyAsync(&tot[0], ptr_s + rows_s, sizeof(int), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(&tot[1], ptr_b + rows_b, sizeof(int), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemsetAsync(cnt_s, 0, sizeof(int) * (rows_s + 1), st);
+        if (e == hipSuccess) e = hipMemsetAsync(cnt_b, 0, sizeof(int) * (rows_b + 1), st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess || tot[0] != tot[1]) { cleanup(true); return e != hipSuccess ? hip_fail(e, "ls_direct_factor leaf lists", __FILE__, __LINE__) : LS_E_INVALID; }
+        n_ent = tot[0];
+        if (!dalloc((void**)&d_sp_ent, sizeof(SpEnt) * 2 * n_ent, true, true)) { cleanup(true); return rc; }
+        hipLaunchKernelGGL(k_leaf_entries<1>, dim3(eg), dim3(256), 0, st, nnz, d_rowidx, d_col, d_val, d_inv, d_non, d_nodes, d_bnd, (long long)bnd0, cnt_s,
+                           cnt_b, (const int*)ptr_s, (const int*)ptr_b, d_sp_ent, (int)n_ent);
+        if (rows_b) hipLaunchKernelGGL(k_leaf_sort, dim3((unsigned)div_up(rows_b, 256)), dim3(256), 0, st, rows_b, (const int*)ptr_b, 0, d_sp_ent);
+        if (rows_s) hipLaunchKernelGGL(k_leaf_sort, dim3((unsigned)div_up(rows_s, 256)), dim3(256), 0, st, rows_s, (const int*)ptr_s, (int)n_ent, d_sp_ent);
+        hipLaunchKernelGGL(k_leaf_ptrs, dim3((unsigned)(leaf1 - leaf0)), dim3(64), 0, st, (int)leaf0, d_nodes, (long long)bnd0, (const int*)d_off_b,
+                           (const int*)d_off_s, (const int*)ptr_b, (const int*)ptr_s, (int)n_ent, d_sp_ptr);
+    } else if (!dalloc((void**)&d_sp_ent, 16, true, true)) { cleanup(true); return rc; }
+    if (e != hipSuccess) { cleanup(true); return hip_fail(e, "ls_direct_factor uploads", __FILE__, __LINE__); }
+    lap("uploads");
     // ---- numeric factorisation -------------------------------------------------------------------------------------------------------
     hipLaunchKernelGGL(k_assemble, dim3((unsigned)div_up(nnz, 256)), dim3(256), 0, st, nnz, d_rowidx, d_col, d_val, d_inv, d_non, d_nodes, d_bnd,
                        fronts, ctx.d_flag);
@@ -524,16 +591,18 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
         return LS_E_INVALID;
     }
     const double t3 = now_s();
+    lap("numeric factorisation");
     // ---- the solver handle ---------------------------------------------------------------------------------------------------------------
     ls_direct_arrays A;
     memset(&A, 0, sizeof(A));
     A.V = V; A.levels = levels; A.arity = arity; A.h_nodes = hn.data(); A.h_perm = P.perm.data(); A.h_ppos = P.ppos.data(); A.n_bnd = P.n_bnd;
     A.h_push_ptr = P.push_ptr.data(); A.h_push_tgt = P.push_tgt.data(); A.n_front = P.n_front;
     A.d_finv = finv; A.d_wf = wf; A.d_wb = wb; A.d_u4 = u4; A.d_d4 = d4; A.d_tri = tri; A.d_sp_ptr = d_sp_ptr; A.d_sp_ent = d_sp_ent;
-    A.n_sp_ptr = (int64_t)sp_ptr.size(); A.n_sp_ent = (int64_t)sp_ent.size();
+    A.n_sp_ptr = n_sp_ptr; A.n_sp_ent = 2 * n_ent;
     A.shard_rank = shard_rank; A.shard_count = shard_count;
     rc = ls_direct_create(&A, device, stream, out);
     if (rc != LS_OK) { for (void* p : owned) (void)hipFree(p); return rc; }
+    lap("solve tables (ls_direct_create)");
     const double secs[3] = {t1 - t0, t2 - t1, t3 - t2};
     return ls_direct_adopt(*out, owned.data(), (int)owned.size(), secs);
 }
