@@ -838,7 +838,8 @@ struct ls_direct {
     int upper_lo = 0;                   // rows [upper_lo, V) of the tree's numbering belong to the levels above the tier
     int tier_root = 0, tier_phases = 0, tier_wgs = 0, tier_region = 0, tier_vec = 0, tier_tri = 0;
     TierItem* d_items = nullptr;
-    int* pull = nullptr;                // tier up sweep: (front position, child) -> child boundary entry (n_front x arity)
+    int* pull = nullptr;                // tier up sweep: (front position - pull_base, child) -> child boundary entry, front positions of the tier's inner nodes
+    int64_t pull_base = 0;
     TierWG* d_wgs = nullptr;
     long long* dbg = nullptr;           // profile = 2: per-wave clock stamps of the tier kernels (2 x tier_wgs x TIER_WAVES x 32)
     hipEvent_t busy = nullptr;          // recorded after every solve: a solve on another stream waits for it (one workspace)
@@ -1089,13 +1090,16 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
     d->upper_lo = (d->tier_root < levels && d->tier_root > 0) ? nodes[level_off[d->tier_root - 1]].own_start : (int)V;
     std::vector<int> pull;
     if (d->tier_root < levels) {
-        pull.assign((size_t)n_front * arity, -1);
+        // only the tier's inner nodes are parents inside the tier: their front positions are one range (fronts are numbered level by level)
+        d->pull_base = nodes[level_off[d->tier_root]].front_off;
+        const int64_t pull_end = nodes[level_off[levels - 1]].front_off;
+        pull.assign((size_t)std::max<int64_t>(0, pull_end - d->pull_base) * arity, -1);
         for (int lv = d->tier_root + 1; lv < levels; ++lv)
             for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i) {
                 const NodeDesc& n = nodes[i];
                 const int cix = (int)((i - level_off[lv]) % arity);
                 const int64_t pf = nodes[n.parent].front_off;
-                for (int k = 0; k < n.b; ++k) pull[(size_t)(pf + h_ppos[n.bnd_off + k]) * arity + cix] = n.bnd_off + k;
+                for (int k = 0; k < n.b; ++k) pull[(size_t)(pf - d->pull_base + h_ppos[n.bnd_off + k]) * arity + cix] = n.bnd_off + k;
             }
     }
     // tiles of the upper levels: a range of rows of one node each
@@ -1286,7 +1290,7 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
     const int top = d->tier_root - 1;            // levels [0, tier_root) are one launch each, the rest is the bottom tier
     TierArgs ta;
     ta.items = d->d_items; ta.wgs = d->d_wgs; ta.perm = d->perm; ta.mask = d->mask; ta.ppos = d->ppos;
-    ta.pull = d->pull; ta.push_ptr = d->push_ptr; ta.push_tgt = d->push_tgt; ta.u4 = d->u4; ta.d4 = d->d4; ta.tri = d->tri;
+    ta.pull = d->pull ? d->pull - (size_t)d->pull_base * d->arity : nullptr; ta.push_ptr = d->push_ptr; ta.push_tgt = d->push_tgt; ta.u4 = d->u4; ta.d4 = d->d4; ta.tri = d->tri;
     ta.sp_ptr = d->sp_ptr; ta.sp_ent = d->sp_ent; ta.bprime = d->bp; ta.braw = d->braw; ta.slots = d->slots; ta.xb = d->xb;
     ta.arity = d->arity; ta.phases = d->tier_phases; ta.region_floats = d->tier_region; ta.vec_floats = d->tier_vec;
     ta.dbg = d->profile == 2 ? d->dbg : nullptr;
