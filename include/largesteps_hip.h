@@ -368,6 +368,11 @@ int ls_vertex_normals_backward(const float* verts, const void* faces, int idx_by
 
 int ls_adam_uniform_step(float* param, const float* grad, float* g1, float* g2, int64_t n, float lr,
                          float beta1, float beta2, int step, void* scratch, int device, void* stream);
+/* The same step with the step count ON THE DEVICE: d_step[0] = steps done so far (int32, zero before the first call; the call
+ * increments it), d_step[1] = scratch. No argument changes from step to step, so the two launches can sit in a captured
+ * graph (torch.cuda.graph around a whole optimisation step) and be replayed. ASYNC. */
+int ls_adam_uniform_step_device(float* param, const float* grad, float* g1, float* g2, int64_t n, float lr, float beta1,
+                                float beta2, int32_t* d_step, void* scratch, int device, void* stream);
 
 #ifdef __cplusplus
 }

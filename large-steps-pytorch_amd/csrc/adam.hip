@@ -52,9 +52,69 @@ __global__ __launch_bounds__(BLOCK) void k_adam_apply(float* __restrict__ param,
         param[i] = param[i] - lr * ((g1[i] * inv_c1) / denom);
 }
 
+// the same two kernels with the step count on the device (d_step[0] = steps done so far): nothing in the launch depends on the
+// step number, so the pair can be replayed from a captured graph. d_step[1] carries the current step from the first kernel
+// to the second, which publishes it as d_step[0] when it is done.
+__device__ __forceinline__ float inv_bias(float beta, int t) { return (float)(1.0 / (1.0 - pow((double)beta, (double)t))); }
+
+__global__ __launch_bounds__(BLOCK) void k_adam_moments_dev(const float* __restrict__ grad, float* __restrict__ g1, float* __restrict__ g2,
+                                                            int64_t n, float b1, float b2, int* __restrict__ d_step, float* __restrict__ pmax) {
+    __shared__ float s_max[BLOCK / WAVE];
+    const int t = d_step[0] + 1;
+    const float inv_c2 = inv_bias(b2, t);
+    float m = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        const float g = grad[i];
+        const float a = g1[i] * b1 + (1.0f - b1) * g;
+        const float v = g2[i] * b2 + (1.0f - b2) * (g * g);
+        g1[i] = a;
+        g2[i] = v;
+        m = nan_max(m, sqrtf(v * inv_c2));
+    }
+    m = wave_nan_max(m);
+    if ((threadIdx.x & (WAVE - 1)) == 0) s_max[threadIdx.x / WAVE] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int j = 1; j < BLOCK / WAVE; ++j) m = nan_max(m, s_max[j]);
+        pmax[blockIdx.x] = m;
+        if (blockIdx.x == 0) d_step[1] = t;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_adam_apply_dev(float* __restrict__ param, const float* __restrict__ g1, int64_t n, float lr, float b1,
+                                                          int* __restrict__ d_step, const float* __restrict__ pmax, int G) {
+    __shared__ float s_max[BLOCK / WAVE];
+    const int t = d_step[1];
+    const float inv_c1 = inv_bias(b1, t);
+    float m = 0.0f;
+    for (int g = threadIdx.x; g < G; g += BLOCK) m = nan_max(m, pmax[g]);
+    m = wave_nan_max(m);
+    if ((threadIdx.x & (WAVE - 1)) == 0) s_max[threadIdx.x / WAVE] = m;
+    __syncthreads();
+    m = s_max[0];
+    for (int j = 1; j < BLOCK / WAVE; ++j) m = nan_max(m, s_max[j]);
+    const float denom = 1e-8f + m;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK)
+        param[i] = param[i] - lr * ((g1[i] * inv_c1) / denom);
+    if (blockIdx.x == 0 && threadIdx.x == 0) d_step[0] = t;          // nobody reads d_step[0] in this kernel
+}
+
 }  // namespace ls
 
 using namespace ls;
+
+extern "C" int ls_adam_uniform_step_device(float* param, const float* grad, float* g1, float* g2, int64_t n, float lr, float beta1,
+                                           float beta2, int32_t* d_step, void* scratch, int device, void* stream) {
+    LS_REQUIRE(n >= 0 && (n == 0 || (param && grad && g1 && g2)) && scratch && d_step, LS_E_INVALID, "ls_adam_uniform_step_device: null pointer or negative size");
+    if (n == 0) return LS_OK;
+    DeviceGuard g(device);
+    LS_HIP(g.err);
+    const int G = (int)std::min<int64_t>(div_up(n, BLOCK), 1024);
+    hipLaunchKernelGGL(k_adam_moments_dev, dim3(G), dim3(BLOCK), 0, (hipStream_t)stream, grad, g1, g2, n, beta1, beta2, d_step, (float*)scratch);
+    hipLaunchKernelGGL(k_adam_apply_dev, dim3(G), dim3(BLOCK), 0, (hipStream_t)stream, param, g1, n, lr, beta1, d_step, (const float*)scratch, G);
+    LS_HIP(hipGetLastError());
+    return LS_OK;
+}
 
 extern "C" int ls_adam_uniform_step(float* param, const float* grad, float* g1, float* g2, int64_t n, float lr, float beta1,
                                     float beta2, int step, void* scratch, int device, void* stream) {

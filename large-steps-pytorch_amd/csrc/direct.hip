@@ -1379,7 +1379,13 @@ extern "C" int ls_direct_solve(ls_direct* d, const float* b, float* x, int k, vo
     hipStream_t st = (hipStream_t)stream;
     // one workspace (b', slots, boundary vectors) per handle: a solve issued on another stream than the previous one
     // waits for it on the device
-    if (d->used && st != d->last_stream) LS_HIP(hipStreamWaitEvent(st, d->busy, 0));
+    // While the stream is being captured into a graph (torch.cuda.graph around a whole optimisation step) the launches become
+    // graph nodes in stream order and the handle's event stays out of it: an event recorded inside a capture cannot be
+    // waited for outside. Replays of such a graph are NOT serialised against eager solves on other streams by the library.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (st) (void)hipStreamIsCapturing(st, &cap);
+    const bool capturing = cap == hipStreamCaptureStatusActive;
+    if (!capturing && d->used && st != d->last_stream) LS_HIP(hipStreamWaitEvent(st, d->busy, 0));
     int rc;
     switch (k) {
         case 1: rc = direct_solve_k<1>(d, b, x, st, -1, nullptr); break;
@@ -1387,7 +1393,7 @@ extern "C" int ls_direct_solve(ls_direct* d, const float* b, float* x, int k, vo
         case 3: rc = direct_solve_k<3>(d, b, x, st, -1, nullptr); break;
         default: rc = direct_solve_k<4>(d, b, x, st, -1, nullptr); break;
     }
-    if (rc == LS_OK) { LS_HIP(hipEventRecord(d->busy, st)); d->last_stream = st; d->used = true; }
+    if (rc == LS_OK && !capturing) { LS_HIP(hipEventRecord(d->busy, st)); d->last_stream = st; d->used = true; }
     return rc;
 }
 

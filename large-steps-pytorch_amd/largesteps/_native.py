@@ -106,6 +106,8 @@ _SIGNATURES = {
     "ls_solver_workspace_bytes": (c_int, [c_void_p, ctypes.POINTER(c_size_t)]),
     "ls_adam_uniform_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_float, c_float, c_float, c_int,
                                      c_void_p, c_int, c_void_p]),
+    "ls_adam_uniform_step_device": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_float, c_float, c_float, c_void_p,
+                                            c_void_p, c_int, c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -23,9 +23,13 @@ class AdamUniform(torch.optim.Optimizer):
     Adam with one global step scale (reference: optimize.py:3-41): the first moment is divided by the LARGEST root second
     moment of the whole parameter instead of element by element, so every coordinate of a vertex (and every vertex) moves
     on the same scale. Constructor arguments and state keys ("step", "g1", "g2") are the reference's.
+
+    capturable=True (as in torch.optim.Adam) keeps the step count on the device -- state["step"] is then an int32 tensor whose
+    first element counts the steps -- so that `step()` can be recorded in a `torch.cuda.graph` together with the forward and
+    backward pass and replayed; the update is the same.
     """
-    def __init__(self, params, lr=0.1, betas=(0.9, 0.999)):
-        defaults = dict(lr=lr, betas=betas)
+    def __init__(self, params, lr=0.1, betas=(0.9, 0.999), capturable=False):
+        defaults = dict(lr=lr, betas=betas, capturable=bool(capturable))
         super(AdamUniform, self).__init__(params, defaults)
 
     def __setstate__(self, state):
@@ -40,11 +44,13 @@ class AdamUniform(torch.optim.Optimizer):
             for p in group["params"]:
                 state = self.state[p]
                 # Lazy initialization
+                capturable = group.get("capturable", False)
                 if len(state) == 0:
-                    state["step"] = 0
+                    state["step"] = torch.zeros(2, dtype=torch.int32, device=p.device) if capturable else 0
                     state["g1"] = torch.zeros_like(p.data, memory_format=torch.contiguous_format)
                     state["g2"] = torch.zeros_like(p.data, memory_format=torch.contiguous_format)
-                state["step"] += 1
+                if not capturable:
+                    state["step"] += 1
                 _native.require_device(p.data, "AdamUniform parameter")
                 if p.dtype != torch.float32:
                     raise TypeError(f"AdamUniform parameters must be float32, got {p.dtype}")
@@ -52,6 +58,13 @@ class AdamUniform(torch.optim.Optimizer):
                     raise ValueError("AdamUniform parameters must be contiguous")
                 grad = p.grad.data.contiguous()
                 dev = p.device
+                if capturable:
+                    with torch.cuda.device(dev):
+                        _native.check(lib.ls_adam_uniform_step_device(_native.ptr(p.data), _native.ptr(grad), _native.ptr(state["g1"]),
+                                                                      _native.ptr(state["g2"]), p.numel(), float(lr), float(b1), float(b2),
+                                                                      _native.ptr(state["step"]), _native.ptr(_scratch_for(dev)), dev.index,
+                                                                      _native.stream_of(dev)))
+                    continue
                 with torch.cuda.device(dev):
                     _native.check(lib.ls_adam_uniform_step(_native.ptr(p.data), _native.ptr(grad), _native.ptr(state["g1"]),
                                                            _native.ptr(state["g2"]), p.numel(), float(lr), float(b1), float(b2),

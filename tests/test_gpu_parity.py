@@ -786,6 +786,72 @@ def test_adam_uniform(golden, dev):
     assert set(opt.state[p].keys()) == {"step", "g1", "g2"}
 
 
+def test_adam_uniform_capturable_matches_the_fixture(golden, dev):
+    """capturable=True keeps the step count on the device (ls_adam_uniform_step_device): same trajectory as the reference's."""
+    from largesteps.optimize import AdamUniform
+    p = torch.nn.Parameter(_t(golden["adam/p0"], dev))
+    tgt = _t(golden["adam/target"], dev)
+    opt = AdamUniform([p], lr=0.05, betas=(0.9, 0.999), capturable=True)
+    for step in range(5):
+        opt.zero_grad()
+        ((p - tgt) ** 2).sum().backward()
+        opt.step()
+        np.testing.assert_allclose(p.detach().cpu().numpy(), golden["adam/traj"][step], rtol=2e-6, atol=2e-7)
+        assert int(opt.state[p]["step"][0]) == step + 1
+
+
+def test_optimisation_step_as_a_captured_graph(dev):
+    """A whole step (from_differential -> normals -> loss -> backward incl. the adjoint solve -> AdamUniform) recorded once
+    with torch.cuda.graph and replayed: after 2 warm-up steps + 4 replays the parameters equal those of 6 eager steps.
+    (The solve skips its cross-stream event while a stream is captured; the optimiser counts its steps on the device.)"""
+    from largesteps import synthetic
+    from largesteps.geometry import compute_matrix
+    from largesteps.parameterize import to_differential, from_differential
+    from largesteps.normals import compute_face_normals, compute_vertex_normals
+    from largesteps.optimize import AdamUniform
+    v, f = synthetic.icosphere(12)
+    v = synthetic.perturb(v, radial=0.02, tangential=0.05, edge=0.1, seed=3)
+    tv, tf = _t(v, dev), _t(f, dev)
+    M = compute_matrix(tv, tf, 8.0)
+    target_n = compute_vertex_normals(tv, tf, compute_face_normals(tv, tf)).detach()
+    target_v = tv * 1.05
+
+    def step(u, opt):
+        x = from_differential(M, u, "Cholesky")
+        n = compute_vertex_normals(x, tf, compute_face_normals(x, tf))
+        loss = (x - target_v).square().mean() + (n - target_n).square().mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+
+    u0 = to_differential(M, tv)
+    u_ref = u0.clone().requires_grad_(True)
+    opt_ref = AdamUniform([u_ref], 1e-2)
+    for _ in range(6):
+        step(u_ref, opt_ref)
+    u = u0.clone().requires_grad_(True)
+    opt = AdamUniform([u], 1e-2, capturable=True)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step(u, opt)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step(u, opt)
+    for _ in range(4):
+        g.replay()
+    torch.cuda.synchronize(dev)
+    assert int(opt.state[u]["step"][0]) == 6
+    a, b = u.detach().cpu().numpy(), u_ref.detach().cpu().numpy()
+    assert np.isfinite(a).all() and np.abs(a - b).max() <= 1e-5 * np.abs(b).max()
+    # an eager solve after the replays still works (the handle's event was never recorded inside the capture)
+    x = from_differential(M, u.detach(), "Cholesky")
+    assert torch.isfinite(x).all()
+
+
 # ---------------------------------------------------------------------------------------------------
 # row f4: remove_duplicates, re-factorisation at a remesh, batched small meshes
 # ---------------------------------------------------------------------------------------------------

@@ -1,5 +1,6 @@
-"""One optimisation step of the path at the 1M-vertex config, as the reference's loop runs it (scripts/main.py:170-200):
-   v = from_differential(M, u) -> face / vertex normals -> loss -> backward (normals, then the adjoint solve) -> AdamUniform.
+"""One optimisation step of the path, as the reference's loop runs it (scripts/main.py:170-200):
+   v = from_differential(M, u) -> face / vertex normals -> loss -> backward (normals, then the adjoint solve) -> AdamUniform,
+   eager and as ONE captured graph (torch.cuda.graph: every launch of the step recorded once, replayed per step).
    python tools/bench_step.py [workload] [steps]"""
 import os, sys, time
 _R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,20 +17,43 @@ dev = torch.device("cuda:0")
 v, f, cfg = synthetic.config_mesh(workload)
 tv, tf = torch.from_numpy(v).to(dev), torch.from_numpy(f).to(dev)
 M = compute_matrix(tv, tf, cfg["lambda_"] if cfg["lambda_"] is not None else 0.0, alpha=cfg["alpha"], cotan=cfg["cotan"])
-u = to_differential(M, tv).requires_grad_(True)
-opt = AdamUniform([u], 3e-2)
 target_n = compute_vertex_normals(tv, tf, compute_face_normals(tv, tf)).detach()
 target_v = tv + 0.01 * torch.randn_like(tv)
-def step():
+
+
+def make(capturable):
+    u = to_differential(M, tv).clone().requires_grad_(True)
+    return u, AdamUniform([u], 3e-2, capturable=capturable)
+
+
+def step(u, opt):
     x = from_differential(M, u, "Cholesky")
     n = compute_vertex_normals(x, tf, compute_face_normals(x, tf))
     loss = (x - target_v).square().mean() + (n - target_n).square().mean()
-    opt.zero_grad()
+    opt.zero_grad(set_to_none=True)
     loss.backward()
     opt.step()
     return loss
-for _ in range(3): step()
+
+
+u, opt = make(False)
+for _ in range(3): step(u, opt)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(steps): l = step()
+for _ in range(steps): l = step(u, opt)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
-print(f"{workload}: {dt*1e3:.3f} ms per optimisation step (forward solve + normals + loss + backward incl. adjoint solve + AdamUniform), loss {float(l):.3e}")
+print(f"{workload}: {dt*1e3:.3f} ms per optimisation step, eager (forward solve + normals + loss + backward incl. adjoint solve + AdamUniform), loss {float(l):.3e}")
+
+u, opt = make(True)
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    for _ in range(3): step(u, opt)
+torch.cuda.current_stream().wait_stream(side)
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    loss = step(u, opt)
+for _ in range(3): g.replay()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(steps): g.replay()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+print(f"{workload}: {dt*1e3:.3f} ms per optimisation step, captured graph replay, loss {float(loss):.3e}")
