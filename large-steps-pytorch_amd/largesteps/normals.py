@@ -48,7 +48,9 @@ def _plan(f, V):
         del _plans[k]
     if len(_plans) >= 8:
         _plans.clear()
-    plan = (vptr, vcorner)
+    # the kernels read the connectivity six times per step: 4-byte indices (validated above) halve that traffic
+    narrow = f.to(torch.int32) if (f.dtype == torch.int64 and V < 2 ** 31) else f
+    plan = (vptr, vcorner, narrow)
     try:
         _plans[key] = (weakref.ref(f), f._version, tuple(f.shape), f.dtype, f.data_ptr(), V, plan)
     except TypeError:           # an object that cannot be weakly referenced: do not cache
@@ -69,8 +71,8 @@ def _prep(verts, faces):
     if v.dtype != torch.float32 or not v.is_contiguous():
         v = v.to(torch.float32).contiguous()
     f = faces if faces.is_contiguous() else faces.contiguous()
-    vptr, vcorner = _plan(f, v.shape[0])
-    return v, f, vptr, vcorner
+    vptr, vcorner, narrow = _plan(f, v.shape[0])
+    return v, narrow, vptr, vcorner
 
 
 def _workspace(F, V, dev):
