@@ -3,7 +3,7 @@
 # trace + FETCH_SIZE / WRITE_SIZE passes of the bench command, constructor profile
 set -u
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/full2; rm -rf $O; mkdir -p $O/pmc
+O=gpurun_out/full3; rm -rf $O; mkdir -p $O/pmc
 export TMPDIR=/tmp
 ( timeout 1500 python -m pytest tests -m gpu -q --timeout 900 2>&1 | tail -30 ) > $O/pytest.log 2>&1
 ( timeout 200 python -c "import __graft_entry__ as g; g.smoke()" ) > $O/smoke.log 2>&1
@@ -17,10 +17,11 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_ctor -o ctor -- python $GRAFT_REPO_ROOT/tools/profile_constructor.py cfg4_plane1m ) > $O/rocprof_ctor.log 2>&1
 cp $(find $O/prof_ctor -name "*kernel_stats.csv" | head -1) $O/constructor_kernel_stats.csv; rm -rf $O/prof_ctor
-for w in cfg4_plane1m cfg3_dragon250k cfg2_bunny70k; do timeout 300 python tools/profile_constructor.py $w 2>&1 | grep constructor; done > $O/constructor_times.txt
+for w in cfg4_plane1m cfg3_dragon250k cfg2_bunny70k; do timeout 300 python tools/profile_constructor.py $w 3 2>&1 | grep constructor; done > $O/constructor_times.txt
+LS_PLAN_TIMING=1 timeout 300 python tools/profile_constructor.py cfg4_plane1m 2 2>&1 | grep -E "ls_direct_factor|nd_plan" | tail -34 >> $O/constructor_times.txt
 for w in cfg4_plane1m cfg3_dragon250k cfg2_bunny70k; do timeout 600 python tools/bench_remesh.py $w 100 3 2>&1 | grep -v amdgpu.ids; done > $O/remesh.txt
 ( timeout 600 python tools/bench_batched.py 64 40 50; timeout 600 python tools/bench_batched.py 256 16 50 ) 2>&1 | grep -v amdgpu.ids > $O/batched.txt
-( timeout 600 python tools/bench_step.py cfg4_plane1m 30; timeout 600 python tools/bench_step.py cfg3_dragon250k 30 ) 2>&1 | grep "ms per" > $O/step.txt
+( timeout 600 python tools/bench_step.py cfg4_plane1m 30; timeout 600 python tools/bench_step.py cfg3_dragon250k 30; timeout 600 python tools/bench_step.py cfg2_bunny70k 30 ) 2>&1 | grep "^cfg" > $O/step.txt
 for N in 2 4 8; do ( LS_DIST_LOOPBACK=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 2951$N bench.py --gpus $N --steps 3 --warmup 1 ) > $O/bench_loopback_$N.json 2> $O/bench_loopback_$N.err; done
 python tools/pmc_summary.py $O/pmc/bench_FETCH_SIZE $O/pmc/bench_WRITE_SIZE cfg4_plane1m $O/pmc_traffic.json > $O/pmc_summary.log 2>&1
 python tools/nd_trace.py $(find $O/prof -name "*kernel_trace.csv" | head -1) > $O/nd_levels.txt 2>&1
