@@ -397,7 +397,15 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     // ---- layouts -------------------------------------------------------------------------------------------------------------------
     // tier_levels < 0: chosen here -- three levels per tier workgroup once the tree has eight (1024 workgroups at arity 4), two
     // below that: a tier of three on a smaller tree leaves most CUs without a workgroup (tools/tier_sweep.py, 576 .. 1M vertices)
-    if (tier_levels < 0) tier_levels = levels >= 8 ? 3 : 2;
+    if (tier_levels < 0) {
+        tier_levels = levels >= 8 ? 3 : 2;
+        if (shard_count > 1) {                  // the cut (first level with a subtree per rank) must not lie inside the tier
+            int cut = 0;
+            int64_t width = 1;
+            while (width < shard_count && cut < levels) { width *= arity; ++cut; }
+            tier_levels = std::max(0, std::min(tier_levels, levels - cut));
+        }
+    }
     tier_levels = std::max(0, std::min(std::min(tier_levels, levels), 6));
     const int tier_root = levels - tier_levels;
     bool leaves_ok = tier_levels > 0 && sparse_leaves;
@@ -500,13 +508,14 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
         hipLaunchKernelGGL(k_leaf_entries<0>, dim3(eg), dim3(256), 0, st, nnz, d_rowidx, d_col, d_val, d_inv, d_non, d_nodes, d_bnd, (long long)bnd0, cnt_s,
                            cnt_b, (const int*)nullptr, (const int*)nullptr, (SpEnt*)nullptr, 0);
         int tot[2] = {0, 0};
-        if (exclusive_scan(cnt_s, rows_s, ptr_s, bsum, st) != LS_OK || exclusive_scan(cnt_b, rows_b, ptr_b, bsum, st) != LS_OK) { cleanup(true); return LS_E_INVALID; }
+        if ((rc = exclusive_scan(cnt_s, rows_s, ptr_s, bsum, st)) != LS_OK || (rc = exclusive_scan(cnt_b, rows_b, ptr_b, bsum, st)) != LS_OK) { cleanup(true); return rc; }
         if (e == hipSuccess) e = hipMemcpyAsync(&tot[0], ptr_s + rows_s, sizeof(int), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipMemcpyAsync(&tot[1], ptr_b + rows_b, sizeof(int), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipMemsetAsync(cnt_s, 0, sizeof(int) * (rows_s + 1), st);
         if (e == hipSuccess) e = hipMemsetAsync(cnt_b, 0, sizeof(int) * (rows_b + 1), st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess || tot[0] != tot[1]) { cleanup(true); return e != hipSuccess ? hip_fail(e, "ls_direct_factor leaf lists", __FILE__, __LINE__) : LS_E_INVALID; }
+        if (e != hipSuccess) { cleanup(true); return hip_fail(e, "ls_direct_factor leaf lists", __FILE__, __LINE__); }
+        if (tot[0] != tot[1]) { cleanup(true); set_error("ls_direct_factor: the leaf lists disagree (%d own-row entries, %d boundary-row entries)", tot[0], tot[1]); return LS_E_INVALID; }
         n_ent = tot[0];
         if (!dalloc((void**)&d_sp_ent, sizeof(SpEnt) * 2 * n_ent, true, true)) { cleanup(true); return rc; }
         hipLaunchKernelGGL(k_leaf_entries<1>, dim3(eg), dim3(256), 0, st, nnz, d_rowidx, d_col, d_val, d_inv, d_non, d_nodes, d_bnd, (long long)bnd0, cnt_s,
