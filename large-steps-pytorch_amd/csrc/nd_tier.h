@@ -141,6 +141,24 @@ __device__ __forceinline__ void pull_compact(const TierArgs& a, size_t f, float 
     }
 }
 
+// the same with the (static) pull indices already in registers: what is left behind a barrier is ONE round trip
+template <int K>
+__device__ __forceinline__ void pull_values(const TierArgs& a, const int (&pl)[4], float (&v)[K]) {
+#pragma unroll
+    for (int q = 0; q < K; ++q) v[q] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (pl[c] >= 0) {
+#pragma unroll
+            for (int q = 0; q < K; ++q) v[q] += a.xb[(size_t)pl[c] * K + q];
+        }
+    }
+}
+__device__ __forceinline__ void pull_indices(const TierArgs& a, size_t f, bool on, int (&pl)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) pl[c] = on ? a.pull[f * 4 + c] : -1;
+}
+
 // ---- sparse leaves --------------------------------------------------------------------------------------------------
 struct LeafIdx {           // stage A: loads that depend on the item record only
     int g, p0, p1, pp;     // up: perm of own row `lane`; row pointers + parent position of boundary row `lane`
@@ -437,40 +455,43 @@ __device__ __forceinline__ void tier_mv16(float v16, const float4& a, const floa
     if (n > 3) { acc = mv_step<12>(v16, d.x, acc); acc = mv_step<13>(v16, d.y, acc); acc = mv_step<14>(v16, d.z, acc); acc = mv_step<15>(v16, d.w, acc); }
 }
 
-// acc[m] += sum over the quads [q0, q1) of col[q * rows] (4 entries each) times the vector sv4[(4 q - base) * 4 + m];
-// cur = the first batch, already requested. The vector is read as registers of 16 entries starting at the batch.
-__device__ __forceinline__ void tier_dot(const float4* __restrict__ col, size_t rows, int q0, int q1, const float* sv4, int base,
-                                         float4 (&cur)[TIER_Q], f32x4& acc) {
-    float4 nxt[TIER_Q];
+// acc[m] += sum over the quads [q0, q1) of col[q * rows] (4 entries each) times the vector sv4[(4 q - base) * 4 + m].
+// A = batch q0, already requested by the caller; B = batch q0 + TIER_Q. The two buffers form a ring: as soon as a batch
+// is multiplied its registers are re-requested for the batch two ahead, so two batches are in flight all the time (the
+// products of a batch are a few dozen cycles: with one batch in flight every batch cost a whole memory round trip).
+__device__ __forceinline__ void tier_mv_batch(const float* sv4, int base, int q, int q1, const float4 (&c)[TIER_Q], f32x4& acc) {
     const int lane = threadIdx.x & 63;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int q = q0; q < q1; q += TIER_Q) {
-        tier_prefetch(col, rows, q + TIER_Q, q1, nxt);
-        if (TIER_Q == 2) tier_mv16(sv4[(4 * q - base) * 4 + lane], cur[0], cur[1], z, z, min(2, q1 - q), acc);
-        if (TIER_Q >= 4) tier_mv16(sv4[(4 * q - base) * 4 + lane], cur[0], cur[1], cur[TIER_Q >= 4 ? 2 : 0], cur[TIER_Q >= 4 ? 3 : 0], q1 - q, acc);
-        if (TIER_Q >= 8 && q + 4 < q1) tier_mv16(sv4[(4 * q + 16 - base) * 4 + lane], cur[TIER_Q >= 8 ? 4 : 0], cur[TIER_Q >= 8 ? 5 : 0],
-                                                 cur[TIER_Q >= 8 ? 6 : 0], cur[TIER_Q >= 8 ? 7 : 0], q1 - q - 4, acc);
-#pragma unroll
-        for (int e = 0; e < TIER_Q; ++e) cur[e] = nxt[e];
+    if (TIER_Q == 2) tier_mv16(sv4[(4 * q - base) * 4 + lane], c[0], c[1], z, z, min(2, q1 - q), acc);
+    if (TIER_Q >= 4) tier_mv16(sv4[(4 * q - base) * 4 + lane], c[0], c[1], c[TIER_Q >= 4 ? 2 : 0], c[TIER_Q >= 4 ? 3 : 0], q1 - q, acc);
+    if (TIER_Q >= 8 && q + 4 < q1) tier_mv16(sv4[(4 * q + 16 - base) * 4 + lane], c[TIER_Q >= 8 ? 4 : 0], c[TIER_Q >= 8 ? 5 : 0],
+                                             c[TIER_Q >= 8 ? 6 : 0], c[TIER_Q >= 8 ? 7 : 0], q1 - q - 4, acc);
+}
+__device__ __forceinline__ void tier_dot(const float4* __restrict__ col, size_t rows, int q0, int q1, const float* sv4, int base,
+                                         float4 (&A)[TIER_Q], f32x4& acc) {
+    float4 B[TIER_Q];
+    tier_prefetch(col, rows, q0 + TIER_Q, q1, B);
+    for (int q = q0; q < q1; q += 2 * TIER_Q) {
+        tier_mv_batch(sv4, base, q, q1, A, acc);
+        tier_prefetch(col, rows, q + 2 * TIER_Q, q1, A);
+        if (q + TIER_Q < q1) tier_mv_batch(sv4, base, q + TIER_Q, q1, B, acc);
+        tier_prefetch(col, rows, q + 3 * TIER_Q, q1, B);
     }
 }
 
+// a split node's row chunk: the sum of its parts (part 0 already carries the children's hand-over) goes to the parent;
+// pp = parent position of boundary row i (requested by the part-0 item before the parts met)
 template <int K>
-__device__ __forceinline__ void node_up_finish(const TierArgs& a, const TierItem& n, int i, const float (&acc)[K]) {
+__device__ __forceinline__ void node_up_finish(const TierArgs& a, const TierItem& n, int i, int pp, const float (&acc)[K]) {
     if (i >= n.b || n.pfront_off < 0) return;
-    float pass[K];
-#pragma unroll
-    for (int q = 0; q < K; ++q) pass[q] = 0.0f;
-    if (!(n.flags & NODE_LEAF)) pull_compact<K>(a, (size_t)(n.front_off + n.s + i), pass);
     if (n.flags & NODE_UPC) {
 #pragma unroll
-        for (int q = 0; q < K; ++q) a.xb[(size_t)(n.bnd_off + i) * K + q] = acc[q] + pass[q];
+        for (int q = 0; q < K; ++q) a.xb[(size_t)(n.bnd_off + i) * K + q] = acc[q];
         return;
     }
-    const int pp = a.ppos[n.bnd_off + i];
     const size_t dst = ((size_t)(n.pfront_off + pp) * a.arity + n.cix) * K;
 #pragma unroll
-    for (int q = 0; q < K; ++q) a.slots[dst + q] = acc[q] + pass[q];
+    for (int q = 0; q < K; ++q) a.slots[dst + q] = acc[q];
 }
 
 // What a dense item can request BEFORE the barrier that ends the previous phase (nothing here depends on that phase):
@@ -481,6 +502,7 @@ struct DensePre {
     float4 cur[TIER_Q];    // first batch of the matrix stream
     float v[K];            // down: b' of reduction entry r0 + lane (if it is an own row)
     int idx;               // up: parent position of this lane's boundary row; down: the caller's id of this lane's own row
+    int plo[4], plb[4];    // up, arity 4: pull indices of own row r0 + lane and of boundary row row0 + lane (static lists)
 };
 
 template <int K>
@@ -489,7 +511,14 @@ __device__ __forceinline__ void node_up_pre(const TierArgs& a, const TierItem& i
     const bool row = i < it.b;
     const float4* col = reinterpret_cast<const float4*>(a.u4 + it.w_off) + (row ? i : 0);
     tier_prefetch(col, (size_t)it.b, it.r0 >> 2, row ? it.r1 >> 2 : it.r0 >> 2, P.cur);
-    P.idx = (it.nparts == 1 && row && it.pfront_off >= 0) ? a.ppos[it.bnd_off + i] : 0;
+    // the item that finishes a (row chunk of a) node -- the only part, or part 0 of a split node -- adds what the children
+    // hand to the boundary rows and knows where the result goes
+    const bool fin = it.part == 0 && row && it.pfront_off >= 0;
+    P.idx = (fin && !(it.flags & NODE_UPC)) ? a.ppos[it.bnd_off + i] : 0;
+    const bool inner = !(it.flags & NODE_LEAF) && a.arity == 4;
+    const int j = it.r0 + lane;
+    pull_indices(a, (size_t)(it.front_off + j), inner && j < it.r1 && j < it.s, P.plo);
+    // (the boundary rows' hand-over is needed only after the product: its two round trips hide behind the matrix stream)
 }
 
 // up: b'_j for the item's reduction range (stored by the row0 == 0 items), partial upd_i = sum_j W[i][j] b'_j.
@@ -504,8 +533,11 @@ __device__ __forceinline__ void node_up(const TierArgs& a, const TierItem& it, D
     float pass[K];
 #pragma unroll
     for (int q = 0; q < K; ++q) pass[q] = 0.0f;
-    const bool fin = it.nparts == 1 && row && it.pfront_off >= 0;
-    if (fin && !(it.flags & NODE_LEAF)) pull_compact<K>(a, (size_t)(it.front_off + it.s + i), pass);
+    const bool fin = it.part == 0 && row && it.pfront_off >= 0;        // this item adds the children's hand-over (and, unsplit, stores)
+    const bool pre4 = a.arity == 4;
+    if (fin && !(it.flags & NODE_LEAF)) {
+        pull_compact<K>(a, (size_t)(it.front_off + it.s + i), pass);
+    }
     for (int j = it.r0 + lane; j < it.r1; j += 64) {
         float v[K];
         if (j >= it.s) {                              // padding of the reduction to a multiple of 4
@@ -523,7 +555,7 @@ __device__ __forceinline__ void node_up(const TierArgs& a, const TierItem& it, D
         }
         if (!(it.flags & NODE_LEAF)) {
             float u[K];
-            pull_compact<K>(a, (size_t)(it.front_off + j), u);
+            if (pre4 && j == it.r0 + lane) pull_values<K>(a, P.plo, u); else pull_compact<K>(a, (size_t)(it.front_off + j), u);
 #pragma unroll
             for (int q = 0; q < K; ++q) v[q] -= u[q];
         }
@@ -548,33 +580,58 @@ __device__ __forceinline__ void node_up(const TierArgs& a, const TierItem& it, D
 #pragma unroll
             for (int q = 0; q < K; ++q) out[dst + q] = acc[q] + pass[q];
         }
-    } else {
+    } else {                                        // part 0 carries the children's hand-over into the sum of the parts
 #pragma unroll
-        for (int q = 0; q < K; ++q) pbuf[lane * 4 + q] = acc[q];
+        for (int q = 0; q < K; ++q) pbuf[lane * 4 + q] = acc[q] + pass[q];
     }
     wave_lds_sync();
 }
 
+// the boundary rows of an inner node hand their x down to the children: independent of the node's own arithmetic (x_bnd is
+// complete when the phase starts), so the item that owns it (row chunk 0, part 0) issues it FIRST and it overlaps with the
+// matrix stream instead of adding three round trips behind it
 template <int K>
-__device__ __forceinline__ void node_down_finish(const TierArgs& a, const TierItem& it, int g_pre, float* __restrict__ x_out, const float (&acc)[K]) {
+__device__ __forceinline__ void node_down_forward(const TierArgs& a, const TierItem& it) {
     const int lane = threadIdx.x & 63;
-    const int j = it.row0 + lane;
-    const bool inner = !(it.flags & NODE_LEAF);
-    if (j < it.s) {
-        const size_t g = (size_t)(g_pre >= 0 ? g_pre : a.perm[it.own_start + j]);
+    for (int i = lane; i < it.b; i += 64) {
+        const size_t f = (size_t)(it.front_off + it.s + i);
+        const int p0 = a.push_ptr[f], p1 = a.push_ptr[f + 1];
+        float v[K];
 #pragma unroll
-        for (int q = 0; q < K; ++q) x_out[g * K + q] = acc[q];
-        if (inner) push_down<K>(a.push_tgt, a.push_ptr[it.front_off + j], a.push_ptr[it.front_off + j + 1], a.xb, acc);
+        for (int q = 0; q < K; ++q) v[q] = a.xb[(size_t)(it.bnd_off + i) * K + q];
+        push_down<K>(a.push_tgt, p0, p1, a.xb, v);
     }
-    if (inner && it.row0 == 0) {          // the boundary rows hand x down too
-        for (int i = lane; i < it.b; i += 64) {
-            const size_t f = (size_t)(it.front_off + it.s + i);
-            float v[K];
+}
+
+// x of the own rows: to the caller's numbering and into the children's boundary vectors. g, [p0, p1) and the first four
+// targets tg were requested before the arithmetic (static lists); a list longer than four entries walks the rest.
+template <int K>
+__device__ __forceinline__ void node_down_store(const TierArgs& a, const TierItem& it, int g, int p0, int p1, const int (&tg)[4],
+                                                float* __restrict__ x_out, const float (&acc)[K]) {
+    const int j = it.row0 + (threadIdx.x & 63);
+    if (j >= it.s) return;
 #pragma unroll
-            for (int q = 0; q < K; ++q) v[q] = a.xb[(size_t)(it.bnd_off + i) * K + q];
-            push_down<K>(a.push_tgt, a.push_ptr[f], a.push_ptr[f + 1], a.xb, v);
+    for (int q = 0; q < K; ++q) x_out[(size_t)g * K + q] = acc[q];
+    if (it.flags & NODE_LEAF) return;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (tg[c] >= 0) {
+#pragma unroll
+            for (int q = 0; q < K; ++q) a.xb[(size_t)tg[c] * K + q] = acc[q];
         }
     }
+    if (p1 - p0 > 4) push_down<K>(a.push_tgt, p0 + 4, p1, a.xb, acc);
+}
+
+// the same without anything requested ahead (a wave that finishes more than one split node in a phase)
+template <int K>
+__device__ __forceinline__ void node_down_finish(const TierArgs& a, const TierItem& it, float* __restrict__ x_out, const float (&acc)[K]) {
+    const int j = it.row0 + (threadIdx.x & 63);
+    if (j >= it.s) return;
+    const size_t g = (size_t)a.perm[it.own_start + j];
+#pragma unroll
+    for (int q = 0; q < K; ++q) x_out[g * K + q] = acc[q];
+    if (!(it.flags & NODE_LEAF)) push_down<K>(a.push_tgt, a.push_ptr[it.front_off + j], a.push_ptr[it.front_off + j + 1], a.xb, acc);
 }
 
 template <int K>
@@ -585,7 +642,12 @@ __device__ __forceinline__ void node_down_pre(const TierArgs& a, const TierItem&
     const int t = it.r0 + lane;
 #pragma unroll
     for (int q = 0; q < K; ++q) P.v[q] = (t < it.r1 && t < s) ? a.bprime[(size_t)(it.own_start + t) * K + q] : 0.0f;
-    P.idx = row ? a.perm[it.own_start + j] : 0;
+    // the item that finishes a row chunk (the only part, or part 0 of a split node): where x goes -- static, requested now
+    const bool fin = it.part == 0 && row;
+    const bool push = fin && !(it.flags & NODE_LEAF);
+    P.idx = fin ? a.perm[it.own_start + j] : 0;
+    P.plo[0] = push ? a.push_ptr[it.front_off + j] : 0;
+    P.plo[1] = push ? a.push_ptr[it.front_off + j + 1] : 0;
 }
 
 // down: partial x_j = sum_{t in [r0, r1)} [Finv | -W^T][j][t] * [b' | x_bnd][t]
@@ -596,6 +658,7 @@ __device__ __forceinline__ void node_down(const TierArgs& a, const TierItem& it,
     const bool row = j < s;
     float* sv4 = region;
     const float4* __restrict__ col = reinterpret_cast<const float4*>(a.d4 + it.finv_off) + (row ? j : 0);
+    if (!(it.flags & NODE_LEAF) && it.row0 == 0 && it.part == 0) node_down_forward<K>(a, it);
     const int s4 = (s + 3) & ~3;                  // reduction index space: [0, s4) own rows (padded), [s4, ..) boundary rows (padded)
     for (int t = it.r0 + lane; t < it.r1; t += 64) {
         float v[K];
@@ -618,12 +681,15 @@ __device__ __forceinline__ void node_down(const TierArgs& a, const TierItem& it,
         for (int q = 0; q < K; ++q) sv4[(t - it.r0) * 4 + q] = v[q];
     }
     wave_lds_sync();
+    // the push targets of this lane's own row (the row pointers arrived while the vector was assembled)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) P.plb[c] = (it.nparts == 1 && P.plo[0] + c < P.plo[1]) ? a.push_tgt[P.plo[0] + c] : -1;
     f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
     tier_dot(col, (size_t)s, it.r0 >> 2, it.r1 >> 2, sv4, it.r0, P.cur, a4);
     float acc[K];
 #pragma unroll
     for (int q = 0; q < K; ++q) acc[q] = a4[q];
-    if (it.nparts == 1) node_down_finish<K>(a, it, P.idx, x_out, acc);
+    if (it.nparts == 1) node_down_store<K>(a, it, P.idx, P.plo[0], P.plo[1], P.plb, x_out, acc);
     else {
 #pragma unroll
         for (int q = 0; q < K; ++q) pbuf[lane * 4 + q] = acc[q];
@@ -677,6 +743,8 @@ __global__ __launch_bounds__(64 * TIER_WAVES, 4) void k_nd_tier(TierArgs a, cons
 #pragma unroll
     for (int q = 0; q < K; ++q) pre.v[q] = 0.0f;
     pre.idx = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { pre.plo[c] = -1; pre.plb[c] = -1; }
     TierItem it_pre = rec_unpack(0);
     bool pre_valid = false;
     for (int ph = 0; ph < a.phases; ++ph) {
@@ -693,6 +761,9 @@ __global__ __launch_bounds__(64 * TIER_WAVES, 4) void k_nd_tier(TierArgs a, cons
             if (!(a.ablate & 8)) leaf_phase<K, UP>(a, i0 + wave, (a.ablate & 32) ? min(i1, i0 + TIER_WAVES) : (a.ablate & 64) ? min(i1, i0 + 2 * TIER_WAVES) : i1, b_in, x_out, region, tri_floats);
         } else if (!(a.ablate & 4)) {
             int rec = (!pre_valid && i0 + wave < i1) ? rec_load(a.items, i0 + wave, lane) : 0;
+            // the (last) split row chunk this wave will finish once its parts have met: record and static indices stay in
+            // registers across that barrier, nothing is loaded behind it
+            int head_k = -1, head_idx = 0, head_p0 = 0, head_p1 = 0;
             for (int k = i0 + wave; k < i1; k += TIER_WAVES) {
                 const int rec_next = k + TIER_WAVES < i1 ? rec_load(a.items, k + TIER_WAVES, lane) : 0;
                 const bool first = k == i0 + wave && pre_valid;
@@ -702,11 +773,16 @@ __global__ __launch_bounds__(64 * TIER_WAVES, 4) void k_nd_tier(TierArgs a, cons
                 if (!first) { if (UP) node_up_pre<K>(a, it, pre); else node_down_pre<K>(a, it, pre); }
                 if (UP) node_up<K>(a, it, pre, b_in, region, pbuf);
                 else node_down<K>(a, it, pre, x_out, region, pbuf);
+                if (it.nparts > 1 && it.part == 0) {
+                    head_k = k; head_idx = pre.idx; head_p0 = pre.plo[0]; head_p1 = pre.plo[1];
+                }
             }
             if ((split >> ph) & 1u) {
+                const int rec_head = head_k >= 0 ? rec_load(a.items, head_k, lane) : 0;      // arrives while the parts meet
                 __syncthreads();
                 for (int k = i0 + wave; k < i1; k += TIER_WAVES) {
-                    const TierItem it = rec_unpack(rec_load(a.items, k, lane));
+                    const bool mine = k == head_k;
+                    const TierItem it = rec_unpack(mine ? rec_head : rec_load(a.items, k, lane));
                     if (it.nparts == 1 || it.part != 0) continue;
                     float acc[K];
 #pragma unroll
@@ -717,8 +793,17 @@ __global__ __launch_bounds__(64 * TIER_WAVES, 4) void k_nd_tier(TierArgs a, cons
 #pragma unroll
                         for (int q = 0; q < K; ++q) acc[q] += pb[lane * 4 + q];
                     }
-                    if (UP) node_up_finish<K>(a, it, it.row0 + lane, acc);
-                    else node_down_finish<K>(a, it, -1, x_out, acc);
+                    if (UP) {
+                        const int i = it.row0 + lane;
+                        const int pp = mine ? head_idx : ((i < it.b && it.pfront_off >= 0 && !(it.flags & NODE_UPC)) ? a.ppos[it.bnd_off + i] : 0);
+                        node_up_finish<K>(a, it, i, pp, acc);
+                    } else if (mine) {
+                        int tg[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) tg[c] = (head_p0 + c < head_p1 && !(it.flags & NODE_LEAF)) ? a.push_tgt[head_p0 + c] : -1;
+                        node_down_store<K>(a, it, head_idx, head_p0, head_p1, tg, x_out, acc);
+                    }
+                    else node_down_finish<K>(a, it, x_out, acc);
                 }
             }
         }
@@ -733,6 +818,8 @@ __global__ __launch_bounds__(64 * TIER_WAVES, 4) void k_nd_tier(TierArgs a, cons
 #pragma unroll
             for (int q = 0; q < K; ++q) pre.v[q] = 0.0f;
             pre.idx = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { pre.plo[c] = -1; pre.plb[c] = -1; }
         }
         tier_stamp(a, 1 + 2 * ph);
         __syncthreads();      // workgroup-scope release/acquire of the slots / boundary vectors written above (same CU)
