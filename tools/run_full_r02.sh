@@ -3,7 +3,7 @@
 # trace + FETCH_SIZE / WRITE_SIZE passes of the bench command, constructor profile
 set -u
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/full3; rm -rf $O; mkdir -p $O/pmc
+O=gpurun_out/full4; rm -rf $O; mkdir -p $O/pmc
 export TMPDIR=/tmp
 ( timeout 1500 python -m pytest tests -m gpu -q --timeout 900 2>&1 | tail -30 ) > $O/pytest.log 2>&1
 ( timeout 200 python -c "import __graft_entry__ as g; g.smoke()" ) > $O/smoke.log 2>&1
