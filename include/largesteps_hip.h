@@ -276,7 +276,7 @@ int ls_direct_create(const ls_direct_arrays* arrays, int device, void* stream, l
  * constructor of the reference's default solver (largesteps/solvers.py:34, CholeskySolverF(n, ii, jj, x, MatrixType.COO)).
  * d_rowptr / d_col / d_val: CSR of the symmetric positive definite matrix (DEVICE, original numbering, column-sorted rows);
  * d_positions: (V, 3) fp32 vertex positions (DEVICE) or NULL (graph-distance pseudo-positions); leaf_size 64 and arity 4 are
- * the tuned defaults; tier_levels deepest levels go into the tier layouts (-1 = chosen by the library: 3 for trees of 8+ levels, else 2; 0 = none), sparse_leaves != 0 stores the leaves
+ * the tuned defaults; tier_levels deepest levels go into the tier layouts (-1 = chosen by the library: tree levels - 5, at least 2 and at most 4; 0 = none), sparse_leaves != 0 stores the leaves
  * as packed triangle + sparse block; shard_rank / shard_count: subtree sharding (0 / 1: none; every rank factorises the whole
  * matrix, the re-solve is sharded, see ls_direct_solve_part). SYNC. Errors: LS_E_INVALID (not symmetric / not positive definite / bad arguments),
  * LS_E_WORKSPACE (fronts or factor beyond the solver's limits, or the tier does not fit LDS: retry with fewer tier_levels). */

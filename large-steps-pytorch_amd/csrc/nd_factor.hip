@@ -395,10 +395,11 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     for (int i = 1; i <= n_nodes; ++i) max_front = std::max(max_front, P.s[i] + P.b[i]);
     LS_REQUIRE(max_front <= 8000, LS_E_WORKSPACE, "ls_direct_factor: a front of %d rows exceeds the solver's limit (the mesh does not dissect)", max_front);
     // ---- layouts -------------------------------------------------------------------------------------------------------------------
-    // tier_levels < 0: chosen here -- three levels per tier workgroup once the tree has eight (1024 workgroups at arity 4), two
-    // below that: a tier of three on a smaller tree leaves most CUs without a workgroup (tools/tier_sweep.py, 576 .. 1M vertices)
+    // tier_levels < 0: chosen here so that about a thousand subtrees (4 workgroups per CU) are left at the tier's root level:
+    // levels - 5 at arity 4 -- three at 1M vertices (8 levels), four at 4M (9 levels: 0.795 ms against 0.850 with three), two
+    // below 8 levels (a tier of three on a 7-level tree leaves most CUs without a workgroup; tools/tier_sweep.py, 576 .. 4M vertices)
     if (tier_levels < 0) {
-        tier_levels = levels >= 8 ? 3 : 2;
+        tier_levels = std::max(2, std::min(4, levels - 5));
         if (shard_count > 1) {                  // the cut (first level with a subtree per rank) must not lie inside the tier
             int cut = 0;
             int64_t width = 1;

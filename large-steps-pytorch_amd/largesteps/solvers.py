@@ -10,6 +10,7 @@ Neither cholespy/CHOLMOD nor torch sparse ops are used; there is no CPU path.
 """
 import ctypes
 import os
+import re
 import warnings
 
 import numpy as np
@@ -331,7 +332,8 @@ class NestedDissectionSolver(Solver):
             except RuntimeError as e:      # a tier whose subtrees need more LDS than a workgroup has: one level less
                 if tier == 0 or "does not fit" not in str(e):
                     raise
-                tier = 2 if tier < 0 or tier > 3 else tier - 1
+                m = re.search(r"a tier of (\d+) levels does not fit", str(e))       # what the library had picked (tier = -1) or was given
+                tier = max(0, int(m.group(1)) - 1) if m else (2 if tier < 0 else tier - 1)
         torch.cuda.synchronize(csr.device)
         self.build_seconds = time.perf_counter() - t0
         self.timings = self._direct.timings
