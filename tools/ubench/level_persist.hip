@@ -153,6 +153,90 @@ __global__ __launch_bounds__(64 * NW) void k_levels(Args A, const float* __restr
     }
 }
 
+// MODE 4: ONE launch for all levels, a workgroup per tile in LEVEL ORDER (the dispatcher hands out workgroup ids in order, so
+// every tile of a level is dispatched before any tile of the next one -- the forward-progress assumption of a decoupled
+// look-back scan); a tile requests its matrix rows at once, then waits for ITS PARENT NODE only (a counter of finished
+// tiles per node, agent-scope release / acquire), multiplies, stores, counts itself in. No device-wide barrier.
+struct FlowArgs { Lv lv[MAXL]; int first[MAXL + 1]; int nlv, fan; };      // first[l]: first workgroup id of level l; fan: children per node
+template <bool COH>
+__global__ __launch_bounds__(64 * NW) void k_flow(FlowArgs A, const float* __restrict__ mat, float* outs, unsigned* done, unsigned epoch) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int l = 0;
+    while (l + 1 < A.nlv && (int)blockIdx.x >= A.first[l + 1]) ++l;
+    const Lv v = A.lv[l];
+    const int t = blockIdx.x - A.first[l];
+    const int L = v.S + v.B, lpr = (L + 255) >> 8;
+    const int node = t / v.tpn, jw = (t % v.tpn) * (NW * v.R) + w * v.R;
+    const int wrows = max(0, min(v.R, v.S - jw));
+    f4u a[CAP];
+    load_rows(mat + v.mat_off + ((size_t)node * v.S + jw) * L, L, lpr, wrows, a);
+    if (l > 0) {
+        const Lv pv = A.lv[l - 1];
+        const int parent = node / A.fan;
+        if (threadIdx.x == 0) {
+            unsigned* c = done + (size_t)(l - 1) * 4096 + parent;
+            const unsigned target = epoch * (unsigned)pv.tpn;
+            int spins = 0;
+            while (__hip_atomic_load(c, COH ? __ATOMIC_RELAXED : __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < 4000000) __builtin_amdgcn_s_sleep(2);
+            if (spins >= 4000000) done[MAXL * 4096] = 1u;
+        }
+        __syncthreads();
+        if (!COH) __atomic_thread_fence(__ATOMIC_ACQUIRE); else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // vector = the parent's results, repeated
+        for (int u = threadIdx.x; u < L; u += blockDim.x) {
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                float* src = outs + pv.out_off + ((size_t)parent * pv.S + (u % pv.S)) * K + q;
+                sm[u * K + q] = COH ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
+            }
+        }
+    } else {
+        for (int u = threadIdx.x; u < L; u += blockDim.x) {
+#pragma unroll
+            for (int q = 0; q < K; ++q) sm[u * K + q] = 1.0f;
+        }
+    }
+    __syncthreads();
+    float mine[K] = {0.f, 0.f, 0.f};
+    fma_rows(a, L, lpr, wrows, sm, mine);
+    if (lane < wrows) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            float* dst = outs + v.out_off + ((size_t)node * v.S + jw + lane) * K + q;
+            if (COH) __hip_atomic_store(dst, mine[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *dst = mine[q];
+        }
+    }
+    if (l + 1 < A.nlv) {                       // the last level has no dependants
+        if (COH) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_waitcnt(0); }
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(done + (size_t)l * 4096 + node, 1u, COH ? __ATOMIC_RELAXED : __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// the same data flow with one launch per level (reference for k_flow: the vector is the parent's results)
+__global__ __launch_bounds__(64 * NW) void k_flow_level(FlowArgs A, const float* __restrict__ mat, float* outs, int l) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const Lv v = A.lv[l];
+    const int t = blockIdx.x;
+    const int L = v.S + v.B, lpr = (L + 255) >> 8;
+    const int node = t / v.tpn, jw = (t % v.tpn) * (NW * v.R) + w * v.R;
+    const int wrows = max(0, min(v.R, v.S - jw));
+    f4u a[CAP];
+    load_rows(mat + v.mat_off + ((size_t)node * v.S + jw) * L, L, lpr, wrows, a);
+    for (int u = threadIdx.x; u < L; u += blockDim.x) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) sm[u * K + q] = l ? outs[A.lv[l - 1].out_off + ((size_t)(node / A.fan) * A.lv[l - 1].S + (u % A.lv[l - 1].S)) * K + q] : 1.0f;
+    }
+    __syncthreads();
+    float mine[K] = {0.f, 0.f, 0.f};
+    fma_rows(a, L, lpr, wrows, sm, mine);
+    if (lane < wrows) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) outs[v.out_off + ((size_t)node * v.S + jw + lane) * K + q] = mine[q];
+    }
+}
+
 int main(int argc, char** argv) {
     int occ1 = 0, occ2 = 0, cus = 0;
     CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
@@ -218,6 +302,45 @@ int main(int argc, char** argv) {
         printf("mode %d (%s): %7.2f us per sweep of %d levels, %.0f GB/s   max diff vs mode 0: %.3g (max |ref| %.3g)\n", mode,
                mode == 0 ? "one launch per level" : mode == 1 ? "persistent, loads after the barrier" : mode == 2 ? "persistent, loads before the barrier" : "persistent, relaxed barrier + coherent vector accesses, loads before the barrier",
                ms / REPS * 1e3, NL, mat_n * 4 / (ms / REPS * 1e-3) * 1e-9, diff, mx);
+    }
+    {   // ---- data flow in one launch (mode 4) against the same data flow with a launch per level
+        FlowArgs F; F.nlv = NL; F.fan = 4;
+        int first = 0;
+        for (int l = 0; l < NL; ++l) {
+            F.lv[l] = A.lv[l];
+            // tiles small enough that a level has at least ~500 of them
+            Lv& v = F.lv[l];
+            const int L = v.S + v.B, lpr = (L + 255) / 256;
+            v.R = std::max(1, std::min(CAP / lpr, v.S / NW));
+            while (v.R > 1 && (long long)v.n * ((v.S + NW * v.R - 1) / (NW * v.R)) < 500) --v.R;
+            v.tpn = (v.S + NW * v.R - 1) / (NW * v.R); v.tiles = v.n * v.tpn;
+            F.first[l] = first; first += v.tiles;
+            printf("flow level %d: R %d tiles %d (%d per node)\n", l, v.R, v.tiles, v.tpn);
+        }
+        F.first[NL] = first;
+        unsigned* done; CK(hipMalloc(&done, (MAXL * 4096 + 4) * 4)); CK(hipMemset(done, 0, (MAXL * 4096 + 4) * 4));
+        unsigned ep = 0;
+        for (int mode = 0; mode < 3; ++mode) {
+            auto run = [&](int r) {
+                const float* m = mat + (size_t)(r % COPIES) * mat_n;
+                if (mode == 0) { for (int l = 0; l < NL; ++l) hipLaunchKernelGGL(k_flow_level, dim3(F.lv[l].tiles), dim3(64 * NW), lds, 0, F, m, outs, l); }
+                else if (mode == 1) { ++ep; hipLaunchKernelGGL(k_flow<false>, dim3(first), dim3(64 * NW), lds, 0, F, m, outs, done, ep); }
+                else { ++ep; hipLaunchKernelGGL(k_flow<true>, dim3(first), dim3(64 * NW), lds, 0, F, m, outs, done, ep); }
+            };
+            for (int r = 0; r < 5; ++r) run(r);
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0));
+            for (int r = 0; r < REPS; ++r) run(r);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            CK(hipMemcpy((mode == 0 ? ref : got).data(), outs, out_n * K * 4, hipMemcpyDeviceToHost));
+            double diff = 0, mx = 0;
+            if (mode) for (size_t i = 0; i < ref.size(); ++i) { diff = std::max(diff, (double)fabsf(ref[i] - got[i])); mx = std::max(mx, (double)fabsf(ref[i])); }
+            unsigned flag = 0; CK(hipMemcpy(&flag, done + MAXL * 4096, 4, hipMemcpyDeviceToHost));
+            if (flag) printf("  A WAIT TIMED OUT\n");
+            printf("flow mode %d (%s): %7.2f us per sweep of %d levels, %.0f GB/s   max diff %.3g (max |ref| %.3g)\n", mode,
+                   mode == 0 ? "one launch per level" : mode == 1 ? "ONE launch, tiles wait for their parent node (acquire / release)" : "ONE launch, tiles wait for their parent node (relaxed counters, L2-coherent vector accesses)", ms / REPS * 1e3, NL, mat_n * 4 / (ms / REPS * 1e-3) * 1e-9, diff, mx);
+        }
     }
     return 0;
 }
