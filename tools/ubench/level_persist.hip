@@ -237,6 +237,30 @@ __global__ __launch_bounds__(64 * NW) void k_flow_level(FlowArgs A, const float*
     }
 }
 
+// the same level kernel for the nodes [n0, n0 + nn) of a level only: one of the independent subtrees below the root
+__global__ __launch_bounds__(64 * NW) void k_flow_part(FlowArgs A, const float* __restrict__ mat, float* outs, int l, int n0) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const Lv v = A.lv[l];
+    const int t = blockIdx.x;
+    const int L = v.S + v.B, lpr = (L + 255) >> 8;
+    const int node = n0 + t / v.tpn, jw = (t % v.tpn) * (NW * v.R) + w * v.R;
+    const int wrows = max(0, min(v.R, v.S - jw));
+    f4u a[CAP];
+    load_rows(mat + v.mat_off + ((size_t)node * v.S + jw) * L, L, lpr, wrows, a);
+    for (int u = threadIdx.x; u < L; u += blockDim.x) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) sm[u * K + q] = l ? outs[A.lv[l - 1].out_off + ((size_t)(node / A.fan) * A.lv[l - 1].S + (u % A.lv[l - 1].S)) * K + q] : 1.0f;
+    }
+    __syncthreads();
+    float mine[K] = {0.f, 0.f, 0.f};
+    fma_rows(a, L, lpr, wrows, sm, mine);
+    if (lane < wrows) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) outs[v.out_off + ((size_t)node * v.S + jw + lane) * K + q] = mine[q];
+    }
+}
+
 int main(int argc, char** argv) {
     int occ1 = 0, occ2 = 0, cus = 0;
     CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
@@ -340,6 +364,54 @@ int main(int argc, char** argv) {
             if (flag) printf("  A WAIT TIMED OUT\n");
             printf("flow mode %d (%s): %7.2f us per sweep of %d levels, %.0f GB/s   max diff %.3g (max |ref| %.3g)\n", mode,
                    mode == 0 ? "one launch per level" : mode == 1 ? "ONE launch, tiles wait for their parent node (acquire / release)" : "ONE launch, tiles wait for their parent node (relaxed counters, L2-coherent vector accesses)", ms / REPS * 1e3, NL, mat_n * 4 / (ms / REPS * 1e-3) * 1e-9, diff, mx);
+        }
+    }
+    {   // ---- the four subtrees below the root as four concurrent chains of launches (streams), replayed as ONE graph
+        FlowArgs F; F.nlv = NL; F.fan = 4;
+        for (int l = 0; l < NL; ++l) {
+            F.lv[l] = A.lv[l];
+            Lv& v = F.lv[l];
+            const int L = v.S + v.B, lpr = (L + 255) / 256;
+            v.R = std::max(1, std::min(CAP / lpr, v.S / NW));
+            while (v.R > 1 && (long long)v.n * ((v.S + NW * v.R - 1) / (NW * v.R)) < 500) --v.R;
+            v.tpn = (v.S + NW * v.R - 1) / (NW * v.R); v.tiles = v.n * v.tpn;
+        }
+        hipStream_t main_s, sub[4];
+        CK(hipStreamCreate(&main_s));
+        for (int q = 0; q < 4; ++q) CK(hipStreamCreate(&sub[q]));
+        hipEvent_t fork, join[4];
+        CK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+        for (int q = 0; q < 4; ++q) CK(hipEventCreateWithFlags(&join[q], hipEventDisableTiming));
+        const float* m = mat;
+        for (int variant = 0; variant < 2; ++variant) {
+            hipGraph_t graph; hipGraphExec_t exec;
+            CK(hipStreamBeginCapture(main_s, hipStreamCaptureModeGlobal));
+            hipLaunchKernelGGL(k_flow_level, dim3(F.lv[0].tiles), dim3(64 * NW), lds, main_s, F, m, outs, 0);
+            if (variant == 0) {
+                for (int l = 1; l < NL; ++l) hipLaunchKernelGGL(k_flow_level, dim3(F.lv[l].tiles), dim3(64 * NW), lds, main_s, F, m, outs, l);
+            } else {
+                CK(hipEventRecord(fork, main_s));
+                for (int q = 0; q < 4; ++q) {
+                    CK(hipStreamWaitEvent(sub[q], fork, 0));
+                    for (int l = 1; l < NL; ++l) {
+                        const int nn = F.lv[l].n / 4;
+                        hipLaunchKernelGGL(k_flow_part, dim3(nn * F.lv[l].tpn), dim3(64 * NW), lds, sub[q], F, m, outs, l, q * nn);
+                    }
+                    CK(hipEventRecord(join[q], sub[q]));
+                    CK(hipStreamWaitEvent(main_s, join[q], 0));
+                }
+            }
+            CK(hipStreamEndCapture(main_s, &graph));
+            CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            for (int r = 0; r < 5; ++r) CK(hipGraphLaunch(exec, main_s));
+            CK(hipStreamSynchronize(main_s));
+            CK(hipEventRecord(e0, main_s));
+            for (int r = 0; r < REPS; ++r) CK(hipGraphLaunch(exec, main_s));
+            CK(hipEventRecord(e1, main_s)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("graph variant %d (%s): %7.2f us per sweep of %d levels (same matrix copy every time)\n", variant,
+                   variant == 0 ? "one chain of 5 launches" : "root, then 4 concurrent chains of 4 launches (one per subtree)", ms / REPS * 1e3, NL);
+            CK(hipGraphExecDestroy(exec)); CK(hipGraphDestroy(graph));
         }
     }
     return 0;
