@@ -10,7 +10,10 @@
 #include <stdlib.h>
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
-constexpr int K = 3, CAP = 16, NW = 4;
+#ifndef CAPV
+#define CAPV 16
+#endif
+constexpr int K = 3, CAP = CAPV, NW = 4;
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f4a __attribute__((ext_vector_type(4)));
 struct alignas(64) Rec { int node, row0, s, b; long long mat_off, vec_off; int pad[8]; };
