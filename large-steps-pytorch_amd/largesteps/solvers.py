@@ -374,7 +374,7 @@ class CholeskySolver(Solver):
     on b only.
 
     * matrices built by `compute_matrix` (vertex positions known): `NestedDissectionSolver` -- factor once on the
-      device, 2 x (tree levels) HIP launches per solve;
+      device, then one HIP launch per upper tree level and sweep plus one per sweep for the deepest levels (11 at 1M vertices);
     * anything else, or a mesh whose fronts exceed that solver's limits: `IterativeCholeskySolver` (Chebyshev-Jacobi /
       Jacobi-PCG run to a residual reduction `rtol`).
     `direct=False` (or LARGESTEPS_NO_DIRECT=1) forces the iterative path; `method` says which one is in use and every

@@ -11,7 +11,7 @@ constructor, two triangular solves per call). Here the constructor
      largest front), assembled by index arithmetic and factorised in fp64 with torch.linalg (rocSOLVER / rocBLAS):
      Finv = F_ss^-1, W = F_bs Finv, U = F_bb - W F_sb -> parent,
   3. packs Finv and W (twice: both sweep layouts) in fp32 and hands the device pointers to ls_direct_create.
-Every solve afterwards is 2 * levels hand-written HIP launches that read the factor once (W twice).
+Every solve afterwards is a handful of hand-written HIP launches (one per upper tree level and sweep, one per sweep for the tier) that read the factor once (W twice).
 """
 import ctypes
 import os

@@ -19,7 +19,7 @@ one batch of small dense matrix-vector products:
                    updates at bnd_i)                       [no atomics, one launch per level]
               down (root -> leaves): x_s = Finv_i b'_s - W_i^T x[bnd_i]
 
-Per solve the GPU reads every W twice and every Finv once -- and launches 2 * levels kernels.
+Per solve the GPU reads every W twice and every Finv once -- one launch per upper tree level and sweep, one per sweep for the deepest levels.
 """
 import numpy as np
 
