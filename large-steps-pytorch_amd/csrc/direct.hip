@@ -20,6 +20,7 @@
 #include <vector>
 #include <algorithm>
 #include <string.h>
+#include <mutex>
 
 namespace ls {
 
@@ -809,6 +810,7 @@ __global__ __launch_bounds__(64) void k_nd_down_p(const PackedTile* __restrict__
 
 }  // namespace ls
 #include "nd_tier.h"
+#include "nd_span.h"
 namespace ls {
 
 // down tiles of a level: compute tiles, then forward tiles
@@ -851,6 +853,18 @@ struct ls_direct {
     int shard_rank = 0, shard_count = 1, cut = 0;
     int64_t exch_f0 = 0, exch_f1 = 0;
     std::vector<unsigned char> owned_rows;    // caller's numbering: 1 = this rank is the designated owner of the row's x
+    // the levels above the tier as ONE persistent launch (nd_span.h); off: one launch per level and sweep (the kernels above)
+    bool span_ok = false, span_on = false;
+    const float *pu = nullptr, *pd = nullptr;                    // caller's arrays (layouts of nd_span.h)
+    SpanJob* d_sjobs = nullptr;
+    SpanSync* d_ssync = nullptr;
+    unsigned* d_swords = nullptr;
+    unsigned* h_sfail = nullptr;        // host-mapped: a wait of the persistent launch timed out
+    int* d_bnd = nullptr;
+    float *pslots = nullptr, *bp4 = nullptr, *xt4 = nullptr;
+    int span_phases = 0, span_grid = 0, span_lcap = 0, span_words = 0;
+    int exp_ablate = 0, exp_stagger = 0;            // -DLS_ND_EXPERIMENTS builds only (LS_ND_ABLATE / LS_ND_STAGGER at creation)
+    long long* span_dbg = nullptr;
     double factor_s[3] = {0, 0, 0};     // ls_direct_factor: symbolic analysis, layout / sparse tables, numeric factorisation
     std::vector<LevelPlan> plan;
     int64_t factor_entries = 0, words_up = 0, words_down = 0;    // 4-byte words of factor data per solve / per sweep
@@ -953,6 +967,136 @@ static size_t plan_tier(const std::vector<NodeD>& nd, const std::vector<int64_t>
     }
     vec_floats = (vec_need + 3) & ~3;
     return (size_t)std::max(vec_floats + pbuf_need, leaf_need);
+}
+
+
+// The levels above the tier as phases of one persistent launch (nd_span.h): workgroup ranges per node (a node's range is the
+// union of its children's), every workgroup's jobs per phase, and the arrival counters / release flags between the phases.
+struct SpanPlan { std::vector<SpanJob> jobs; std::vector<SpanSync> sync; int phases = 0, grid = 0, lcap = 0, words = 0; };
+static bool plan_span(const std::vector<NodeDesc>& nodes, const std::vector<int64_t>& level_off, int T, int levels, int arity,
+                      const int64_t* pu_off, const int64_t* pd_off, int G, SpanPlan& sp) {
+    if (T < 1 || G < 1) return false;
+    const int64_t n_upper = level_off[T] - 1;
+    auto s4 = [](int x) { return (x + 3) & ~3; };
+    // weights: fp32 words of a subtree's upper levels
+    std::vector<double> wt((size_t)n_upper + 2, 0.0);
+    for (int lv = T - 1; lv >= 0; --lv)
+        for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i) {
+            const NodeDesc& n = nodes[i];
+            double w = (double)n.b * s4(n.s) + (double)n.s * (s4(n.s) + s4(n.b));
+            if (lv + 1 < T) for (int c = 0; c < arity; ++c) w += wt[(size_t)(level_off[lv + 1] + (i - level_off[lv]) * arity + c)];
+            wt[(size_t)i] = w;
+        }
+    std::vector<int> g0((size_t)n_upper + 2, 0), g1((size_t)n_upper + 2, 0);
+    g0[1] = 0; g1[1] = G;
+    for (int lv = 0; lv + 1 < T; ++lv)
+        for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i) {
+            const int lo = g0[(size_t)i], sz = g1[(size_t)i] - lo;
+            const int64_t c0 = level_off[lv + 1] + (i - level_off[lv]) * arity;
+            int nz = 0;
+            double tot = 0.0;
+            for (int c = 0; c < arity; ++c) if (wt[(size_t)(c0 + c)] > 0.0) { ++nz; tot += wt[(size_t)(c0 + c)]; }
+            std::vector<int> cnt((size_t)arity, 0);
+            if (nz && sz >= nz) {           // at least one workgroup per working child, the rest in proportion (largest remainders)
+                const int left = sz - nz;
+                std::vector<double> rem((size_t)arity, -1.0);
+                int given = 0;
+                for (int c = 0; c < arity; ++c) if (wt[(size_t)(c0 + c)] > 0.0) {
+                    const double share = (double)left * wt[(size_t)(c0 + c)] / tot;
+                    cnt[(size_t)c] = 1 + (int)share; rem[(size_t)c] = share - (int)share; given += (int)share;
+                }
+                for (int r = left - given; r > 0; --r) {      // r < nz: every child gets at most one of the remaining workgroups
+                    int best = -1;
+                    for (int c = 0; c < arity; ++c) if (rem[(size_t)c] >= 0.0 && (best < 0 || rem[(size_t)c] > rem[(size_t)best])) best = c;
+                    if (best < 0) break;
+                    ++cnt[(size_t)best]; rem[(size_t)best] = -1.0;
+                }
+                int at = lo;
+                for (int c = 0; c < arity; ++c) {
+                    g0[(size_t)(c0 + c)] = std::min(at, lo + sz - 1);
+                    g1[(size_t)(c0 + c)] = cnt[(size_t)c] ? at + cnt[(size_t)c] : g0[(size_t)(c0 + c)] + 1;
+                    at += cnt[(size_t)c];
+                }
+            } else {                        // fewer workgroups than working children: they share
+                int k = 0;
+                for (int c = 0; c < arity; ++c) {
+                    const int g = lo + (nz ? (int)((int64_t)k * sz / nz) : 0);
+                    g0[(size_t)(c0 + c)] = g; g1[(size_t)(c0 + c)] = g + 1;
+                    if (wt[(size_t)(c0 + c)] > 0.0) ++k;
+                }
+            }
+        }
+    // phases: up(T-1) .. up(1), root, down(1) .. down(T-1)
+    const int P = 2 * (T - 1) + 1;
+    std::vector<std::vector<SpanJob>> jb((size_t)P * G);
+    int lcap = 4;
+    auto add_jobs = [&](int ph, int kind, int lv) {
+        for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i) {
+            const NodeDesc& n = nodes[i];
+            if (n.s == 0 && n.b == 0) continue;
+            const int lo = g0[(size_t)i], z = g1[(size_t)i] - lo;
+            const int rows = kind == SPAN_UP ? n.b : n.s;
+            const int last = lv == T - 1, leaf = lv + 1 >= levels;
+            const int keep = kind == SPAN_UP ? n.s : (kind == SPAN_DOWN && last && !leaf) ? n.b : 0;     // positions whose b' is stored / whose x is forwarded
+            for (int k = 0; k < z; ++k) {
+                SpanJob j;
+                memset(&j, 0, sizeof(j));
+                j.kind = kind; j.s = n.s; j.b = n.b; j.own_start = n.own_start; j.bnd_off = n.bnd_off; j.front_off = n.front_off;
+                j.pfront_off = i > 1 ? nodes[n.parent].front_off : -1; j.cix = lv ? (int)((i - level_off[lv]) % arity) : 0;
+                j.flags = (leaf ? SPAN_F_LEAF : 0) | ((last && !leaf) ? (SPAN_F_CHTIER | SPAN_F_LAST) : 0);
+                j.row0 = (int)((int64_t)rows * k / z); j.nrows = (int)((int64_t)rows * (k + 1) / z) - j.row0;
+                j.v0 = (int)((int64_t)keep * k / z); j.v1 = (int)((int64_t)keep * (k + 1) / z);
+                j.s4 = s4(n.s); j.len = kind == SPAN_UP ? s4(n.s) : s4(n.s) + s4(n.b);
+                j.mat_off = kind == SPAN_UP ? pu_off[i] : pd_off[i];
+                if (j.nrows == 0 && j.v1 == j.v0) continue;
+                lcap = std::max(lcap, j.len);
+                jb[(size_t)ph * G + lo + k].push_back(j);
+            }
+        }
+    };
+    int ph = 0;
+    for (int lv = T - 1; lv >= 1; --lv) add_jobs(ph++, SPAN_UP, lv);
+    add_jobs(ph++, SPAN_ROOT, 0);
+    for (int lv = 1; lv <= T - 1; ++lv) add_jobs(ph++, SPAN_DOWN, lv);
+    sp.jobs.clear();
+    sp.sync.assign((size_t)P * G, SpanSync());
+    for (auto& y : sp.sync) { memset(&y, 0, sizeof(y)); y.wait_flag = y.arr_ctr = y.top_ctr = -1; }
+    for (int w = 0; w < G; ++w)
+        for (int p = 0; p < P; ++p) {
+            SpanSync& y = sp.sync[(size_t)p * G + w];
+            y.job0 = (int)sp.jobs.size();
+            for (const SpanJob& j : jb[(size_t)p * G + w]) sp.jobs.push_back(j);
+            y.job1 = (int)sp.jobs.size();
+        }
+    for (int w = 0; w < G; ++w)
+        for (int p = 0; p + 1 < P; ++p) {
+            sp.sync[(size_t)p * G + w].njob0 = sp.sync[(size_t)(p + 1) * G + w].job0;
+            sp.sync[(size_t)p * G + w].njob1 = sp.sync[(size_t)(p + 1) * G + w].job1;
+        }
+    if (sp.jobs.empty()) return false;
+    // barriers: after phase p the workgroups of a DOMAIN node meet -- up(l): the nodes of level l - 1 (their children are done);
+    // root / down(l): the nodes of that level (their x is complete, the children may start)
+    int words = 0;
+    for (int p = 0; p + 1 < P; ++p) {
+        const int dom_lv = p < T - 1 ? (T - 1 - p) - 1 : p - (T - 1);
+        for (int64_t i = level_off[dom_lv]; i < level_off[dom_lv + 1]; ++i) {
+            const int lo = g0[(size_t)i], z = g1[(size_t)i] - lo;
+            if (z <= 1 || wt[(size_t)i] <= 0.0) continue;
+            const int nblk = (z + SPAN_DOMAIN - 1) / SPAN_DOMAIN;
+            const int ctr0 = words, top = nblk > 1 ? words + nblk : -1, flag0 = words + nblk + (nblk > 1 ? 1 : 0);
+            words = flag0 + nblk;
+            for (int k = 0; k < z; ++k) {
+                SpanSync& y = sp.sync[(size_t)p * G + lo + k];
+                if (y.arr_ctr >= 0) return false;             // (ranges of one level are disjoint: cannot happen)
+                const int blk = k / SPAN_DOMAIN;
+                y.arr_ctr = ctr0 + blk; y.arr_size = std::min(SPAN_DOMAIN, z - blk * SPAN_DOMAIN);
+                y.top_ctr = top; y.top_size = nblk; y.rel_flag0 = flag0; y.rel_n = nblk;
+                sp.sync[(size_t)(p + 1) * G + lo + k].wait_flag = flag0 + blk;
+            }
+        }
+    }
+    sp.phases = P; sp.grid = G; sp.lcap = (lcap + 3) & ~3; sp.words = std::max(words, 1);
+    return true;
 }
 
 extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* stream, ls_direct** out) {
@@ -1087,6 +1231,9 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
         }
     }
     d->fuse_root = getenv("LS_ND_NO_FUSE_ROOT") == nullptr;
+#ifdef LS_ND_EXPERIMENTS
+    d->exp_ablate = env_int0("LS_ND_ABLATE", 0); d->exp_stagger = env_int0("LS_ND_STAGGER", 0);
+#endif
     d->upper_lo = (d->tier_root < levels && d->tier_root > 0) ? nodes[level_off[d->tier_root - 1]].own_start : (int)V;
     std::vector<int> pull;
     if (d->tier_root < levels) {
@@ -1230,6 +1377,32 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
                 if (lv < cut ? rank == 0 : active(i, lv))
                     for (int r = 0; r < nodes[i].s; ++r) d->owned_rows[(size_t)h_perm[nodes[i].own_start + r]] = 1;
     }
+    // the levels above the tier as one persistent launch (nd_span.h): needs the caller's pu / pd layouts and the boundary ids
+    SpanPlan sp;
+    bool span = A->d_pu && A->d_pd && A->h_pu_off && A->h_pd_off && A->h_bnd && n_ranks == 1 && d->tier_root >= 1 && d->tier_wgs > 0 && !getenv("LS_ND_NO_SPAN");
+    if (span) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 8) span = false;
+        int G = env_int("LS_ND_SPAN_GRID", 0);
+        if (span && G <= 0) {
+            // one workgroup per CU; small trees: fewer workgroups (a phase should leave ~16 KB of factor per workgroup, barriers among
+            // fewer workgroups are cheaper)
+            int64_t phase_max = 0;
+            for (int lv = 0; lv < d->tier_root; ++lv) {
+                int64_t up_w = 0, down_w = 0;
+                for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i) {
+                    const int64_t s4 = (nodes[i].s + 3) & ~3, b4 = (nodes[i].b + 3) & ~3;
+                    up_w += s4 * nodes[i].b; down_w += (s4 + b4) * nodes[i].s;
+                }
+                phase_max = std::max(phase_max, std::max(up_w, down_w));
+            }
+            G = cus & ~7;
+            while (G > 8 && phase_max * 4 < (int64_t)G * 16384) G >>= 1;
+            G &= ~7;
+        }
+        span = span && plan_span(nodes, level_off, d->tier_root, levels, arity, A->h_pu_off, A->h_pd_off, std::min(G, cus), sp);
+        if (span && ((size_t)d->kmax * sp.lcap + SPAN_WAVES * 256) * sizeof(float) > 150 * 1024) span = false;
+    }
     int rc = LS_OK;
     auto up = [&](auto** dst, const auto* src, size_t n) -> int {
         LS_HIP(hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(**dst)));
@@ -1241,11 +1414,23 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
         !(rc = up(&d->ppos, h_ppos, (size_t)n_bnd)) && !(rc = up(&d->push_ptr, h_push_ptr, (size_t)n_front + 1)) &&
         !(rc = up(&d->push_tgt, h_push_tgt, (size_t)n_bnd)) && !(rc = up(&d->mask, mask.data(), mask.size())) &&
         !(rc = up(&d->d_items, items.data(), items.size())) && !(rc = up(&d->pull, pull.data(), pull.size())) &&
-        !(rc = up(&d->d_wgs, wgs.data(), wgs.size()))) {
+        !(rc = up(&d->d_wgs, wgs.data(), wgs.size())) &&
+        (!span || (!(rc = up(&d->d_sjobs, sp.jobs.data(), sp.jobs.size())) && !(rc = up(&d->d_ssync, sp.sync.data(), sp.sync.size())) &&
+                   !(rc = up(&d->d_bnd, A->h_bnd, (size_t)n_bnd))))) {
         hipError_t e = hipMalloc((void**)&d->bp, sizeof(float) * (size_t)V * d->kmax);
         if (e == hipSuccess) e = hipMalloc((void**)&d->braw, sizeof(float) * (size_t)V * d->kmax);
         if (e == hipSuccess) e = hipMalloc((void**)&d->slots, sizeof(float) * (size_t)n_front * arity * d->kmax);
         if (e == hipSuccess) e = hipMalloc((void**)&d->xb, sizeof(float) * (size_t)std::max<int64_t>(n_bnd, 1) * d->kmax);
+        if (e == hipSuccess && span) {
+            const size_t up_rows = (size_t)(V - d->upper_lo);
+            const size_t n_pf = d->tier_root < levels ? (size_t)nodes[level_off[d->tier_root]].front_off : (size_t)n_front;
+            e = hipMalloc((void**)&d->pslots, sizeof(float) * 4 * std::max<size_t>(n_pf * arity, 1));
+            if (e == hipSuccess) e = hipMalloc((void**)&d->bp4, sizeof(float) * 4 * std::max<size_t>(up_rows, 1));
+            if (e == hipSuccess) e = hipMalloc((void**)&d->xt4, sizeof(float) * 4 * std::max<size_t>(up_rows, 1));
+            if (e == hipSuccess) e = hipMalloc((void**)&d->d_swords, sizeof(unsigned) * 16 * (size_t)sp.words);
+            if (e == hipSuccess) e = hipHostMalloc((void**)&d->h_sfail, sizeof(unsigned), hipHostMallocMapped);
+            if (e == hipSuccess) *d->h_sfail = 0u;
+        }
         if (e == hipSuccess) e = hipEventCreateWithFlags(&d->busy, hipEventDisableTiming);
         if (e == hipSuccess) e = hipStreamSynchronize(st);      // the host vectors above go out of scope
         if (e != hipSuccess) rc = hip_fail(e, "ls_direct_create allocations", __FILE__, __LINE__);
@@ -1266,6 +1451,21 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
     (void)hipFuncSetAttribute((const void*)k_nd_tier<KK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     LS_OPTIN(1) LS_OPTIN(2) LS_OPTIN(3) LS_OPTIN(4)
 #undef LS_OPTIN
+    if (span) {
+        d->pu = A->d_pu; d->pd = A->d_pd;
+        d->span_phases = sp.phases; d->span_grid = sp.grid; d->span_lcap = sp.lcap; d->span_words = sp.words;
+        d->span_ok = true;
+        // measured on the MI355X (profiles/r03_span_*): 166 us for the nine phases of a 1M-vertex solve against 120 us for nine
+        // launches -- a workgroup's requests for the next phase, its wait, vector assembly, products and stores are one serial
+        // chain (~22 us per phase), while separate launches overlap those stages across 8 resident workgroups per CU. Off by default.
+        d->span_on = env_int0("LS_ND_PERSIST", 0) != 0;
+#define LS_OPTIN(KK)                                                                                                        \
+        (void)hipFuncSetAttribute((const void*)k_nd_span<KK, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+        (void)hipFuncSetAttribute((const void*)k_nd_span<KK, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+        (void)hipFuncSetAttribute((const void*)k_nd_span<KK, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        LS_OPTIN(1) LS_OPTIN(2) LS_OPTIN(3) LS_OPTIN(4)
+#undef LS_OPTIN
+    }
     *out = d;
     return LS_OK;
 }
@@ -1276,6 +1476,9 @@ extern "C" int ls_direct_destroy(ls_direct* d) {
     (void)hipFree(d->tiles); (void)hipFree(d->ptiles); (void)hipFree(d->perm); (void)hipFree(d->ppos); (void)hipFree(d->push_ptr); (void)hipFree(d->push_tgt);
     (void)hipFree(d->mask); (void)hipFree(d->bp); (void)hipFree(d->braw); (void)hipFree(d->slots); (void)hipFree(d->xb);
     (void)hipFree(d->d_items); (void)hipFree(d->d_wgs); (void)hipFree(d->dbg); (void)hipFree(d->pull);
+    (void)hipFree(d->d_sjobs); (void)hipFree(d->d_ssync); (void)hipFree(d->d_swords); (void)hipFree(d->d_bnd); (void)hipFree(d->pslots);
+    (void)hipFree(d->bp4); (void)hipFree(d->xt4); (void)hipFree(d->span_dbg);
+    if (d->h_sfail) (void)hipHostFree(d->h_sfail);
     if (d->busy) (void)hipEventDestroy(d->busy);
     for (void* p : d->owned) (void)hipFree(p);
     for (hipEvent_t e : d->ev) (void)hipEventDestroy(e);
@@ -1293,11 +1496,47 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
     ta.pull = d->pull ? d->pull - (size_t)d->pull_base * d->arity : nullptr; ta.push_ptr = d->push_ptr; ta.push_tgt = d->push_tgt; ta.u4 = d->u4; ta.d4 = d->d4; ta.tri = d->tri;
     ta.sp_ptr = d->sp_ptr; ta.sp_ent = d->sp_ent; ta.bprime = d->bp; ta.braw = d->braw; ta.slots = d->slots; ta.xb = d->xb;
     ta.arity = d->arity; ta.phases = d->tier_phases; ta.region_floats = d->tier_region; ta.vec_floats = d->tier_vec;
-    ta.dbg = d->profile == 2 ? d->dbg : nullptr;
     ta.upper_lo = d->upper_lo; ta.upper_hi = (int)d->V;
-    ta.ablate = env_int0("LS_ND_ABLATE", 0);
-    ta.stagger = env_int0("LS_ND_STAGGER", 0);
+    ta.dbg = nullptr; ta.ablate = 0; ta.stagger = 0;
+#ifdef LS_ND_EXPERIMENTS
+    ta.dbg = d->profile == 2 ? d->dbg : nullptr;
+    ta.ablate = d->exp_ablate; ta.stagger = d->exp_stagger;     // read once, when the handle was created
+#endif
     const size_t tier_lds = (size_t)d->tier_region * TIER_WAVES * sizeof(float);
+    if (d->span_ok && d->span_on && part == -1) {
+        // tier up -> every level above the tier, both sweeps, as ONE persistent launch -> tier down
+        SpanArgs sa;
+        sa.jobs = d->d_sjobs; sa.sync = d->d_ssync; sa.words = d->d_swords; sa.fail = d->h_sfail;
+        sa.phases = d->span_phases; sa.grid = d->span_grid; sa.lcap = d->span_lcap; sa.arity = d->arity; sa.upper_lo = d->upper_lo;
+        sa.pu = d->pu; sa.pd = d->pd; sa.braw = d->braw; sa.tslots = d->slots; sa.txb = d->xb; sa.mask = d->mask; sa.ppos = d->ppos;
+        sa.perm = d->perm; sa.bnd = d->d_bnd; sa.push_ptr = d->push_ptr; sa.push_tgt = d->push_tgt; sa.pslots = d->pslots; sa.bp4 = d->bp4;
+        sa.xt4 = d->xt4; sa.dbg = nullptr;
+#ifdef LS_ND_EXPERIMENTS
+        sa.dbg = d->profile == 2 ? d->span_dbg : nullptr;
+#endif
+        if (d->profile) LS_HIP(hipEventRecord(d->ev[0], st));
+        LS_HIP(hipMemsetAsync(d->d_swords, 0, sizeof(unsigned) * 16 * (size_t)d->span_words, st));
+        hipLaunchKernelGGL((k_nd_tier<K, true>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
+        if (d->profile) LS_HIP(hipEventRecord(d->ev[1], st));
+        const size_t span_lds = ((size_t)K * d->span_lcap + SPAN_WAVES * 256) * sizeof(float);
+        if (d->arity == 4) hipLaunchKernelGGL((k_nd_span<K, 4>), dim3(d->span_grid), dim3(SPAN_THREADS), span_lds, st, sa, x);
+        else if (d->arity == 2) hipLaunchKernelGGL((k_nd_span<K, 2>), dim3(d->span_grid), dim3(SPAN_THREADS), span_lds, st, sa, x);
+        else hipLaunchKernelGGL((k_nd_span<K, 8>), dim3(d->span_grid), dim3(SPAN_THREADS), span_lds, st, sa, x);
+        if (d->profile) LS_HIP(hipEventRecord(d->ev[2], st));
+        if (ta.dbg) ta.dbg += (size_t)d->tier_wgs * TIER_WAVES * 32;
+        hipLaunchKernelGGL((k_nd_tier<K, false>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
+        if (d->profile) LS_HIP(hipEventRecord(d->ev[3], st));
+        LS_HIP(hipGetLastError());
+        if (d->profile) {
+            LS_HIP(hipStreamSynchronize(st));
+            float u = 0, m = 0, w = 0;
+            LS_HIP(hipEventElapsedTime(&u, d->ev[0], d->ev[1]));
+            LS_HIP(hipEventElapsedTime(&m, d->ev[1], d->ev[2]));
+            LS_HIP(hipEventElapsedTime(&w, d->ev[2], d->ev[3]));
+            d->prof_ms[0] = u; d->prof_ms[1] = w; d->prof_ms[2] = m;
+        }
+        return LS_OK;
+    }
     const size_t exch_off = (size_t)d->exch_f0 * d->arity * K, exch_n = (size_t)(d->exch_f1 - d->exch_f0) * d->arity * K;
     if (part != 1) {
     if (d->profile) LS_HIP(hipEventRecord(d->ev[0], st));
@@ -1371,6 +1610,18 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
     return LS_OK;
 }
 
+// one event per device: recorded after every persistent launch, waited for before the next one (see ls_direct_solve)
+static hipEvent_t g_span_chain[64];
+static void rc_chain_init() {
+    static std::once_flag once;
+    std::call_once(once, [] { for (hipEvent_t& e : g_span_chain) e = nullptr; });
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!g_span_chain[dev & 63]) (void)hipEventCreateWithFlags(&g_span_chain[dev & 63], hipEventDisableTiming);
+}
+
 extern "C" int ls_direct_solve(ls_direct* d, const float* b, float* x, int k, void* stream) {
     LS_REQUIRE(d && b && x && k >= 1 && k <= d->kmax, LS_E_INVALID, "ls_direct_solve: bad argument (1 <= k <= %d)", d ? d->kmax : 4);
     LS_REQUIRE(b != x, LS_E_INVALID, "ls_direct_solve: b and x must not alias");
@@ -1386,6 +1637,22 @@ extern "C" int ls_direct_solve(ls_direct* d, const float* b, float* x, int k, vo
     if (st) (void)hipStreamIsCapturing(st, &cap);
     const bool capturing = cap == hipStreamCaptureStatusActive;
     if (!capturing && d->used && st != d->last_stream) LS_HIP(hipStreamWaitEvent(st, d->busy, 0));
+    if (d->h_sfail && *d->h_sfail) {          // a wait inside an earlier persistent launch gave up: its x was wrong
+        *d->h_sfail = 0u;
+        d->span_on = false;
+        set_error("ls_direct_solve: a previous solve of this handle timed out inside the persistent upper-level launch (its result is invalid): "
+                  "workgroups were not co-resident -- another process shares the GPU? The handle now runs one launch per tree level");
+        return LS_E_STATE;
+    }
+    // two persistent launches must never share the chip (each waits for ALL its workgroups to be resident): launches of this
+    // process are chained through one event per device, whatever their streams and handles
+    const bool span = d->span_ok && d->span_on;
+    hipEvent_t chain = nullptr;
+    if (span && !capturing) {
+        rc_chain_init();
+        chain = g_span_chain[d->device & 63];
+        if (chain) LS_HIP(hipStreamWaitEvent(st, chain, 0));
+    }
     int rc;
     switch (k) {
         case 1: rc = direct_solve_k<1>(d, b, x, st, -1, nullptr); break;
@@ -1394,6 +1661,7 @@ extern "C" int ls_direct_solve(ls_direct* d, const float* b, float* x, int k, vo
         default: rc = direct_solve_k<4>(d, b, x, st, -1, nullptr); break;
     }
     if (rc == LS_OK && !capturing) { LS_HIP(hipEventRecord(d->busy, st)); d->last_stream = st; d->used = true; }
+    if (rc == LS_OK && chain) LS_HIP(hipEventRecord(chain, st));
     return rc;
 }
 
@@ -1429,13 +1697,21 @@ extern "C" int ls_direct_set(ls_direct* d, const char* name, int value) {
         DeviceGuard g(d->device);
         LS_HIP(g.err);
         d->profile = value < 0 ? 0 : std::min(value, 2);
-        while (d->profile && d->ev.size() < 3) { hipEvent_t e; LS_HIP(hipEventCreate(&e)); d->ev.push_back(e); }
+        while (d->profile && d->ev.size() < 4) { hipEvent_t e; LS_HIP(hipEventCreate(&e)); d->ev.push_back(e); }
+#ifdef LS_ND_EXPERIMENTS
+        if (d->profile == 2 && !d->span_dbg && d->span_ok) {
+            const size_t n = (size_t)d->span_grid * d->span_phases * 8;
+            LS_HIP(hipMalloc((void**)&d->span_dbg, sizeof(long long) * n));
+            LS_HIP(hipMemset(d->span_dbg, 0, sizeof(long long) * n));
+        }
+#endif
         if (d->profile == 2 && !d->dbg && d->tier_wgs) {
             LS_HIP(hipMalloc((void**)&d->dbg, sizeof(long long) * 2 * (size_t)d->tier_wgs * TIER_WAVES * 32));
             LS_HIP(hipMemset(d->dbg, 0, sizeof(long long) * 2 * (size_t)d->tier_wgs * TIER_WAVES * 32));
         }
         return LS_OK;
     }
+    if (!strcmp(name, "persist")) { d->span_on = d->span_ok && value != 0; return LS_OK; }
     set_error("ls_direct_set: unknown option '%s'", name);
     return LS_E_INVALID;
 }
@@ -1475,6 +1751,19 @@ extern "C" int ls_direct_tier_stamps(const ls_direct* d, long long* h_out, int64
     return LS_OK;
 }
 
+extern "C" int ls_direct_span_stamps(const ls_direct* d, long long* h_out, int64_t n, int* h_workgroups, int* h_phases) {
+    LS_REQUIRE(d, LS_E_INVALID, "ls_direct_span_stamps: bad argument");
+    if (h_workgroups) *h_workgroups = d->span_ok ? d->span_grid : 0;
+    if (h_phases) *h_phases = d->span_ok ? d->span_phases : 0;
+    if (!h_out || n <= 0) return LS_OK;
+    const int64_t have = d->span_dbg ? (int64_t)d->span_grid * d->span_phases * 8 : 0;
+    LS_REQUIRE(n <= have, LS_E_INVALID, "ls_direct_span_stamps: %lld stamps recorded (experiments build, \"profile\" = 2, solve first)", (long long)have);
+    DeviceGuard g(d->device);
+    LS_HIP(g.err);
+    LS_HIP(hipMemcpy(h_out, d->span_dbg, sizeof(long long) * (size_t)n, hipMemcpyDeviceToHost));
+    return LS_OK;
+}
+
 extern "C" int ls_direct_info(const ls_direct* d, int64_t* h_factor_entries, int* h_launches, double* h_ms3) {
     LS_REQUIRE(d, LS_E_INVALID, "ls_direct_info: bad argument");
     if (h_factor_entries) *h_factor_entries = d->factor_entries;
@@ -1485,7 +1774,7 @@ extern "C" int ls_direct_info(const ls_direct* d, int64_t* h_factor_entries, int
             const bool fused = lv == 0 && d->tier_root > 0 && d->fuse_root && !p.down_p && !p.down_s;     // the root's up step rides in its down tiles
             n += (((p.up_p ? p.up_p_tiles : p.up_tiles) && !fused) ? 1 : 0) + ((p.down_p ? p.down_p_tiles : p.down_tiles) ? 1 : 0);
         }
-        *h_launches = n + (d->tier_wgs ? 2 : 0);
+        *h_launches = (d->span_ok && d->span_on) ? 3 : n + (d->tier_wgs ? 2 : 0);
     }
     if (h_ms3) for (int i = 0; i < 3; ++i) h_ms3[i] = d->prof_ms[i];
     return LS_OK;

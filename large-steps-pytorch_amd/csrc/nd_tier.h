@@ -21,8 +21,8 @@
 // copied into LDS with 16-byte loads (contiguous, fully coalesced) and read row-per-lane from there; the packed index
 // T(j) + c, T(j) = j (j + 1) / 2, is conflict free over the 32 lanes of an LDS access group because j -> T(j) mod 32 is a
 // permutation of 0..31 (the triangular-probing property), as is the transposed access T(c) + j (consecutive).
-// A wave software-pipelines its leaves: while leaf r is multiplied out of LDS, the triangle, right-hand side and sparse
-// entries of leaf r + 1 are in flight to registers and the index lists of leaf r + 2 are being fetched.
+// A wave runs its leaves one after the other; only the small loads of the NEXT leaf (its record and the index lists that
+// depend on it) are requested ahead -- a full software pipeline was measured slower (see leaf_phase).
 #pragma once
 
 namespace ls {
@@ -81,16 +81,24 @@ struct TierArgs {
     float* slots;
     float* xb;
     int arity, phases, region_floats, vec_floats;    // LDS per wave: [vec_floats | partial sums: rounds x 64 x 4]
-    long long* dbg;                                  // profile = 2: shader-clock stamps, 32 per wave (see k_nd_tier)
-    int stagger;                                     // LS_ND_STAGGER: half of the workgroups start this many x ~4 us (at 2 GHz) late
-    int ablate;                                      // LS_ND_ABLATE (timing experiments only, WRONG results): 1 no leaf mat-vec, 2 no sparse product,
+    // Timing experiments exist only in builds with -DLS_ND_EXPERIMENTS (tools/ubench/Makefile builds such a library next to
+    // the product); the product library contains neither the fields' uses nor a way to set them.
+    long long* dbg;                                  // experiments, profile = 2: shader-clock stamps, 32 per wave (see k_nd_tier)
+    int stagger;                                     // experiments: half of the workgroups start this many x ~4 us (at 2 GHz) late
+    int ablate;                                      // experiments (WRONG results): 1 no leaf mat-vec, 2 no sparse product,
                                                      // 4 no dense phases, 8 no leaf phase, 16 no triangle loads
 };
 
+#ifdef LS_ND_EXPERIMENTS
+#define LS_ABLATE(a, bits) ((a).ablate & (bits))
 __device__ __forceinline__ void tier_stamp(const TierArgs& a, int slot) {
     if (a.dbg && (threadIdx.x & 63) == 0)
         a.dbg[((size_t)blockIdx.x * TIER_WAVES + (threadIdx.x >> 6)) * 32 + slot] = (long long)__builtin_amdgcn_s_memtime();
 }
+#else
+#define LS_ABLATE(a, bits) 0
+__device__ __forceinline__ void tier_stamp(const TierArgs&, int) {}
+#endif
 
 // Item records and the workgroup header are fetched with VECTOR loads (lane i takes dword i) and unpacked with
 // v_readlane: a scalar load on the critical path costs ~3 us next to a streaming CU (the scalar cache path queues behind
@@ -191,7 +199,7 @@ template <int K, bool UP>
 __device__ __forceinline__ void leaf_dat(const TierArgs& a, const TierItem& n, const LeafIdx& ix, const float* __restrict__ b_in,
                                          int lane, LeafDat<K>& d) {
     const float4* __restrict__ p = reinterpret_cast<const float4*>(a.tri + n.finv_off);
-    const int n4 = (a.ablate & 16) ? 0 : (n.s * (n.s + 1) / 2 + 3) >> 2;
+    const int n4 = LS_ABLATE(a, 16) ? 0 : (n.s * (n.s + 1) / 2 + 3) >> 2;
 #pragma unroll
     for (int e = 0; e < TIER_TRI4; ++e) {
         const int i = lane + e * 64;
@@ -316,7 +324,7 @@ __device__ __forceinline__ void leaf_up_compute(const TierArgs& a, const TierIte
     }
     wave_lds_sync();
     float y[K];
-    if (a.ablate & 1) { for (int q = 0; q < K; ++q) y[q] = bj[q]; } else
+    if (LS_ABLATE(a, 1)) { for (int q = 0; q < K; ++q) y[q] = bj[q]; } else
     tri_matvec<K>(region, yv, s, lane, y);
     tier_stamp(a, 29);
     wave_lds_sync();
@@ -325,7 +333,7 @@ __device__ __forceinline__ void leaf_up_compute(const TierArgs& a, const TierIte
         for (int q = 0; q < K; ++q) { yv[lane * 4 + q] = y[q]; a.bprime[(size_t)(n.own_start + lane) * K + q] = y[q]; }
     }
     wave_lds_sync();
-    if (n.pfront_off >= 0 && !(a.ablate & 2)) {
+    if (n.pfront_off >= 0 && !LS_ABLATE(a, 2)) {
         const bool upc = n.flags & NODE_UPC;
         if (lane < b) {
             float u[K];
@@ -370,7 +378,7 @@ __device__ __forceinline__ void leaf_down_compute(const TierArgs& a, const TierI
     }
     wave_lds_sync();
     float t[K];
-    if (a.ablate & 2) { for (int q = 0; q < K; ++q) t[q] = yj[q]; } else
+    if (LS_ABLATE(a, 2)) { for (int q = 0; q < K; ++q) t[q] = yj[q]; } else
     sparse_row<K>(a, ix, e, xbv, t);
     float* tv = region + tri_floats;
     {
@@ -380,7 +388,7 @@ __device__ __forceinline__ void leaf_down_compute(const TierArgs& a, const TierI
     }
     wave_lds_sync();
     float z[K];
-    if (a.ablate & 1) { for (int q = 0; q < K; ++q) z[q] = t[q]; } else
+    if (LS_ABLATE(a, 1)) { for (int q = 0; q < K; ++q) z[q] = t[q]; } else
     tri_matvec<K>(region, tv, s, lane, z);
     if (lane < s) {
 #pragma unroll
@@ -709,9 +717,11 @@ __global__ __launch_bounds__(64 * TIER_WAVES, 4) void k_nd_tier(TierArgs a, cons
     const int obase = UP ? 0 : TIER_MAX_H + 1;
     const unsigned split = (unsigned)rl(hdr, UP ? 14 : 15), leafy = (unsigned)rl(hdr, UP ? 16 : 17);
     tier_stamp(a, 0);
+#ifdef LS_ND_EXPERIMENTS
     if (a.stagger > 0 && (blockIdx.x & 8)) {            // phase shift for every other group of 8 workgroups (one per XCD)
         for (int t = 0; t < a.stagger; ++t) __builtin_amdgcn_s_sleep(127);
     }
+#endif
     if (UP) {
         // right-hand side of the tier's inner-node rows, gathered once into the tree's numbering (braw): the dense items
         // read it from a static address instead of walking perm -> b behind a barrier
@@ -758,8 +768,8 @@ __global__ __launch_bounds__(64 * TIER_WAVES, 4) void k_nd_tier(TierArgs a, cons
             if (has_nx) rec_nx = rec_load(a.items, j0, lane);
         }
         if ((leafy >> ph) & 1u) {
-            if (!(a.ablate & 8)) leaf_phase<K, UP>(a, i0 + wave, (a.ablate & 32) ? min(i1, i0 + TIER_WAVES) : (a.ablate & 64) ? min(i1, i0 + 2 * TIER_WAVES) : i1, b_in, x_out, region, tri_floats);
-        } else if (!(a.ablate & 4)) {
+            if (!LS_ABLATE(a, 8)) leaf_phase<K, UP>(a, i0 + wave, LS_ABLATE(a, 32) ? min(i1, i0 + TIER_WAVES) : LS_ABLATE(a, 64) ? min(i1, i0 + 2 * TIER_WAVES) : i1, b_in, x_out, region, tri_floats);
+        } else if (!LS_ABLATE(a, 4)) {
             int rec = (!pre_valid && i0 + wave < i1) ? rec_load(a.items, i0 + wave, lane) : 0;
             // the (last) split row chunk this wave will finish once its parts have met: record and static indices stay in
             // registers across that barrier, nothing is loaded behind it
@@ -808,7 +818,7 @@ __global__ __launch_bounds__(64 * TIER_WAVES, 4) void k_nd_tier(TierArgs a, cons
             }
         }
         // every field of `pre` is rewritten here on every path: nothing of it stays live across a leaf phase
-        pre_valid = has_nx && !(a.ablate & 4);
+        pre_valid = has_nx && !LS_ABLATE(a, 4);
         it_pre = rec_unpack(rec_nx);
         if (pre_valid) {
             if (UP) node_up_pre<K>(a, it_pre, pre); else node_down_pre<K>(a, it_pre, pre);
