@@ -192,12 +192,8 @@ int ls_solver_poll(ls_solver* s, int k, int n_enqueued, ls_solve_info* h_info, v
 /* dst[t,:] = src[idx[t],:] for t < n (halo send buffer packing), k in 1..4 */
 int ls_gather_rows(const float* src, const int32_t* idx, int64_t n, int k, float* dst, int device, void* stream);
 
-/* ------------------------------------------------------------------------------------------------
- * AdamUniform step (optimize.py:18-41) on n contiguous fp32 elements, two kernels, no host sync:
- *   g1 = b1 g1 + (1-b1) g ; g2 = b2 g2 + (1-b2) g^2 ; p -= lr * (g1/(1-b1^t)) / (1e-8 + max sqrt(g2/(1-b2^t)))
- * scratch: at least 4096 bytes of device memory owned by the caller.
- * --------------------------------------------------------------------------------------------- */
-/* ---- factor-once / re-solve direct solver (nested dissection, multifrontal; plan: largesteps/nested.py) ---------
+/* ---- factor-once / re-solve direct solver (nested dissection, multifrontal; symbolic analysis: csrc/nd_plan.cpp,
+ *      numeric factorisation: csrc/nd_factor.hip, re-solve: csrc/direct.hip + csrc/nd_tier.h + csrc/nd_span.h) ---------
  * The elimination tree is a complete `arity`-ary tree (2, 4 or 8) of `levels` levels; node ids are 1-based and
  * level-major (level l: arity^l nodes, node (l, q) has the children (l+1, arity*q + c)). The vertices are renumbered
  * deepest level first (h_perm[new] = old); node i owns the new ids [own_start, own_start + s) and has b boundary
@@ -290,7 +286,8 @@ int ls_direct_create(const ls_direct_arrays* arrays, int device, void* stream, l
  * the tuned defaults; tier_levels deepest levels go into the tier layouts (-1 = chosen by the library: tree levels - 5, at least 2 and at most 4; 0 = none), sparse_leaves != 0 stores the leaves
  * as packed triangle + sparse block; shard_rank / shard_count: subtree sharding (0 / 1: none; every rank factorises the whole
  * matrix, the re-solve is sharded, see ls_direct_solve_part). SYNC. Errors: LS_E_INVALID (not symmetric / not positive definite / bad arguments),
- * LS_E_WORKSPACE (fronts or factor beyond the solver's limits, or the tier does not fit LDS: retry with fewer tier_levels). */
+ * LS_E_WORKSPACE (fronts or factor beyond the solver's limits; or an EXPLICIT tier_levels whose subtrees do not fit a workgroup's LDS --
+ * tier_levels = -1 lowers its own choice until it fits and never fails for that reason). */
 int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, const float* d_val, int64_t V, int64_t nnz,
                      const float* d_positions, int leaf_size, int arity, int tier_levels, int sparse_leaves, int shard_rank,
                      int shard_count, int device, void* stream, ls_direct** out);
@@ -384,6 +381,11 @@ int ls_vertex_normals_backward(const float* verts, const void* faces, int idx_by
                                const int32_t* cpos, const float* fn, const float* raw, const float* norms, const float* g_out,
                                float* grad_verts, float* grad_fn, void* workspace, size_t ws_bytes, int device, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * AdamUniform step (optimize.py:18-41) on n contiguous fp32 elements, two kernels, no host sync:
+ *   g1 = b1 g1 + (1-b1) g ; g2 = b2 g2 + (1-b2) g^2 ; p -= lr * (g1/(1-b1^t)) / (1e-8 + max sqrt(g2/(1-b2^t)))
+ * scratch: at least 4096 bytes of device memory owned by the caller. ASYNC.
+ * --------------------------------------------------------------------------------------------- */
 int ls_adam_uniform_step(float* param, const float* grad, float* g1, float* g2, int64_t n, float lr,
                          float beta1, float beta2, int step, void* scratch, int device, void* stream);
 /* The same step with the step count ON THE DEVICE: d_step[0] = steps done so far (int32, zero before the first call; the call

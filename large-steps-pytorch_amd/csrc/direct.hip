@@ -970,6 +970,32 @@ static size_t plan_tier(const std::vector<NodeD>& nd, const std::vector<int64_t>
 }
 
 
+// Host only, called by ls_direct_factor BEFORE it lays the factor out: would a tier of `tier_levels` levels (sparse or dense leaves)
+// fit the tier kernels' LDS budget on this tree? (s, b, own_start: per node id, 1-based, level-major.)
+bool direct_tier_fits(int levels, int arity, const int* s, const int* b, const int* own_start, int tier_levels, bool sparse_leaves) {
+    if (tier_levels <= 0) return true;
+    if (tier_levels > levels || tier_levels > TIER_MAX_H) return false;
+    std::vector<int64_t> level_off((size_t)levels + 1);
+    int64_t cnt = 1, off = 1;
+    for (int lv = 0; lv <= levels; ++lv) { level_off[lv] = off; off += cnt; cnt *= arity; }
+    const int64_t n_nodes = level_off[levels] - 1;
+    std::vector<NodeD> nd((size_t)n_nodes + 1);
+    memset(nd.data(), 0, nd.size() * sizeof(NodeD));
+    const int root = levels - tier_levels;
+    for (int lv = root; lv < levels; ++lv)
+        for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i) {
+            NodeD& q = nd[(size_t)i];
+            q.s = s[i]; q.b = b[i]; q.own_start = own_start[i];
+            const bool sparse = sparse_leaves && lv == levels - 1 && q.s >= 1;
+            q.flags = (lv + 1 >= levels ? NODE_LEAF : 0) | (sparse ? NODE_SPARSE : NODE_QUAD);
+        }
+    std::vector<TierItem> items;
+    std::vector<TierWG> wgs;
+    int vec = 0, tri = 0;
+    const size_t region = plan_tier(nd, level_off, levels, arity, root, 0, level_off[root + 1] - level_off[root], items, wgs, vec, tri);
+    return region && region * sizeof(float) * TIER_WAVES <= 150 * 1024;
+}
+
 // The levels above the tier as phases of one persistent launch (nd_span.h): workgroup ranges per node (a node's range is the
 // union of its children's), every workgroup's jobs per phase, and the arrival counters / release flags between the phases.
 struct SpanPlan { std::vector<SpanJob> jobs; std::vector<SpanSync> sync; int phases = 0, grid = 0, lcap = 0, words = 0; };

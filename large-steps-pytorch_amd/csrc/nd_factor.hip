@@ -368,6 +368,7 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 // defined in direct.hip: builds the handle from plan + factor arrays and takes ownership of the device arrays
 extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* stream, ls_direct** out);
 int ls_direct_adopt(ls_direct* d, void* const* owned, int n_owned, const double* seconds3);
+bool direct_tier_fits(int levels, int arity, const int* s, const int* b, const int* own_start, int tier_levels, bool sparse_leaves);
 
 extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, const float* d_val, int64_t V, int64_t nnz,
                                 const float* d_positions, int leaf_size, int arity, int tier_levels, int sparse_leaves, int shard_rank,
@@ -404,6 +405,7 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     // tier_levels < 0: chosen here so that about a thousand subtrees (4 workgroups per CU) are left at the tier's root level:
     // levels - 5 at arity 4 -- three at 1M vertices (8 levels), four at 4M (9 levels: 0.795 ms against 0.850 with three), two
     // below 8 levels (a tier of three on a 7-level tree leaves most CUs without a workgroup; tools/tier_sweep.py, 576 .. 4M vertices)
+    const bool tier_auto = tier_levels < 0;
     if (tier_levels < 0) {
         tier_levels = std::max(2, std::min(4, levels - 5));
         if (shard_count > 1) {                  // the cut (first level with a subtree per rank) must not lie inside the tier
@@ -414,9 +416,14 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
         }
     }
     tier_levels = std::max(0, std::min(std::min(tier_levels, levels), 6));
-    const int tier_root = levels - tier_levels;
     bool leaves_ok = tier_levels > 0 && sparse_leaves;
     for (int64_t i = P.level_off[levels - 1]; i < P.level_off[levels] && leaves_ok; ++i) leaves_ok = P.s[i] <= 64;
+    // a tier the library picked itself never fails for lack of LDS: one level less until its subtrees fit a workgroup
+    // (an explicit tier_levels that does not fit is reported by ls_direct_create: LS_E_WORKSPACE)
+    if (tier_auto)
+        while (tier_levels > 0 && !direct_tier_fits(levels, arity, P.s.data(), P.b.data(), P.own_start.data(), tier_levels, leaves_ok)) --tier_levels;
+    if (tier_levels == 0) leaves_ok = false;
+    const int tier_root = levels - tier_levels;
     std::vector<FactorNode> fn((size_t)n_nodes + 1);
     memset(fn.data(), 0, fn.size() * sizeof(FactorNode));
     std::vector<int64_t> hn((size_t)(n_nodes + 1) * LS_DIRECT_NODE_COLS, 0);

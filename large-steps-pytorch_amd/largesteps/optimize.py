@@ -34,6 +34,19 @@ class AdamUniform(torch.optim.Optimizer):
 
     def __setstate__(self, state):
         super(AdamUniform, self).__setstate__(state)
+        self._restore_step_counters()
+
+    def load_state_dict(self, state_dict):
+        """torch.optim.Optimizer.load_state_dict casts a tensor-valued "step" to float32 when the group is capturable (and
+        every other tensor state to the parameter's dtype); the kernel reads the counter as int32 -- convert it back BY VALUE."""
+        super(AdamUniform, self).load_state_dict(state_dict)
+        self._restore_step_counters()
+
+    def _restore_step_counters(self):
+        for st in self.state.values():
+            step = st.get("step") if isinstance(st, dict) else None
+            if torch.is_tensor(step) and step.dtype != torch.int32:
+                st["step"] = step.round().to(torch.int32).contiguous()
 
     @torch.no_grad()
     def step(self):
@@ -59,6 +72,9 @@ class AdamUniform(torch.optim.Optimizer):
                 grad = p.grad.data.contiguous()
                 dev = p.device
                 if capturable:
+                    step = state["step"]
+                    if not (torch.is_tensor(step) and step.dtype == torch.int32 and step.numel() >= 2 and step.device == dev):
+                        raise TypeError("AdamUniform(capturable=True): state['step'] must be an int32 tensor of two elements on the parameter's device")
                     with torch.cuda.device(dev):
                         _native.check(lib.ls_adam_uniform_step_device(_native.ptr(p.data), _native.ptr(grad), _native.ptr(state["g1"]),
                                                                       _native.ptr(state["g2"]), p.numel(), float(lr), float(b1), float(b2),

@@ -10,7 +10,6 @@ Neither cholespy/CHOLMOD nor torch sparse ops are used; there is no CPU path.
 """
 import ctypes
 import os
-import re
 import warnings
 
 import numpy as np
@@ -323,17 +322,9 @@ class NestedDissectionSolver(Solver):
         if not csr.symmetric:
             raise ValueError("NestedDissectionSolver: the matrix is not symmetric")
         t0 = time.perf_counter()
-        tier = max(-1, min(6, int(os.environ.get("LS_ND_TIER_H", "-1"))))      # -1: the library picks (2 or 3 by tree depth)
+        tier = max(-1, min(6, int(os.environ.get("LS_ND_TIER_H", "-1"))))      # -1: the library picks (and never picks one that does not fit)
         sparse = not os.environ.get("LS_ND_DENSE_LEAVES")
-        while True:
-            try:
-                self._direct = _NativeDirect(csr, leaf_size, arity, tier, sparse, shard=shard)
-                break
-            except RuntimeError as e:      # a tier whose subtrees need more LDS than a workgroup has: one level less
-                if tier == 0 or "does not fit" not in str(e):
-                    raise
-                m = re.search(r"a tier of (\d+) levels does not fit", str(e))       # what the library had picked (tier = -1) or was given
-                tier = max(0, int(m.group(1)) - 1) if m else (2 if tier < 0 else tier - 1)
+        self._direct = _NativeDirect(csr, leaf_size, arity, tier, sparse, shard=shard)
         torch.cuda.synchronize(csr.device)
         self.build_seconds = time.perf_counter() - t0
         self.timings = self._direct.timings

@@ -15,6 +15,7 @@ What is restated (reference = rgl-epfl/large-steps-pytorch @ 0.2.2, paths relati
   solve.reference_cg            largesteps/solvers.py:58-126     ('CG', fp32, abs 1e-5 stop)
   solve.jacobi_pcg              fp64 statement of the algorithm the HIP PCG implements
   normals.face_normals / vertex_normals (+ *_backward)   scripts/geometry.py:91-110, :115-147 and their analytic gradients
+  step.run / step.AdamUniform   the loop body of scripts/main.py:172-208 (no renderer) with largesteps/optimize.py:18-41
 
 Third-party dependency holding the default solver's arithmetic: `cholespy` (requirements.txt:1,
 `cholespy>=0.1.4`, unpinned, a nanobind wrapper of SuiteSparse CHOLMOD). It is absent from
@@ -32,4 +33,4 @@ itself (cholespy) could not be executed anywhere: for that single call the parit
 the mathematical definition (residual of the fp64 solve), i.e. "parity unpinned" at the cholespy
 boundary.
 """
-from . import laplacian, normals, solve  # noqa: F401
+from . import laplacian, normals, solve, step  # noqa: F401

@@ -138,3 +138,22 @@ def test_synthetic_meshes():
     a = synthetic.config_mesh("cfg2_bunny70k")
     b = synthetic.config_mesh("cfg2_bunny70k")
     assert a[0].shape[0] == 70562 and np.array_equal(a[0], b[0])
+
+
+def test_adam_uniform_capturable_state_dict_round_trip_keeps_an_int32_counter():
+    """torch's load_state_dict casts a tensor "step" of a capturable group to float32; the kernel reads int32 (advisor finding,
+    round 2): the optimizer converts it back by value."""
+    from largesteps.optimize import AdamUniform
+    p = torch.zeros(6, 3, requires_grad=True)
+    opt = AdamUniform([p], lr=0.05, capturable=True)
+    opt.state[p] = dict(step=torch.tensor([100, 0], dtype=torch.int32), g1=torch.ones_like(p), g2=torch.ones_like(p))
+    sd = opt.state_dict()
+    q = torch.zeros(6, 3, requires_grad=True)
+    opt2 = AdamUniform([q], lr=0.05, capturable=True)
+    opt2.load_state_dict(sd)
+    step = opt2.state[q]["step"]
+    assert step.dtype == torch.int32 and step.tolist() == [100, 0]
+    assert opt2.state[q]["g1"].dtype == torch.float32
+    import copy
+    opt3 = copy.deepcopy(opt2)                       # __setstate__ path
+    assert next(iter(opt3.state.values()))["step"].dtype == torch.int32

@@ -91,6 +91,57 @@ def test_sharded_direct_solver(tmp_path, mesh, world, k):
         assert all(int(i[0]) >= 1 and int(i[1]) > 0 for i in info)
 
 
+def test_sharded_direct_solver_at_world_eight_in_one_process():
+    """N = 8 cuts the elimination tree one level deeper than N = 2 / 4 (level 2: sixteen subtrees, two per rank; levels 0 and 1
+    replicated). Eight shard handles in ONE process stand in for the eight ranks: part 0 on each, the exchange buffers summed
+    (what the all-reduce does), part 1 on each, x stitched by row ownership -- against the fp64 oracle at the solver's
+    tolerance and against the unsharded solver."""
+    import ctypes
+    import torch
+    from largesteps import synthetic, _native
+    from largesteps.geometry import compute_matrix
+    from largesteps.solvers import NestedDissectionSolver
+    from oracle import solve as osv
+    dev = torch.device("cuda:0")
+    v, f = synthetic.plane(300)
+    M = compute_matrix(torch.from_numpy(v).to(dev), torch.from_numpy(f).to(dev), 25.0)
+    idx, val = M.indices().cpu().numpy(), M.values().cpu().numpy()
+    k, world = 3, 8
+    b_np = np.random.default_rng(2).standard_normal((v.shape[0], k)).astype(np.float32)
+    x64 = osv.from_differential(idx[0], idx[1], val, b_np)
+    b = torch.from_numpy(b_np).to(dev)
+    lib = _native.lib()
+    ranks = [NestedDissectionSolver(M, shard=(r, world)) for r in range(world)]
+    owned, per_col, cuts = [], None, set()
+    for s in ranks:
+        rk, cnt, cut, pc = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int64(0)
+        mask = np.zeros(v.shape[0], dtype=np.uint8)
+        _native.check(lib.ls_direct_shard_info(s._direct._h, ctypes.byref(rk), ctypes.byref(cnt), ctypes.byref(cut), ctypes.byref(pc),
+                                               mask.ctypes.data_as(ctypes.c_void_p)))
+        assert cnt.value == world
+        owned.append(mask.astype(bool)); cuts.add(cut.value); per_col = pc.value
+    assert cuts == {2}, "eight ranks cut the arity-4 tree at level 2"
+    assert np.array_equal(np.sum(owned, axis=0), np.ones(v.shape[0])), "ownership partitions the rows"
+    ex = [torch.zeros(per_col * k, dtype=torch.float32, device=dev) for _ in ranks]
+    xs = [torch.zeros_like(b) for _ in ranks]
+    st = _native.stream_of(dev)
+    for s, e, x in zip(ranks, ex, xs):
+        _native.check(lib.ls_direct_solve_part(s._direct._h, _native.ptr(b), _native.ptr(x), k, 0, _native.ptr(e), st))
+    total = torch.stack(ex).sum(0)
+    # every entry of the exchange has exactly one non-zero contributor: the sum is exact and order independent
+    assert int((torch.stack(ex) != 0).sum(0).max()) <= 1
+    for s, x in zip(ranks, xs):
+        e = total.clone()
+        _native.check(lib.ls_direct_solve_part(s._direct._h, _native.ptr(b), _native.ptr(x), k, 1, _native.ptr(e), st))
+    x = torch.zeros_like(b)
+    for o, xr in zip(owned, xs):
+        m = torch.from_numpy(o).to(dev)
+        x[m] = xr[m]
+    assert np.abs(x.cpu().numpy() - x64).max() <= 2e-5 * np.abs(x64).max()
+    x1 = NestedDissectionSolver(M).solve(b)
+    assert float((x - x1).abs().max()) <= 2e-5 * np.abs(x64).max()
+
+
 def test_rccl_process_group_initialises():
     """backend 'nccl' (= RCCL on ROCm) with world size 1 on the real device: the branch bench.py --gpus N takes, executed once
     on hardware (one all-reduce through RCCL)."""

@@ -207,3 +207,20 @@ def test_remove_duplicates_oracle_equals_reference_fixture():
         assert np.array_equal(uv, d[f"{n}/unique"]) and np.array_equal(nf, d[f"{n}/new_faces"]) and np.array_equal(inv, d[f"{n}/inverse"])
         assert inv.dtype == np.int64 and nf.dtype == np.int64
         assert np.array_equal(uv[inv], d[f"{n}/v"])
+
+
+@pytest.mark.parametrize("name", ["ico5_uni", "ico6_cot"])
+def test_oracle_step_trajectory_vs_reference(name):
+    """The whole optimisation step (solve -> normals -> loss -> backward incl. the adjoint solve -> AdamUniform), five steps,
+    against the trajectory recorded by EXECUTING the reference's own files (tests/golden/make_golden_step.py). The oracle is
+    fp64, the reference fp32: 5e-5 on u and v (coordinates of order 1), 1e-4 relative on the loss."""
+    import os
+    from oracle import step
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_step.npz"))
+    g = lambda k: z[f"{name}/{k}"]       # noqa: E731
+    alpha = None if float(g("alpha")) < 0 else float(g("alpha"))
+    us, vs, losses = step.run(g("verts").astype(np.float64), g("faces"), float(g("lambda")), alpha, bool(g("cotan")), g("target_v").astype(np.float64),
+                              g("target_n").astype(np.float64), 5, float(g("lr")), float(g("reg")))
+    assert np.abs(vs - g("v_steps")).max() <= 5e-5
+    assert np.abs(us - g("u_steps")).max() <= 5e-5 * max(1.0, np.abs(g("u_steps")).max())
+    np.testing.assert_allclose(losses, g("losses"), rtol=1e-4, atol=1e-9)

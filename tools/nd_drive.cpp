@@ -101,31 +101,23 @@ int main(int argc, char** argv) {
         LS(ls_direct_solve(h, d_b, d_x, k, st));
         std::vector<long long> sm((size_t)G * P * 8, 0);
         if (G && P && ls_direct_span_stamps(h, sm.data(), (int64_t)sm.size(), nullptr, nullptr) == 0) {
-            long long t00 = 0;
-            for (int w = 0; w < G; ++w) { const long long t = sm[((size_t)w * P) * 8]; if (t && (!t00 || t < t00)) t00 = t; }
-            long long t11 = 0;
-            for (int w = 0; w < G; ++w) t11 = std::max(t11, sm[((size_t)w * P + P - 1) * 8 + 4]);
-            // s_memtime counts shader clocks: calibrated with the launch's duration from HIP events (last persist = 1 profile above)
-            const double us = span_us > 0 && t11 > t00 ? span_us / (double)(t11 - t00) : 1.0 / 2100.0;
-            printf("clock calibration: %.0f ticks per us\n", 1.0 / us);
-            printf("persistent launch, %d workgroups x %d phases (us; mean over workgroups; start / end = first entry / last jobs-done since the launch's first stamp):\n", G, P);
-            printf("  phase   start     end |    wait  vector products epilogue   drain  arrive request\n");
+            // the counters of different XCDs are not synchronised: only differences inside one workgroup mean anything.
+            // Calibration: a workgroup's first to last stamp is (nearly) the launch's duration from HIP events.
+            double tick_sum = 0;
+            for (int w = 0; w < G; ++w) tick_sum += (double)(sm[((size_t)w * P + P - 1) * 8 + 4] - sm[((size_t)w * P) * 8]);
+            const double us = span_us > 0 && tick_sum > 0 ? span_us / (tick_sum / G) : 1.0 / 2100.0;
+            printf("persistent launch, %d workgroups x %d phases, %.0f clock ticks per us; us, mean over the workgroups:\n", G, P, 1.0 / us);
+            printf("  phase  length |    wait  vector products epilogue   drain  arrive request\n");
             for (int ph = 0; ph < P; ++ph) {
-                double d[7] = {0, 0, 0, 0, 0, 0, 0};
-                long long lo = 0, hi = 0;
-                int cnt = 0;
+                double d[7] = {0, 0, 0, 0, 0, 0, 0}, len = 0;
                 for (int w = 0; w < G; ++w) {
                     const long long* t = &sm[((size_t)w * P + ph) * 8];
-                    if (!t[0]) continue;
-                    ++cnt;
-                    if (!lo || t[0] < lo) lo = t[0];
-                    hi = std::max(hi, t[4]);
                     long long prev = t[0];
                     for (int q = 1; q < 8; ++q) { if (t[q]) { d[q - 1] += (double)(t[q] - prev); prev = t[q]; } }
+                    len += (double)((ph + 1 < P ? t[8] : t[4]) - t[0]);
                 }
-                if (!cnt) continue;
-                printf("  %5d %7.1f %7.1f | %7.2f %7.2f %8.2f %8.2f %7.2f %7.2f %7.2f\n", ph, (lo - t00) * us, (hi - t00) * us, d[0] / cnt * us, d[1] / cnt * us,
-                       d[2] / cnt * us, d[3] / cnt * us, d[4] / cnt * us, d[5] / cnt * us, d[6] / cnt * us);
+                printf("  %5d %7.2f | %7.2f %7.2f %8.2f %8.2f %7.2f %7.2f %7.2f\n", ph, len / G * us, d[0] / G * us, d[1] / G * us, d[2] / G * us, d[3] / G * us,
+                       d[4] / G * us, d[5] / G * us, d[6] / G * us);
             }
         }
         LS(ls_direct_set(h, "profile", 0));
