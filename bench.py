@@ -64,22 +64,43 @@ def algorithmic_bytes(V, nnz, k, iters, method="pcg", implicit_values=False):
     return dict(k1=b_spmv, k2=b_k2, k3=b_k3, iter=b_iter, solve=(4 * k + 1) * 4 * V + iters * b_iter)
 
 
-def pmc_traffic(kernel_prefix, workload):
-    """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/r02_pmc_traffic.json: separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 correction applied), or None."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_FILE = "r03_pmc_traffic.json"
+
+
+def _pmc_doc(workload):
+    path = os.path.join(ROOT, "profiles", PMC_FILE)
     try:
         with open(path) as fh:
             d = json.load(fh)
-        if d.get("workload") != workload:
-            return None
-        hits = [rec for name, rec in d["kernels"].items() if name.startswith(kernel_prefix)]
-        if hits:      # several kernels share the prefix (the tree-level kernels): dispatch-weighted mean per launch
-            n = sum(r.get("dispatches", 1) for r in hits)
-            return sum(r["traffic_bytes"] * r.get("dispatches", 1) for r in hits) / max(n, 1)
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+        return d if d.get("workload") == workload else None
+    except (OSError, ValueError):
+        return None
+
+
+def pmc_traffic(kernel_prefix, workload):
+    """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/r03_pmc_traffic.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 correction applied), or None."""
+    d = _pmc_doc(workload)
+    if not d:
+        return None
+    hits = [rec for name, rec in d["kernels"].items() if name.startswith(kernel_prefix)]
+    if not hits:
+        return None
+    n = sum(r.get("dispatches", 1) for r in hits)
+    return sum(r["traffic_bytes"] * r.get("dispatches", 1) for r in hits) / max(n, 1)
+
+
+def pmc_traffic_group(prefixes, workload):
+    """(bytes per launch, launches counted) over the kernels of one GROUP (every kernel whose name starts with one of the
+    prefixes), dispatch weighted -- the same population `roofline.bytes_per_launch` is computed over."""
+    d = _pmc_doc(workload)
+    if not d:
+        return None, 0
+    hits = [rec for name, rec in d["kernels"].items() if any(name.startswith(p) for p in prefixes)]
+    n = sum(r.get("dispatches", 1) for r in hits)
+    if not n:
+        return None, 0
+    return sum(r["traffic_bytes"] * r.get("dispatches", 1) for r in hits) / n, n
 
 
 def cpu_baseline(v, f, cfg, u_np, seconds_cap=120.0):
@@ -306,27 +327,52 @@ def report_direct(args, solver, M, u, x, tv, v, f, cfg, ms, t_assemble):
     """JSON line for the factor-once / re-solve direct solver (largesteps.solvers.NestedDissectionSolver)."""
     from largesteps.parameterize import to_differential
     V, nnz, k = v.shape[0], M._nnz(), 3
-    # profiled pass right after the timed region: HIP events around the up sweep and the down sweep (solve's stream)
-    solver.set_option("profile", 1)
+    # profiled passes right after the timed region (same workload, HIP events on the solve's own stream):
+    #   "profile" 1: events around the up sweep and the down sweep;  "profile" 3: an event in front of every launch
     n_prof = max(1, min(args.steps, 5))
-    up_ms = down_ms = 0.0
+    solver.set_option("profile", 1)
+    up_ms = down_ms = mid_ms = 0.0
     for _ in range(n_prof):
         solver.solve(u)
         inf = solver.info()
         up_ms += inf["up_ms"] / n_prof
         down_ms += inf["down_ms"] / n_prof
+        mid_ms += inf.get("mid_ms", 0.0) / n_prof
+    solver.set_option("profile", 3)
+    table = None
+    for _ in range(n_prof):
+        solver.solve(u)
+        lp = solver.launch_profile()
+        if table is None:
+            table = [dict(levels=list(r["levels"]), sweep=r["sweep"], factor_bytes=4 * r["words"], us=0.0) for r in lp]
+        for row, r in zip(table, lp):
+            row["us"] += r["ms"] * 1e3 / n_prof
     solver.set_option("profile", 0)
-    n_down = (inf["launches"] + 1) // 2          # the root has no up-sweep launch of its own (its down tiles form b')
-    n_up = inf["launches"] - n_down
+    for row in table:
+        row["tb_per_s"] = row["factor_bytes"] / (row["us"] * 1e-6) / 1e12 if row["us"] > 0 else None
+        row["frac_of_8tbs"] = row["tb_per_s"] / 8.0 if row["tb_per_s"] else None
+    persistent = inf["launches"] == 3 and len(table) == 3        # tier up / persistent upper-level launch / tier down
+    n_down = sum(1 for r in table if r["sweep"] == "down")
+    n_up = sum(1 for r in table if r["sweep"] == "up")
     n_bnd = inf["n_bnd"]
     # algorithmic bytes: the fp32 factor data each sweep reads (dense nodes: W in both sweeps, Finv in the down sweep; leaves:
     # one packed triangle per sweep + their sparse block) + the vectors once per sweep (b / b' / x rows, boundary vectors)
-    up_bytes = 4 * inf["words_up"] + 4 * k * (2 * V + 3 * n_bnd) + 4 * V
-    down_bytes = 4 * inf["words_down"] + 4 * k * (2 * V + 3 * n_bnd) + 4 * V
+    vec_bytes = 4 * k * (2 * V + 3 * n_bnd) + 4 * V
+    up_bytes = 4 * inf["words_up"] + vec_bytes
+    down_bytes = 4 * inf["words_down"] + vec_bytes
     solve_bytes = up_bytes + down_bytes
     r = to_differential(M, x) - u
     rel_res = [float(a / b) for a, b in zip(r.norm(dim=0).tolist(), u.norm(dim=0).tolist())]
-    down_gbs = down_bytes / (down_ms * 1e-3) / 1e9
+    if persistent:          # the sweeps are not separate launch groups: the whole solve is the group
+        grp_bytes, grp_ms, grp_n, grp_name = solve_bytes, up_ms + mid_ms + down_ms, 3, "whole solve: k_nd_tier<3, true> + k_nd_span<3, 4> + k_nd_tier<3, false>"
+        grp_prefixes = ("ls::k_nd_tier<3", "ls::k_nd_span<3")
+    else:
+        grp_bytes, grp_ms, grp_n = down_bytes, down_ms, n_down
+        grp_name = (f"down sweep: k_nd_down_b<3> x {n_down - 1} + k_nd_tier<3, false> ({n_down} launches: x_s = Finv b'_s - W^T x_bnd "
+                    f"per upper tree level, then the deepest {inf['tier_levels']} levels in one launch)")
+        grp_prefixes = ("ls::k_nd_down", "ls::k_nd_tier<3, false>")
+    grp_gbs = grp_bytes / (grp_ms * 1e-3) / 1e9
+    traffic, traffic_n = pmc_traffic_group(grp_prefixes, args.workload)
     tm = solver.timings
     out = dict(
         metric="from_differential_solves_per_sec", value=1e3 / ms, unit="solves/s", n_gpus=1, steps=args.steps,
@@ -343,16 +389,23 @@ def report_direct(args, solver, M, u, x, tv, v, f, cfg, ms, t_assemble):
                     factor_stages_seconds=dict(symbolic_host=tm["plan_seconds"], tables_host=tm["table_seconds"], numeric_device=tm["factor_seconds"]),
                     solve_bytes=solve_bytes, solve_gbs=solve_bytes / (ms * 1e-3) / 1e9,
                     solve_frac_of_8tbs=solve_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    kernel_us=dict(up_sweep=up_ms * 1e3, down_sweep=down_ms * 1e3, up_launches=n_up, down_launches=n_down),
+                    kernel_us=dict(up_sweep=up_ms * 1e3, down_sweep=down_ms * 1e3, upper_levels_persistent=mid_ms * 1e3,
+                                   up_launches=n_up, down_launches=n_down),
+                    # every launch of one solve: tree levels it runs, the factor bytes it reads (ls_direct_level_words), its
+                    # duration between two HIP events on the solve's stream ("profile" 3 pass; events between the launches
+                    # add ~1 us each, so the rows sum to a little more than ms_per_step), bytes / time
+                    launches=table, vector_bytes_per_sweep=vec_bytes,
                     device=torch.cuda.get_device_name(0)),
-        roofline=dict(bound="hbm", kernel=f"down sweep: k_nd_down_b<3> x {n_down - 1} + k_nd_tier<3, false> ({n_down} launches: x_s = Finv b'_s - W^T x_bnd "
-                                          f"per upper tree level, then the deepest {inf['tier_levels']} levels in one launch)",
-                      achieved=down_gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=down_gbs / HBM_PEAK_GBS,
-                      frac_of_achievable=down_gbs / HBM_ACHIEVABLE_GBS, bytes_per_launch=down_bytes / n_down,
-                      avg_launch_us=down_ms * 1e3 / n_down, launches_timed=n_down * n_prof,
-                      traffic=pmc_traffic("ls::k_nd_", args.workload),
-                      note="latency bound, not bandwidth bound: every upper tree level is one dependent launch (~10 us of launch + "
-                           "dependent memory round trips), the tier kernels are bound by dependent round trips and instruction issue"),
+        roofline=dict(bound="hbm", kernel=grp_name,
+                      achieved=grp_gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=grp_gbs / HBM_PEAK_GBS,
+                      frac_of_achievable=grp_gbs / HBM_ACHIEVABLE_GBS, bytes_per_launch=grp_bytes / grp_n,
+                      avg_launch_us=grp_ms * 1e3 / grp_n, launches_timed=grp_n * n_prof,
+                      traffic=traffic,
+                      traffic_source=(f"profiles/{PMC_FILE}: FETCH_SIZE x 2 + WRITE_SIZE of separate rocprofv3 --pmc passes of this command, "
+                                      f"mean over the {traffic_n} launches of the SAME kernel group, per launch like bytes_per_launch; "
+                                      f"NOT measured in this run") if traffic is not None else None,
+                      note="latency bound, not bandwidth bound: every upper tree level is one dependent launch (T_stream + ~4.5 us of launch "
+                           "boundary, first-byte latency and reduction tail), the tier kernels are bound by dependent round trips per phase"),
     )
     if not args.no_cpu_baseline:
         base, x_oracle = cpu_baseline(v, f, cfg, u.cpu().numpy())

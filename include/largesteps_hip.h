@@ -201,7 +201,8 @@ int ls_gather_rows(const float* src, const int32_t* idx, int64_t n, int k, float
  * fronts (n_front positions). h_ppos[bnd_off + i] = position of boundary vertex i in the PARENT's front (n_bnd entries).
  * h_push_ptr (n_front + 1) / h_push_tgt (n_bnd): CSR lists, front position -> indices (into the concatenated boundary
  * vectors) of the children's boundary entries that are this vertex.
- * Factor arrays (DEVICE, fp32, owned by the caller and kept alive for the handle's lifetime):
+ * Factor arrays (DEVICE, fp32, owned by the caller and kept alive for the handle's lifetime; the kernels read rows with 16-byte
+ * loads that are only 4-byte aligned, so d_finv / d_wf / d_wb need at least 12 readable bytes of slack behind their last entry):
  * d_finv[finv_off + t*s + j] = (F_ss^-1)[t][j]; W = F_bs F_ss^-1 twice: d_wf[w_off + j*b + i] = d_wb[w_off + i*s + j] = W[i][j].
  * h_nodes: (n_nodes + 1, 8) int64, row i = {s, b, own_start, bnd_off, front_off, finv_off, w_off, parent} (row 0 unused).
  * One solve = one launch per upper level upwards
@@ -295,6 +296,14 @@ int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, const float*
  * down sweep reads, total boundary entries (any pointer may be NULL) */
 int ls_direct_shape(const ls_direct* d, int* h_levels, int* h_arity, int* h_tier_levels, int* h_tier_workgroups,
                     int64_t* h_words_up, int64_t* h_words_down, int64_t* h_n_bnd);
+/* 4-byte words of factor data each tree level reads in the up / the down sweep (h_up, h_down: `cap` entries, level 0 = root;
+ * the sparse leaves' lists are counted with the last level). Host only. */
+int ls_direct_level_words(const ls_direct* d, int cap, int64_t* h_up, int64_t* h_down);
+/* After a solve with "profile" = 3 (an event in front of every launch; the solve synchronises): number of launches and, for
+ * the first `cap` of them, duration in ms, factor words read, tree levels [lo, hi] covered, sweep (0 up, 1 down, 2 both).
+ * Any pointer may be NULL. */
+int ls_direct_launch_profile(const ls_direct* d, int cap, int* h_n, double* h_ms, int64_t* h_words, int32_t* h_level_lo,
+                             int32_t* h_level_hi, int32_t* h_sweep);
 /* seconds of the three constructor stages of a handle made by ls_direct_factor: symbolic analysis, layout tables, numeric */
 int ls_direct_factor_seconds(const ls_direct* d, double* h_s3);
 /* SYNC: *h_symmetric = 1 iff every stored entry (r, c, v) has a stored mirror (c, r, v') with |v - v'| <= tol */
@@ -316,7 +325,8 @@ int ls_direct_solve(ls_direct* d, const float* b, float* x, int k, void* stream)
 int ls_direct_solve_part(ls_direct* d, const float* b, float* x, int k, int part, float* exchange, void* stream);
 int ls_direct_shard_info(const ls_direct* d, int* h_rank, int* h_count, int* h_cut_level, int64_t* h_exchange_floats_per_column,
                          unsigned char* h_owned_rows);
-/* knobs: "profile" (1: the next solves time the up sweep and the down sweep with HIP events and synchronise; 2: the
+/* knobs: "profile" (1: the next solves time the up sweep and the down sweep with HIP events and synchronise; 3: an event in
+ * front of every launch, read back by ls_direct_launch_profile; 2: the
  * tier kernels also record shader-clock stamps per wave, read back by ls_direct_tier_stamps -- experiments builds only);
  * "persist" (1 / 0: the levels above the tier as one persistent launch, csrc/nd_span.h, or one launch per level and sweep;
  * default 0 -- measured slower on the MI355X; environment LS_ND_PERSIST=1 at creation turns it on where the

@@ -696,9 +696,10 @@ __global__ __launch_bounds__(256) void k_transpose_emit(const int* __restrict__ 
     t_val[i] = val[e];
 }
 template <typename IdxT>
-__global__ __launch_bounds__(256) void k_faces_to_i32(const IdxT* __restrict__ f, int64_t m, int* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_faces_to_i32(const IdxT* __restrict__ f, int64_t m, int64_t V, int* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < m) out[i] = (int)f[i];
+    // the range check sees the ORIGINAL value: 2^32 + 3 must not wrap into a valid vertex (-1 fails k_count_keys' check)
+    if (i < m) { const IdxT x = f[i]; out[i] = (x < 0 || (int64_t)x >= V) ? -1 : (int)x; }
 }
 __global__ __launch_bounds__(256) void k_invert_order(const int* __restrict__ order, int64_t n, int* __restrict__ rank) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -775,8 +776,8 @@ extern "C" int ls_corner_ranks(const void* faces, int idx_bytes, int64_t F, int6
     int* keys = bsum + div_up(std::max<int64_t>(std::max<int64_t>(std::max<int64_t>(n, V + 1), 256 * (int64_t)nb), 1), SCAN_CHUNK) + 64;
     LS_HIP(hipMemsetAsync(cnt, 0, sizeof(int) * (V + 1), st));
     if (n) {
-        if (idx_bytes == 4) hipLaunchKernelGGL(k_faces_to_i32<int32_t>, dim3(div_up(n, 256)), dim3(256), 0, st, (const int32_t*)faces, n, keys);
-        else hipLaunchKernelGGL(k_faces_to_i32<int64_t>, dim3(div_up(n, 256)), dim3(256), 0, st, (const int64_t*)faces, n, keys);
+        if (idx_bytes == 4) hipLaunchKernelGGL(k_faces_to_i32<int32_t>, dim3(div_up(n, 256)), dim3(256), 0, st, (const int32_t*)faces, n, V, keys);
+        else hipLaunchKernelGGL(k_faces_to_i32<int64_t>, dim3(div_up(n, 256)), dim3(256), 0, st, (const int64_t*)faces, n, V, keys);
         hipLaunchKernelGGL(k_count_keys, dim3(div_up(n, 256)), dim3(256), 0, st, (const int*)keys, n, V, cnt, cnt + V);
     }
     int rc = exclusive_scan(cnt, V, (int*)vptr, bsum, st);

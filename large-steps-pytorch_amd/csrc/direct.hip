@@ -870,6 +870,12 @@ struct ls_direct {
     int64_t factor_entries = 0, words_up = 0, words_down = 0;    // 4-byte words of factor data per solve / per sweep
     int profile = 0;
     std::vector<hipEvent_t> ev;
+    // "profile" = 3: one event in front of every launch of a solve (+ one behind the last)
+    struct LaunchMeta { int lo, hi, sweep; };         // tree levels [lo, hi] the launch runs; sweep 0 up, 1 down, 2 both
+    std::vector<hipEvent_t> lev;
+    std::vector<LaunchMeta> lmeta;
+    std::vector<double> launch_ms;
+    std::vector<int64_t> lvl_up, lvl_down;            // 4-byte words of factor data per tree level and sweep
     double prof_ms[3] = {0, 0, 0};     // up sweep, down sweep, 0 (last profiled solve)
 };
 
@@ -1188,9 +1194,14 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
         const int64_t up_w = sparse ? tri_w : quad ? s4 * n.b : (int64_t)n.s * n.b;
         const int64_t down_w = sparse ? tri_w : quad ? (s4 + b4) * n.s : (int64_t)n.s * n.s + (int64_t)n.s * n.b;
         fe += up_w + down_w; fe_up += up_w; fe_down += down_w;
+        int lv = 0;
+        while (lv + 1 < levels && i >= level_off[lv + 1]) ++lv;
+        if (d->lvl_up.empty()) { d->lvl_up.assign((size_t)levels, 0); d->lvl_down.assign((size_t)levels, 0); }
+        d->lvl_up[(size_t)lv] += up_w; d->lvl_down[(size_t)lv] += down_w;
     }
     fe += 2 * A->n_sp_ent + A->n_sp_ptr;        // each CSR list is read by one sweep (8-byte entries, 4-byte pointers)
     fe_up += A->n_sp_ent + A->n_sp_ptr / 2; fe_down += A->n_sp_ent + A->n_sp_ptr - A->n_sp_ptr / 2;
+    if (!d->lvl_up.empty()) { d->lvl_up[(size_t)levels - 1] += A->n_sp_ent + A->n_sp_ptr / 2; d->lvl_down[(size_t)levels - 1] += A->n_sp_ent + A->n_sp_ptr - A->n_sp_ptr / 2; }
     d->factor_entries = fe; d->words_up = fe_up; d->words_down = fe_down;
     for (int lv = 0; lv < levels; ++lv)
         for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i) {
@@ -1508,6 +1519,7 @@ extern "C" int ls_direct_destroy(ls_direct* d) {
     if (d->busy) (void)hipEventDestroy(d->busy);
     for (void* p : d->owned) (void)hipFree(p);
     for (hipEvent_t e : d->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : d->lev) (void)hipEventDestroy(e);
     delete d;
     return LS_OK;
 }
@@ -1529,6 +1541,23 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
     ta.ablate = d->exp_ablate; ta.stagger = d->exp_stagger;     // read once, when the handle was created
 #endif
     const size_t tier_lds = (size_t)d->tier_region * TIER_WAVES * sizeof(float);
+    int n_mark = 0;
+    auto mark = [&](int lo, int hi, int sweep) -> hipError_t {        // "profile" = 3: an event in front of every launch
+        if (d->profile != 3) return hipSuccess;
+        while ((int)d->lev.size() <= n_mark + 1) { hipEvent_t e; const hipError_t r = hipEventCreate(&e); if (r != hipSuccess) return r; d->lev.push_back(e); }
+        if ((int)d->lmeta.size() <= n_mark) d->lmeta.resize((size_t)n_mark + 1);
+        d->lmeta[(size_t)n_mark] = {lo, hi, sweep};
+        return hipEventRecord(d->lev[(size_t)n_mark++], st);
+    };
+    auto mark_end = [&]() -> hipError_t {
+        if (d->profile != 3) return hipSuccess;
+        hipError_t r = hipEventRecord(d->lev[(size_t)n_mark], st);
+        if (r == hipSuccess) r = hipStreamSynchronize(st);
+        d->launch_ms.assign((size_t)n_mark, 0.0);
+        d->lmeta.resize((size_t)n_mark);
+        for (int i = 0; i < n_mark && r == hipSuccess; ++i) { float ms = 0; r = hipEventElapsedTime(&ms, d->lev[(size_t)i], d->lev[(size_t)i + 1]); d->launch_ms[(size_t)i] = ms; }
+        return r;
+    };
     if (d->span_ok && d->span_on && part == -1) {
         // tier up -> every level above the tier, both sweeps, as ONE persistent launch -> tier down
         SpanArgs sa;
@@ -1542,7 +1571,9 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
 #endif
         if (d->profile) LS_HIP(hipEventRecord(d->ev[0], st));
         LS_HIP(hipMemsetAsync(d->d_swords, 0, sizeof(unsigned) * 16 * (size_t)d->span_words, st));
+        LS_HIP(mark(d->tier_root, d->levels - 1, 0));
         hipLaunchKernelGGL((k_nd_tier<K, true>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
+        LS_HIP(mark(0, d->tier_root - 1, 2));
         if (d->profile) LS_HIP(hipEventRecord(d->ev[1], st));
         const size_t span_lds = ((size_t)K * d->span_lcap + SPAN_WAVES * 256) * sizeof(float);
         if (d->arity == 4) hipLaunchKernelGGL((k_nd_span<K, 4>), dim3(d->span_grid), dim3(SPAN_THREADS), span_lds, st, sa, x);
@@ -1550,9 +1581,11 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
         else hipLaunchKernelGGL((k_nd_span<K, 8>), dim3(d->span_grid), dim3(SPAN_THREADS), span_lds, st, sa, x);
         if (d->profile) LS_HIP(hipEventRecord(d->ev[2], st));
         if (ta.dbg) ta.dbg += (size_t)d->tier_wgs * TIER_WAVES * 32;
+        LS_HIP(mark(d->tier_root, d->levels - 1, 1));
         hipLaunchKernelGGL((k_nd_tier<K, false>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
         if (d->profile) LS_HIP(hipEventRecord(d->ev[3], st));
         LS_HIP(hipGetLastError());
+        LS_HIP(mark_end());
         if (d->profile) {
             LS_HIP(hipStreamSynchronize(st));
             float u = 0, m = 0, w = 0;
@@ -1567,8 +1600,10 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
     if (part != 1) {
     if (d->profile) LS_HIP(hipEventRecord(d->ev[0], st));
     if (part == 0 && exch_n) LS_HIP(hipMemsetAsync(d->slots + exch_off, 0, exch_n * sizeof(float), st));
-    if (d->tier_wgs)
+    if (d->tier_wgs) {
+        LS_HIP(mark(d->tier_root, d->levels - 1, 0));
         hipLaunchKernelGGL((k_nd_tier<K, true>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
+    }
     }
     if (part == 1 && exch_n) LS_HIP(hipMemcpyAsync(d->slots + exch_off, exchange, exch_n * sizeof(float), hipMemcpyDeviceToDevice, st));
     // the tier's up-sweep launch gathers b of the upper levels' rows into the tree's numbering (braw): their kernels skip perm -> b
@@ -1581,6 +1616,7 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
         const LevelPlan& p = d->plan[lv];
         if (!(p.up_p ? p.up_p_tiles : p.up_tiles)) continue;
         if (lv == 0 && fuse_root) continue;
+        LS_HIP(mark(lv, lv, 0));
         if (p.up_p)
             hipLaunchKernelGGL(k_nd_up_p<K>, dim3(p.up_p_tiles), dim3(WAVE), (size_t)std::max(p.up_p_lds, 1) * K * sizeof(float), st,
                                d->ptiles + p.up_p_first, up_perm, d->mask, d->ppos, d->wf, up_b, d->bp, d->slots);
@@ -1603,6 +1639,7 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
     for (int lv = 0; lv <= top; ++lv) {
         const LevelPlan& p = d->plan[lv];
         if (!(p.down_p ? p.down_p_tiles : p.down_tiles)) continue;
+        LS_HIP(mark(lv, lv, 1));
         if (p.down_p)
             hipLaunchKernelGGL(k_nd_down_p<K>, dim3(p.down_p_tiles), dim3(WAVE), (size_t)std::max(p.down_p_s + p.down_p_lds, 1) * K * sizeof(float), st,
                                d->ptiles + p.down_p_first, d->perm, d->push_ptr, d->push_tgt, d->finv, d->wb, (const float*)d->bp, d->xb, x,
@@ -1622,10 +1659,13 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
                                lv == 0 ? rf : RootFill{nullptr, nullptr, nullptr, nullptr});
     }
     if (ta.dbg) ta.dbg += (size_t)d->tier_wgs * TIER_WAVES * 32;
-    if (d->tier_wgs)
+    if (d->tier_wgs) {
+        LS_HIP(mark(d->tier_root, d->levels - 1, 1));
         hipLaunchKernelGGL((k_nd_tier<K, false>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
+    }
     if (d->profile) LS_HIP(hipEventRecord(d->ev[2], st));
     LS_HIP(hipGetLastError());
+    LS_HIP(mark_end());
     if (d->profile) {
         LS_HIP(hipStreamSynchronize(st));
         float a = 0, c = 0;
@@ -1698,12 +1738,20 @@ extern "C" int ls_direct_solve_part(ls_direct* d, const float* b, float* x, int 
     DeviceGuard g(d->device);
     LS_HIP(g.err);
     hipStream_t st = (hipStream_t)stream;
+    // one workspace per handle, as in ls_direct_solve: a part issued on another stream than the previous call waits for it
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (st) (void)hipStreamIsCapturing(st, &cap);
+    const bool capturing = cap == hipStreamCaptureStatusActive;
+    if (!capturing && d->used && st != d->last_stream) LS_HIP(hipStreamWaitEvent(st, d->busy, 0));
+    int rc;
     switch (k) {
-        case 1: return direct_solve_k<1>(d, b, x, st, part, exchange);
-        case 2: return direct_solve_k<2>(d, b, x, st, part, exchange);
-        case 3: return direct_solve_k<3>(d, b, x, st, part, exchange);
-        default: return direct_solve_k<4>(d, b, x, st, part, exchange);
+        case 1: rc = direct_solve_k<1>(d, b, x, st, part, exchange); break;
+        case 2: rc = direct_solve_k<2>(d, b, x, st, part, exchange); break;
+        case 3: rc = direct_solve_k<3>(d, b, x, st, part, exchange); break;
+        default: rc = direct_solve_k<4>(d, b, x, st, part, exchange); break;
     }
+    if (rc == LS_OK && !capturing) { LS_HIP(hipEventRecord(d->busy, st)); d->last_stream = st; d->used = true; }
+    return rc;
 }
 
 extern "C" int ls_direct_shard_info(const ls_direct* d, int* h_rank, int* h_count, int* h_cut_level, int64_t* h_exchange_floats_per_column,
@@ -1722,7 +1770,7 @@ extern "C" int ls_direct_set(ls_direct* d, const char* name, int value) {
     if (!strcmp(name, "profile")) {
         DeviceGuard g(d->device);
         LS_HIP(g.err);
-        d->profile = value < 0 ? 0 : std::min(value, 2);
+        d->profile = value < 0 ? 0 : std::min(value, 3);
         while (d->profile && d->ev.size() < 4) { hipEvent_t e; LS_HIP(hipEventCreate(&e)); d->ev.push_back(e); }
 #ifdef LS_ND_EXPERIMENTS
         if (d->profile == 2 && !d->span_dbg && d->span_ok) {
@@ -1774,6 +1822,36 @@ extern "C" int ls_direct_tier_stamps(const ls_direct* d, long long* h_out, int64
     DeviceGuard g(d->device);
     LS_HIP(g.err);
     LS_HIP(hipMemcpy(h_out, d->dbg, sizeof(long long) * (size_t)n, hipMemcpyDeviceToHost));
+    return LS_OK;
+}
+
+extern "C" int ls_direct_level_words(const ls_direct* d, int cap, int64_t* h_up, int64_t* h_down) {
+    LS_REQUIRE(d && cap >= 0, LS_E_INVALID, "ls_direct_level_words: bad argument");
+    for (int lv = 0; lv < cap && lv < d->levels; ++lv) {
+        if (h_up) h_up[lv] = lv < (int)d->lvl_up.size() ? d->lvl_up[(size_t)lv] : 0;
+        if (h_down) h_down[lv] = lv < (int)d->lvl_down.size() ? d->lvl_down[(size_t)lv] : 0;
+    }
+    return LS_OK;
+}
+
+extern "C" int ls_direct_launch_profile(const ls_direct* d, int cap, int* h_n, double* h_ms, int64_t* h_words, int32_t* h_level_lo,
+                                        int32_t* h_level_hi, int32_t* h_sweep) {
+    LS_REQUIRE(d && cap >= 0, LS_E_INVALID, "ls_direct_launch_profile: bad argument");
+    const int n = (int)d->launch_ms.size();
+    if (h_n) *h_n = n;
+    for (int i = 0; i < n && i < cap; ++i) {
+        const ls_direct::LaunchMeta m = d->lmeta[(size_t)i];
+        int64_t w = 0;
+        for (int lv = std::max(m.lo, 0); lv <= m.hi && lv < d->levels; ++lv) {
+            if (m.sweep != 1) w += d->lvl_up[(size_t)lv];
+            if (m.sweep != 0) w += d->lvl_down[(size_t)lv];
+        }
+        if (h_ms) h_ms[i] = d->launch_ms[(size_t)i];
+        if (h_words) h_words[i] = w;
+        if (h_level_lo) h_level_lo[i] = m.lo;
+        if (h_level_hi) h_level_hi[i] = m.hi;
+        if (h_sweep) h_sweep[i] = m.sweep;
+    }
     return LS_OK;
 }
 

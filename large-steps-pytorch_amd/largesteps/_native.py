@@ -76,6 +76,8 @@ _SIGNATURES = {
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "ls_direct_tier_stamps": (c_int, [c_void_p, c_void_p, c_i64]),
     "ls_direct_span_stamps": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
+    "ls_direct_level_words": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "ls_direct_launch_profile": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ls_direct_factor": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                  c_void_p, ctypes.POINTER(c_void_p)]),
     "ls_direct_solve_part": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
@@ -188,13 +190,18 @@ def ptr(t):
 class CsrMatrix:
     """int32 CSR (rowptr, col) + fp32 val of a (V,V) matrix on one HIP device. `val` is the very tensor
     that backs M.values() (same order: row-major sorted COO == CSR order), so no value copy exists."""
-    __slots__ = ("V", "nnz", "rowptr", "col", "val", "device", "symmetric", "a_min", "uniform", "positions", "_transposed", "__weakref__")
+    __slots__ = ("V", "nnz", "rowptr", "col", "val", "device", "symmetric", "exact_symmetric", "a_min", "uniform", "positions", "_transposed",
+                 "_transposed_version", "__weakref__")
 
     def __init__(self, V, rowptr, col, val, symmetric, a_min=None, uniform=None, positions=None):
         self.V, self.nnz = int(V), int(col.shape[0])
         self.rowptr, self.col, self.val = rowptr, col, val
         self.device = val.device
+        # two different facts (None: not determined yet, see is_symmetric):
+        #   symmetric        M = M^T up to 1e-6 max|M_ij| -- what the factorisation needs
+        #   exact_symmetric  M = M^T entry for entry -- what lets a backward pass apply M instead of M^T
         self.symmetric = symmetric
+        self.exact_symmetric = symmetric
         # certified lower bound of lambda_min(M): M = a I + b L with L positive semi-definite => a (None: unknown)
         self.a_min = a_min
         # (a, b) if M = a I + b L_uniform (all off-diagonal values equal -b): lets the solver drop the value array
@@ -203,6 +210,32 @@ class CsrMatrix:
         # the mesh into compact patches for the LDS-resident solver kernel)
         self.positions = positions
         self._transposed = None
+        self._transposed_version = None
+
+
+def is_symmetric(csr, exact=False):
+    """M = M^T? exact: entry for entry (tolerance 0); otherwise up to 1e-6 of the largest entry. Determined once per side
+    car and tolerance by a native kernel (ls_csr_is_symmetric); matrices built by compute_matrix carry the answer."""
+    have = csr.exact_symmetric if exact else csr.symmetric
+    if have is not None:
+        return have
+    if not exact and csr.exact_symmetric:
+        csr.symmetric = True
+        return True
+    ok = ctypes.c_int(0)
+    tol = 0.0 if exact else (1e-6 * float(csr.val.abs().max()) if csr.nnz else 0.0)
+    with torch.cuda.device(csr.device):
+        check(lib().ls_csr_is_symmetric(ptr(csr.rowptr), ptr(csr.col), ptr(csr.val), csr.V, csr.nnz, tol, ctypes.byref(ok), csr.device.index,
+                                        stream_of(csr.device)))
+    if exact:
+        csr.exact_symmetric = bool(ok.value)
+        if ok.value:
+            csr.symmetric = True
+    else:
+        csr.symmetric = bool(ok.value)
+        if not ok.value:
+            csr.exact_symmetric = False
+    return bool(ok.value)
 
 
 # (id(M)) -> (CsrMatrix, weakref(M)). Mirrors the reference's solver cache (parameterize.py:5-17): keyed by
@@ -271,7 +304,7 @@ def spmv(csr, x, variant=0):
 def csr_transposed(csr):
     """CSR side car of M^T (cached on the side car of M): native radix sort of the entries by column, no torch sort."""
     t = getattr(csr, "_transposed", None)
-    if t is not None:
+    if t is not None and csr._transposed_version == csr.val._version:     # (the values may have been updated in place since)
         return t
     dev = csr.device
     n = c_size_t(0)
@@ -284,5 +317,7 @@ def csr_transposed(csr):
         check(lib().ls_csr_transpose(ptr(csr.rowptr), ptr(csr.col), ptr(csr.val), csr.V, csr.nnz, ptr(rowptr), ptr(col), ptr(val), ptr(ws),
                                      ws.numel(), dev.index, stream_of(dev)))
     t = CsrMatrix(csr.V, rowptr, col, val, symmetric=csr.symmetric)
+    t.exact_symmetric = csr.exact_symmetric
     csr._transposed = t
+    csr._transposed_version = csr.val._version
     return t

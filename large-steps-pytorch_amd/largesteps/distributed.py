@@ -512,6 +512,15 @@ class ShardedDirect:
         return x
 
 
+def _all_reduce_min(t, group):
+    if dist.get_backend(group) == "gloo" and t.is_cuda:
+        host = t.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.MIN, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+
+
 def _all_reduce_sum(t, group):
     """all-reduce of a device tensor; the gloo backend (loopback tests: several ranks on one GPU) is staged through the host"""
     if dist.get_backend(group) == "gloo" and t.is_cuda:
@@ -608,6 +617,11 @@ def bench_sharded(workload, device, steps, warmup, shard="auto"):
             sd = ShardedDirect(M)
         except (ValueError, RuntimeError):
             sd = None            # no direct factorisation for this matrix: vertex blocks of the iteration instead
+        # every rank must take the same branch (a rank alone in the fallback's collectives would hang the job): agree on the minimum
+        ok = torch.tensor([1 if sd is not None else 0], dtype=torch.int32, device=device)
+        _all_reduce_min(ok, None)
+        if int(ok.item()) == 0:
+            sd = None
         if sd is not None:
             x = None
             for _ in range(warmup):

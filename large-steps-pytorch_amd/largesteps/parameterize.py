@@ -37,14 +37,9 @@ class _SpMV(torch.autograd.Function):
         if not ctx.needs_input_grad[1]:
             return None, None
         csr = ctx.csr
-        if csr.symmetric is None:           # a foreign matrix: find out once whether L^T = L
-            import ctypes
-            ok = ctypes.c_int(0)
-            with torch.cuda.device(csr.device):
-                _native.check(_native.lib().ls_csr_is_symmetric(_native.ptr(csr.rowptr), _native.ptr(csr.col), _native.ptr(csr.val), csr.V, csr.nnz,
-                                                                0.0, ctypes.byref(ok), csr.device.index, _native.stream_of(csr.device)))
-            csr.symmetric = bool(ok.value)
-        return None, _native.spmv(csr if csr.symmetric else _native.csr_transposed(csr), g.contiguous())
+        # a foreign matrix: find out once whether L^T = L entry for entry (a matrix that is symmetric only up to rounding gets its
+        # transpose applied -- the gradient is exact either way)
+        return None, _native.spmv(csr if _native.is_symmetric(csr, exact=True) else _native.csr_transposed(csr), g.contiguous())
 
 
 def to_differential(L, v):

@@ -288,8 +288,25 @@ class _NativeDirect:
         wu, wd, nb = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
         _native.check(_native.lib().ls_direct_shape(self._h, ctypes.byref(lv), ctypes.byref(ar), ctypes.byref(th), ctypes.byref(tw),
                                                     ctypes.byref(wu), ctypes.byref(wd), ctypes.byref(nb)))
-        return dict(factor_entries=fe.value, launches=nl.value, up_ms=ms[0], down_ms=ms[1], levels=lv.value, arity=ar.value,
+        return dict(factor_entries=fe.value, launches=nl.value, up_ms=ms[0], down_ms=ms[1], mid_ms=ms[2], levels=lv.value, arity=ar.value,
                     tier_levels=th.value, tier_workgroups=tw.value, words_up=wu.value, words_down=wd.value, n_bnd=nb.value)
+
+
+    def level_words(self):
+        """fp32 words of factor data per tree level: (up sweep, down sweep), level 0 = root"""
+        n = self.info()["levels"]
+        up, down = (ctypes.c_int64 * n)(), (ctypes.c_int64 * n)()
+        _native.check(_native.lib().ls_direct_level_words(self._h, n, up, down))
+        return list(up), list(down)
+
+    def launch_profile(self):
+        """Launches of the last solve run with set_option("profile", 3): dicts of ms, factor words, levels (lo, hi), sweep."""
+        n = ctypes.c_int(0)
+        _native.check(_native.lib().ls_direct_launch_profile(self._h, 0, ctypes.byref(n), None, None, None, None, None))
+        ms, words = (ctypes.c_double * n.value)(), (ctypes.c_int64 * n.value)()
+        lo, hi, sw = (ctypes.c_int32 * n.value)(), (ctypes.c_int32 * n.value)(), (ctypes.c_int32 * n.value)()
+        _native.check(_native.lib().ls_direct_launch_profile(self._h, n.value, ctypes.byref(n), ms, words, lo, hi, sw))
+        return [dict(ms=ms[i], words=words[i], levels=(lo[i], hi[i]), sweep=("up", "down", "both")[sw[i]]) for i in range(n.value)]
 
 
 class NestedDissectionSolver(Solver):
@@ -311,15 +328,8 @@ class NestedDissectionSolver(Solver):
         csr = _native.csr_of(M)
         self._csr = csr
         self.last_info = None
-        if csr.symmetric is None:          # a matrix that was not built by compute_matrix: the factorisation needs M = M^T
-            ok = ctypes.c_int(0)
-            tol = 1e-6 * float(csr.val.abs().max()) if csr.nnz else 0.0
-            with torch.cuda.device(csr.device):
-                _native.check(_native.lib().ls_csr_is_symmetric(_native.ptr(csr.rowptr), _native.ptr(csr.col), _native.ptr(csr.val), csr.V,
-                                                                csr.nnz, tol, ctypes.byref(ok), csr.device.index,
-                                                                _native.stream_of(csr.device)))
-            csr.symmetric = bool(ok.value)
-        if not csr.symmetric:
+        # a matrix that was not built by compute_matrix: the factorisation needs M = M^T (up to rounding: 1e-6 of the largest entry)
+        if not _native.is_symmetric(csr):
             raise ValueError("NestedDissectionSolver: the matrix is not symmetric")
         t0 = time.perf_counter()
         tier = max(-1, min(6, int(os.environ.get("LS_ND_TIER_H", "-1"))))      # -1: the library picks (and never picks one that does not fit)
@@ -356,6 +366,12 @@ class NestedDissectionSolver(Solver):
 
     def info(self):
         return self._direct.info()
+
+    def level_words(self):
+        return self._direct.level_words()
+
+    def launch_profile(self):
+        return self._direct.launch_profile()
 
 
 class CholeskySolver(Solver):

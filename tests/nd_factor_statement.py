@@ -119,10 +119,11 @@ def factorize(plan, rowptr, col, val, device, sparse_leaves=True, tier_levels=0)
     r_loc = prow - plan.own_start[node]
     c_loc = pcol - plan.own_start[node]
     level = plan.level_of[node]
+    # (+ 4 floats: the level kernels read rows with unaligned 16-byte loads and may touch 12 bytes behind the last entry, see the header)
     val64 = val.to(torch.float64)
-    finv = torch.zeros(max(finv_size, 1), dtype=torch.float32, device=device)
-    wf = torch.zeros(max(w_size, 1), dtype=torch.float32, device=device)
-    wb = torch.zeros(max(w_size, 1), dtype=torch.float32, device=device)
+    finv = torch.zeros(max(finv_size, 1) + 4, dtype=torch.float32, device=device)
+    wf = torch.zeros(max(w_size, 1) + 4, dtype=torch.float32, device=device)
+    wb = torch.zeros(max(w_size, 1) + 4, dtype=torch.float32, device=device)
     sp_ptr = np.zeros(1, dtype=np.int32)
     sp_ent = np.zeros(0, dtype=np.dtype([("val", np.float32), ("idx", np.int32)]))
     spb_off = np.full(plan.n_nodes + 1, -1, dtype=np.int64)

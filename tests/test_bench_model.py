@@ -35,7 +35,7 @@ def test_pmc_traffic_lookup(tmp_path, monkeypatch):
     b = load_bench()
     prof = tmp_path / "profiles"
     prof.mkdir()
-    (prof / "r02_pmc_traffic.json").write_text(json.dumps(dict(workload="cfg4_plane1m", kernels={
+    (prof / b.PMC_FILE).write_text(json.dumps(dict(workload="cfg4_plane1m", kernels={
         "ls::k_nd_down<3>": dict(dispatches=3, traffic_bytes=100.0),
         "ls::k_nd_down_b<3>": dict(dispatches=5, traffic_bytes=20.0),
         "ls::k_cheb<3, 512, false>": dict(dispatches=7, traffic_bytes=9.0)})))
@@ -44,12 +44,16 @@ def test_pmc_traffic_lookup(tmp_path, monkeypatch):
     assert b.pmc_traffic("ls::k_cheb<3", "cfg4_plane1m") == 9.0
     assert b.pmc_traffic("ls::k_nd_down", "another_workload") is None
     assert b.pmc_traffic("ls::nothing", "cfg4_plane1m") is None
+    # one kernel GROUP (what roofline.traffic of the direct solver's line reports): dispatch-weighted over its kernels only
+    t, n = b.pmc_traffic_group(("ls::k_nd_down", "ls::k_cheb"), "cfg4_plane1m")
+    assert n == 15 and abs(t - (3 * 100.0 + 5 * 20.0 + 7 * 9.0) / 15) < 1e-12
+    assert b.pmc_traffic_group(("ls::nothing",), "cfg4_plane1m") == (None, 0)
 
 
 def test_committed_profiles_are_consistent():
     """the committed bench line of the final run carries the contract's keys and agrees with itself"""
     import glob
-    path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_*bench_direct*.json")) or [os.path.join(ROOT, "profiles", "r01_run18_bench_direct.json")])[-1]
+    path = sorted((glob.glob(os.path.join(ROOT, "profiles", "r03_*bench_direct*.json")) or glob.glob(os.path.join(ROOT, "profiles", "r02_*bench_direct*.json"))) or [os.path.join(ROOT, "profiles", "r01_run18_bench_direct.json")])[-1]
     line = [ln for ln in open(path).read().splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",

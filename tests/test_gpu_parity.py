@@ -1087,3 +1087,35 @@ def test_to_differential_backward_on_unsymmetric_matrix(dev):
     ref = (A.tocsr().T @ g.astype(np.float64))
     assert np.abs(v.grad.cpu().numpy() - ref).max() <= 1e-5 * np.abs(ref).max()
     assert np.abs(u.detach().cpu().numpy() - A.tocsr() @ v.detach().cpu().numpy().astype(np.float64)).max() <= 1e-5 * np.abs(ref).max()
+
+
+def test_nearly_symmetric_foreign_matrix_and_in_place_values(golden, dev):
+    """A foreign matrix that is symmetric only up to rounding (advisor finding, round 2): whichever runs first -- a
+    to_differential backward (exact test -> applies the transpose) or the direct solver (tolerance test -> factorises) --
+    must not decide the other's question; and the cached transposed side car follows an in-place update of the values."""
+    from largesteps import _native
+    from largesteps.parameterize import to_differential, from_differential
+    from largesteps.solvers import CholeskySolver
+    v, f = golden["ico6/verts"], golden["ico6/faces"]
+    r, c, val = ol.compute_matrix(v, f, 10.0)
+    val = val.astype(np.float32).copy()
+    upper = r < c
+    val[upper] = val[upper] * np.float32(1 + 2e-7)             # one ulp-scale asymmetry
+    M = torch.sparse_coo_tensor(_t(np.stack([r, c]).astype(np.int64), dev), _t(val, dev), (v.shape[0],) * 2).coalesce()
+    x = _t(v, dev).clone().requires_grad_(True)
+    g = np.random.default_rng(4).standard_normal(v.shape).astype(np.float32)
+    (to_differential(M, x) * _t(g, dev)).sum().backward()                       # first user: the backward pass
+    csr = _native.csr_of(M)
+    assert csr.exact_symmetric is False and csr.symmetric is None
+    import scipy.sparse as sp
+    A = sp.csr_matrix((M.values().cpu().numpy().astype(np.float64), (r, c)), shape=(v.shape[0],) * 2)
+    assert np.abs(x.grad.cpu().numpy() - A.T @ g).max() <= 1e-5 * np.abs(A.T @ g).max()
+    s = CholeskySolver(M)                                                        # second user: the factorisation
+    assert s.method == "nested-dissection" and csr.symmetric is True and csr.exact_symmetric is False
+    u = to_differential(M, _t(v, dev))
+    assert np.abs(from_differential(M, u, "Cholesky").cpu().numpy() - v).max() <= 2e-5
+    # values updated in place: the transposed side car is rebuilt (its values were a copy)
+    t0 = _native.csr_transposed(csr)
+    M.values().mul_(2.0)
+    t1 = _native.csr_transposed(csr)
+    assert t1 is not t0 and torch.allclose(t1.val.sum(), 2.0 * t0.val.sum())
