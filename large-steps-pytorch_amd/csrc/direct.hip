@@ -54,7 +54,7 @@ __device__ __forceinline__ Tile load_tile(const Tile* __restrict__ tiles, int id
 }
 
 #ifndef LS_ND_UNROLL
-#define LS_ND_UNROLL 8
+#define LS_ND_UNROLL 32       // (8: 17.1 / 17.1 us for the two row-per-lane up levels of a 1M-vertex solve, 16: 19.9 / 19.3, 32: 16.6 / 16.0)
 #endif
 constexpr int ND_UNROLL = LS_ND_UNROLL;   // independent matrix loads in flight per lane (row-per-lane kernels)
 #ifndef LS_ND_ROWS
@@ -62,9 +62,9 @@ constexpr int ND_UNROLL = LS_ND_UNROLL;   // independent matrix loads in flight 
 #endif
 constexpr int ND_ROWS = LS_ND_ROWS;     // rows a wave processes together (lanes-along-the-reduction kernels)
 #ifndef LS_ND_BW
-#define LS_ND_BW 4
+#define LS_ND_BW 8
 #endif
-constexpr int ND_BW = LS_ND_BW;       // waves per workgroup of the *_b kernels -> ND_ROWS * ND_BW rows per tile
+constexpr int ND_BW = LS_ND_BW;       // most waves per workgroup of the *_b kernels (a level runs 4 or ND_BW of them: ND_ROWS x waves x chunks rows per tile)
 
 // Sum of the valid child slots of front position f: slots[(f * A + c) * K + q], valid iff bit c of m. All A slots are
 // loaded unconditionally (contiguous; never-written ones hold garbage and are masked out): no load waits for the mask.
@@ -1317,13 +1317,27 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
         }
         // long reductions: lanes along the reduction (k_nd_*_b), ND_ROWS * ND_BW rows per tile; short: a row per lane
         p.up_b = red_up >= long_up; p.down_b = red_down >= long_red;
-        p.up_nw = p.up_b ? ND_BW : pick_nw(red_up, true); p.down_nw = p.down_b ? ND_BW : pick_nw(red_down);
-        // *_b kernels: a wave keeps about ND_INFLIGHT row loads in flight -> short rows come in several chunks of ND_ROWS
-        const int inflight = env_int("LS_ND_INFLIGHT", 6);       // 16-byte requests per lane
+        // *_b kernels, shape per level (measured at 1M vertices, profiles/r03_level_kernel_variants.txt):
+        //  * every tile assembles its node's whole reduction vector -- long vectors (the top levels: 2000 entries, four 16-byte slot
+        //    records each) want FEW, FAT workgroups: 8 waves from ~1400 entries on (root 15.0 -> 13.9 us, level 1 15.2 -> 14.3 / 17.3 -> 16.3);
+        //  * below that 4 waves, and as many row chunks per wave (<= 4) as still leave ~500 tiles in the level (two per CU; 1M: level 4 down
+        //    19.6 -> 17.2 us with 4 chunks, level 3 down 18.9 -> 15.7 with 2).
+        // LS_ND_INFLIGHT (16-byte requests per lane) selects the chunks by requests in flight instead (the round-2 rule).
+        const int bw_long = env_int("LS_ND_BW_LONG", 1400), tile_target = env_int("LS_ND_TILES", 500), inflight = env_int("LS_ND_INFLIGHT", 0);
+        const int up_bw = std::min(ND_BW, red_up >= bw_long ? 8 : 4), down_bw = std::min(ND_BW, red_down >= bw_long ? 8 : 4);
+        p.up_nw = p.up_b ? up_bw : pick_nw(red_up, true); p.down_nw = p.down_b ? down_bw : pick_nw(red_down);
         const int lpr_up = div_up(std::max(p.s_cap, 1), 4 * WAVE), lpr_down = lpr_up + div_up(std::max(p.b_cap, 1), 4 * WAVE);   // 16-byte requests per row and lane
-        p.up_chunks = std::min(4, std::max(1, div_up(inflight, ND_ROWS * lpr_up)));
-        p.down_chunks = std::min(4, std::max(1, div_up(inflight, ND_ROWS * lpr_down)));
-        const int up_rows = p.up_b ? ND_ROWS * ND_BW * p.up_chunks : WAVE, down_rows = p.down_b ? ND_ROWS * ND_BW * p.down_chunks : WAVE;
+        int64_t rows_up = 0, rows_down = 0;
+        for (int64_t i = a0; i < a1; ++i) { rows_up += nodes[i].b; rows_down += nodes[i].s; }
+        auto pick_chunks = [&](int64_t rows, int bw, int lpr) {
+            if (inflight > 0) return std::min(4, std::max(1, div_up(inflight, ND_ROWS * lpr)));
+            int c = 4;
+            while (c > 1 && rows / (ND_ROWS * bw * c) < tile_target) --c;
+            return c;
+        };
+        p.up_chunks = pick_chunks(rows_up, up_bw, lpr_up);
+        p.down_chunks = pick_chunks(rows_down, down_bw, lpr_down);
+        const int up_rows = p.up_b ? ND_ROWS * up_bw * p.up_chunks : WAVE, down_rows = p.down_b ? ND_ROWS * down_bw * p.down_chunks : WAVE;
         // small nodes: whole matrix staged in LDS, one workgroup per node, a row per thread
         const int small_lds = env_int("LS_ND_SMALL_KB", 40) * 1024;
         const size_t up_s_bytes = ((size_t)p.s_cap * p.b_cap + (size_t)p.s_cap * d->kmax) * sizeof(float);
@@ -1624,7 +1638,7 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
             hipLaunchKernelGGL(k_nd_up_s<K>, dim3(p.up_tiles), dim3(WAVE * p.up_nw), ((size_t)p.s_cap * p.b_cap + (size_t)p.s_cap * K) * sizeof(float), st,
                                d->tiles + p.up_first, up_perm, d->mask, d->ppos, d->wf, up_b, d->bp, d->slots, p.s_cap, p.b_cap);
         else if (p.up_b)
-            hipLaunchKernelGGL(k_nd_up_b<K>, dim3(p.up_tiles), dim3(WAVE * ND_BW), (size_t)p.s_cap * K * sizeof(float), st, d->tiles + p.up_first,
+            hipLaunchKernelGGL(k_nd_up_b<K>, dim3(p.up_tiles), dim3(WAVE * p.up_nw), (size_t)p.s_cap * K * sizeof(float), st, d->tiles + p.up_first,
                                up_perm, d->mask, d->ppos, d->wb, up_b, d->bp, d->slots, p.s_cap, p.up_chunks);
         else
             hipLaunchKernelGGL(k_nd_up<K>, dim3(p.up_tiles), dim3(WAVE * p.up_nw), ((size_t)p.s_cap + (size_t)(p.up_nw - 1) * WAVE) * K * sizeof(float),
@@ -1649,7 +1663,7 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
                                ((size_t)p.s_cap * (p.s_cap + p.b_cap) + (size_t)(p.s_cap + p.b_cap) * K) * sizeof(float), st, d->tiles + p.down_first,
                                d->perm, d->push_ptr, d->push_tgt, d->finv, d->wb, (const float*)d->bp, d->xb, x, p.s_cap, p.b_cap);
         else if (p.down_b)
-            hipLaunchKernelGGL(k_nd_down_b<K>, dim3(p.down_tiles), dim3(WAVE * ND_BW), ((size_t)p.s_cap + p.b_cap) * K * sizeof(float), st,
+            hipLaunchKernelGGL(k_nd_down_b<K>, dim3(p.down_tiles), dim3(WAVE * p.down_nw), ((size_t)p.s_cap + p.b_cap) * K * sizeof(float), st,
                                d->tiles + p.down_first, d->perm, d->push_ptr, d->push_tgt, d->finv, d->wf, (const float*)d->bp, d->xb, x,
                                p.s_cap, p.b_cap, p.down_chunks, lv == 0 ? rf : RootFill{nullptr, nullptr, nullptr, nullptr});
         else

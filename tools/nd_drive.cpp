@@ -90,6 +90,27 @@ int main(int argc, char** argv) {
         for (int r = 0; r < 10; ++r) { LS(ls_direct_solve(h, d_b, d_x, k, st)); LS(ls_direct_info(h, nullptr, nullptr, pm)); for (int t = 0; t < 3; ++t) acc[t] += pm[t] / 10; }
         LS(ls_direct_set(h, "profile", 0));
         if (mode) span_us = acc[2] * 1e3;
+        {   // every launch of a solve: an event in front of each ("profile" 3), mean of 10 solves
+            LS(ls_direct_set(h, "profile", 3));
+            int nl = 0;
+            double ms[64], sum[64] = {0};
+            int64_t words[64]; int32_t lo[64], hi[64], sw[64];
+            for (int r = 0; r < 10; ++r) {
+                LS(ls_direct_solve(h, d_b, d_x, k, st));
+                LS(ls_direct_launch_profile(h, 64, &nl, ms, words, lo, hi, sw));
+                for (int t = 0; t < nl && t < 64; ++t) sum[t] += ms[t] / 10;
+            }
+            LS(ls_direct_set(h, "profile", 0));
+            if (getenv("ND_DRIVE_TABLE")) {
+                double tot = 0;
+                for (int t = 0; t < nl && t < 64; ++t) {
+                    tot += sum[t] * 1e3;
+                    printf("    levels %d-%d %-4s %8.1f MB %7.2f us %6.2f TB/s\n", lo[t], hi[t], sw[t] == 0 ? "up" : sw[t] == 1 ? "down" : "both", words[t] * 4e-6,
+                           sum[t] * 1e3, words[t] * 4e-6 / (sum[t] * 1e3));
+                }
+                printf("    sum of the launches (with an event between each two) %.1f us\n", tot);
+            }
+        }
         printf("persist %d: %2d launches  %8.2f us per solve   max |x - x*| %.2e   ||b - M x|| / ||b|| %.2e   events: first part %.1f us, last part %.1f us, middle %.1f us\n",
                mode, launches, ms / solves * 1e3, err, sqrt(res / bn), acc[0] * 1e3, acc[1] * 1e3, acc[2] * 1e3);
     }
