@@ -325,6 +325,23 @@ int ls_direct_solve(ls_direct* d, const float* b, float* x, int k, void* stream)
 int ls_direct_solve_part(ls_direct* d, const float* b, float* x, int k, int part, float* exchange, void* stream);
 int ls_direct_shard_info(const ls_direct* d, int* h_rank, int* h_count, int* h_cut_level, int64_t* h_exchange_floats_per_column,
                          unsigned char* h_owned_rows);
+/* the region of the handle's own workspace that holds the exchange of a k-column solve (what part 0 leaves and part 1 reads):
+ * passing it as `exchange` to ls_direct_solve_part skips the staging copies -- the caller then reduces it in place */
+int ls_direct_exchange_region(ls_direct* d, int k, float** h_region, int64_t* h_floats);
+
+/* ---- the collective of the sharded solve behind the C ABI (one process per GPU; RCCL over xGMI, looked up at run time) --------------
+ * ls_dist_unique_id: rank 0 creates a 128-byte communicator id and ships it to the other ranks (any transport: the caller's);
+ * ls_dist_create: COLLECTIVE, every rank calls it with the same id (ncclCommInitRank on `device`);
+ * ls_dist_allreduce_sum: in-place sum of n floats over the ranks, ASYNC on `stream`;
+ * ls_dist_direct_solve: one sharded solve = ls_direct_solve_part(0), the all-reduce of the exchange region in place, part (1),
+ *   all on `stream` with no host round trip in between (a consumer needs no Python and no all-reduce of its own).
+ * LS_E_STATE: librccl.so is not loadable; values >= 2000: 2000 + ncclResult_t. */
+typedef struct ls_dist ls_dist;
+int ls_dist_unique_id(void* h_id128);
+int ls_dist_create(const void* h_id128, int rank, int world, int device, ls_dist** out);
+int ls_dist_destroy(ls_dist* c);
+int ls_dist_allreduce_sum(ls_dist* c, float* d_buf, int64_t n, void* stream);
+int ls_dist_direct_solve(ls_dist* c, ls_direct* d, const float* b, float* x, int k, void* stream);
 /* knobs: "profile" (1: the next solves time the up sweep and the down sweep with HIP events and synchronise; 3: an event in
  * front of every launch, read back by ls_direct_launch_profile; 2: the
  * tier kernels also record shader-clock stamps per wave, read back by ls_direct_tier_stamps -- experiments builds only);

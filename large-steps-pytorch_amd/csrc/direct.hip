@@ -1619,7 +1619,8 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
         hipLaunchKernelGGL((k_nd_tier<K, true>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
     }
     }
-    if (part == 1 && exch_n) LS_HIP(hipMemcpyAsync(d->slots + exch_off, exchange, exch_n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (part == 1 && exch_n && exchange != d->slots + exch_off)
+        LS_HIP(hipMemcpyAsync(d->slots + exch_off, exchange, exch_n * sizeof(float), hipMemcpyDeviceToDevice, st));
     // the tier's up-sweep launch gathers b of the upper levels' rows into the tree's numbering (braw): their kernels skip perm -> b
     const int* up_perm = d->tier_wgs ? nullptr : d->perm;
     const float* up_b = d->tier_wgs ? d->braw : b;
@@ -1645,7 +1646,8 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
                                st, d->tiles + p.up_first, up_perm, d->mask, d->ppos, d->wf, up_b, d->bp, d->slots, p.s_cap);
     }
     if (part == 0) {
-        if (exch_n) LS_HIP(hipMemcpyAsync(exchange, d->slots + exch_off, exch_n * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (exch_n && exchange != d->slots + exch_off)
+            LS_HIP(hipMemcpyAsync(exchange, d->slots + exch_off, exch_n * sizeof(float), hipMemcpyDeviceToDevice, st));
         LS_HIP(hipGetLastError());
         return LS_OK;
     }
@@ -1766,6 +1768,14 @@ extern "C" int ls_direct_solve_part(ls_direct* d, const float* b, float* x, int 
     }
     if (rc == LS_OK && !capturing) { LS_HIP(hipEventRecord(d->busy, st)); d->last_stream = st; d->used = true; }
     return rc;
+}
+
+// the part of the handle's slot array that the ranks of a sharded solve sum (k columns): ls_dist_direct_solve reduces it in place
+extern "C" int ls_direct_exchange_region(ls_direct* d, int k, float** region, int64_t* floats) {
+    LS_REQUIRE(d && region && floats && k >= 1 && k <= d->kmax, LS_E_INVALID, "ls_direct_exchange_region: bad argument");
+    *region = d->slots + (size_t)d->exch_f0 * d->arity * k;
+    *floats = (d->exch_f1 - d->exch_f0) * d->arity * k;
+    return LS_OK;
 }
 
 extern "C" int ls_direct_shard_info(const ls_direct* d, int* h_rank, int* h_count, int* h_cut_level, int64_t* h_exchange_floats_per_column,

@@ -19,7 +19,13 @@ namespace {
 int n_threads() {          // read at every build: tests compare the one-thread and the many-thread paths
     const char* e = getenv("LS_PLAN_THREADS");
     const int want = e ? atoi(e) : 32;
-    const int hw = (int)std::thread::hardware_concurrency();
+    int hw = (int)std::thread::hardware_concurrency();
+    // one process per GPU (torchrun): the N ranks of a node analyse their matrices at the same moment on the same host cores --
+    // every rank takes its share (LOCAL_WORLD_SIZE is set by torch.distributed.run; WORLD_SIZE as a fallback on one node)
+    const char* lw = getenv("LOCAL_WORLD_SIZE");
+    if (!lw) lw = getenv("WORLD_SIZE");
+    const int ranks = lw ? atoi(lw) : 1;
+    if (hw > 0 && ranks > 1) hw = std::max(1, hw / ranks);
     return std::max(1, std::min(want, hw > 0 ? hw : 1));
 }
 

@@ -77,6 +77,12 @@ _SIGNATURES = {
     "ls_direct_tier_stamps": (c_int, [c_void_p, c_void_p, c_i64]),
     "ls_direct_span_stamps": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
     "ls_direct_level_words": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "ls_direct_exchange_region": (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_i64)]),
+    "ls_dist_unique_id": (c_int, [c_void_p]),
+    "ls_dist_create": (c_int, [c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "ls_dist_destroy": (c_int, [c_void_p]),
+    "ls_dist_allreduce_sum": (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
+    "ls_dist_direct_solve": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ls_direct_launch_profile": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ls_direct_factor": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                  c_void_p, ctypes.POINTER(c_void_p)]),

@@ -20,6 +20,7 @@ Layers (so that the host logic is testable without a GPU):
     HipShardOps    LocalOps on the HIP kernels -- the only implementation shipped.  (GPU tests)
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -483,6 +484,69 @@ class ShardedDirect:
         self._exchange = {}
         self.method = "nested-dissection"
         self.last_info = dict(iterations=0, converged=True, method="nested-dissection", exchanges=1 if self.P > 1 else 0)
+        # the exchange through the library's own RCCL communicator (ls_dist_*: part 0, all-reduce in place, part 1 as ONE native
+        # call on the solve's stream, no host round trip) when the job runs on RCCL; torch.distributed only ships the 128-byte id
+        self._comm = ctypes.c_void_p(None)
+        want = os.environ.get("LARGESTEPS_NATIVE_COLLECTIVE", "1") != "0"
+        if want and self.P > 1 and dist.is_initialized() and dist.get_backend(group) == "nccl":
+            self._native_collective()
+
+    def _native_collective(self):
+        lib = _native.lib()
+        ident = torch.zeros(128, dtype=torch.uint8)
+        ok = torch.ones(1, dtype=torch.int32, device=self.device)
+        if self.rank == 0:
+            buf = (ctypes.c_ubyte * 128)()
+            if lib.ls_dist_unique_id(buf) == 0:
+                ident = torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone()
+            else:
+                ok.zero_()
+        ident = ident.to(self.device)
+        dist.broadcast(ident, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        if int(ok.item()) == 0:
+            return                                   # no RCCL for the library on some rank: every rank keeps the torch.distributed path
+        raw = (ctypes.c_ubyte * 128).from_buffer_copy(bytes(ident.cpu().numpy().tobytes()))
+        h = ctypes.c_void_p(None)
+        with torch.cuda.device(self.device):
+            rc = lib.ls_dist_create(raw, self.rank, self.P, self.device.index, ctypes.byref(h))
+        ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=self.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        if int(ok.item()) == 0:
+            if rc == 0:
+                lib.ls_dist_destroy(h)
+            return
+        self._comm = h
+        # never trust an untested transport with the job: one solve through each path, same right-hand side on every rank; the
+        # exchange sum is exact (one non-zero contributor per entry), so the two results must be IDENTICAL on this rank's rows
+        good = 1
+        try:
+            gen = torch.Generator(device="cpu").manual_seed(1234)
+            bt = torch.randn((self.V, 3), generator=gen, dtype=torch.float32).to(self.device)
+            xa = self.solve(bt)
+            self._comm = ctypes.c_void_p(None)
+            xb = self.solve(bt)
+            torch.cuda.synchronize(self.device)
+            good = int(torch.equal(xa[self.owned], xb[self.owned]))
+        except Exception:
+            good = 0
+        self._comm = h
+        ok = torch.tensor([good], dtype=torch.int32, device=self.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        if int(ok.item()) == 0:
+            lib.ls_dist_destroy(h)
+            self._comm = ctypes.c_void_p(None)
+            return
+        self.last_info["collective"] = "ls_dist (RCCL, in place, on the solve's stream)"
+
+    def __del__(self):
+        c = getattr(self, "_comm", None)
+        if c is not None and c.value:
+            try:
+                _native.lib().ls_dist_destroy(c)
+            except Exception:
+                pass
+            self._comm = None
 
     def info(self):
         return self.local.info()
@@ -498,6 +562,10 @@ class ShardedDirect:
         if self.P == 1:
             self.local._direct.solve(b, x)
             return x
+        if self._comm.value and not gather:
+            with torch.cuda.device(dev):
+                _native.check(lib.ls_dist_direct_solve(self._comm, h, _native.ptr(b), _native.ptr(x), k, _native.stream_of(dev)))
+            return x
         ex = self._exchange.get(k)
         if ex is None:
             ex = self._exchange[k] = torch.zeros(max(1, self.exchange_floats_per_column * k), dtype=torch.float32, device=dev)
@@ -509,6 +577,94 @@ class ShardedDirect:
         if gather:
             x = x * self.owned[:, None]
             _all_reduce_sum(x, self.group)
+        return x
+
+
+class MultiDeviceDirect:
+    """The subtree-sharded direct solver driven by ONE process over several devices (SURVEY.md section 8e "process model"): what
+    `CholeskySolver` builds when LARGESTEPS_DEVICES names more than one device, so that the reference's call sites
+    (`from_differential(M, u, 'Cholesky')`, scripts/main.py:173) use several GPUs unchanged -- no torchrun, no rank logic.
+
+    Device r holds shard r of the factor (`ls_direct_factor(shard_rank = r, shard_count = N)`; the matrix is copied to it once).
+    A solve:  b -> every device (peer copies);  part 0 on every device;  the exchange buffers summed -- RCCL
+    (`torch.cuda.nccl.all_reduce`, one communicator over the N devices) when the devices are distinct, peer copies through the
+    first device when a device is listed twice (the loopback form the 1-GPU tests run);  part 1;  every device's own rows of x
+    back to the first device. All launches are asynchronous, ordered by torch's streams. The host issues ~10 operations per
+    device and solve, so this mode pays from a few million vertices on (a 1M-vertex solve is 0.24 ms on ONE device); the
+    one-process-per-GPU form (`ShardedDirect` under torchrun) has no such overhead."""
+
+    def __init__(self, M, devices, leaf_size=64, arity=4):
+        from .solvers import _NativeDirect
+        csr = _native.csr_of(M)
+        if not _native.is_symmetric(csr):
+            raise ValueError("MultiDeviceDirect: the matrix is not symmetric")
+        self.V, self.home = csr.V, csr.device
+        self.devices = [torch.device("cuda", int(d)) for d in devices]
+        n = len(self.devices)
+        if n < 2:
+            raise ValueError("MultiDeviceDirect needs at least two device entries")
+        self.loopback = len({d.index for d in self.devices}) < n
+        self._csr, self.parts, self.owned, self._ex = [], [], [], {}
+        per_col = None
+        for r, dev in enumerate(self.devices):
+            if dev == self.home:
+                c = csr
+            else:
+                c = _native.CsrMatrix(csr.V, csr.rowptr.to(dev), csr.col.to(dev), csr.val.to(dev), symmetric=csr.symmetric, a_min=csr.a_min,
+                                      uniform=csr.uniform, positions=None if csr.positions is None else csr.positions.to(dev))
+            self._csr.append(c)
+            part = _NativeDirect(c, leaf_size, arity, -1, True, shard=(r, n))
+            rk, cnt, cut, pc = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int64(0)
+            mask = np.zeros(self.V, dtype=np.uint8)
+            _native.check(_native.lib().ls_direct_shard_info(part._h, ctypes.byref(rk), ctypes.byref(cnt), ctypes.byref(cut), ctypes.byref(pc),
+                                                             mask.ctypes.data_as(ctypes.c_void_p)))
+            idx = torch.from_numpy(np.flatnonzero(mask).astype(np.int64))
+            self.parts.append(part)
+            self.owned.append((idx.to(dev), idx.to(self.home)))
+            per_col = pc.value
+        self.exchange_floats_per_column = per_col
+        self.method = "nested-dissection"
+        self.last_info = dict(iterations=0, converged=True, method="nested-dissection", devices=[d.index for d in self.devices],
+                              transport="peer copies (loopback)" if self.loopback else "RCCL (torch.cuda.nccl)")
+
+    def solve(self, b, backward=False):
+        _native.require_device(b, "b")
+        if b.device != self.home:
+            raise RuntimeError(f"matrix ({self.home}) and b ({b.device}) must be on the same device")
+        if b.dtype != torch.float32 or b.dim() not in (1, 2) or b.shape[0] != self.V:
+            raise ValueError(f"Invalid right-hand side {tuple(b.shape)} {b.dtype}: expected float32 ({self.V}, k)")
+        squeeze = b.dim() == 1
+        b2 = (b.detach().unsqueeze(1) if squeeze else b.detach()).contiguous()
+        out = torch.empty_like(b2)
+        for c0 in range(0, b2.shape[1], 4):
+            c1 = min(b2.shape[1], c0 + 4)
+            out[:, c0:c1] = self._solve4(b2 if (c0 == 0 and c1 == b2.shape[1]) else b2[:, c0:c1].contiguous())
+        return out.squeeze(1) if squeeze else out
+
+    def _solve4(self, b):
+        lib, k = _native.lib(), b.shape[1]
+        bs = [b if d == self.home else b.to(d, non_blocking=True) for d in self.devices]
+        xs = [torch.empty_like(t) for t in bs]
+        ex = self._ex.get(k)
+        if ex is None:
+            ex = self._ex[k] = [torch.zeros(max(1, self.exchange_floats_per_column * k), dtype=torch.float32, device=d) for d in self.devices]
+        for part, d, br, xr, er in zip(self.parts, self.devices, bs, xs, ex):
+            with torch.cuda.device(d):
+                _native.check(lib.ls_direct_solve_part(part._h, _native.ptr(br), _native.ptr(xr), k, 0, _native.ptr(er), _native.stream_of(d)))
+        if self.loopback:
+            total = ex[0].clone()
+            for er in ex[1:]:
+                total += er.to(self.devices[0])
+            for er in ex:
+                er.copy_(total)
+        else:
+            torch.cuda.nccl.all_reduce(ex)
+        for part, d, br, xr, er in zip(self.parts, self.devices, bs, xs, ex):
+            with torch.cuda.device(d):
+                _native.check(lib.ls_direct_solve_part(part._h, _native.ptr(br), _native.ptr(xr), k, 1, _native.ptr(er), _native.stream_of(d)))
+        x = torch.empty_like(b)
+        for (on_dev, on_home), xr in zip(self.owned, xs):
+            x.index_copy_(0, on_home, xr.index_select(0, on_dev).to(self.home, non_blocking=True))
         return x
 
 

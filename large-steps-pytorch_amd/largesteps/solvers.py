@@ -393,7 +393,17 @@ class CholeskySolver(Solver):
             direct = not os.environ.get("LARGESTEPS_NO_DIRECT")
         self._impl = None
         self.direct_error = None
-        if direct:
+        devices = [t for t in os.environ.get("LARGESTEPS_DEVICES", "").replace(" ", "").split(",") if t != ""]
+        if direct and len(devices) > 1:
+            # one process, several devices: the subtree-sharded solver behind the unchanged call sites
+            try:
+                from .distributed import MultiDeviceDirect
+                self._impl = MultiDeviceDirect(M, devices, leaf_size=leaf_size, arity=arity)
+            except (ValueError, RuntimeError) as e:
+                self.direct_error = str(e)
+                warnings.warn(f"CholeskySolver: LARGESTEPS_DEVICES={','.join(devices)} could not be used ({e}); one device instead",
+                              RuntimeWarning, stacklevel=2)
+        if direct and self._impl is None:
             try:
                 self._impl = NestedDissectionSolver(M, leaf_size=leaf_size, arity=arity)
             except (ValueError, RuntimeError) as e:      # no positions / fronts too large / numerically not SPD
@@ -403,7 +413,7 @@ class CholeskySolver(Solver):
                                   RuntimeWarning, stacklevel=2)
         if self._impl is None:
             self._impl = IterativeCholeskySolver(M, rtol=rtol, max_iter=max_iter, chebyshev=chebyshev, patch_columns=patch_columns)
-        self.method = "nested-dissection" if isinstance(self._impl, NestedDissectionSolver) else "iterative"
+        self.method = "iterative" if isinstance(self._impl, IterativeCholeskySolver) else "nested-dissection"
 
     def solve(self, b, backward=False):
         return self._impl.solve(b, backward=backward)

@@ -142,6 +142,65 @@ def test_sharded_direct_solver_at_world_eight_in_one_process():
     assert float((x - x1).abs().max()) <= 2e-5 * np.abs(x64).max()
 
 
+def test_single_process_multi_device_mode(monkeypatch):
+    """LARGESTEPS_DEVICES: the reference's call sites use the subtree-sharded solver from ONE process, unchanged (SURVEY.md 8e
+    process model). On the 1-GPU box the device list repeats device 0 (loopback: the exchange goes through peer copies instead
+    of RCCL): from_differential and its backward equal the single-device solver's to the solver's tolerance."""
+    import torch
+    from largesteps import synthetic, parameterize
+    from largesteps.geometry import compute_matrix
+    from largesteps.parameterize import from_differential, to_differential
+    from oracle import solve as osv
+    dev = torch.device("cuda:0")
+    v, f = synthetic.plane(200)
+    tv, tf = torch.from_numpy(v).to(dev), torch.from_numpy(f).to(dev)
+    M = compute_matrix(tv, tf, 25.0)
+    idx, val = M.indices().cpu().numpy(), M.values().cpu().numpy()
+    u = to_differential(M, tv)
+    x64 = osv.from_differential(idx[0], idx[1], val, u.cpu().numpy())
+    monkeypatch.setenv("LARGESTEPS_DEVICES", "0,0,0,0")
+    ur = u.clone().requires_grad_(True)
+    x = from_differential(M, ur, "Cholesky")
+    solver = parameterize._cache[(id(M), "Cholesky")][0]
+    assert solver.method == "nested-dissection" and solver.last_info["devices"] == [0, 0, 0, 0]
+    assert np.abs(x.detach().cpu().numpy() - x64).max() <= 2e-5 * np.abs(x64).max()
+    w = torch.from_numpy(np.random.default_rng(1).standard_normal(v.shape).astype(np.float32)).to(dev)
+    (x * w).sum().backward()
+    g64 = osv.from_differential(idx[0], idx[1], val, w.cpu().numpy())
+    assert np.abs(ur.grad.cpu().numpy() - g64).max() <= 2e-5 * np.abs(g64).max()
+
+
+def test_native_collective_at_world_one():
+    """ls_dist_* (the sharded solve's all-reduce behind the C ABI, RCCL looked up at run time) on the real device with a
+    communicator of ONE rank -- all a 1-GPU box can run: unique id, ncclCommInitRank, an in-place all-reduce on the solve's
+    stream, and ls_dist_direct_solve == ls_direct_solve. In a subprocess: RCCL state should not leak into the test process."""
+    import subprocess
+    code = (
+        "import ctypes, numpy as np, torch\n"
+        "from largesteps import _native, synthetic\n"
+        "from largesteps.geometry import compute_matrix\n"
+        "from largesteps.solvers import NestedDissectionSolver\n"
+        "dev = torch.device('cuda', 0); lib = _native.lib()\n"
+        "buf = (ctypes.c_ubyte * 128)()\n"
+        "_native.check(lib.ls_dist_unique_id(buf))\n"
+        "c = ctypes.c_void_p(None)\n"
+        "_native.check(lib.ls_dist_create(buf, 0, 1, 0, ctypes.byref(c)))\n"
+        "t = torch.arange(1000, dtype=torch.float32, device=dev)\n"
+        "_native.check(lib.ls_dist_allreduce_sum(c, _native.ptr(t), t.numel(), _native.stream_of(dev)))\n"
+        "torch.cuda.synchronize(); assert float(t.sum()) == 499500.0\n"
+        "v, f = synthetic.plane(150)\n"
+        "M = compute_matrix(torch.from_numpy(v).to(dev), torch.from_numpy(f).to(dev), 25.0)\n"
+        "b = torch.from_numpy(np.random.default_rng(0).standard_normal((v.shape[0], 3)).astype(np.float32)).to(dev)\n"
+        "s = NestedDissectionSolver(M, shard=(0, 1))\n"
+        "x0 = s.solve(b); x1 = torch.zeros_like(b)\n"
+        "_native.check(lib.ls_dist_direct_solve(c, s._direct._h, _native.ptr(b), _native.ptr(x1), 3, _native.stream_of(dev)))\n"
+        "torch.cuda.synchronize(); assert torch.equal(x0, x1)\n"
+        "_native.check(lib.ls_dist_destroy(c)); print('ls_dist ok')\n")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=os.pathsep.join(sys.path))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ls_dist ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_rccl_process_group_initialises():
     """backend 'nccl' (= RCCL on ROCm) with world size 1 on the real device: the branch bench.py --gpus N takes, executed once
     on hardware (one all-reduce through RCCL)."""

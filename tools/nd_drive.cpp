@@ -3,7 +3,7 @@
 // above the tier as one launch per level ("persist" 0) and as one persistent launch ("persist" 1, csrc/nd_span.h), checks both
 // against the residual on the host and against each other, and times them with HIP events.
 //   build: hipcc -O2 -std=c++17 tools/nd_drive.cpp -Iinclude -L large-steps-pytorch_amd/lib -llargesteps_hip -Wl,-rpath,'$ORIGIN/../../large-steps-pytorch_amd/lib' -o tools/build/nd_drive
-//   run:   tools/build/nd_drive [n = 1000] [solves = 200] [k = 3]
+//   run:   tools/build/nd_drive [n = 1000] [solves = 200] [k = 3] [tier levels = -1] [modes: 1 = both, 0 = launches only]
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -18,6 +18,7 @@
 
 int main(int argc, char** argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 1000, solves = argc > 2 ? atoi(argv[2]) : 200, k = argc > 3 ? atoi(argv[3]) : 3;
+    const int tier = argc > 4 ? atoi(argv[4]) : -1, max_mode = argc > 5 ? atoi(argv[5]) : 1;          // tier levels (-1: the library picks); 0: skip the persistent mode
     const float lambda = 50.0f;
     const int64_t V = (int64_t)n * n;
     // uniform Laplacian of the plane's triangulation (cell (x, y): triangles (i, i+1, i+n+1), (i, i+n+1, i+n)): neighbours E, W, N, S, NE, SW
@@ -57,7 +58,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(d_b, b.data(), V * k * 4, hipMemcpyHostToDevice));
     hipStream_t st; CK(hipStreamCreate(&st));
     ls_direct* h = nullptr;
-    LS(ls_direct_factor(d_rowptr, d_col, d_val, V, nnz, d_pos, 64, 4, -1, 1, 0, 1, 0, st, &h));
+    LS(ls_direct_factor(d_rowptr, d_col, d_val, V, nnz, d_pos, 64, 4, tier, 1, 0, 1, 0, st, &h));
     int levels, arity, tl, tw, launches; int64_t wu, wd, nb;
     LS(ls_direct_shape(h, &levels, &arity, &tl, &tw, &wu, &wd, &nb));
     printf("plane %d x %d: V %lld nnz %lld, %d levels, tier of %d (%d workgroups), factor %.1f MB up + %.1f MB down\n", n, n, (long long)V, (long long)nnz,
@@ -65,7 +66,7 @@ int main(int argc, char** argv) {
     std::vector<float> x0((size_t)V * k), x1((size_t)V * k);
     double span_us = 0;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int mode = 0; mode < 2; ++mode) {
+    for (int mode = 0; mode <= max_mode; ++mode) {
         LS(ls_direct_set(h, "persist", mode));
         LS(ls_direct_info(h, nullptr, &launches, nullptr));
         CK(hipMemsetAsync(d_x, 0xff, V * k * 4, st));
