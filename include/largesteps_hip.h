@@ -213,6 +213,36 @@ int ls_gather_rows(const float* src, const int32_t* idx, int64_t n, int k, float
  * b is read and x written in the caller's numbering. No atomics: bitwise reproducible. A handle owns one workspace:
  * solves issued on different streams are serialised on the device (event wait), concurrent host threads must not
  * share a handle. ls_direct_create is SYNC (copies the host tables). */
+/* ---- host-side analysis for the LDS-resident s-step Chebyshev kernel (ls_solver_set_patches; csrc/patch_plan.cpp, host threads, no
+ * device): the mesh cut into 2^m equally sized compact patches (recursive coordinate bisection of h_positions, (V, 3)), every patch with
+ * its ghost layers 1..depth and patch-local uint16 neighbour ids. h_rowptr / h_col: CSR pattern of M (diagonal included), h_diag: its
+ * diagonal. The deepest plan <= depth whose patches keep <= cap_local local vertices (LDS) and <= cap_rows computed rows is built;
+ * *out stays NULL (status LS_OK) when even min_depth does not fit. Arrays: table (n_patches x 20 int32: own_start, n_own, n_rows,
+ * n_local, W, off_gid, off_cols, off_diag, lim[12]), ghost_gid, cols16 ((W, n_rows) per patch), diag, perm (new -> old, V). */
+typedef struct ls_patch_plan ls_patch_plan;
+int ls_patch_plan_create(int64_t V, const int32_t* h_rowptr, const int32_t* h_col, const float* h_diag, const float* h_positions,
+                         int patch_size, int depth, int cap_local, int min_depth, int cap_rows, ls_patch_plan** out);
+int ls_patch_plan_destroy(ls_patch_plan* p);
+int ls_patch_plan_info(const ls_patch_plan* p, int* n_patches, int* depth, int* max_local, int* max_rows, int* max_width, int64_t* n_gid,
+                       int64_t* n_cols, int64_t* n_diag, double* seconds);
+int ls_patch_plan_arrays(const ls_patch_plan* p, int32_t* table, int32_t* ghost_gid, uint16_t* cols16, float* diag, int32_t* perm);
+
+/* ---- host-side analysis of a vertex-block shard of the iterative solvers (csrc/shard_plan.cpp; one process per GPU, halo exchange):
+ * rank `rank` of P owns the rows [rank V / P, (rank + 1) V / P) of the CSR matrix (h_rowptr, h_col, h_val); with depth s it also computes
+ * the ghost layers 1..s-1 redundantly and reads layer s. Local column ids: [owned | computed ghosts | read-only ghosts], each ghost group
+ * sorted by global id. Arrays: local rowptr (n_own + n_inner + 1) / col / val (n_entries), ghosts (global ids, n_ghosts), recv3 (n_recv x
+ * {source rank, offset in the ghost region, count}), send lists as CSR: send_ptr (n_send + 1), send_dst (n_send), send_ids (owned-row
+ * indices, message for message in the RECEIVER's order). ls_shard_layer_sizes: sizes of the ghost layers 1..depth of a block [lo, hi). */
+typedef struct ls_shard_plan ls_shard_plan;
+int ls_shard_plan_create(int64_t V, const int32_t* h_rowptr, const int32_t* h_col, const float* h_val, int P, int rank, int depth,
+                         ls_shard_plan** out);
+int ls_shard_plan_destroy(ls_shard_plan* s);
+int ls_shard_plan_info(const ls_shard_plan* s, int64_t* lo, int64_t* hi, int64_t* n_inner, int64_t* n_ghosts, int64_t* n_entries,
+                       int* n_recv, int* n_send, int64_t* n_send_ids);
+int ls_shard_plan_arrays(const ls_shard_plan* s, int32_t* rowptr, int32_t* col, float* val, int32_t* ghosts, int32_t* recv3,
+                         int32_t* send_ptr, int32_t* send_dst, int32_t* send_ids);
+int ls_shard_layer_sizes(int64_t V, const int32_t* h_rowptr, const int32_t* h_col, int64_t lo, int64_t hi, int depth, int64_t* h_sizes);
+
 /* Symbolic analysis alone, on the HOST (no device is touched): the elimination tree and everything static of the solver above
  * for the CSR pattern (h_rowptr, h_col; structurally symmetric) of a V x V matrix. h_positions: (V, 3) vertex positions the
  * geometric bisection runs on (only their spatial order matters), or NULL: graph-distance pseudo-positions are derived from

@@ -76,6 +76,15 @@ _SIGNATURES = {
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "ls_direct_tier_stamps": (c_int, [c_void_p, c_void_p, c_i64]),
     "ls_direct_span_stamps": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
+    "ls_shard_plan_create": (c_int, [c_i64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "ls_shard_plan_destroy": (c_int, [c_void_p]),
+    "ls_shard_plan_info": (c_int, [c_void_p] + [ctypes.POINTER(c_i64)] * 5 + [ctypes.POINTER(c_int)] * 2 + [ctypes.POINTER(c_i64)]),
+    "ls_shard_plan_arrays": (c_int, [c_void_p] + [c_void_p] * 8),
+    "ls_shard_layer_sizes": (c_int, [c_i64, c_void_p, c_void_p, c_i64, c_i64, c_int, c_void_p]),
+    "ls_patch_plan_create": (c_int, [c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "ls_patch_plan_destroy": (c_int, [c_void_p]),
+    "ls_patch_plan_info": (c_int, [c_void_p] + [ctypes.POINTER(c_int)] * 5 + [ctypes.POINTER(c_i64)] * 3 + [ctypes.POINTER(ctypes.c_double)]),
+    "ls_patch_plan_arrays": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ls_direct_level_words": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "ls_direct_exchange_region": (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_i64)]),
     "ls_dist_unique_id": (c_int, [c_void_p]),

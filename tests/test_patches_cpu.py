@@ -1,7 +1,8 @@
 """
-Host-side patch plan of the LDS-resident s-step Chebyshev kernel (largesteps/patches.py), CPU only:
-structure invariants and the numpy statement of the kernel -- s steps on overlapping patches must reproduce s global
-steps exactly on every owned vertex.
+Host-side patch plan of the LDS-resident s-step Chebyshev kernel, CPU only: the NATIVE analysis (csrc/patch_plan.cpp behind
+ls_patch_plan_*, what largesteps.patches.PatchPlan.build calls) and its numpy statement (tests/patch_plan_statement.py) --
+structure invariants, and the numpy statement of the kernel: s steps on overlapping patches must reproduce s global steps
+exactly on every owned vertex.
 """
 import math
 
@@ -10,7 +11,8 @@ import pytest
 import scipy.sparse as sp
 
 from largesteps import synthetic
-from largesteps.patches import PatchPlan, cell_patches
+from largesteps.patches import PatchPlan
+import patch_plan_statement as pps
 from statements import patch_steps
 from oracle import laplacian as ol
 
@@ -51,13 +53,15 @@ def _schedule(A, a_min, reduction):
     return n, c1, c2
 
 
+@pytest.mark.parametrize("impl", ["native", "statement"])
 @pytest.mark.parametrize("name", ["plane", "sphere"])
 @pytest.mark.parametrize("patch_size,depth", [(400, 3), (900, 5)])
-def test_patch_plan_reproduces_global_iteration(name, patch_size, depth):
+def test_patch_plan_reproduces_global_iteration(name, patch_size, depth, impl):
     v, lam, rp, c, A = _system(name)
     V = v.shape[0]
     d = A.diagonal()
-    plan = PatchPlan.build(rp, c, d, v, patch_size=patch_size, depth=depth, cap_local=6000)
+    build = PatchPlan.build if impl == "native" else pps.PatchPlan.build
+    plan = build(rp, c, d, v, patch_size=patch_size, depth=depth, cap_local=6000)
     assert plan is not None and plan.depth == depth
     T = plan.table
     # patches tile the new numbering; sizes bounded; local ids fit uint16 with the zero slot
@@ -82,19 +86,41 @@ def test_patch_plan_reproduces_global_iteration(name, patch_size, depth):
     assert np.abs(x - v).max() <= 1e-5
 
 
-def test_cell_patches_and_refusal():
+@pytest.mark.parametrize("impl", ["native", "statement"])
+def test_cell_patches_and_refusal(impl):
     v, f = synthetic.plane(60)
-    perm, starts = cell_patches(v, 500)
-    assert starts[0] == 0 and starts[-1] == v.shape[0] and (np.diff(starts) > 0).all() and np.diff(starts).max() <= 500
-    # every patch is spatially compact: its bounding box is small compared with the mesh
-    for a, b in zip(starts[:-1], starts[1:]):
-        p = v[perm[a:b]]
-        assert (p.max(0) - p.min(0))[:2].max() <= 0.6
     r, c, val = ol.compute_matrix(v, f, 5.0)
     rp = np.zeros(v.shape[0] + 1, np.int64)
     np.add.at(rp, r + 1, 1)
     rp = np.cumsum(rp)
     d = np.ones(v.shape[0], np.float32)
-    assert PatchPlan.build(rp, c, d, v, patch_size=500, depth=4, cap_local=100) is None, "patches that cannot fit are refused"
-    plan = PatchPlan.build(rp, c, d, v, patch_size=500, depth=8, cap_local=700)
+    build = PatchPlan.build if impl == "native" else pps.PatchPlan.build
+    if impl == "statement":
+        perm, starts = pps.cell_patches(v, 500)
+    else:
+        plan0 = build(rp, c, d, v, patch_size=500, depth=2, cap_local=60000)
+        perm, starts = plan0.perm, np.concatenate([plan0.table[:, 0], [v.shape[0]]]).astype(np.int64)
+    assert starts[0] == 0 and starts[-1] == v.shape[0] and (np.diff(starts) > 0).all() and np.diff(starts).max() <= 500
+    # every patch is spatially compact: its bounding box is small compared with the mesh
+    for a, b in zip(starts[:-1], starts[1:]):
+        p = v[perm[a:b]]
+        assert (p.max(0) - p.min(0))[:2].max() <= 0.6
+    assert build(rp, c, d, v, patch_size=500, depth=4, cap_local=100) is None, "patches that cannot fit are refused"
+    plan = build(rp, c, d, v, patch_size=500, depth=8, cap_local=700)
     assert plan is not None and 2 <= plan.depth < 8 and plan.max_local <= 700, "depth is reduced until the patches fit"
+
+
+def test_native_patch_plan_is_independent_of_the_thread_count(monkeypatch):
+    v, f = synthetic.icosphere(24)
+    r, c, val = ol.compute_matrix(v, f, 5.0)
+    rp = np.zeros(v.shape[0] + 1, np.int64)
+    np.add.at(rp, r + 1, 1)
+    rp = np.cumsum(rp)
+    d = np.ones(v.shape[0], np.float32)
+    plans = []
+    for t in ("1", "3", "8"):
+        monkeypatch.setenv("LS_PLAN_THREADS", t)
+        plans.append(PatchPlan.build(rp, c, d, v, patch_size=700, depth=4, cap_local=6000))
+    for q in plans[1:]:
+        for name in ("perm", "table", "ghost_gid", "cols16", "diag"):
+            assert np.array_equal(getattr(plans[0], name), getattr(q, name)), name
