@@ -15,7 +15,7 @@ Everything else is the single-GPU kernels of csrc/pcg.hip, launched one at a tim
 matrix (owned rows x [owned | halo] columns) through the C ABI (ls_solver_create_ext / ls_solver_phase).
 
 Layers (so that the host logic is testable without a GPU):
-    ShardPlan      pure numpy: row block, local column ids, halo / send lists.      (CPU tests)
+    ShardPlan      native analysis (csrc/shard_plan.cpp): row block, local column ids, halo / send lists.
     ShardedPCG     the iteration driver: collectives + a LocalOps object.           (CPU tests with gloo)
     HipShardOps    LocalOps on the HIP kernels -- the only implementation shipped.  (GPU tests)
 """
@@ -38,7 +38,9 @@ def block_bounds(V, P):
 
 
 class ShardPlan:
-    """Everything rank `rank` of `P` needs to know about its block of a V x V CSR matrix (host side, numpy).
+    """Everything rank `rank` of `P` needs to know about its block of a V x V CSR matrix. The analysis is native
+    (csrc/shard_plan.cpp behind ls_shard_plan_*: breadth-first ghost layers, local column ids, receive / send lists); this class
+    only owns the arrays. numpy statement of the same plan: tests/shard_plan_statement.py.
 
     depth = 1 (PCG): the shard computes its owned rows; columns are [owned | halo layer 1].
     depth = s > 1 (Chebyshev, one halo exchange per s iterations): the shard ALSO computes the ghost layers
@@ -62,86 +64,35 @@ class ShardPlan:
         self.halo_global, self.recv, self.send = ghost_global, recv, send
 
     @staticmethod
-    def _entries(rowptr, rows):
-        """Flat positions (into col / val) of all entries of the CSR rows `rows`, row after row, + the row lengths."""
-        starts = rowptr[rows]
-        lens = rowptr[rows + 1] - starts
-        total = int(lens.sum())
-        if total == 0:
-            return np.empty(0, np.int64), lens
-        first = np.cumsum(lens) - lens                       # position of each row's first entry in the output
-        pos = np.arange(total, dtype=np.int64) - np.repeat(first, lens) + np.repeat(starts, lens)
-        return pos, lens
-
-    @staticmethod
-    def _layers(rowptr, col, V, lo, hi, depth):
-        """Ghost layers 1..depth of the block [lo, hi): breadth-first search on the matrix pattern."""
-        seen = np.zeros(V, dtype=bool)
-        seen[lo:hi] = True
-        frontier = np.arange(lo, hi, dtype=np.int64)
-        layers = []
-        for _ in range(depth):
-            pos, _ = ShardPlan._entries(rowptr, frontier)
-            nb = np.unique(col[pos])
-            nb = nb[~seen[nb]]
-            seen[nb] = True
-            layers.append(nb.astype(np.int64))
-            frontier = nb
-        return layers
-
-    @staticmethod
-    def _ghost_groups(rowptr, col, V, bounds, q, depth):
-        """(computed ghosts, read-only ghosts) of rank q, each sorted by (owner, global id)."""
-        layers = ShardPlan._layers(rowptr, col, V, bounds[q], bounds[q + 1], depth)
-        inner = np.sort(np.concatenate(layers[:-1])) if depth > 1 else np.empty(0, np.int64)
-        outer = np.sort(layers[-1])
-        return inner, outer      # contiguous blocks => sorting by id sorts by owner first
-
-    @staticmethod
     def build(rowptr, col, val, V, P, rank, depth=1):
-        rowptr = np.asarray(rowptr).astype(np.int64)
-        col = np.asarray(col).astype(np.int64)
-        val = np.asarray(val, dtype=np.float32)
-        if P < 1 or not (0 <= rank < P):
-            raise ValueError(f"invalid rank {rank} of {P}")
-        if P > max(V, 1):
-            raise ValueError(f"cannot cut {V} vertices into {P} non-empty blocks")
-        if depth < 1:
-            raise ValueError("halo depth must be >= 1")
-        bounds = block_bounds(V, P)
-        lo, hi = bounds[rank], bounds[rank + 1]
-        inner, outer = ShardPlan._ghost_groups(rowptr, col, V, bounds, rank, depth)
-        ghosts = np.concatenate([inner, outer])
-        glob = np.concatenate([np.arange(lo, hi), ghosts])
-        lut = np.full(V, -1, dtype=np.int64)
-        lut[glob] = np.arange(glob.shape[0])
-        rows_global = glob[: (hi - lo) + inner.shape[0]]
-        pos, lens = ShardPlan._entries(rowptr, rows_global)    # rows in local order, columns still global
-        local_rowptr = np.concatenate([[0], np.cumsum(lens)])
-        local_col = lut[col[pos]]
-        assert (local_col >= 0).all(), "a computed row references a column outside the halo"
-        # per-owner contiguous ranges of the two ghost groups
-        recv = []
-        for group, base in ((inner, 0), (outer, inner.shape[0])):
-            owner = np.searchsorted(bounds, group, side="right") - 1
-            for q in np.unique(owner):
-                idx = np.nonzero(owner == q)[0]
-                assert idx[-1] - idx[0] + 1 == idx.shape[0]
-                recv.append((int(q), int(base + idx[0]), int(idx.shape[0])))
-        # what the others need from me, in THEIR order (group by group, ids ascending)
-        send = []
-        groups_of = {q: ShardPlan._ghost_groups(rowptr, col, V, bounds, q, depth) for q in range(P) if q != rank}
-        for gi in (0, 1):
-            for q in range(P):
-                if q == rank:
-                    continue
-                g = groups_of[q][gi]
-                mine = g[(g >= lo) & (g < hi)]
-                if mine.shape[0]:
-                    send.append((q, (mine - lo).astype(np.int32)))
-        # the receiver walks its recv list group by group and, inside a group, owner by owner: same order here
-        return ShardPlan(rank, P, lo, hi, depth, local_rowptr.astype(np.int32), local_col.astype(np.int32),
-                         val[pos].astype(np.float32), ghosts, inner.shape[0], recv, send)
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        val = np.ascontiguousarray(val, dtype=np.float32)
+        lib = _native.lib()
+        as_p = lambda a: a.ctypes.data_as(ctypes.c_void_p)   # noqa: E731
+        h = ctypes.c_void_p(None)
+        _native.check(lib.ls_shard_plan_create(int(V), as_p(rowptr), as_p(col), as_p(val), int(P), int(rank), int(depth), ctypes.byref(h)))
+        try:
+            lo, hi, n_inner, n_ghosts, n_ent, n_ids = (ctypes.c_int64(0) for _ in range(6))
+            n_recv, n_send = ctypes.c_int(0), ctypes.c_int(0)
+            _native.check(lib.ls_shard_plan_info(h, ctypes.byref(lo), ctypes.byref(hi), ctypes.byref(n_inner), ctypes.byref(n_ghosts),
+                                                 ctypes.byref(n_ent), ctypes.byref(n_recv), ctypes.byref(n_send), ctypes.byref(n_ids)))
+            n_rows = hi.value - lo.value + n_inner.value
+            l_rowptr = np.empty(n_rows + 1, dtype=np.int32)
+            l_col = np.empty(n_ent.value, dtype=np.int32)
+            l_val = np.empty(n_ent.value, dtype=np.float32)
+            ghosts = np.empty(n_ghosts.value, dtype=np.int32)
+            recv3 = np.empty((n_recv.value, 3), dtype=np.int32)
+            s_ptr = np.empty(n_send.value + 1, dtype=np.int32)
+            s_dst = np.empty(n_send.value, dtype=np.int32)
+            s_ids = np.empty(n_ids.value, dtype=np.int32)
+            _native.check(lib.ls_shard_plan_arrays(h, as_p(l_rowptr), as_p(l_col), as_p(l_val), as_p(ghosts), as_p(recv3), as_p(s_ptr),
+                                                   as_p(s_dst), as_p(s_ids)))
+        finally:
+            lib.ls_shard_plan_destroy(h)
+        recv = [(int(q), int(o), int(c)) for q, o, c in recv3]
+        send = [(int(s_dst[i]), s_ids[s_ptr[i]:s_ptr[i + 1]].copy()) for i in range(n_send.value)]
+        return ShardPlan(rank, P, lo.value, hi.value, depth, l_rowptr, l_col, l_val, ghosts.astype(np.int64), n_inner.value, recv, send)
 
 
 class HipShardOps:
@@ -694,15 +645,17 @@ def pick_depth(rowptr, col, V, P, max_depth=64, max_overhead=1.0):
     host-driven RCCL group launch, so recomputing ghost rows is far cheaper than talking more often."""
     if P == 1:
         return 1
-    rowptr, col = np.asarray(rowptr).astype(np.int64), np.asarray(col).astype(np.int64)
+    rowptr, col = np.ascontiguousarray(rowptr, dtype=np.int32), np.ascontiguousarray(col, dtype=np.int32)
     bounds = block_bounds(V, P)
     best = max_depth
+    sizes = np.zeros(max_depth, dtype=np.int64)
     for q in range(P):
-        layers = ShardPlan._layers(rowptr, col, V, bounds[q], bounds[q + 1], max_depth)
+        _native.check(_native.lib().ls_shard_layer_sizes(int(V), rowptr.ctypes.data_as(ctypes.c_void_p), col.ctypes.data_as(ctypes.c_void_p),
+                                                         int(bounds[q]), int(bounds[q + 1]), int(max_depth), sizes.ctypes.data_as(ctypes.c_void_p)))
         own = bounds[q + 1] - bounds[q]
         extra, d = 0, 1
-        for j, L in enumerate(layers[:-1]):                     # depth j+2 computes layers 1..j+1
-            extra += L.shape[0]
+        for j in range(max_depth - 1):                          # depth j+2 computes layers 1..j+1
+            extra += int(sizes[j])
             if extra > max_overhead * own:
                 break
             d = j + 2

@@ -69,6 +69,15 @@ def test_shard_plan(mesh, P, depth):
         assert plans[0].n_halo == 0 and not plans[0].send and not plans[0].recv
     with pytest.raises(ValueError):
         ShardPlan.build(rowptr, col, val, V, P, P)
+    # the native analysis (csrc/shard_plan.cpp) against its numpy statement, array for array
+    import shard_plan_statement as sps
+    for p in plans:
+        q = sps.ShardPlan.build(rowptr, col, val, V, P, p.rank, depth=depth)
+        assert (p.lo, p.hi, p.n_rows, p.n_cols, p.n_halo) == (q.lo, q.hi, q.n_rows, q.n_cols, q.n_halo)
+        for name in ("rowptr", "col", "val", "halo_global"):
+            assert np.array_equal(getattr(p, name), getattr(q, name)), name
+        assert p.recv == q.recv and len(p.send) == len(q.send)
+        assert all(a[0] == b[0] and np.array_equal(a[1], b[1]) for a, b in zip(p.send, q.send))
 
 
 def run_world(tmp_path, world, mesh, k=3, ops="numpy", backend="gloo", timeout=300, solver="pcg", depth=1):
