@@ -244,6 +244,7 @@ __global__ __launch_bounds__(1024) void k_nd_up(const Tile* __restrict__ tiles, 
     float* sb = sm;
     float* red = sm + (size_t)s_cap * K;
     const Tile t = load_tile(tiles, blockIdx.x);
+    if (t.store == 3) return;                   // padding of the XCD-aware tile order
     if (t.store == 2) { store_bprime<K>(t, perm, mask, slots, b_in, bprime); return; }
     const int nw = blockDim.x >> 6, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i = t.row0 + lane, s = t.s, b = t.b;
@@ -301,6 +302,7 @@ __global__ __launch_bounds__(1024) void k_nd_down(const Tile* __restrict__ tiles
     float* sx = sm + (size_t)s_cap * K;
     float* red = sx + (size_t)b_cap * K;
     const Tile t = load_tile(tiles, blockIdx.x);
+    if (t.forward == 2) return;                 // padding of the XCD-aware tile order
     if (t.forward) { forward_rows<K>(t, push_ptr, push_tgt, xb); return; }
     const int nw = blockDim.x >> 6, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int s = t.s, b = t.b, L = s + b;
@@ -441,6 +443,7 @@ __global__ __launch_bounds__(64 * ND_BW) void k_nd_up_b(const Tile* __restrict__
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sb = sm;
     const Tile t = load_tile(tiles, blockIdx.x);
+    if (t.store == 3) return;                   // padding of the XCD-aware tile order
     if (t.store == 2) { store_bprime<K>(t, perm, mask, slots, b_in, bprime); return; }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int s = t.s, b = t.b;
@@ -494,6 +497,7 @@ __global__ __launch_bounds__(64 * ND_BW) void k_nd_down_b(const Tile* __restrict
     float* sb = sm;
     float* sx = sm + (size_t)s_cap * K;
     const Tile t = load_tile(tiles, blockIdx.x);
+    if (t.forward == 2) return;                 // padding of the XCD-aware tile order
     if (t.forward) { forward_rows<K>(t, push_ptr, push_tgt, xb); return; }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int s = t.s, b = t.b;
@@ -611,6 +615,7 @@ __global__ __launch_bounds__(256) void k_nd_down_s(const Tile* __restrict__ tile
     float* sx = sm + (size_t)s_cap * K;              // b_cap * K
     float* mf = sx + (size_t)b_cap * K;              // s * s: Finv, mf[t * s + j]
     const Tile t = load_tile(tiles, blockIdx.x);
+    if (t.forward == 2) return;                 // padding of the XCD-aware tile order
     if (t.forward) { forward_rows<K>(t, push_ptr, push_tgt, xb); return; }
     const int s = t.s, b = t.b, j = threadIdx.x;
     float* mw = mf + (size_t)s * s;                  // b * s: W, mw[i * s + j]
@@ -1388,6 +1393,7 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
         if (p.down_p) { pack_level(false, p.down_p_first, p.down_p_tiles, p.down_p_s, p.down_p_lds); p.down_s = 0; p.down_b = 0; }
         p.up_first = (int)tiles.size();
         const int up_threads = WAVE * p.up_nw;
+        std::vector<int> up_nodes;                                 // node (index within the level) of every tile pushed below
         for (int64_t i = a0; i < a1; ++i) {
             // b' of the own rows is kept for the down sweep: by the first compute tile (small nodes, or nodes whose only
             // tile exists for that purpose), or by store-only tiles of blockDim rows each (large nodes: the one tile
@@ -1397,18 +1403,41 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
             for (int r = 0; r < rows; r += (p.up_s ? 1 << 30 : up_rows)) {
                 tiles.push_back(tile_of(i, r, lv, 0));
                 tiles.back().store = (r == 0 && !store_tiles) ? 1 : 0;
+                up_nodes.push_back((int)(i - a0));
             }
             if (store_tiles)
-                for (int r = 0; r < nodes[i].s; r += up_threads) { tiles.push_back(tile_of(i, r, lv, 0)); tiles.back().store = 2; }
+                for (int r = 0; r < nodes[i].s; r += up_threads) { tiles.push_back(tile_of(i, r, lv, 0)); tiles.back().store = 2; up_nodes.push_back((int)(i - a0)); }
         }
+        // XCD-aware order: workgroup b runs on XCD b % 8 (observed placement, speed only) and every tile of a node re-assembles
+        // the node's reduction vector (slots, masks, b) -- with a node's tiles on ONE XCD those reads hit that XCD's L2 instead of
+        // being fetched once per XCD (PMC, round 3: 55 MB per launch of the row-per-lane up kernel for 29 MB of factor). Levels
+        // with fewer than 8 nodes keep the plain order (a node must not be confined to the 32 CUs of one XCD).
+        auto xcd_order = [&](int first, std::vector<int>& node_of_tile, bool up_sweep) {
+            const int n = (int)tiles.size() - first;
+            if (a1 - a0 < 8 || n < 16 || !env_int0("LS_ND_XCD", 1)) return;
+            std::vector<std::vector<Tile>> bucket(8);
+            for (int t = 0; t < n; ++t) bucket[(size_t)(node_of_tile[(size_t)t] & 7)].push_back(tiles[(size_t)(first + t)]);
+            size_t longest = 0;
+            for (auto& bk : bucket) longest = std::max(longest, bk.size());
+            Tile idle;
+            memset(&idle, 0, sizeof(idle));
+            idle.store = 3; idle.forward = 2;                     // a tile that returns at once (pads the shorter buckets)
+            tiles.resize((size_t)first);
+            for (size_t r = 0; r < longest; ++r)
+                for (int x = 0; x < 8; ++x) tiles.push_back(r < bucket[(size_t)x].size() ? bucket[(size_t)x][r] : idle);
+            (void)up_sweep;
+        };
+        xcd_order(p.up_first, up_nodes, true);
         p.up_tiles = (int)tiles.size() - p.up_first;
         p.down_first = (int)tiles.size();
+        std::vector<int> down_nodes;
         for (int64_t i = a0; i < a1; ++i)
-            for (int r = 0; r < nodes[i].s; r += (p.down_s ? 1 << 30 : down_rows)) tiles.push_back(tile_of(i, r, lv, 0));
+            for (int r = 0; r < nodes[i].s; r += (p.down_s ? 1 << 30 : down_rows)) { tiles.push_back(tile_of(i, r, lv, 0)); down_nodes.push_back((int)(i - a0)); }
         if (lv + 1 < levels)      // forward tiles: boundary rows of every node (staged kernel: only of nodes without own rows)
             for (int64_t i = a0; i < a1; ++i)
                 if (!p.down_s || !nodes[i].s)
-                    for (int r = 0; r < nodes[i].b; r += WAVE * p.down_nw) tiles.push_back(tile_of(i, r, lv, 1));
+                    for (int r = 0; r < nodes[i].b; r += WAVE * p.down_nw) { tiles.push_back(tile_of(i, r, lv, 1)); down_nodes.push_back((int)(i - a0)); }
+        xcd_order(p.down_first, down_nodes, false);
         p.down_tiles = (int)tiles.size() - p.down_first;
         lds_max = std::max(lds_max, ((size_t)p.s_cap + p.b_cap + 16 * WAVE) * d->kmax * sizeof(float));
     }

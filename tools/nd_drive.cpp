@@ -115,7 +115,7 @@ int main(int argc, char** argv) {
         printf("persist %d: %2d launches  %8.2f us per solve   max |x - x*| %.2e   ||b - M x|| / ||b|| %.2e   events: first part %.1f us, last part %.1f us, middle %.1f us\n",
                mode, launches, ms / solves * 1e3, err, sqrt(res / bn), acc[0] * 1e3, acc[1] * 1e3, acc[2] * 1e3);
     }
-    {   // experiments library (-DLS_ND_EXPERIMENTS): where the persistent launch spends its time, from per-workgroup clock stamps
+    if (max_mode >= 1) {   // experiments library (-DLS_ND_EXPERIMENTS): where the persistent launch spends its time, from per-workgroup clock stamps
         int G = 0, P = 0;
         LS(ls_direct_span_stamps(h, nullptr, 0, &G, &P));
         LS(ls_direct_set(h, "profile", 2));
@@ -145,6 +145,7 @@ int main(int argc, char** argv) {
         LS(ls_direct_set(h, "profile", 0));
     }
     double diff = 0;
+    if (max_mode < 1) { LS(ls_direct_destroy(h)); return 0; }
     for (size_t i = 0; i < x0.size(); ++i) diff = std::max(diff, (double)fabsf(x0[i] - x1[i]));
     printf("max |x(persist 1) - x(persist 0)| = %.3e\n", diff);
     // a second run of the persistent path must be bitwise identical to the first

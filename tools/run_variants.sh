@@ -4,11 +4,9 @@
 n=${1:-1000}
 D=tools/build/nd_drive
 [ "${2:-0}" = 1 ] && export ND_DRIVE_TABLE=1
-run() { echo "=== $1"; shift; env "$@" timeout 120 $D $n 200 3 2>&1 | awk '/persist 0:/{print; exit} {print}' | grep -E "persist 0|levels|error|HIP"; }
-run "default" X=1
-run "round-2 rule (LS_ND_INFLIGHT=6, 4 waves)" LS_ND_INFLIGHT=6 LS_ND_BW_LONG=100000
-run "LS_ND_TILES=500" LS_ND_TILES=500
-run "LS_ND_TILES=2000" LS_ND_TILES=2000
-run "LS_ND_BW_LONG=900" LS_ND_BW_LONG=900
-run "LS_ND_BW_LONG=400" LS_ND_BW_LONG=400
-for v in tools/build/v_*; do run "$(basename $v)" LD_LIBRARY_PATH=$v; done
+run() { echo "=== $1"; shift; env "$@" timeout 120 $D $n 300 3 -1 0 2>&1 | grep -E "persist 0|levels|error|HIP"; }
+for rep in 1 2; do
+run "default (XCD-aware tile order)" X=1
+run "LS_ND_XCD=0" LS_ND_XCD=0
+done
+for v in tools/build/v_*; do [ -d $v ] && run "$(basename $v)" LD_LIBRARY_PATH=$v; done
