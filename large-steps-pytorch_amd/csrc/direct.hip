@@ -868,6 +868,7 @@ struct ls_direct {
     int* d_bnd = nullptr;
     float *pslots = nullptr, *bp4 = nullptr, *xt4 = nullptr;
     int span_phases = 0, span_grid = 0, span_lcap = 0, span_words = 0;
+    int tier_xcd = 1;                   // LS_ND_XCD=0 at creation: plain workgroup -> subtree order in the tier kernels
     int exp_ablate = 0, exp_stagger = 0;            // -DLS_ND_EXPERIMENTS builds only (LS_ND_ABLATE / LS_ND_STAGGER at creation)
     long long* span_dbg = nullptr;
     double factor_s[3] = {0, 0, 0};     // ls_direct_factor: symbolic analysis, layout / sparse tables, numeric factorisation
@@ -1273,6 +1274,7 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
         }
     }
     d->fuse_root = getenv("LS_ND_NO_FUSE_ROOT") == nullptr;
+    d->tier_xcd = env_int0("LS_ND_XCD_TIER", env_int0("LS_ND_XCD", 1)) != 0;
 #ifdef LS_ND_EXPERIMENTS
     d->exp_ablate = env_int0("LS_ND_ABLATE", 0); d->exp_stagger = env_int0("LS_ND_STAGGER", 0);
 #endif
@@ -1578,6 +1580,7 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
     ta.sp_ptr = d->sp_ptr; ta.sp_ent = d->sp_ent; ta.bprime = d->bp; ta.braw = d->braw; ta.slots = d->slots; ta.xb = d->xb;
     ta.arity = d->arity; ta.phases = d->tier_phases; ta.region_floats = d->tier_region; ta.vec_floats = d->tier_vec;
     ta.upper_lo = d->upper_lo; ta.upper_hi = (int)d->V;
+    ta.xcd_order = d->tier_xcd;
     ta.dbg = nullptr; ta.ablate = 0; ta.stagger = 0;
 #ifdef LS_ND_EXPERIMENTS
     ta.dbg = d->profile == 2 ? d->dbg : nullptr;

@@ -81,6 +81,7 @@ struct TierArgs {
     float* slots;
     float* xb;
     int arity, phases, region_floats, vec_floats;    // LDS per wave: [vec_floats | partial sums: rounds x 64 x 4]
+    int xcd_order;                                   // 1: workgroup -> subtree map that keeps neighbouring subtrees on one XCD
     // Timing experiments exist only in builds with -DLS_ND_EXPERIMENTS (tools/ubench/Makefile builds such a library next to
     // the product); the product library contains neither the fields' uses nor a way to set them.
     long long* dbg;                                  // experiments, profile = 2: shader-clock stamps, 32 per wave (see k_nd_tier)
@@ -713,7 +714,12 @@ __global__ __launch_bounds__(64 * TIER_WAVES, 4) void k_nd_tier(TierArgs a, cons
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     float* region = sm + (size_t)wave * a.region_floats;
     // workgroup header: up_off[7] | down_off[7] | up_split down_split up_leaf down_leaf | n_dense pad | dense_rng[12]
-    const int hdr = lane < 32 ? reinterpret_cast<const int*>(a.wgs + blockIdx.x)[lane] : 0;
+    // XCD-aware subtree order: workgroup b runs on XCD b % 8 (observed placement, speed only); consecutive subtrees are spatial
+    // neighbours (they share cache lines of b / x in the caller's numbering and of the hand-off arrays), so each XCD takes a
+    // contiguous eighth of them: subtree = (b % 8) * (n / 8) + b / 8
+    const int n_wg = (int)gridDim.x;
+    const int sub = (a.xcd_order && (n_wg & 7) == 0) ? (int)(blockIdx.x & 7) * (n_wg >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int hdr = lane < 32 ? reinterpret_cast<const int*>(a.wgs + sub)[lane] : 0;
     const int obase = UP ? 0 : TIER_MAX_H + 1;
     const unsigned split = (unsigned)rl(hdr, UP ? 14 : 15), leafy = (unsigned)rl(hdr, UP ? 16 : 17);
     tier_stamp(a, 0);

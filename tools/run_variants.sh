@@ -4,9 +4,8 @@
 n=${1:-1000}
 D=tools/build/nd_drive
 [ "${2:-0}" = 1 ] && export ND_DRIVE_TABLE=1
-run() { echo "=== $1"; shift; env "$@" timeout 120 $D $n 300 3 -1 0 2>&1 | grep -E "persist 0|levels|error|HIP"; }
-for rep in 1 2; do
-run "default (XCD-aware tile order)" X=1
-run "LS_ND_XCD=0" LS_ND_XCD=0
+run() { echo "=== $1"; shift; env "$@" timeout 120 $D $n 300 3 -1 0 2>&1 | grep -E "persist 0|levels 5|error|HIP"; }
+for rep in 1 2 3; do
+run "default (XCD-aware subtree order in the tier)" X=1
+run "LS_ND_XCD_TIER=0" LS_ND_XCD_TIER=0
 done
-for v in tools/build/v_*; do [ -d $v ] && run "$(basename $v)" LD_LIBRARY_PATH=$v; done
