@@ -437,6 +437,28 @@ int ls_vertex_normals(const float* verts, const void* faces, int idx_bytes, int6
 int ls_vertex_normals_backward(const float* verts, const void* faces, int idx_bytes, int64_t F, int64_t V, const int32_t* vptr,
                                const int32_t* cpos, const float* fn, const float* raw, const float* norms, const float* g_out,
                                float* grad_verts, float* grad_fn, void* workspace, size_t ws_bytes, int device, void* stream);
+/* The PAIR compute_face_normals -> compute_vertex_normals on one mesh (scripts/main.py:178-179: the face normals handed to
+ * compute_vertex_normals ARE the normalised cross products of the same vertices). Then the two are one function of the
+ * vertices and the passes share work: the face-normal pass also reduces the three edge norms, later passes recompute n_f from
+ * the positions they load anyway instead of reading (3, F), and the backward stores the corner buffer once:
+ *   forward    ls_face_normals_with_norms (fn, norms[3])  ->  ls_vertex_normals_from_norms (out, raw)
+ *   backward   ls_normals_pair_backward_faces: g_raw (V, 3) = gradient of the unnormalised sums, gN[3] = dL/d(edge norms),
+ *              grad_fn (3, F) = what reaches the face normals through the vertex normals -- an OUTPUT of the pair, the
+ *              caller adds what other consumers of the face normals contribute -- then
+ *              ls_normals_pair_backward_verts: grad_verts (V, 3) of everything, g_fn = that total (nullptr: none).
+ * Same values as the separate calls up to the order of a few additions. g_raw / gN are the caller's (they live between the
+ * two backward calls); workspace as above. */
+int ls_face_normals_with_norms(const float* verts, const void* faces, int idx_bytes, int64_t F, int64_t V, float* fn, float* norms,
+                               void* workspace, size_t ws_bytes, int device, void* stream);
+int ls_vertex_normals_from_norms(const float* verts, const void* faces, int idx_bytes, int64_t F, int64_t V, const int32_t* vptr,
+                                 const int32_t* cpos, const float* norms, float* out, float* raw, void* workspace, size_t ws_bytes,
+                                 int device, void* stream);
+int ls_normals_pair_backward_faces(const float* verts, const void* faces, int idx_bytes, int64_t F, int64_t V, const float* raw,
+                                   const float* norms, const float* g_out, float* g_raw, float* gN, float* grad_fn, void* workspace,
+                                   size_t ws_bytes, int device, void* stream);
+int ls_normals_pair_backward_verts(const float* verts, const void* faces, int idx_bytes, int64_t F, int64_t V, const int32_t* vptr,
+                                   const int32_t* cpos, const float* norms, const float* g_raw, const float* gN, const float* g_fn,
+                                   float* grad_verts, void* workspace, size_t ws_bytes, int device, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * AdamUniform step (optimize.py:18-41) on n contiguous fp32 elements, two kernels, no host sync:

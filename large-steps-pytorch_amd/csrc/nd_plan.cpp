@@ -30,17 +30,15 @@ int n_threads() {          // read at every build: tests compare the one-thread 
 }
 
 // A pool of host threads that lives for one nd_plan_build call: a round of the bisection issues a handful of short parallel
-// passes (0.1 - 1 ms each, ~150 of them per build), and creating 32 threads for each of them costs more than the passes themselves.
-// The workers SPIN between passes (atomics only; they yield after a while so that an oversubscribed host still makes progress):
-// waking 31 threads through a condition variable and handing out chunks under a mutex cost 0.1 - 0.2 ms per pass -- a third of the
-// bisection's time at 1M vertices. The pool lives for ~0.1 s, so the spinning is cheap.
+// passes, and creating 32 threads for each of them costs more than the passes themselves.
 class Pool {
 public:
     explicit Pool(int threads) {
         for (int t = 1; t < threads; ++t) th_.emplace_back([this] { worker(); });
     }
     ~Pool() {
-        stop_.store(true, std::memory_order_release);
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        cv_.notify_all();
         for (auto& t : th_) t.join();
     }
     int size() const { return (int)th_.size() + 1; }
@@ -53,56 +51,53 @@ public:
             for (int c = 0; c < chunks; ++c) { const int64_t lo = c * step, hi = std::min(n, lo + step); if (lo < hi) fn(c, lo, hi); }
             return;
         }
-        fn_ = &fn; n_ = n; chunks_ = chunks; step_ = (n + chunks - 1) / chunks;
-        next_.store(0, std::memory_order_relaxed);
-        pending_.store(chunks, std::memory_order_release);            // a worker that reads a non-zero count (acquire) sees the pass's state
-        gen_.fetch_add(1, std::memory_order_release);                 // wakes the spinning workers
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fn_ = &fn; n_ = n; chunks_ = chunks; step_ = (n + chunks - 1) / chunks; next_ = 0; pending_ = chunks; ++gen_;
+        }
+        cv_.notify_all();
         work();
-        for (int spins = 0; pending_.load(std::memory_order_acquire) != 0; ++spins) relax(spins);
-        // every worker has left work() for this pass before the next one is published: wait for them to be idle
-        for (int spins = 0; active_.load(std::memory_order_acquire) != 0; ++spins) relax(spins);
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [&] { return pending_ == 0; });
         fn_ = nullptr;
     }
 
 private:
-    static void relax(int spins) {
-        if (spins < 4096) {
-#if defined(__x86_64__) || defined(__i386__)
-            __builtin_ia32_pause();
-#endif
-        } else std::this_thread::yield();
-    }
     void work() {
         for (;;) {
-            const int c = next_.fetch_add(1, std::memory_order_relaxed);
-            if (c >= chunks_) return;
-            const int64_t lo = (int64_t)c * step_, hi = std::min(n_, lo + step_);
-            if (lo < hi) (*fn_)(c, lo, hi);
-            pending_.fetch_sub(1, std::memory_order_release);
+            const std::function<void(int, int64_t, int64_t)>* fn;
+            int c;
+            int64_t lo, hi;
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (!fn_ || next_ >= chunks_) return;
+                c = next_++; fn = fn_; lo = c * step_; hi = std::min(n_, lo + step_);
+            }
+            if (lo < hi) (*fn)(c, lo, hi);
+            std::lock_guard<std::mutex> lk(m_);
+            if (--pending_ == 0) done_.notify_all();
         }
     }
     void worker() {
         uint64_t seen = 0;
-        for (int spins = 0;; ++spins) {
-            if (stop_.load(std::memory_order_acquire)) return;
-            const uint64_t g = gen_.load(std::memory_order_acquire);
-            if (g == seen) { relax(spins); continue; }
-            active_.fetch_add(1, std::memory_order_acq_rel);
-            // the pass may already be over (and the next one published) by the time this worker looks: re-read the generation
-            // under the `active` count -- run() does not publish a new pass while a worker is active
-            seen = gen_.load(std::memory_order_acquire);
-            if (pending_.load(std::memory_order_acquire) != 0) work();
-            active_.fetch_sub(1, std::memory_order_release);
-            spins = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+            }
+            work();
         }
     }
     std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
     const std::function<void(int, int64_t, int64_t)>* fn_ = nullptr;
     int64_t n_ = 0, step_ = 0;
-    int chunks_ = 0;
-    std::atomic<int> next_{0}, pending_{0}, active_{0};
-    std::atomic<uint64_t> gen_{0};
-    std::atomic<bool> stop_{false};
+    int chunks_ = 0, next_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
 };
 
 thread_local Pool* g_pool = nullptr;      // the pool of the nd_plan_build call running on this thread

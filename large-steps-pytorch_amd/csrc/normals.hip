@@ -132,13 +132,13 @@ __global__ __launch_bounds__(BLOCK) void k_edge_norm_partials(const float* __res
     }
 }
 
-// out[i] = (take_sqrt ? sqrt : id)(sum of the G partials of slot i), i < 3, one workgroup, fixed order
-__global__ __launch_bounds__(BLOCK) void k_finish3(const double* __restrict__ part, int G, int take_sqrt, float* __restrict__ out) {
+// out[i] = (take_sqrt ? sqrt : id)(sum of the G partials of slot i), i < 3, one workgroup, fixed order; P = slots per row of `part`
+__global__ __launch_bounds__(BLOCK) void k_finish3(const double* __restrict__ part, int G, int P, int take_sqrt, float* __restrict__ out) {
     __shared__ double smem[3 * (BLOCK / WAVE)];
     double acc[3] = {0.0, 0.0, 0.0};
     for (int g = threadIdx.x; g < G; g += BLOCK) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) acc[i] += part[(size_t)i * NRM_MAXG + g];
+        for (int i = 0; i < 3; ++i) acc[i] += part[(size_t)i * P + g];
     }
     block_sum3(acc, smem);
     if (threadIdx.x == 0) {
@@ -291,7 +291,187 @@ __global__ __launch_bounds__(BLOCK) void k_vertex_normals_bwd2(const float* __re
     }
 }
 
+// ---- the pair compute_face_normals -> compute_vertex_normals on ONE mesh (scripts/main.py:178-179) -------------------------
+// When the face normals handed to compute_vertex_normals ARE the normalised cross products of the same vertices, the pair is
+// one function of the vertices and the passes can share work: the face-normal pass also accumulates the three edge norms; the
+// later passes recompute n_f from the positions they load anyway (the library is built with -ffp-contract=off: the same
+// expression gives the same bits as the stored array) instead of reading (3, F); and the backward writes the corner buffer
+// ONCE -- the vertex-normal pass and the face-normal pass of the chain rule run as one kernel over the faces.
+//
+// Workgroup -> block of faces: workgroup b runs on XCD b % 8 (observed placement, speed only). Neighbouring face blocks share
+// vertices (gathers) and corner-buffer lines (the 6 corners of a vertex are 72 contiguous bytes written by up to 6 faces), so
+// every XCD takes a contiguous eighth of the blocks and those lines meet in ONE L2.
+__device__ __forceinline__ int64_t xcd_block() {
+    const int per = (int)gridDim.x >> 3, b = (int)blockIdx.x;
+    return b < 8 * per ? (int64_t)(b & 7) * per + (b >> 3) : (int64_t)b;
+}
+
+struct FaceGeo { float a[3], b[3], n[3], len; };
+__device__ __forceinline__ FaceGeo face_geo(const float (&p)[3][3]) {
+    FaceGeo g;
+    float c[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { g.a[q] = p[1][q] - p[0][q]; g.b[q] = p[2][q] - p[0][q]; }
+    cross3(g.a, g.b, c);
+    g.len = sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) g.n[q] = c[q] / g.len;
+    return g;
+}
+
+// face normals + the partial sums of |e01|^2, |e02|^2, |e12|^2 of this workgroup's faces (slot = its block of faces)
+template <typename IDX>
+__global__ __launch_bounds__(BLOCK) void k_face_normals_norms(const float* __restrict__ verts, const IDX* __restrict__ faces, int64_t F,
+                                                              float* __restrict__ fn, double* __restrict__ part, int P) {
+    __shared__ double smem[3 * (BLOCK / WAVE)];
+    const int64_t blk = xcd_block(), f = blk * BLOCK + threadIdx.x;
+    double acc[3] = {0.0, 0.0, 0.0};
+    if (f < F) {
+        int id[3];
+        float p[3][3];
+        load_face(faces, f, verts, id, p);
+        const FaceGeo g = face_geo(p);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            fn[(size_t)q * F + f] = g.n[q];
+            const float e12 = p[2][q] - p[1][q];
+            acc[0] += (double)(g.a[q] * g.a[q]); acc[1] += (double)(g.b[q] * g.b[q]); acc[2] += (double)(e12 * e12);
+        }
+    }
+    block_sum3(acc, smem);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) part[(size_t)i * P + blk] = acc[i];
+    }
+}
+
+// the corner vectors n_f * theta_i with n_f recomputed
+template <typename IDX>
+__global__ __launch_bounds__(BLOCK) void k_vertex_normals_scatter_geo(const float* __restrict__ verts, const IDX* __restrict__ faces, int64_t F,
+                                                                      const float* __restrict__ norms, const int* __restrict__ cpos,
+                                                                      float* __restrict__ corner) {
+    const int64_t f = xcd_block() * BLOCK + threadIdx.x;
+    if (f >= F) return;
+    int id[3];
+    float p[3][3];
+    load_face(faces, f, verts, id, p);
+    const int c0 = cpos[f * 3], c1 = cpos[f * 3 + 1], c2 = cpos[f * 3 + 2];
+    const FaceGeo g = face_geo(p);
+    const int cp[3] = {c0, c1, c2};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const Corner c = corner_of(p, i, norms);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) corner[(size_t)cp[i] * 3 + q] = g.n[q] * c.theta;
+    }
+}
+
+// first half of the pair's backward: the gradient that reaches the face normals (an output of the pair: other consumers
+// may add to it) and the partial sums of dL/dN for the three global norms; nothing is scattered
+template <typename IDX>
+__global__ __launch_bounds__(BLOCK) void k_pair_bwd_face(const float* __restrict__ verts, const IDX* __restrict__ faces, int64_t F,
+                                                         const float* __restrict__ norms, const float* __restrict__ g_raw,
+                                                         float* __restrict__ grad_fn, double* __restrict__ part, int P) {
+    __shared__ double smem[3 * (BLOCK / WAVE)];
+    const int64_t blk = xcd_block(), f = blk * BLOCK + threadIdx.x;
+    double gN[3] = {0.0, 0.0, 0.0};
+    if (f < F) {
+        int id[3];
+        float p[3][3], gr[3][3], gf[3] = {0.0f, 0.0f, 0.0f};
+        load_face(faces, f, verts, id, p);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) gr[i][q] = g_raw[(size_t)id[i] * 3 + q];
+        }
+        const FaceGeo g = face_geo(p);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const Corner c = corner_of(p, i, norms);
+            float gth = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { gf[q] += c.theta * gr[i][q]; gth += g.n[q] * gr[i][q]; }
+            const float gs = gth * dtheta_ds(c.s);
+            gN[c.na] += (double)(gs * (-c.s / c.Na));
+            gN[c.nb] += (double)(gs * (-c.s / c.Nb));
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) grad_fn[(size_t)q * F + f] = gf[q];
+    }
+    block_sum3(gN, smem);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) part[(size_t)i * P + blk] = gN[i];
+    }
+}
+
+// second half: everything that reaches the vertices, one corner vector per corner -- through the corner angles and the three
+// global norms (the vertex-normal pass, as k_vertex_normals_bwd2) and through n_f = c / |c| with the TOTAL gradient of the
+// face normals g_fn (the face-normal pass, as k_face_normals_bwd; nullptr = no gradient reached them)
+template <typename IDX>
+__global__ __launch_bounds__(BLOCK) void k_pair_bwd_verts(const float* __restrict__ verts, const IDX* __restrict__ faces, int64_t F,
+                                                          const float* __restrict__ norms, const float* __restrict__ g_raw,
+                                                          const float* __restrict__ gN, const float* __restrict__ g_fn,
+                                                          const int* __restrict__ cpos, float* __restrict__ corner) {
+    const int64_t f = xcd_block() * BLOCK + threadIdx.x;
+    if (f >= F) return;
+    int id[3];
+    float p[3][3], gr[3][3], gv[3][3], gt[3] = {0.0f, 0.0f, 0.0f};
+    load_face(faces, f, verts, id, p);
+    const int cp[3] = {cpos[f * 3], cpos[f * 3 + 1], cpos[f * 3 + 2]};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { gr[i][q] = g_raw[(size_t)id[i] * 3 + q]; gv[i][q] = 0.0f; }
+    }
+    if (g_fn) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) gt[q] = g_fn[(size_t)q * F + f];
+    }
+    const FaceGeo g = face_geo(p);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const Corner c = corner_of(p, i, norms);
+        float gth = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) gth += g.n[q] * gr[i][q];
+        const float w = gth * dtheta_ds(c.s) / (c.Na * c.Nb);
+        const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float ga = w * c.eb[q], gb = w * c.ea[q];
+            gv[i1][q] += ga; gv[i2][q] += gb; gv[i][q] -= ga + gb;
+        }
+    }
+    const float w01 = gN[0] / norms[0], w02 = gN[1] / norms[1], w12 = gN[2] / norms[2];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const float e12 = p[2][q] - p[1][q];
+        gv[1][q] += w01 * g.a[q]; gv[0][q] -= w01 * g.a[q];
+        gv[2][q] += w02 * g.b[q]; gv[0][q] -= w02 * g.b[q];
+        gv[2][q] += w12 * e12; gv[1][q] -= w12 * e12;
+    }
+    if (g_fn) {
+        float ng = 0.0f, gc[3], ga[3], gb[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) ng += g.n[q] * gt[q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) gc[q] = (gt[q] - g.n[q] * ng) / g.len;
+        cross3(g.b, gc, ga);
+        cross3(gc, g.a, gb);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { gv[1][q] += ga[q]; gv[2][q] += gb[q]; gv[0][q] += -ga[q] - gb[q]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) corner[(size_t)cp[i] * 3 + q] = gv[i][q];
+    }
+}
+
 static int reduce_grid(int64_t F) { return (int)std::min<int64_t>(NRM_MAXG, std::max<int64_t>(1, div_up(F, BLOCK))); }
+// slots per row of the partial-sum array: the looping reductions use NRM_MAXG, the per-block ones one per block of faces
+static int64_t part_slots(int64_t F) { return std::max<int64_t>(NRM_MAXG, div_up(std::max<int64_t>(F, 1), BLOCK)); }
 
 }  // namespace ls
 
@@ -304,8 +484,8 @@ using namespace ls;
 
 extern "C" int ls_normals_workspace_bytes(int64_t F, int64_t V, size_t* h_bytes) {
     LS_REQUIRE(h_bytes && F >= 0 && V >= 0, LS_E_INVALID, "ls_normals_workspace_bytes: bad argument");
-    // reduction partials | 4 floats | g_raw (V, 3) | one 3-vector per corner (3 F, 3)
-    *h_bytes = sizeof(double) * 3 * NRM_MAXG + sizeof(float) * 4 + sizeof(float) * 3 * (size_t)std::max<int64_t>(V, 1) +
+    // reduction partials (one slot per block of faces) | 4 floats | g_raw (V, 3) | one 3-vector per corner (3 F, 3)
+    *h_bytes = sizeof(double) * 3 * (size_t)part_slots(F) + sizeof(float) * 4 + sizeof(float) * 3 * (size_t)std::max<int64_t>(V, 1) +
                sizeof(float) * 9 * (size_t)std::max<int64_t>(F, 1);
     return LS_OK;
 }
@@ -317,10 +497,10 @@ static int check_mesh_args(const void* verts, const void* faces, int idx_bytes, 
 }
 
 struct NormalsWs { double* part; float* gN; float* g_raw; float* corner; };
-static NormalsWs carve(void* workspace, int64_t V) {
+static NormalsWs carve(void* workspace, int64_t V, int64_t F) {
     NormalsWs w;
     w.part = (double*)workspace;
-    w.gN = (float*)(w.part + 3 * NRM_MAXG);
+    w.gN = (float*)(w.part + 3 * part_slots(F));
     w.g_raw = w.gN + 4;
     w.corner = w.g_raw + 3 * (size_t)std::max<int64_t>(V, 1);
     return w;
@@ -352,7 +532,7 @@ extern "C" int ls_face_normals_backward(const float* verts, const void* faces, i
     DeviceGuard g(device);
     LS_HIP(g.err);
     hipStream_t st = (hipStream_t)stream;
-    const NormalsWs w = carve(workspace, V);
+    const NormalsWs w = carve(workspace, V, F);
     if (F > 0)
         LS_IDX(idx_bytes, hipLaunchKernelGGL(k_face_normals_bwd<IDX>, dim3(div_up(F, BLOCK)), dim3(BLOCK), 0, st, verts, (const IDX*)faces, F, g_fn,
                                              cpos, w.corner));
@@ -374,11 +554,11 @@ extern "C" int ls_vertex_normals(const float* verts, const void* faces, int idx_
     DeviceGuard g(device);
     LS_HIP(g.err);
     hipStream_t st = (hipStream_t)stream;
-    const NormalsWs w = carve(workspace, V);
+    const NormalsWs w = carve(workspace, V, F);
     if (F > 0) {
         const int G = reduce_grid(F);
         LS_IDX(idx_bytes, hipLaunchKernelGGL(k_edge_norm_partials<IDX>, dim3(G), dim3(BLOCK), 0, st, verts, (const IDX*)faces, F, w.part));
-        hipLaunchKernelGGL(k_finish3, dim3(1), dim3(BLOCK), 0, st, (const double*)w.part, G, 1, norms);
+        hipLaunchKernelGGL(k_finish3, dim3(1), dim3(BLOCK), 0, st, (const double*)w.part, G, NRM_MAXG, 1, norms);
         LS_IDX(idx_bytes, hipLaunchKernelGGL(k_vertex_normals_scatter<IDX>, dim3(div_up(F, BLOCK)), dim3(BLOCK), 0, st, verts, (const IDX*)faces,
                                              F, fn, (const float*)norms, cpos, w.corner));
     } else {
@@ -402,16 +582,109 @@ extern "C" int ls_vertex_normals_backward(const float* verts, const void* faces,
     DeviceGuard g(device);
     LS_HIP(g.err);
     hipStream_t st = (hipStream_t)stream;
-    const NormalsWs w = carve(workspace, V);
+    const NormalsWs w = carve(workspace, V, F);
     if (F > 0) {
         hipLaunchKernelGGL(k_normalize_rows_bwd, dim3(div_up(V, BLOCK)), dim3(BLOCK), 0, st, raw, g_out, V, w.g_raw);
         const int G = reduce_grid(F);
         LS_IDX(idx_bytes, hipLaunchKernelGGL(k_vertex_normals_bwd1<IDX>, dim3(G), dim3(BLOCK), 0, st, verts, (const IDX*)faces, F, fn, norms,
                                              (const float*)w.g_raw, grad_fn, w.part));
-        hipLaunchKernelGGL(k_finish3, dim3(1), dim3(BLOCK), 0, st, (const double*)w.part, G, 0, w.gN);
+        hipLaunchKernelGGL(k_finish3, dim3(1), dim3(BLOCK), 0, st, (const double*)w.part, G, NRM_MAXG, 0, w.gN);
         LS_IDX(idx_bytes, hipLaunchKernelGGL(k_vertex_normals_bwd2<IDX>, dim3(div_up(F, BLOCK)), dim3(BLOCK), 0, st, verts, (const IDX*)faces, F, fn,
                                              norms, (const float*)w.g_raw, (const float*)w.gN, cpos, w.corner));
     }
+    hipLaunchKernelGGL(k_gather_corners, dim3(div_up(V, BLOCK)), dim3(BLOCK), 0, st, vptr, (const float*)w.corner, V, grad_verts,
+                       (float*)nullptr);
+    LS_HIP(hipGetLastError());
+    return LS_OK;
+}
+
+// ---- the pair on one mesh (see k_face_normals_norms) ---------------------------------------------------------------------
+extern "C" int ls_face_normals_with_norms(const float* verts, const void* faces, int idx_bytes, int64_t F, int64_t V, float* fn, float* norms,
+                                          void* workspace, size_t ws_bytes, int device, void* stream) {
+    int rc = check_mesh_args(verts, faces, idx_bytes, F, V, "ls_face_normals_with_norms");
+    if (rc) return rc;
+    size_t need = 0;
+    ls_normals_workspace_bytes(F, V, &need);
+    LS_REQUIRE((fn || F == 0) && norms && workspace, LS_E_INVALID, "ls_face_normals_with_norms: null argument");
+    LS_REQUIRE(ws_bytes >= need, LS_E_WORKSPACE, "ls_face_normals_with_norms: workspace too small (%zu < %zu bytes)", ws_bytes, need);
+    DeviceGuard g(device);
+    LS_HIP(g.err);
+    hipStream_t st = (hipStream_t)stream;
+    if (F == 0) { LS_HIP(hipMemsetAsync(norms, 0, sizeof(float) * 3, st)); return LS_OK; }
+    const NormalsWs w = carve(workspace, V, F);
+    const int G = (int)div_up(F, BLOCK), P = (int)part_slots(F);
+    LS_IDX(idx_bytes, hipLaunchKernelGGL(k_face_normals_norms<IDX>, dim3(G), dim3(BLOCK), 0, st, verts, (const IDX*)faces, F, fn, w.part, P));
+    hipLaunchKernelGGL(k_finish3, dim3(1), dim3(BLOCK), 0, st, (const double*)w.part, G, P, 1, norms);
+    LS_HIP(hipGetLastError());
+    return LS_OK;
+}
+
+extern "C" int ls_vertex_normals_from_norms(const float* verts, const void* faces, int idx_bytes, int64_t F, int64_t V, const int32_t* vptr,
+                                            const int32_t* cpos, const float* norms, float* out, float* raw, void* workspace,
+                                            size_t ws_bytes, int device, void* stream) {
+    int rc = check_mesh_args(verts, faces, idx_bytes, F, V, "ls_vertex_normals_from_norms");
+    if (rc) return rc;
+    size_t need = 0;
+    ls_normals_workspace_bytes(F, V, &need);
+    LS_REQUIRE(out && raw && norms && workspace && vptr && (cpos || F == 0), LS_E_INVALID, "ls_vertex_normals_from_norms: null argument");
+    LS_REQUIRE(ws_bytes >= need, LS_E_WORKSPACE, "ls_vertex_normals_from_norms: workspace too small (%zu < %zu bytes)", ws_bytes, need);
+    DeviceGuard g(device);
+    LS_HIP(g.err);
+    hipStream_t st = (hipStream_t)stream;
+    const NormalsWs w = carve(workspace, V, F);
+    if (F > 0)
+        LS_IDX(idx_bytes, hipLaunchKernelGGL(k_vertex_normals_scatter_geo<IDX>, dim3(div_up(F, BLOCK)), dim3(BLOCK), 0, st, verts, (const IDX*)faces,
+                                             F, norms, cpos, w.corner));
+    hipLaunchKernelGGL(k_gather_corners, dim3(div_up(V, BLOCK)), dim3(BLOCK), 0, st, vptr, (const float*)w.corner, V, raw, out);
+    LS_HIP(hipGetLastError());
+    return LS_OK;
+}
+
+extern "C" int ls_normals_pair_backward_faces(const float* verts, const void* faces, int idx_bytes, int64_t F, int64_t V, const float* raw,
+                                              const float* norms, const float* g_out, float* g_raw, float* gN, float* grad_fn,
+                                              void* workspace, size_t ws_bytes, int device, void* stream) {
+    int rc = check_mesh_args(verts, faces, idx_bytes, F, V, "ls_normals_pair_backward_faces");
+    if (rc) return rc;
+    size_t need = 0;
+    ls_normals_workspace_bytes(F, V, &need);
+    LS_REQUIRE(raw && norms && g_out && g_raw && gN && workspace && (grad_fn || F == 0), LS_E_INVALID,
+               "ls_normals_pair_backward_faces: null argument");
+    LS_REQUIRE(ws_bytes >= need, LS_E_WORKSPACE, "ls_normals_pair_backward_faces: workspace too small (%zu < %zu bytes)", ws_bytes, need);
+    DeviceGuard g(device);
+    LS_HIP(g.err);
+    hipStream_t st = (hipStream_t)stream;
+    const NormalsWs w = carve(workspace, V, F);
+    hipLaunchKernelGGL(k_normalize_rows_bwd, dim3(div_up(V, BLOCK)), dim3(BLOCK), 0, st, raw, g_out, V, g_raw);
+    if (F > 0) {
+        const int G = (int)div_up(F, BLOCK), P = (int)part_slots(F);
+        LS_IDX(idx_bytes, hipLaunchKernelGGL(k_pair_bwd_face<IDX>, dim3(G), dim3(BLOCK), 0, st, verts, (const IDX*)faces, F, norms, (const float*)g_raw,
+                                             grad_fn, w.part, P));
+        hipLaunchKernelGGL(k_finish3, dim3(1), dim3(BLOCK), 0, st, (const double*)w.part, G, P, 0, gN);
+    } else {
+        LS_HIP(hipMemsetAsync(gN, 0, sizeof(float) * 3, st));
+    }
+    LS_HIP(hipGetLastError());
+    return LS_OK;
+}
+
+extern "C" int ls_normals_pair_backward_verts(const float* verts, const void* faces, int idx_bytes, int64_t F, int64_t V, const int32_t* vptr,
+                                              const int32_t* cpos, const float* norms, const float* g_raw, const float* gN,
+                                              const float* g_fn, float* grad_verts, void* workspace, size_t ws_bytes, int device,
+                                              void* stream) {
+    int rc = check_mesh_args(verts, faces, idx_bytes, F, V, "ls_normals_pair_backward_verts");
+    if (rc) return rc;
+    size_t need = 0;
+    ls_normals_workspace_bytes(F, V, &need);
+    LS_REQUIRE(norms && g_raw && gN && grad_verts && workspace && vptr && (cpos || F == 0), LS_E_INVALID,
+               "ls_normals_pair_backward_verts: null argument");
+    LS_REQUIRE(ws_bytes >= need, LS_E_WORKSPACE, "ls_normals_pair_backward_verts: workspace too small (%zu < %zu bytes)", ws_bytes, need);
+    DeviceGuard g(device);
+    LS_HIP(g.err);
+    hipStream_t st = (hipStream_t)stream;
+    const NormalsWs w = carve(workspace, V, F);
+    if (F > 0)
+        LS_IDX(idx_bytes, hipLaunchKernelGGL(k_pair_bwd_verts<IDX>, dim3(div_up(F, BLOCK)), dim3(BLOCK), 0, st, verts, (const IDX*)faces, F, norms,
+                                             g_raw, gN, g_fn, cpos, w.corner));
     hipLaunchKernelGGL(k_gather_corners, dim3(div_up(V, BLOCK)), dim3(BLOCK), 0, st, vptr, (const float*)w.corner, V, grad_verts,
                        (float*)nullptr);
     LS_HIP(hipGetLastError());

@@ -74,6 +74,13 @@ _SIGNATURES = {
                                   c_void_p, c_size_t, c_int, c_void_p]),
     "ls_vertex_normals_backward": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "ls_face_normals_with_norms": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "ls_vertex_normals_from_norms": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_void_p, c_size_t, c_int, c_void_p]),
+    "ls_normals_pair_backward_faces": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "ls_normals_pair_backward_verts": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "ls_direct_tier_stamps": (c_int, [c_void_p, c_void_p, c_i64]),
     "ls_direct_span_stamps": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
     "ls_shard_plan_create": (c_int, [c_i64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),

@@ -10,6 +10,8 @@ forward and backward are a handful of hand-written HIP kernels each (csrc/normal
 There is no CPU path.
 """
 import ctypes
+import os
+import threading
 import weakref
 
 import torch
@@ -81,71 +83,163 @@ def _workspace(F, V, dev):
     return torch.empty(n.value, dtype=torch.uint8, device=dev)
 
 
+# ---- the pair on one mesh ------------------------------------------------------------------------------------------------
+# scripts/main.py:178-179 calls compute_face_normals and hands its result straight to compute_vertex_normals: the two are then
+# one function of the vertices, and csrc/normals.hip has passes for exactly that case (one reduction less in the forward, the
+# corner buffer written and gathered once in the backward instead of twice). The reference's two-function signature stays; the
+# face-normal tensor carries a tag that says which vertex / face tensors (objects and versions) it was computed from, and
+# compute_vertex_normals takes the shared passes only when it is handed that very tensor together with the same vertices and
+# faces -- a detached copy, a view, face normals from elsewhere or an in-place edit take the general path (face normals as an
+# independent input), exactly as before.
+#
+# Backward of the pair: autograd runs the vertex-normal node first. It returns the gradient that reaches the face normals
+# (other consumers of them may add theirs) and NO gradient for the vertices: that part is handed, through the tag, to the
+# face-normal node, whose single pass over the faces produces the whole vertex gradient. The hand-over is labelled with the
+# id of the running backward call (torch._C._current_graph_task_id): the face-normal node only takes what was left for it
+# in the same call, so a backward that stops at the face normals cannot leak into a later one.
+class _PairTag:
+    __slots__ = ("verts", "verts_version", "faces", "faces_version", "fn", "fn_version", "norms", "pending", "__weakref__")
+
+    def __init__(self, verts, faces, norms):
+        self.verts, self.verts_version = weakref.ref(verts), verts._version
+        self.faces, self.faces_version = weakref.ref(faces), faces._version
+        self.fn, self.fn_version = None, 0
+        self.norms = norms
+        self.pending = {}              # id(ctx of a vertex-normal node) -> (graph task, g_raw, gN)
+
+    def matches(self, verts, faces, fn):
+        return (self.verts() is verts and self.verts_version == verts._version and self.faces() is faces
+                and self.faces_version == faces._version and self.fn is not None and self.fn() is fn and self.fn_version == fn._version)
+
+
+_graph_task_id = getattr(torch._C, "_current_graph_task_id", None)
+_handoff = threading.local()   # .tag: the tag of the face-normal node this thread's forward just ran (picked up by compute_face_normals)
+
+
 class _FaceNormals(Function):
     @staticmethod
     def forward(ctx, verts, faces):
         v, f, vptr, vcorner = _prep(verts, faces)
         F, V, dev = f.shape[0], v.shape[0], v.device
         fn = torch.empty((3, F), dtype=torch.float32, device=dev)
+        norms = torch.empty(3, dtype=torch.float32, device=dev)
+        ws = _workspace(F, V, dev)
         with torch.cuda.device(dev):
-            _native.check(_native.lib().ls_face_normals(_native.ptr(v), _native.ptr(f), f.element_size(), F, V, _native.ptr(fn),
-                                                        dev.index, _native.stream_of(dev)))
+            _native.check(_native.lib().ls_face_normals_with_norms(_native.ptr(v), _native.ptr(f), f.element_size(), F, V, _native.ptr(fn),
+                                                                   _native.ptr(norms), _native.ptr(ws), ws.numel(), dev.index,
+                                                                   _native.stream_of(dev)))
         ctx.save_for_backward(v, f, vptr, vcorner)
+        ctx.set_materialize_grads(False)
+        ctx.tag = _PairTag(verts, faces, norms)
+        _handoff.tag = ctx.tag
         return fn
 
     @staticmethod
     def backward(ctx, g):
         v, f, vptr, vcorner = ctx.saved_tensors
-        if not ctx.needs_input_grad[0]:
+        task = _graph_task_id() if _graph_task_id is not None else -1
+        mine = [e for e in ctx.tag.pending.values() if e[0] == task and task >= 0]
+        ctx.tag.pending.clear()
+        if not ctx.needs_input_grad[0] or (g is None and not mine):
             return None, None
-        g = g.contiguous().to(torch.float32)
-        dev = v.device
-        gv = torch.empty_like(v)
-        ws = _workspace(f.shape[0], v.shape[0], dev)
+        if g is not None:
+            g = g.contiguous().to(torch.float32)
+        F, V, dev = f.shape[0], v.shape[0], v.device
+        ws = _workspace(F, V, dev)
+        lib = _native.lib()
         with torch.cuda.device(dev):
-            _native.check(_native.lib().ls_face_normals_backward(_native.ptr(v), _native.ptr(f), f.element_size(), f.shape[0], v.shape[0],
-                                                                 _native.ptr(vptr), _native.ptr(vcorner), _native.ptr(g), _native.ptr(gv),
+            if not mine:
+                gv = torch.empty_like(v)
+                _native.check(lib.ls_face_normals_backward(_native.ptr(v), _native.ptr(f), f.element_size(), F, V, _native.ptr(vptr),
+                                                           _native.ptr(vcorner), _native.ptr(g), _native.ptr(gv), _native.ptr(ws),
+                                                           ws.numel(), dev.index, _native.stream_of(dev)))
+                return gv, None
+            total = None
+            for k, (_, g_raw, gN) in enumerate(mine):          # one entry unless several vertex-normal nodes share these face normals
+                gv = torch.empty_like(v)
+                _native.check(lib.ls_normals_pair_backward_verts(_native.ptr(v), _native.ptr(f), f.element_size(), F, V, _native.ptr(vptr),
+                                                                 _native.ptr(vcorner), _native.ptr(ctx.tag.norms), _native.ptr(g_raw),
+                                                                 _native.ptr(gN), _native.ptr(g if k == 0 else None), _native.ptr(gv),
                                                                  _native.ptr(ws), ws.numel(), dev.index, _native.stream_of(dev)))
-        return gv, None
+                total = gv if total is None else total + gv
+        return total, None
 
 
 class _VertexNormals(Function):
     @staticmethod
-    def forward(ctx, verts, faces, face_normals):
+    def forward(ctx, verts, faces, face_normals, tag):
         v, f, vptr, vcorner = _prep(verts, faces)
         F, V, dev = f.shape[0], v.shape[0], v.device
         _native.require_device(face_normals, "face_normals")
         if tuple(face_normals.shape) != (3, F):
             raise ValueError(f"face_normals must be (3, {F}), got {tuple(face_normals.shape)}")
-        fn = face_normals.detach().to(torch.float32).contiguous()
         out = torch.empty((V, 3), dtype=torch.float32, device=dev)
         raw = torch.empty((V, 3), dtype=torch.float32, device=dev)
-        norms = torch.empty(3, dtype=torch.float32, device=dev)
         ws = _workspace(F, V, dev)
+        lib = _native.lib()
+        ctx.tag = tag
+        if tag is not None:                                     # the pair: norms are there, n_f is recomputed
+            with torch.cuda.device(dev):
+                _native.check(lib.ls_vertex_normals_from_norms(_native.ptr(v), _native.ptr(f), f.element_size(), F, V, _native.ptr(vptr),
+                                                               _native.ptr(vcorner), _native.ptr(tag.norms), _native.ptr(out), _native.ptr(raw),
+                                                               _native.ptr(ws), ws.numel(), dev.index, _native.stream_of(dev)))
+            ctx.save_for_backward(v, f, raw, vptr, vcorner)
+            return out
+        fn = face_normals.detach().to(torch.float32).contiguous()
+        norms = torch.empty(3, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _native.check(_native.lib().ls_vertex_normals(_native.ptr(v), _native.ptr(f), f.element_size(), F, V, _native.ptr(vptr),
-                                                          _native.ptr(vcorner), _native.ptr(fn), _native.ptr(out), _native.ptr(raw),
-                                                          _native.ptr(norms), _native.ptr(ws), ws.numel(), dev.index, _native.stream_of(dev)))
+            _native.check(lib.ls_vertex_normals(_native.ptr(v), _native.ptr(f), f.element_size(), F, V, _native.ptr(vptr),
+                                                _native.ptr(vcorner), _native.ptr(fn), _native.ptr(out), _native.ptr(raw),
+                                                _native.ptr(norms), _native.ptr(ws), ws.numel(), dev.index, _native.stream_of(dev)))
         ctx.save_for_backward(v, f, fn, raw, norms, vptr, vcorner)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        v, f, fn, raw, norms, vptr, vcorner = ctx.saved_tensors
         if not (ctx.needs_input_grad[0] or ctx.needs_input_grad[2]):
-            return None, None, None
+            return None, None, None, None
         g = g.contiguous().to(torch.float32)
+        lib = _native.lib()
+        tag = ctx.tag
+        if tag is not None:
+            v, f, raw, vptr, vcorner = ctx.saved_tensors
+            F, V, dev = f.shape[0], v.shape[0], v.device
+            ws = _workspace(F, V, dev)
+            g_raw = torch.empty_like(v)
+            gN = torch.empty(4, dtype=torch.float32, device=dev)
+            gfn = torch.empty((3, F), dtype=torch.float32, device=dev)
+            task = _graph_task_id() if _graph_task_id is not None else -1
+            # the face-normal node runs later in this backward call exactly when its output needs a gradient here and the
+            # vertices need one: then it finishes the job (one corner buffer). Otherwise both halves run now.
+            defer = task >= 0 and ctx.needs_input_grad[0] and ctx.needs_input_grad[2]
+            with torch.cuda.device(dev):
+                _native.check(lib.ls_normals_pair_backward_faces(_native.ptr(v), _native.ptr(f), f.element_size(), F, V, _native.ptr(raw),
+                                                                 _native.ptr(tag.norms), _native.ptr(g), _native.ptr(g_raw), _native.ptr(gN),
+                                                                 _native.ptr(gfn), _native.ptr(ws), ws.numel(), dev.index,
+                                                                 _native.stream_of(dev)))
+                if defer:
+                    tag.pending[id(ctx)] = (task, g_raw, gN)
+                    return None, None, gfn, None
+                gv = None
+                if ctx.needs_input_grad[0]:
+                    gv = torch.empty_like(v)
+                    _native.check(lib.ls_normals_pair_backward_verts(_native.ptr(v), _native.ptr(f), f.element_size(), F, V, _native.ptr(vptr),
+                                                                     _native.ptr(vcorner), _native.ptr(tag.norms), _native.ptr(g_raw),
+                                                                     _native.ptr(gN), _native.ptr(None), _native.ptr(gv), _native.ptr(ws),
+                                                                     ws.numel(), dev.index, _native.stream_of(dev)))
+            return gv, None, (gfn if ctx.needs_input_grad[2] else None), None
+        v, f, fn, raw, norms, vptr, vcorner = ctx.saved_tensors
         F, V, dev = f.shape[0], v.shape[0], v.device
         gv = torch.empty_like(v)
         gfn = torch.empty_like(fn)
         ws = _workspace(F, V, dev)
         with torch.cuda.device(dev):
-            _native.check(_native.lib().ls_vertex_normals_backward(_native.ptr(v), _native.ptr(f), f.element_size(), F, V, _native.ptr(vptr),
-                                                                   _native.ptr(vcorner), _native.ptr(fn),
-                                                                   _native.ptr(raw), _native.ptr(norms), _native.ptr(g), _native.ptr(gv),
-                                                                   _native.ptr(gfn), _native.ptr(ws), ws.numel(), dev.index,
-                                                                   _native.stream_of(dev)))
-        return (gv if ctx.needs_input_grad[0] else None), None, (gfn if ctx.needs_input_grad[2] else None)
+            _native.check(lib.ls_vertex_normals_backward(_native.ptr(v), _native.ptr(f), f.element_size(), F, V, _native.ptr(vptr),
+                                                         _native.ptr(vcorner), _native.ptr(fn),
+                                                         _native.ptr(raw), _native.ptr(norms), _native.ptr(g), _native.ptr(gv),
+                                                         _native.ptr(gfn), _native.ptr(ws), ws.numel(), dev.index,
+                                                         _native.stream_of(dev)))
+        return (gv if ctx.needs_input_grad[0] else None), None, (gfn if ctx.needs_input_grad[2] else None), None
 
 
 def compute_face_normals(verts, faces):
@@ -159,7 +253,12 @@ def compute_face_normals(verts, faces):
     faces : torch.Tensor
         Triangle faces (F, 3), int32 or int64
     """
-    return _FaceNormals.apply(verts, faces)
+    fn = _FaceNormals.apply(verts, faces)
+    tag, _handoff.tag = getattr(_handoff, "tag", None), None
+    if tag is not None:                            # tag the result: compute_vertex_normals recognises the pair by it
+        tag.fn, tag.fn_version = weakref.ref(fn), fn._version
+        fn._largesteps_pair = tag
+    return fn
 
 
 def compute_vertex_normals(verts, faces, face_normals):
@@ -175,4 +274,7 @@ def compute_vertex_normals(verts, faces, face_normals):
     face_normals : torch.Tensor
         Per-face normals (3, F), normally the output of `compute_face_normals`
     """
-    return _VertexNormals.apply(verts, faces, face_normals)
+    tag = getattr(face_normals, "_largesteps_pair", None)
+    if tag is not None and not (tag.matches(verts, faces, face_normals) and os.environ.get("LARGESTEPS_NORMALS_PAIR", "1") != "0"):
+        tag = None
+    return _VertexNormals.apply(verts, faces, face_normals, tag)

@@ -100,6 +100,51 @@ def test_hip_vs_reference(ref, dev, name, idx):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", MESHES)
+def test_hip_pair_paths_vs_reference(ref, dev, name, monkeypatch):
+    """compute_face_normals -> compute_vertex_normals on one mesh share passes (one corner buffer in the backward, the
+    vertex gradient finished by the face-normal node). Every way the two nodes can meet in a backward call must give the
+    reference's gradients: both outputs used, a backward that stops at the face normals followed by one that does not, two
+    vertex-normal nodes on one face-normal tensor, and the general path (LARGESTEPS_NORMALS_PAIR=0) next to the pair."""
+    from largesteps.normals import compute_face_normals, compute_vertex_normals
+    v, f = ref[f"{name}/verts"], ref[f"{name}/faces"]
+    tv, tf = _t(v, dev).requires_grad_(True), _t(f, dev)
+    w_v, w_f = _t(ref[f"{name}/w_v"], dev), _t(ref[f"{name}/w_f"], dev)
+    g_all, g_face = ref[f"{name}/grad_all"], ref[f"{name}/grad_face"]
+    tol = 2e-5 * max(np.abs(g_all).max(), 1e-3) + 1e-5 * max(np.abs(g_face).max(), 1.0)
+    fn = compute_face_normals(tv, tf)
+    vn = compute_vertex_normals(tv, tf, fn)
+    assert getattr(fn, "_largesteps_pair", None) is not None
+    both, = torch.autograd.grad((vn * w_v).sum() + (fn * w_f).sum(), tv, retain_graph=True)
+    close(both.cpu().numpy(), g_all + g_face, tol)
+    # a backward that ends at the face normals leaves nothing behind for the next one
+    g_fn, = torch.autograd.grad((vn * w_v).sum(), fn, retain_graph=True)
+    close(g_fn.cpu().numpy(), ref[f"{name}/grad_vn_fn"], 1e-5 * max(np.abs(ref[f"{name}/grad_vn_fn"]).max(), 1.0))
+    only_face, = torch.autograd.grad((fn * w_f).sum(), tv, retain_graph=True)
+    close(only_face.cpu().numpy(), g_face, 1e-5 * max(np.abs(g_face).max(), 1.0))
+    # two vertex-normal nodes on the same face normals
+    vn_b = compute_vertex_normals(tv, tf, fn)
+    twice, = torch.autograd.grad((vn * w_v).sum() + (vn_b * w_v).sum(), tv, retain_graph=True)
+    close(twice.cpu().numpy(), 2 * g_all, 2 * tol)
+    # the pair and the general path agree (values: the same arithmetic; gradients: a different order of a few additions)
+    g_pair, = torch.autograd.grad((vn * w_v).sum(), tv)
+    monkeypatch.setenv("LARGESTEPS_NORMALS_PAIR", "0")
+    fn2 = compute_face_normals(tv, tf)
+    vn2 = compute_vertex_normals(tv, tf, fn2)
+    assert torch.equal(fn2, fn)
+    close(vn2.detach().cpu().numpy(), vn.detach().cpu().numpy(), 1e-6)
+    g_gen, = torch.autograd.grad((vn2 * w_v).sum(), tv)
+    close(g_gen.cpu().numpy(), g_all, tol)
+    close(g_pair.cpu().numpy(), g_all, tol)
+    # face normals computed without a graph: a constant for the vertex normals, in the pair's kernels as well
+    monkeypatch.delenv("LARGESTEPS_NORMALS_PAIR")
+    with torch.no_grad():
+        fn3 = compute_face_normals(tv, tf)
+    g_const, = torch.autograd.grad((compute_vertex_normals(tv, tf, fn3) * w_v).sum(), tv)
+    close(g_const.cpu().numpy(), ref[f"{name}/grad_vn_verts"], 2e-5 * max(np.abs(g_all).max(), 1e-3))
+
+
+@pytest.mark.gpu
 def test_hip_large_mesh_vs_oracle_and_errors(dev):
     from largesteps import synthetic
     from largesteps.normals import compute_face_normals, compute_vertex_normals
