@@ -92,9 +92,24 @@ __global__ __launch_bounds__(BLOCK) void k_gather_corners(const int* __restrict_
                                                           float* __restrict__ dst, float* __restrict__ out) {
     const int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (v >= V) return;
+    const int e0 = vptr[v], e1 = vptr[v + 1];
+    // the first GC corners (a vertex of a triangle mesh has ~6) are requested together, from clamped addresses (no branch between
+    // the loads); the sum runs over them in rank order as before
+    constexpr int GC = 8;
+    float c[GC][3];
+    const int last = max(e1 - 1, e0);            // e1 == e0 (unreferenced vertex): a valid address, the value is not used
+#pragma unroll
+    for (int t = 0; t < GC; ++t) {
+        const size_t e = (size_t)min(e0 + t, last);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) c[t][q] = corner[e * 3 + q];
+    }
     float x = 0.0f, y = 0.0f, z = 0.0f;
-    const int e1 = vptr[v + 1];
-    for (int e = vptr[v]; e < e1; ++e) {
+#pragma unroll
+    for (int t = 0; t < GC; ++t) {
+        if (e0 + t < e1) { x += c[t][0]; y += c[t][1]; z += c[t][2]; }
+    }
+    for (int e = e0 + GC; e < e1; ++e) {
         x += corner[(size_t)e * 3]; y += corner[(size_t)e * 3 + 1]; z += corner[(size_t)e * 3 + 2];
     }
     dst[v * 3] = x; dst[v * 3 + 1] = y; dst[v * 3 + 2] = z;
@@ -132,39 +147,71 @@ __global__ __launch_bounds__(BLOCK) void k_edge_norm_partials(const float* __res
     }
 }
 
-// out[i] = (take_sqrt ? sqrt : id)(sum of the G partials of slot i), i < 3, one workgroup, fixed order; P = slots per row of `part`
-__global__ __launch_bounds__(BLOCK) void k_finish3(const double* __restrict__ part, int G, int P, int take_sqrt, float* __restrict__ out) {
-    __shared__ double smem[3 * (BLOCK / WAVE)];
+// out[i] = (take_sqrt ? sqrt : id)(sum of the G partials of slot i), i < 3, one workgroup of FIN threads, fixed order; P = slots per
+// row of `part`. Everything a thread adds is requested before the first addition (the launch is one round trip + a tree).
+constexpr int FIN = 1024, FIN_U = 4;
+__global__ __launch_bounds__(FIN) void k_finish3(const double* __restrict__ part, int G, int P, int take_sqrt, float* __restrict__ out) {
+    __shared__ double smem[3 * (FIN / WAVE)];
     double acc[3] = {0.0, 0.0, 0.0};
-    for (int g = threadIdx.x; g < G; g += BLOCK) {
+    for (int g0 = threadIdx.x; g0 < G; g0 += FIN * FIN_U) {
+        double v[FIN_U][3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) acc[i] += part[(size_t)i * P + g];
+        for (int u = 0; u < FIN_U; ++u) {
+            const int g = g0 + u * FIN;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) v[u][i] = g < G ? part[(size_t)i * P + g] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < FIN_U; ++u) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) acc[i] += v[u][i];
+        }
     }
-    block_sum3(acc, smem);
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        acc[i] = wave_sum(acc[i]);
+        if (lane == 0) smem[w * 3 + i] = acc[i];
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) out[i] = take_sqrt ? sqrtf((float)acc[i]) : (float)acc[i];
+        for (int i = 0; i < 3; ++i) {
+            double t = 0.0;
+            for (int j = 0; j < FIN / WAVE; ++j) t += smem[j * 3 + i];
+            out[i] = take_sqrt ? sqrtf((float)t) : (float)t;
+        }
     }
 }
 
 // corner i of a face: edges e_a = v[i+1] - v[i], e_b = v[i+2] - v[i]; the global norms they are divided by
-// (index into norms[]: 0 = ||E01||, 1 = ||E02||, 2 = ||E12||); s = sum((e_a / N_a) * (e_b / N_b)), theta = acos(clamp(s))
-struct Corner { float ea[3], eb[3], Na, Nb, s, theta; int na, nb; };
-__device__ __forceinline__ Corner corner_of(const float (&p)[3][3], int i, const float* __restrict__ norms) {
+// (index into norms[]: 0 = ||E01||, 1 = ||E02||, 2 = ||E12||); s = sum((e_a / N_a) * (e_b / N_b)), theta = acos(clamp(s)).
+// The kernels are bound by their arithmetic, not by bytes (2M faces x 3 corners x ~25 IEEE divisions were a third of it): the
+// three reciprocal norms are formed once per thread and s = (e_a . e_b) * (1 / N_a) * (1 / N_b) -- the reference's value up to a
+// few ulp of s (its own fp32 sum has the same freedom), far inside the 1e-6 the parity tests allow on the normals.
+struct InvNorms { float N[3], inv[3]; };
+__device__ __forceinline__ InvNorms inv_norms(const float* __restrict__ norms) {
+    InvNorms n;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { n.N[i] = norms[i]; n.inv[i] = 1.0f / n.N[i]; }
+    return n;
+}
+struct Corner { float ea[3], eb[3], iab, s, theta; int na, nb; };     // iab = 1 / (N_a N_b)
+__device__ __forceinline__ Corner corner_of(const float (&p)[3][3], int i, const InvNorms& nr) {
     Corner c;
     const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
     c.na = i == 0 ? 0 : (i == 1 ? 2 : 1);
     c.nb = i == 0 ? 1 : (i == 1 ? 0 : 2);
-    c.Na = norms[c.na]; c.Nb = norms[c.nb];
+    c.iab = nr.inv[c.na] * nr.inv[c.nb];
     float d = 0.0f;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         c.ea[q] = p[i1][q] - p[i][q];
         c.eb[q] = p[i2][q] - p[i][q];
-        d += (c.ea[q] / c.Na) * (c.eb[q] / c.Nb);
+        d += c.ea[q] * c.eb[q];
     }
-    c.s = d;
-    c.theta = acosf(fminf(fmaxf(d, -1.0f), 1.0f));
+    c.s = d * c.iab;
+    c.theta = acosf(fminf(fmaxf(c.s, -1.0f), 1.0f));
     return c;
 }
 
@@ -172,6 +219,7 @@ template <typename IDX>
 __global__ __launch_bounds__(BLOCK) void k_vertex_normals_scatter(const float* __restrict__ verts, const IDX* __restrict__ faces, int64_t F,
                                                                   const float* __restrict__ fn, const float* __restrict__ norms,
                                                                   const int* __restrict__ cpos, float* __restrict__ corner) {
+    const InvNorms nr = inv_norms(norms);
     const int64_t f = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (f >= F) return;
     int id[3];
@@ -181,7 +229,7 @@ __global__ __launch_bounds__(BLOCK) void k_vertex_normals_scatter(const float* _
     for (int q = 0; q < 3; ++q) n[q] = fn[(size_t)q * F + f];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const Corner c = corner_of(p, i, norms);
+        const Corner c = corner_of(p, i, nr);
 #pragma unroll
         for (int q = 0; q < 3; ++q) corner[(size_t)cpos[f * 3 + i] * 3 + q] = n[q] * c.theta;
     }
@@ -202,7 +250,7 @@ __global__ __launch_bounds__(BLOCK) void k_normalize_rows_bwd(const float* __res
 }
 
 // d theta / d s through acos(clamp(s, -1, 1)): -1 / sqrt(1 - s^2) inside the clamp, 0 outside
-__device__ __forceinline__ float dtheta_ds(float s) { return fabsf(s) < 1.0f ? -1.0f / sqrtf(1.0f - s * s) : 0.0f; }
+__device__ __forceinline__ float dtheta_ds(float s) { return fabsf(s) < 1.0f ? -rsqrtf(1.0f - s * s) : 0.0f; }
 
 // pass 1 of the vertex-normal backward: grad of the face normals (no scatter) and the partial sums of dL/dN for the
 // three global norms
@@ -211,6 +259,7 @@ __global__ __launch_bounds__(BLOCK) void k_vertex_normals_bwd1(const float* __re
                                                                const float* __restrict__ fn, const float* __restrict__ norms,
                                                                const float* __restrict__ g_raw, float* __restrict__ grad_fn,
                                                                double* __restrict__ part) {
+    const InvNorms nr = inv_norms(norms);
     __shared__ double smem[3 * (BLOCK / WAVE)];
     double gN[3] = {0.0, 0.0, 0.0};
     for (int64_t f = (int64_t)blockIdx.x * BLOCK + threadIdx.x; f < F; f += (int64_t)gridDim.x * BLOCK) {
@@ -221,7 +270,7 @@ __global__ __launch_bounds__(BLOCK) void k_vertex_normals_bwd1(const float* __re
         for (int q = 0; q < 3; ++q) n[q] = fn[(size_t)q * F + f];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const Corner c = corner_of(p, i, norms);
+            const Corner c = corner_of(p, i, nr);
             float gth = 0.0f;
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
@@ -230,8 +279,8 @@ __global__ __launch_bounds__(BLOCK) void k_vertex_normals_bwd1(const float* __re
                 gth += n[q] * gr;
             }
             const float gs = gth * dtheta_ds(c.s);
-            gN[c.na] += (double)(gs * (-c.s / c.Na));
-            gN[c.nb] += (double)(gs * (-c.s / c.Nb));
+            gN[c.na] += (double)(gs * (-c.s * nr.inv[c.na]));
+            gN[c.nb] += (double)(gs * (-c.s * nr.inv[c.nb]));
         }
 #pragma unroll
         for (int q = 0; q < 3; ++q) grad_fn[(size_t)q * F + f] = gf[q];
@@ -249,6 +298,7 @@ __global__ __launch_bounds__(BLOCK) void k_vertex_normals_bwd2(const float* __re
                                                                const float* __restrict__ fn, const float* __restrict__ norms,
                                                                const float* __restrict__ g_raw, const float* __restrict__ gN,
                                                                const int* __restrict__ cpos, float* __restrict__ corner) {
+    const InvNorms nr = inv_norms(norms);
     const int64_t f = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (f >= F) return;
     int id[3];
@@ -263,11 +313,11 @@ __global__ __launch_bounds__(BLOCK) void k_vertex_normals_bwd2(const float* __re
     for (int q = 0; q < 3; ++q) n[q] = fn[(size_t)q * F + f];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const Corner c = corner_of(p, i, norms);
+        const Corner c = corner_of(p, i, nr);
         float gth = 0.0f;
 #pragma unroll
         for (int q = 0; q < 3; ++q) gth += n[q] * g_raw[(size_t)id[i] * 3 + q];
-        const float w = gth * dtheta_ds(c.s) / (c.Na * c.Nb);
+        const float w = gth * dtheta_ds(c.s) * c.iab;
         const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -276,7 +326,7 @@ __global__ __launch_bounds__(BLOCK) void k_vertex_normals_bwd2(const float* __re
         }
     }
     // N_ab = sqrt(sum over all faces |v_b - v_a|^2): dN/d(v_b - v_a) = (v_b - v_a) / N
-    const float w01 = gN[0] / norms[0], w02 = gN[1] / norms[1], w12 = gN[2] / norms[2];
+    const float w01 = gN[0] * nr.inv[0], w02 = gN[1] * nr.inv[1], w12 = gN[2] * nr.inv[2];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         const float e01 = p[1][q] - p[0][q], e02 = p[2][q] - p[0][q], e12 = p[2][q] - p[1][q];
@@ -319,23 +369,33 @@ __device__ __forceinline__ FaceGeo face_geo(const float (&p)[3][3]) {
     return g;
 }
 
+// The two face passes that end in a reduction take PF faces per thread (face j of a thread: block * PF * BLOCK + j * BLOCK + thread):
+// the workgroup reduction (3 doubles through DPP + LDS + two barriers) costs as much as a face's arithmetic, and the loads of
+// the PF faces are requested together (clamped addresses, no branch in between).
+constexpr int PF = 4;
+
 // face normals + the partial sums of |e01|^2, |e02|^2, |e12|^2 of this workgroup's faces (slot = its block of faces)
 template <typename IDX>
 __global__ __launch_bounds__(BLOCK) void k_face_normals_norms(const float* __restrict__ verts, const IDX* __restrict__ faces, int64_t F,
                                                               float* __restrict__ fn, double* __restrict__ part, int P) {
     __shared__ double smem[3 * (BLOCK / WAVE)];
-    const int64_t blk = xcd_block(), f = blk * BLOCK + threadIdx.x;
+    const int64_t blk = xcd_block(), f0 = blk * (PF * BLOCK) + threadIdx.x;
     double acc[3] = {0.0, 0.0, 0.0};
-    if (f < F) {
-        int id[3];
-        float p[3][3];
-        load_face(faces, f, verts, id, p);
-        const FaceGeo g = face_geo(p);
+    int id[PF][3];
+    float p[PF][3][3];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            fn[(size_t)q * F + f] = g.n[q];
-            const float e12 = p[2][q] - p[1][q];
-            acc[0] += (double)(g.a[q] * g.a[q]); acc[1] += (double)(g.b[q] * g.b[q]); acc[2] += (double)(e12 * e12);
+    for (int j = 0; j < PF; ++j) load_face(faces, min(f0 + j * BLOCK, F - 1), verts, id[j], p[j]);
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+        const int64_t f = f0 + j * BLOCK;
+        if (f < F) {
+            const FaceGeo g = face_geo(p[j]);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                fn[(size_t)q * F + f] = g.n[q];
+                const float e12 = p[j][2][q] - p[j][1][q];
+                acc[0] += (double)(g.a[q] * g.a[q]); acc[1] += (double)(g.b[q] * g.b[q]); acc[2] += (double)(e12 * e12);
+            }
         }
     }
     block_sum3(acc, smem);
@@ -350,6 +410,7 @@ template <typename IDX>
 __global__ __launch_bounds__(BLOCK) void k_vertex_normals_scatter_geo(const float* __restrict__ verts, const IDX* __restrict__ faces, int64_t F,
                                                                       const float* __restrict__ norms, const int* __restrict__ cpos,
                                                                       float* __restrict__ corner) {
+    const InvNorms nr = inv_norms(norms);
     const int64_t f = xcd_block() * BLOCK + threadIdx.x;
     if (f >= F) return;
     int id[3];
@@ -360,7 +421,7 @@ __global__ __launch_bounds__(BLOCK) void k_vertex_normals_scatter_geo(const floa
     const int cp[3] = {c0, c1, c2};
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const Corner c = corner_of(p, i, norms);
+        const Corner c = corner_of(p, i, nr);
 #pragma unroll
         for (int q = 0; q < 3; ++q) corner[(size_t)cp[i] * 3 + q] = g.n[q] * c.theta;
     }
@@ -372,31 +433,41 @@ template <typename IDX>
 __global__ __launch_bounds__(BLOCK) void k_pair_bwd_face(const float* __restrict__ verts, const IDX* __restrict__ faces, int64_t F,
                                                          const float* __restrict__ norms, const float* __restrict__ g_raw,
                                                          float* __restrict__ grad_fn, double* __restrict__ part, int P) {
+    const InvNorms nr = inv_norms(norms);
     __shared__ double smem[3 * (BLOCK / WAVE)];
-    const int64_t blk = xcd_block(), f = blk * BLOCK + threadIdx.x;
+    const int64_t blk = xcd_block(), f0 = blk * (PF * BLOCK) + threadIdx.x;
     double gN[3] = {0.0, 0.0, 0.0};
-    if (f < F) {
-        int id[3];
-        float p[3][3], gr[3][3], gf[3] = {0.0f, 0.0f, 0.0f};
-        load_face(faces, f, verts, id, p);
+    int id[PF][3];
+    float p[PF][3][3], gr[PF][3][3];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) load_face(faces, min(f0 + j * BLOCK, F - 1), verts, id[j], p[j]);
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) gr[i][q] = g_raw[(size_t)id[i] * 3 + q];
+            for (int q = 0; q < 3; ++q) gr[j][i][q] = g_raw[(size_t)id[j][i] * 3 + q];
         }
-        const FaceGeo g = face_geo(p);
+    }
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const Corner c = corner_of(p, i, norms);
-            float gth = 0.0f;
+    for (int j = 0; j < PF; ++j) {
+        const int64_t f = f0 + j * BLOCK;
+        if (f < F) {
+            float gf[3] = {0.0f, 0.0f, 0.0f};
+            const FaceGeo g = face_geo(p[j]);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) { gf[q] += c.theta * gr[i][q]; gth += g.n[q] * gr[i][q]; }
-            const float gs = gth * dtheta_ds(c.s);
-            gN[c.na] += (double)(gs * (-c.s / c.Na));
-            gN[c.nb] += (double)(gs * (-c.s / c.Nb));
+            for (int i = 0; i < 3; ++i) {
+                const Corner c = corner_of(p[j], i, nr);
+                float gth = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { gf[q] += c.theta * gr[j][i][q]; gth += g.n[q] * gr[j][i][q]; }
+                const float gs = gth * dtheta_ds(c.s);
+                gN[c.na] += (double)(gs * (-c.s * nr.inv[c.na]));
+                gN[c.nb] += (double)(gs * (-c.s * nr.inv[c.nb]));
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) grad_fn[(size_t)q * F + f] = gf[q];
         }
-#pragma unroll
-        for (int q = 0; q < 3; ++q) grad_fn[(size_t)q * F + f] = gf[q];
     }
     block_sum3(gN, smem);
     if (threadIdx.x == 0) {
@@ -413,6 +484,7 @@ __global__ __launch_bounds__(BLOCK) void k_pair_bwd_verts(const float* __restric
                                                           const float* __restrict__ norms, const float* __restrict__ g_raw,
                                                           const float* __restrict__ gN, const float* __restrict__ g_fn,
                                                           const int* __restrict__ cpos, float* __restrict__ corner) {
+    const InvNorms nr = inv_norms(norms);
     const int64_t f = xcd_block() * BLOCK + threadIdx.x;
     if (f >= F) return;
     int id[3];
@@ -431,11 +503,11 @@ __global__ __launch_bounds__(BLOCK) void k_pair_bwd_verts(const float* __restric
     const FaceGeo g = face_geo(p);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const Corner c = corner_of(p, i, norms);
+        const Corner c = corner_of(p, i, nr);
         float gth = 0.0f;
 #pragma unroll
         for (int q = 0; q < 3; ++q) gth += g.n[q] * gr[i][q];
-        const float w = gth * dtheta_ds(c.s) / (c.Na * c.Nb);
+        const float w = gth * dtheta_ds(c.s) * c.iab;
         const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -443,7 +515,7 @@ __global__ __launch_bounds__(BLOCK) void k_pair_bwd_verts(const float* __restric
             gv[i1][q] += ga; gv[i2][q] += gb; gv[i][q] -= ga + gb;
         }
     }
-    const float w01 = gN[0] / norms[0], w02 = gN[1] / norms[1], w12 = gN[2] / norms[2];
+    const float w01 = gN[0] * nr.inv[0], w02 = gN[1] * nr.inv[1], w12 = gN[2] * nr.inv[2];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         const float e12 = p[2][q] - p[1][q];
@@ -453,10 +525,11 @@ __global__ __launch_bounds__(BLOCK) void k_pair_bwd_verts(const float* __restric
     }
     if (g_fn) {
         float ng = 0.0f, gc[3], ga[3], gb[3];
+        const float il = 1.0f / g.len;
 #pragma unroll
         for (int q = 0; q < 3; ++q) ng += g.n[q] * gt[q];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) gc[q] = (gt[q] - g.n[q] * ng) / g.len;
+        for (int q = 0; q < 3; ++q) gc[q] = (gt[q] - g.n[q] * ng) * il;
         cross3(g.b, gc, ga);
         cross3(gc, g.a, gb);
 #pragma unroll
@@ -558,7 +631,7 @@ extern "C" int ls_vertex_normals(const float* verts, const void* faces, int idx_
     if (F > 0) {
         const int G = reduce_grid(F);
         LS_IDX(idx_bytes, hipLaunchKernelGGL(k_edge_norm_partials<IDX>, dim3(G), dim3(BLOCK), 0, st, verts, (const IDX*)faces, F, w.part));
-        hipLaunchKernelGGL(k_finish3, dim3(1), dim3(BLOCK), 0, st, (const double*)w.part, G, NRM_MAXG, 1, norms);
+        hipLaunchKernelGGL(k_finish3, dim3(1), dim3(FIN), 0, st, (const double*)w.part, G, NRM_MAXG, 1, norms);
         LS_IDX(idx_bytes, hipLaunchKernelGGL(k_vertex_normals_scatter<IDX>, dim3(div_up(F, BLOCK)), dim3(BLOCK), 0, st, verts, (const IDX*)faces,
                                              F, fn, (const float*)norms, cpos, w.corner));
     } else {
@@ -588,7 +661,7 @@ extern "C" int ls_vertex_normals_backward(const float* verts, const void* faces,
         const int G = reduce_grid(F);
         LS_IDX(idx_bytes, hipLaunchKernelGGL(k_vertex_normals_bwd1<IDX>, dim3(G), dim3(BLOCK), 0, st, verts, (const IDX*)faces, F, fn, norms,
                                              (const float*)w.g_raw, grad_fn, w.part));
-        hipLaunchKernelGGL(k_finish3, dim3(1), dim3(BLOCK), 0, st, (const double*)w.part, G, NRM_MAXG, 0, w.gN);
+        hipLaunchKernelGGL(k_finish3, dim3(1), dim3(FIN), 0, st, (const double*)w.part, G, NRM_MAXG, 0, w.gN);
         LS_IDX(idx_bytes, hipLaunchKernelGGL(k_vertex_normals_bwd2<IDX>, dim3(div_up(F, BLOCK)), dim3(BLOCK), 0, st, verts, (const IDX*)faces, F, fn,
                                              norms, (const float*)w.g_raw, (const float*)w.gN, cpos, w.corner));
     }
@@ -612,9 +685,9 @@ extern "C" int ls_face_normals_with_norms(const float* verts, const void* faces,
     hipStream_t st = (hipStream_t)stream;
     if (F == 0) { LS_HIP(hipMemsetAsync(norms, 0, sizeof(float) * 3, st)); return LS_OK; }
     const NormalsWs w = carve(workspace, V, F);
-    const int G = (int)div_up(F, BLOCK), P = (int)part_slots(F);
+    const int G = (int)div_up(F, (int64_t)PF * BLOCK), P = (int)part_slots(F);
     LS_IDX(idx_bytes, hipLaunchKernelGGL(k_face_normals_norms<IDX>, dim3(G), dim3(BLOCK), 0, st, verts, (const IDX*)faces, F, fn, w.part, P));
-    hipLaunchKernelGGL(k_finish3, dim3(1), dim3(BLOCK), 0, st, (const double*)w.part, G, P, 1, norms);
+    hipLaunchKernelGGL(k_finish3, dim3(1), dim3(FIN), 0, st, (const double*)w.part, G, P, 1, norms);
     LS_HIP(hipGetLastError());
     return LS_OK;
 }
@@ -656,10 +729,10 @@ extern "C" int ls_normals_pair_backward_faces(const float* verts, const void* fa
     const NormalsWs w = carve(workspace, V, F);
     hipLaunchKernelGGL(k_normalize_rows_bwd, dim3(div_up(V, BLOCK)), dim3(BLOCK), 0, st, raw, g_out, V, g_raw);
     if (F > 0) {
-        const int G = (int)div_up(F, BLOCK), P = (int)part_slots(F);
+        const int G = (int)div_up(F, (int64_t)PF * BLOCK), P = (int)part_slots(F);
         LS_IDX(idx_bytes, hipLaunchKernelGGL(k_pair_bwd_face<IDX>, dim3(G), dim3(BLOCK), 0, st, verts, (const IDX*)faces, F, norms, (const float*)g_raw,
                                              grad_fn, w.part, P));
-        hipLaunchKernelGGL(k_finish3, dim3(1), dim3(BLOCK), 0, st, (const double*)w.part, G, P, 0, gN);
+        hipLaunchKernelGGL(k_finish3, dim3(1), dim3(FIN), 0, st, (const double*)w.part, G, P, 0, gN);
     } else {
         LS_HIP(hipMemsetAsync(gN, 0, sizeof(float) * 3, st));
     }

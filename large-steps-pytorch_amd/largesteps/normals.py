@@ -77,10 +77,35 @@ def _prep(verts, faces):
     return v, narrow, vptr, vcorner
 
 
+_ws_bytes = {}
+
+
 def _workspace(F, V, dev):
-    n = ctypes.c_size_t(0)
-    _native.check(_native.lib().ls_normals_workspace_bytes(F, V, ctypes.byref(n)))
-    return torch.empty(n.value, dtype=torch.uint8, device=dev)
+    n = _ws_bytes.get((F, V))
+    if n is None:
+        c = ctypes.c_size_t(0)
+        _native.check(_native.lib().ls_normals_workspace_bytes(F, V, ctypes.byref(c)))
+        if len(_ws_bytes) > 64:
+            _ws_bytes.clear()
+        n = _ws_bytes[(F, V)] = c.value
+    return torch.empty(n, dtype=torch.uint8, device=dev)
+
+
+class _Here:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_here = _Here()
+
+
+def _on(dev):
+    """torch's device context only when `dev` is not the current device already (the library selects the device it is handed
+    itself; entering torch's context costs several microseconds per call on the host, and an eager step is host-bound)"""
+    return _here if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
 
 
 # ---- the pair on one mesh ------------------------------------------------------------------------------------------------
@@ -124,7 +149,7 @@ class _FaceNormals(Function):
         fn = torch.empty((3, F), dtype=torch.float32, device=dev)
         norms = torch.empty(3, dtype=torch.float32, device=dev)
         ws = _workspace(F, V, dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _native.check(_native.lib().ls_face_normals_with_norms(_native.ptr(v), _native.ptr(f), f.element_size(), F, V, _native.ptr(fn),
                                                                    _native.ptr(norms), _native.ptr(ws), ws.numel(), dev.index,
                                                                    _native.stream_of(dev)))
@@ -147,7 +172,7 @@ class _FaceNormals(Function):
         F, V, dev = f.shape[0], v.shape[0], v.device
         ws = _workspace(F, V, dev)
         lib = _native.lib()
-        with torch.cuda.device(dev):
+        with _on(dev):
             if not mine:
                 gv = torch.empty_like(v)
                 _native.check(lib.ls_face_normals_backward(_native.ptr(v), _native.ptr(f), f.element_size(), F, V, _native.ptr(vptr),
@@ -179,7 +204,7 @@ class _VertexNormals(Function):
         lib = _native.lib()
         ctx.tag = tag
         if tag is not None:                                     # the pair: norms are there, n_f is recomputed
-            with torch.cuda.device(dev):
+            with _on(dev):
                 _native.check(lib.ls_vertex_normals_from_norms(_native.ptr(v), _native.ptr(f), f.element_size(), F, V, _native.ptr(vptr),
                                                                _native.ptr(vcorner), _native.ptr(tag.norms), _native.ptr(out), _native.ptr(raw),
                                                                _native.ptr(ws), ws.numel(), dev.index, _native.stream_of(dev)))
@@ -187,7 +212,7 @@ class _VertexNormals(Function):
             return out
         fn = face_normals.detach().to(torch.float32).contiguous()
         norms = torch.empty(3, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _native.check(lib.ls_vertex_normals(_native.ptr(v), _native.ptr(f), f.element_size(), F, V, _native.ptr(vptr),
                                                 _native.ptr(vcorner), _native.ptr(fn), _native.ptr(out), _native.ptr(raw),
                                                 _native.ptr(norms), _native.ptr(ws), ws.numel(), dev.index, _native.stream_of(dev)))
@@ -212,7 +237,7 @@ class _VertexNormals(Function):
             # the face-normal node runs later in this backward call exactly when its output needs a gradient here and the
             # vertices need one: then it finishes the job (one corner buffer). Otherwise both halves run now.
             defer = task >= 0 and ctx.needs_input_grad[0] and ctx.needs_input_grad[2]
-            with torch.cuda.device(dev):
+            with _on(dev):
                 _native.check(lib.ls_normals_pair_backward_faces(_native.ptr(v), _native.ptr(f), f.element_size(), F, V, _native.ptr(raw),
                                                                  _native.ptr(tag.norms), _native.ptr(g), _native.ptr(g_raw), _native.ptr(gN),
                                                                  _native.ptr(gfn), _native.ptr(ws), ws.numel(), dev.index,
@@ -233,7 +258,7 @@ class _VertexNormals(Function):
         gv = torch.empty_like(v)
         gfn = torch.empty_like(fn)
         ws = _workspace(F, V, dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _native.check(lib.ls_vertex_normals_backward(_native.ptr(v), _native.ptr(f), f.element_size(), F, V, _native.ptr(vptr),
                                                          _native.ptr(vcorner), _native.ptr(fn),
                                                          _native.ptr(raw), _native.ptr(norms), _native.ptr(g), _native.ptr(gv),

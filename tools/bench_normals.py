@@ -1,6 +1,7 @@
 """time the normals forward + backward at the 1M-vertex config: python tools/bench_normals.py"""
 import os, sys, time
-sys.path[:0] = [os.getcwd(), os.path.join(os.getcwd(), "large-steps-pytorch_amd")]
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [_R, os.path.join(_R, "large-steps-pytorch_amd")]
 import torch
 from largesteps import synthetic
 from largesteps.normals import compute_face_normals, compute_vertex_normals
