@@ -250,6 +250,11 @@ int ls_shard_layer_sizes(int64_t V, const int32_t* h_rowptr, const int32_t* h_co
 typedef struct ls_nd_plan ls_nd_plan;
 int ls_nd_plan_create(int64_t V, const int32_t* h_rowptr, const int32_t* h_col, const float* h_positions, int leaf_size,
                       int arity, int smooth, ls_nd_plan** out);
+/* The same plan as ls_direct_factor forms it: the positions' smoothing and the bisection rounds run ON THE DEVICE (csrc/nd_bisect.hip:
+ * three coordinate orders by radix sort, a stable partition per round), the rest on the host. d_positions may be NULL. Bit-identical
+ * to ls_nd_plan_create on the same input -- the GPU tests compare the two. SYNC. */
+int ls_nd_plan_create_device(const int32_t* d_rowptr, const int32_t* d_col, const float* d_positions, int64_t V, int64_t nnz,
+                             int leaf_size, int arity, int smooth, int device, void* stream, ls_nd_plan** out);
 int ls_nd_plan_destroy(ls_nd_plan* p);
 int ls_nd_plan_info(const ls_nd_plan* p, int* levels, int* arity, int* n_nodes, int64_t* n_bnd, int64_t* n_front, double* seconds);
 /* copies out: perm (V), s / b / own_start / parent (n_nodes + 1 each, node ids are 1-based), bnd / ppos / push_tgt (n_bnd),

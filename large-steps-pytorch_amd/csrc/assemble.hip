@@ -12,6 +12,7 @@
 // The fp32 operation order of the cotangents is the one of oracle/laplacian.py (explicit fma chain
 // in the edge norm, everything else unfused): this file is compiled with -ffp-contract=off.
 #include "common.h"
+#include "radix.h"
 #include <algorithm>
 
 #pragma STDC FP_CONTRACT OFF
@@ -498,67 +499,6 @@ extern "C" int ls_csr_from_coo(const int64_t* coo_rows, const int64_t* coo_cols,
 // ------------------------------------------------------------------------------------------------
 namespace ls {
 
-constexpr int RS_CHUNK = 4096;      // elements per workgroup (histogram: 256 threads; scatter: one wave)
-
-// order-preserving map of a float to uint32; -0.0 is folded into +0.0 first (torch compares values)
-__device__ __forceinline__ unsigned key_of(float x) {
-    unsigned u = __float_as_uint(x);
-    if (u == 0x80000000u) u = 0u;
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-// key policies of the radix sort: the 12 bytes of a vertex row (x most significant) / the 4 bytes of an int32 key
-struct KeyVerts {
-    const float* verts;
-    __device__ __forceinline__ unsigned digit(int row, int pass) const { return (key_of(verts[3 * (size_t)row + (2 - pass / 4)]) >> (8 * (pass & 3))) & 255u; }
-};
-struct KeyInt {
-    const int* keys;
-    __device__ __forceinline__ unsigned digit(int row, int pass) const { return ((unsigned)keys[row] >> (8 * pass)) & 255u; }
-};
-
-template <typename Key>
-__global__ __launch_bounds__(256) void k_rs_hist(Key key, const int* __restrict__ order, int64_t n, int pass,
-                                                 int nblocks, int* __restrict__ hist /* [256][nblocks] */) {
-    __shared__ int h[256];
-    h[threadIdx.x] = 0;
-    __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * RS_CHUNK;
-    for (int e = threadIdx.x; e < RS_CHUNK && base + e < n; e += 256) atomicAdd(&h[key.digit(order ? order[base + e] : (int)(base + e), pass)], 1);
-    __syncthreads();
-    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
-}
-
-template <typename Key>
-__global__ __launch_bounds__(64) void k_rs_scatter(Key key, const int* __restrict__ order, int64_t n, int pass,
-                                                   int nblocks, const int* __restrict__ offs /* scanned hist */, int* __restrict__ out) {
-    __shared__ int run[256];
-    const int lane = threadIdx.x;
-    for (int d = lane; d < 256; d += 64) run[d] = offs[(size_t)d * nblocks + blockIdx.x];
-    __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * RS_CHUNK;
-    const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
-    for (int t = 0; t < RS_CHUNK && base + t < n; t += 64) {
-        const int64_t e = base + t + lane;
-        const bool ok = e < n;
-        const int row = ok ? (order ? order[e] : (int)e) : 0;
-        const unsigned dg = ok ? key.digit(row, pass) : 0u;
-        unsigned long long peers = __ballot(ok);
-#pragma unroll
-        for (int bit = 0; bit < 8; ++bit) {
-            const unsigned long long b = __ballot((dg >> bit) & 1u);
-            peers &= ((dg >> bit) & 1u) ? b : ~b;
-        }
-        const int rank = __popcll(peers & lt), cnt = __popcll(peers);
-        const int start = ok ? run[dg] : 0;
-        __syncthreads();                       // one wave: orders the reads of run[] before the updates below
-        if (ok) {
-            out[start + rank] = row;
-            if (rank == cnt - 1) run[dg] = start + cnt;
-        }
-        __syncthreads();
-    }
-}
-
 __global__ __launch_bounds__(256) void k_dedup_flags(const float* __restrict__ verts, const int* __restrict__ order, int64_t n, int* __restrict__ flag) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -595,24 +535,6 @@ __global__ __launch_bounds__(256) void k_dedup_faces(const IdxT* __restrict__ fa
 }
 
 }  // namespace ls
-
-// order = the ids 0..n-1 sorted stably by `passes` key bytes; tmp: n ints; hist / offs: 256 nb + 16 ints each; returns where the result is
-template <typename Key>
-static int radix_argsort(Key key, int64_t n, int passes, int* ord_a, int* ord_b, int* hist, int* offs, int* bsum, hipStream_t st, const int** result) {
-    const int nb = div_up(n, RS_CHUNK);
-    const int* src = nullptr;                  // pass 0 reads the identity order
-    int* dst = ord_a;
-    for (int pass = 0; pass < passes; ++pass) {
-        hipLaunchKernelGGL(k_rs_hist<Key>, dim3(nb), dim3(256), 0, st, key, src, n, pass, nb, hist);
-        int rc = exclusive_scan(hist, 256 * (int64_t)nb, offs, bsum, st);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_rs_scatter<Key>, dim3(nb), dim3(64), 0, st, key, src, n, pass, nb, (const int*)offs, dst);
-        src = dst;
-        dst = (dst == ord_a) ? ord_b : ord_a;
-    }
-    *result = src;
-    return LS_OK;
-}
 
 extern "C" int ls_remove_duplicates_workspace_bytes(int64_t V, size_t* h_bytes) {
     LS_REQUIRE(h_bytes && V >= 0, LS_E_INVALID, "ls_remove_duplicates_workspace_bytes: bad argument");

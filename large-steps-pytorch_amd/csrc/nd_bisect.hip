@@ -1,0 +1,371 @@
+// nd_bisect.hip -- the bisection rounds of the nested-dissection analysis ON THE DEVICE (gfx950, wave64).
+//
+// The host version (csrc/nd_plan.cpp, nd_plan_build without a callback) walks the domains of a round with host threads: per
+// domain a bounding box, a median selection (std::nth_element over (coordinate, id) pairs), the end points of the cut edges, a
+// compaction -- 14 rounds x ~4 ms at 1M vertices, two thirds of the solver's constructor (the reference's constructor is one
+// call, largesteps/solvers.py:34; here it is paid at every remesh, scripts/main.py:137-169). None of it needs a host:
+//
+//   * the ORDER of the vertices along every axis is fixed once (stable radix sort by (coordinate, id), three lists); a domain
+//     is a contiguous segment of each list, and splitting a domain is a STABLE PARTITION of its three segments -- the lists stay
+//     sorted inside every segment, so in every later round the bounding box of a domain is its segments' first and last entries and
+//     its median is the entry in the middle: no reduction, no selection;
+//   * a round is eight launches over the live vertices: axis + half per domain, side of every vertex (from its position in the
+//     split axis' list), cut-edge end points (+ per-domain counts of the two sides' end points: integer atomics), the smaller
+//     end-point set becomes the separator and the sizes of the 2 x n_dom child segments are scanned (one workgroup), then a
+//     packed two-counter scan per list (reduce / block offsets / scan + scatter) moves every surviving vertex to
+//     next_start[child] + its rank among the survivors of its side -- the stable partition;
+//   * nothing is read back between rounds (the number of live vertices is read from the segment table on the device; grids are
+//     sized for V). One copy at the end: node[v], the binary heap id of the domain v ended in.
+//
+// The result is bit-identical to the host rounds (the same total order (coordinate, id), the same tie rules: first longest axis,
+// smaller end-point set with ties to side 0): tests/test_nested_gpu.py compares node[] round by round and the finished plans.
+#include "common.h"
+#include "radix.h"
+#include "nd_plan.h"
+#include <string>
+#include <vector>
+
+namespace ls {
+namespace {
+
+constexpr int BI = 8;                       // list positions per thread in the regroup kernels
+constexpr int BCH = BLOCK * BI;             // list positions per workgroup
+
+struct Round {
+    int n_dom;
+    const int* seg;                         // [n_dom + 1] segment starts of this round (seg[n_dom] = live vertices)
+    int* seg_next;                          // [2 n_dom + 1]
+    const int* L[3];                        // the three lists, grouped by domain, sorted by their axis inside a domain
+    int* Ln[3];
+    const double* pos;                      // V x 3
+    long long* state;                       // (heap id << 2) | side << 1 | fixed
+    unsigned char* endp;
+    int* ax; int* half; int* ecnt; int* use1; int* base0; int* base1;
+    unsigned long long* bsum;               // [3][nb] packed block sums / offsets
+    int nb;
+};
+
+__global__ __launch_bounds__(BLOCK) void k_f32_to_f64(const float* __restrict__ in, int64_t n, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) out[i] = (double)in[i];
+}
+
+// one averaging pass over the matrix neighbours, the host's arithmetic to the letter (nd_plan.cpp "positions": sums in CSR order,
+// then times 1.0 / count; the library is built with -ffp-contract=off)
+__global__ __launch_bounds__(BLOCK) void k_smooth(const int* __restrict__ rowptr, const int* __restrict__ col, int64_t V,
+                                                  const double* __restrict__ pos, double* __restrict__ nxt) {
+    const int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (v >= V) return;
+    double a = 0.0, b = 0.0, c = 0.0;
+    const int p0 = rowptr[v], p1 = rowptr[v + 1];
+    for (int p = p0; p < p1; ++p) {
+        const size_t w = (size_t)col[p];
+        a += pos[3 * w]; b += pos[3 * w + 1]; c += pos[3 * w + 2];
+    }
+    const double inv = 1.0 / (double)(p1 - p0);
+    nxt[3 * v] = a * inv; nxt[3 * v + 1] = b * inv; nxt[3 * v + 2] = c * inv;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_init(int64_t V, long long* __restrict__ state, int* __restrict__ seg) {
+    const int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (v < V) state[v] = 4;                                        // heap id 1, side 0, live
+    if (v == 0) { seg[0] = 0; seg[1] = (int)V; }
+}
+
+// per domain: the longest axis of its bounding box (first / last entry of its three segments), half of its size
+__global__ __launch_bounds__(BLOCK) void k_axis(Round r) {
+    const int d = blockIdx.x * BLOCK + threadIdx.x;
+    if (d >= r.n_dom) return;
+    const int a = r.seg[d], e = r.seg[d + 1], cnt = e - a;
+    r.ecnt[2 * d] = 0; r.ecnt[2 * d + 1] = 0;
+    r.half[d] = cnt / 2;
+    int ax = 0;
+    if (cnt > 0) {
+        double ext[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ext[k] = r.pos[3 * (size_t)r.L[k][e - 1] + k] - r.pos[3 * (size_t)r.L[k][a] + k];
+        for (int k = 1; k < 3; ++k) if (ext[k] > ext[ax]) ax = k;
+    }
+    r.ax[d] = ax;
+}
+
+// side of every live vertex: its position in the list of its domain's split axis (blockIdx.y = list)
+__global__ __launch_bounds__(BLOCK) void k_side(Round r) {
+    const int k = blockIdx.y, i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= r.seg[r.n_dom]) return;
+    const int u = r.L[k][i];
+    const long long node = r.state[u] >> 2;
+    const int d = (int)(node - r.n_dom);
+    if (r.ax[d] != k) return;
+    const long long s = (i - r.seg[d]) >= r.half[d];
+    r.state[u] = (node << 2) | (s << 1);
+}
+
+// end points of the cut edges (a neighbour in the same domain, live, on the other side) and their count per (domain, side)
+__global__ __launch_bounds__(BLOCK) void k_cut(Round r, const int* __restrict__ rowptr, const int* __restrict__ col) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= r.seg[r.n_dom]) return;
+    const int u = r.L[0][i];
+    const long long mine = r.state[u];
+    bool cut = false;
+    const int p1 = rowptr[u + 1];
+    for (int p = rowptr[u]; p < p1 && !cut; ++p) cut = (r.state[col[p]] ^ mine) == 2;
+    r.endp[u] = cut;
+    if (cut) atomicAdd(&r.ecnt[2 * (int)((mine >> 2) - r.n_dom) + (int)((mine >> 1) & 1)], 1);
+}
+
+// one workgroup: which side gives the separator, the sizes of the child segments and their scans:
+// base0[d] / base1[d] = survivors on side 0 / 1 in the domains before d; seg_next[2 d] = base0 + base1, seg_next[2 d + 1] = + keep0[d]
+constexpr int PLAN_T = 1024;
+__global__ __launch_bounds__(PLAN_T) void k_plan(Round r) {
+    __shared__ int tot0[PLAN_T], tot1[PLAN_T];
+    const int t = threadIdx.x, per = (r.n_dom + PLAN_T - 1) / PLAN_T, d0 = t * per, d1 = min(r.n_dom, d0 + per);
+    int s0 = 0, s1 = 0;
+    for (int d = d0; d < d1; ++d) {
+        const int cnt = r.seg[d + 1] - r.seg[d], n0 = r.half[d], n1 = cnt - n0, e0 = r.ecnt[2 * d], e1 = r.ecnt[2 * d + 1];
+        const int u1 = e1 < e0;
+        r.use1[d] = u1;
+        s0 += n0 - (u1 ? 0 : e0);
+        s1 += n1 - (u1 ? e1 : 0);
+    }
+    tot0[t] = s0; tot1[t] = s1;
+    __syncthreads();
+    if (t == 0) {                                                   // 1024 entries: a serial scan is microseconds
+        int a = 0, b = 0;
+        for (int j = 0; j < PLAN_T; ++j) { const int x = tot0[j], y = tot1[j]; tot0[j] = a; tot1[j] = b; a += x; b += y; }
+    }
+    __syncthreads();
+    int b0 = tot0[t], b1 = tot1[t];
+    for (int d = d0; d < d1; ++d) {
+        const int cnt = r.seg[d + 1] - r.seg[d], n0 = r.half[d], n1 = cnt - n0, e0 = r.ecnt[2 * d], e1 = r.ecnt[2 * d + 1];
+        const int u1 = e1 < e0, k0 = n0 - (u1 ? 0 : e0), k1 = n1 - (u1 ? e1 : 0);
+        r.base0[d] = b0; r.base1[d] = b1;
+        r.seg_next[2 * d] = b0 + b1;
+        r.seg_next[2 * d + 1] = b0 + b1 + k0;
+        b0 += k0; b1 += k1;
+        if (d == r.n_dom - 1) r.seg_next[2 * r.n_dom] = b0 + b1;
+    }
+}
+
+// what happens to list position i: 0 = leaves (separator), 1 / 2 = survives on side 0 / 1 -- packed as two 32-bit counters
+__device__ __forceinline__ unsigned long long survivor(const Round& r, int u, int& d, int& side) {
+    const long long st = r.state[u];
+    d = (int)((st >> 2) - r.n_dom);
+    side = (int)((st >> 1) & 1);
+    const bool sep = r.endp[u] && side == r.use1[d];
+    return sep ? 0ull : (side ? (1ull << 32) : 1ull);
+}
+
+__device__ __forceinline__ unsigned long long wave_sum64(unsigned long long x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, WAVE);
+    return x;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_regroup_reduce(Round r) {
+    __shared__ unsigned long long sm[BLOCK / WAVE];
+    const int k = blockIdx.y, n_live = r.seg[r.n_dom];
+    const int i0 = blockIdx.x * BCH + threadIdx.x * BI;
+    unsigned long long acc = 0;
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+        const int i = i0 + j;
+        if (i < n_live) { int d, s; acc += survivor(r, r.L[k][i], d, s); }
+    }
+    acc = wave_sum64(acc);
+    if ((threadIdx.x & (WAVE - 1)) == 0) sm[threadIdx.x / WAVE] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int j = 0; j < BLOCK / WAVE; ++j) t += sm[j];
+        r.bsum[(size_t)k * r.nb + blockIdx.x] = t;
+    }
+}
+
+// exclusive scan of the block sums of one list (one workgroup per list)
+__global__ __launch_bounds__(PLAN_T) void k_regroup_offsets(Round r) {
+    __shared__ unsigned long long tot[PLAN_T];
+    unsigned long long* b = r.bsum + (size_t)blockIdx.x * r.nb;
+    const int t = threadIdx.x, per = (r.nb + PLAN_T - 1) / PLAN_T, j0 = t * per, j1 = min(r.nb, j0 + per);
+    unsigned long long s = 0;
+    for (int j = j0; j < j1; ++j) s += b[j];
+    tot[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        unsigned long long a = 0;
+        for (int j = 0; j < PLAN_T; ++j) { const unsigned long long x = tot[j]; tot[j] = a; a += x; }
+    }
+    __syncthreads();
+    unsigned long long run = tot[t];
+    for (int j = j0; j < j1; ++j) { const unsigned long long x = b[j]; b[j] = run; run += x; }
+}
+
+// the stable partition: survivor of side s of domain d at list position i moves to seg_next[2 d + s] + (survivors of side s of d
+// before i). List 0's thread of a vertex also writes its new state (the child's heap id, or the fixed bit of a separator vertex)
+// while the threads of the other lists need the old one: the host launches lists 1 and 2 first (k0 = 1), list 0 after them.
+__global__ __launch_bounds__(BLOCK) void k_regroup_scatter(Round r, int k0) {
+    __shared__ unsigned long long sm[BLOCK / WAVE + 1];
+    const int k = k0 + blockIdx.y, n_live = r.seg[r.n_dom];
+    const int i0 = blockIdx.x * BCH + threadIdx.x * BI;
+    int u[BI], d[BI], sd[BI];
+    unsigned long long f[BI], mine = 0;
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+        const int i = i0 + j;
+        u[j] = 0; d[j] = 0; sd[j] = 0; f[j] = 0;
+        if (i < n_live) { u[j] = r.L[k][i]; f[j] = survivor(r, u[j], d[j], sd[j]); }
+        mine += f[j];
+    }
+    // exclusive scan of `mine` over the workgroup
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    unsigned long long inc = mine;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const unsigned long long y = __shfl_up(inc, o, WAVE);
+        if (lane >= o) inc += y;
+    }
+    if (lane == WAVE - 1) sm[w] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long a = 0;
+        for (int j = 0; j < BLOCK / WAVE; ++j) { const unsigned long long x = sm[j]; sm[j] = a; a += x; }
+    }
+    __syncthreads();
+    unsigned long long run = r.bsum[(size_t)k * r.nb + blockIdx.x] + sm[w] + (inc - mine);
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+        const int i = i0 + j;
+        if (i < n_live) {
+            if (f[j]) {
+                const int rank = sd[j] ? (int)(run >> 32) - r.base1[d[j]] : (int)(run & 0xffffffffull) - r.base0[d[j]];
+                r.Ln[k][r.seg_next[2 * d[j] + sd[j]] + rank] = u[j];
+            }
+            if (k == 0) {
+                const long long st = r.state[u[j]];
+                r.state[u[j]] = f[j] ? (((st >> 2) * 2 + sd[j]) << 2) : (st | 1);
+            }
+        }
+        run += f[j];
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_nodes(int64_t V, const long long* __restrict__ state, long long* __restrict__ node) {
+    const int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (v < V) node[v] = state[v] >> 2;
+}
+
+}  // namespace
+
+struct NdBisectDevice { const int32_t* d_rowptr; const int32_t* d_col; const float* d_pos; int64_t nnz; hipStream_t st; };
+
+std::string nd_bisect_device(void* ctx, int64_t V, int D, int smooth, const double* embedded, int64_t* node) {
+    const NdBisectDevice& A = *(const NdBisectDevice*)ctx;
+    hipStream_t st = A.st;
+    if (D > 24) return "nd_bisect_device: more than 24 bisection rounds";
+    if (D == 0) { for (int64_t v = 0; v < V; ++v) node[v] = 1; return ""; }
+    const int max_dom = 1 << (D - 1), nb = div_up(V, BCH);
+    const size_t nbr = (size_t)div_up(V, RS_CHUNK);
+    // one allocation: positions (two copies), 3 x 2 lists, state, node, end-point flags, per-domain tables, scan scratch, sort scratch
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_pos = take(sizeof(double) * 3 * V), o_pos2 = take(sizeof(double) * 3 * V);
+    size_t o_L[6];
+    for (int k = 0; k < 6; ++k) o_L[k] = take(sizeof(int) * V);
+    const size_t o_state = take(sizeof(long long) * V), o_node = take(sizeof(long long) * V), o_endp = take(V);
+    const size_t o_seg0 = take(sizeof(int) * (2 * (size_t)max_dom + 2)), o_seg1 = take(sizeof(int) * (2 * (size_t)max_dom + 2));
+    const size_t o_ax = take(sizeof(int) * max_dom), o_half = take(sizeof(int) * max_dom), o_ecnt = take(sizeof(int) * 2 * (size_t)max_dom),
+                 o_use1 = take(sizeof(int) * max_dom), o_b0 = take(sizeof(int) * max_dom), o_b1 = take(sizeof(int) * max_dom);
+    const size_t o_bsum = take(sizeof(unsigned long long) * 3 * (size_t)nb);
+    const size_t o_hist = take(sizeof(int) * (256 * nbr + 16)), o_offs = take(sizeof(int) * (256 * nbr + 16)),
+                 o_sb = take(sizeof(int) * ((size_t)scan_blocks(256 * (int64_t)nbr) + 64));
+    char* base = nullptr;
+    if (hipMalloc(&base, off) != hipSuccess) return "nd_bisect_device: out of device memory";
+    struct Free { char* p; ~Free() { (void)hipFree(p); } } guard{base};
+    double* pos = (double*)(base + o_pos);
+    double* pos2 = (double*)(base + o_pos2);
+    int* L[6];
+    for (int k = 0; k < 6; ++k) L[k] = (int*)(base + o_L[k]);
+    long long* state = (long long*)(base + o_state);
+    long long* d_node = (long long*)(base + o_node);
+    int* seg[2] = {(int*)(base + o_seg0), (int*)(base + o_seg1)};
+    // ---- positions ------------------------------------------------------------------------------------------------------------------
+    if (embedded) {
+        if (hipMemcpyAsync(pos, embedded, sizeof(double) * 3 * V, hipMemcpyHostToDevice, st) != hipSuccess) return "nd_bisect_device: copy failed";
+    } else {
+        hipLaunchKernelGGL(k_f32_to_f64, dim3(div_up(3 * V, BLOCK)), dim3(BLOCK), 0, st, A.d_pos, 3 * V, pos);
+        for (int it = 0; it < smooth; ++it) {
+            hipLaunchKernelGGL(k_smooth, dim3(div_up(V, BLOCK)), dim3(BLOCK), 0, st, A.d_rowptr, A.d_col, V, (const double*)pos, pos2);
+            std::swap(pos, pos2);
+        }
+    }
+    // ---- the three coordinate orders: stable LSD radix sort of the ids by the 8 key bytes -> (coordinate, id) order -----------------
+    const int* Lc[3];
+    int* Lo[3];
+    for (int k = 0; k < 3; ++k) {
+        const int* res = nullptr;
+        const int rc = radix_argsort(KeyF64{pos, k}, V, 8, L[2 * k], L[2 * k + 1], (int*)(base + o_hist), (int*)(base + o_offs), (int*)(base + o_sb), st, &res);
+        if (rc) return "nd_bisect_device: sort failed";
+        Lc[k] = res;
+        Lo[k] = res == L[2 * k] ? L[2 * k + 1] : L[2 * k];
+    }
+    hipLaunchKernelGGL(k_init, dim3(div_up(V, BLOCK)), dim3(BLOCK), 0, st, V, state, seg[0]);
+    // ---- D rounds ---------------------------------------------------------------------------------------------------------------------
+    for (int r = 0; r < D; ++r) {
+        Round R;
+        R.n_dom = 1 << r;
+        R.seg = seg[r & 1]; R.seg_next = seg[(r + 1) & 1];
+        for (int k = 0; k < 3; ++k) { R.L[k] = Lc[k]; R.Ln[k] = Lo[k]; }
+        R.pos = pos; R.state = state; R.endp = (unsigned char*)(base + o_endp);
+        R.ax = (int*)(base + o_ax); R.half = (int*)(base + o_half); R.ecnt = (int*)(base + o_ecnt); R.use1 = (int*)(base + o_use1);
+        R.base0 = (int*)(base + o_b0); R.base1 = (int*)(base + o_b1);
+        R.bsum = (unsigned long long*)(base + o_bsum); R.nb = nb;
+        const int gv = div_up(V, BLOCK);
+        hipLaunchKernelGGL(k_axis, dim3(div_up(R.n_dom, BLOCK)), dim3(BLOCK), 0, st, R);
+        hipLaunchKernelGGL(k_side, dim3(gv, 3), dim3(BLOCK), 0, st, R);
+        hipLaunchKernelGGL(k_cut, dim3(gv), dim3(BLOCK), 0, st, R, A.d_rowptr, A.d_col);
+        hipLaunchKernelGGL(k_plan, dim3(1), dim3(PLAN_T), 0, st, R);
+        hipLaunchKernelGGL(k_regroup_reduce, dim3(nb, 3), dim3(BLOCK), 0, st, R);
+        hipLaunchKernelGGL(k_regroup_offsets, dim3(3), dim3(PLAN_T), 0, st, R);
+        // lists 1 and 2 first (their threads read the old states), then list 0, whose threads write the new ones
+        hipLaunchKernelGGL(k_regroup_scatter, dim3(nb, 2), dim3(BLOCK), 0, st, R, 1);
+        hipLaunchKernelGGL(k_regroup_scatter, dim3(nb, 1), dim3(BLOCK), 0, st, R, 0);
+        for (int k = 0; k < 3; ++k) { const int* t = Lc[k]; Lc[k] = Lo[k]; Lo[k] = (int*)t; }
+    }
+    hipLaunchKernelGGL(k_nodes, dim3(div_up(V, BLOCK)), dim3(BLOCK), 0, st, V, (const long long*)state, d_node);
+    if (hipMemcpyAsync(node, d_node, sizeof(long long) * V, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess ||
+        hipGetLastError() != hipSuccess)
+        return "nd_bisect_device: device error";
+    return "";
+}
+
+}  // namespace ls
+
+// the whole analysis with the rounds on the device: what ls_direct_factor runs (csrc/nd_factor.hip), and -- as a plan object -- what
+// the GPU tests compare with the host-only ls_nd_plan_create
+std::string ls::nd_plan_build_device(const int32_t* d_rowptr, const int32_t* d_col, const float* d_positions, int64_t V, int64_t nnz,
+                                     const int32_t* h_rowptr, const int32_t* h_col, int leaf_size, int arity, int smooth, void* stream,
+                                     NdPlan& out) {
+    NdBisectDevice ctx{d_rowptr, d_col, d_positions, nnz, (hipStream_t)stream};
+    const float given = 0.0f;                  // "positions were given": nd_plan_build only tests the pointer, the values are read on the device
+    return nd_plan_build(V, h_rowptr, h_col, d_positions ? &given : nullptr, leaf_size, arity, smooth, out, nd_bisect_device, &ctx);
+}
+
+extern "C" int ls_nd_plan_create_device(const int32_t* d_rowptr, const int32_t* d_col, const float* d_positions, int64_t V, int64_t nnz,
+                                        int leaf_size, int arity, int smooth, int device, void* stream, ls_nd_plan** out) {
+    using namespace ls;
+    LS_REQUIRE(out && d_rowptr && d_col && V > 0 && nnz > 0 && nnz < INT32_MAX, LS_E_INVALID, "ls_nd_plan_create_device: bad argument");
+    *out = nullptr;
+    DeviceGuard g(device);
+    LS_HIP(g.err);
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<int32_t> rowptr((size_t)V + 1), col((size_t)nnz);
+    LS_HIP(hipMemcpyAsync(rowptr.data(), d_rowptr, sizeof(int32_t) * (V + 1), hipMemcpyDeviceToHost, st));
+    LS_HIP(hipMemcpyAsync(col.data(), d_col, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost, st));
+    LS_HIP(hipStreamSynchronize(st));
+    LS_REQUIRE(rowptr[0] == 0 && rowptr[V] == nnz, LS_E_INVALID, "ls_nd_plan_create_device: rowptr does not match nnz");
+    ls_nd_plan* h = new ls_nd_plan();
+    const std::string err = nd_plan_build_device(d_rowptr, d_col, d_positions, V, nnz, rowptr.data(), col.data(), leaf_size, arity, smooth, st, h->p);
+    if (!err.empty()) { delete h; set_error("%s", err.c_str()); return LS_E_INVALID; }
+    *out = h;
+    return LS_OK;
+}

@@ -381,18 +381,16 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     const double t0 = now_s();
     const bool timing = getenv("LS_PLAN_TIMING") != nullptr;
     auto lap = [&](const char* what) { if (timing) { (void)hipStreamSynchronize(st); fprintf(stderr, "[ls_direct_factor] %-30s %.3f s\n", what, now_s() - t0); } };
-    // ---- symbolic analysis on the host -------------------------------------------------------------------------------------------
+    // ---- symbolic analysis: the bisection rounds on the device (nd_bisect.hip), the tree / fronts / index lists on the host ------------
     std::vector<int32_t> rowptr((size_t)V + 1), col((size_t)nnz);
-    std::vector<float> pos;
     LS_HIP(hipMemcpyAsync(rowptr.data(), d_rowptr, sizeof(int32_t) * (V + 1), hipMemcpyDeviceToHost, st));
     LS_HIP(hipMemcpyAsync(col.data(), d_col, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost, st));
-    if (d_positions) { pos.resize((size_t)V * 3); LS_HIP(hipMemcpyAsync(pos.data(), d_positions, sizeof(float) * 3 * V, hipMemcpyDeviceToHost, st)); }
     LS_HIP(hipStreamSynchronize(st));
     LS_REQUIRE(rowptr[0] == 0 && rowptr[V] == nnz, LS_E_INVALID, "ls_direct_factor: rowptr does not match nnz");
     lap("matrix to the host");
     NdPlan P;
     {
-        const std::string err = nd_plan_build(V, rowptr.data(), col.data(), d_positions ? pos.data() : nullptr, leaf_size, arity, 4, P);
+        const std::string err = nd_plan_build_device(d_rowptr, d_col, d_positions, V, nnz, rowptr.data(), col.data(), leaf_size, arity, 4, st, P);
         LS_REQUIRE(err.empty(), LS_E_INVALID, "%s", err.c_str());
     }
     const double t1 = now_s();

@@ -176,8 +176,15 @@ void graph_embedding(int64_t V, const int32_t* rowptr, const int32_t* col, std::
 
 }  // namespace
 
+int nd_plan_rounds(int64_t V, int leaf_size, int arity) {
+    const int m = arity == 2 ? 1 : arity == 4 ? 2 : 3;
+    int D = 0;
+    while ((V >> D) > leaf_size) ++D;
+    return (D + m - 1) / m * m;
+}
+
 std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, const float* pos_in, int leaf_size, int arity,
-                          int smooth, NdPlan& P) {
+                          int smooth, NdPlan& P, NdBisectFn bisect, void* bisect_ctx) {
     const auto t_start = std::chrono::steady_clock::now();
     const bool timing = getenv("LS_PLAN_TIMING") != nullptr;
     auto lap = [&](const char* what) { if (timing) fprintf(stderr, "[nd_plan] %-28s %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count()); };
@@ -192,233 +199,245 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
     while ((V >> D) > leaf_size) ++D;
     D = (D + m - 1) / m * m;
     if (D > 40) return "nd_plan_build: tree too deep";
-    // ---- positions (averaged `smooth` times over the matrix neighbours: a rough surface bisects badly otherwise) ----
-    std::vector<double> pos((size_t)V * 3);
-    if (pos_in) {
-        for (int64_t i = 0; i < 3 * V; ++i) pos[i] = pos_in[i];
-        bool all_rows = true;
-        for (int64_t v = 0; v < V && all_rows; ++v) all_rows = rowptr[v + 1] > rowptr[v];
-        if (smooth > 0 && all_rows) {
-            std::vector<double> nxt((size_t)V * 3);
-            for (int it = 0; it < smooth; ++it) {
-                parallel_for(V, 4096, [&](int64_t lo, int64_t hi) {
-                    for (int64_t v = lo; v < hi; ++v) {
-                        double a = 0, b = 0, c = 0;
-                        for (int p = rowptr[v]; p < rowptr[v + 1]; ++p) { const int w = col[p]; a += pos[3 * (size_t)w]; b += pos[3 * (size_t)w + 1]; c += pos[3 * (size_t)w + 2]; }
-                        const double inv = 1.0 / (rowptr[v + 1] - rowptr[v]);
-                        nxt[3 * v] = a * inv; nxt[3 * v + 1] = b * inv; nxt[3 * v + 2] = c * inv;
-                    }
-                });
-                pos.swap(nxt);
-            }
-        }
-    } else {
-        graph_embedding(V, rowptr, col, pos);
-    }
-    lap("positions");
-    // ---- D rounds of bisection ------------------------------------------------------------------------------------------
     std::vector<int64_t> node((size_t)V, 1);          // binary heap id of the domain a vertex lives in / became a separator of
-    std::vector<char> fixed((size_t)V, 0), side((size_t)V, 0), endp((size_t)V, 0);
-    // (domain << 2 | side << 1 | fixed) of every vertex in ONE word: the cut detection touches one cache line per neighbour
-    std::vector<int64_t> state((size_t)V, 4);
-    std::vector<int> live((size_t)V);                 // live vertices grouped by domain
-    std::iota(live.begin(), live.end(), 0);
-    int64_t n_live = V;
-    std::vector<int64_t> seg_start;
-    std::vector<int> tmp((size_t)V);
-    // `live` holds the live vertices grouped by domain: domain d of the round owns live[seg_start[d] .. seg_start[d + 1]).
-    // A median split partitions the segment in place, so the next round's grouping is the two halves minus the separator
-    // vertices -- compacted per half with per-domain counts: every pass of a round is parallel over domains or vertices.
-    seg_start.assign(2, 0);
-    seg_start[1] = V;
-    std::vector<int64_t> next_start, keep_cnt;
-    std::vector<int> cnt0, cnt1;
-    // Rounds with fewer domains than threads run their passes parallel INSIDE a domain (the first round is one domain of V
-    // vertices); later rounds run one domain per thread. Both produce the same sets: which vertices land left of the median
-    // is decided by the (key, id) order alone, the arrangement inside `live` is irrelevant.
-    typedef std::pair<double, int> KV;
-    std::vector<KV> kv_a, kv_b;
-    constexpr int NB = 2048;                          // buckets of the parallel selection
-    std::vector<int> hist;
-    struct Piece { int64_t d, lo, hi; int n0, e0, n1, e1; int64_t w0, w1; };
-    std::vector<Piece> pieces;
-    for (int r = 0; r < D; ++r) {
-        const int64_t n_dom = (int64_t)1 << r;
-        const bool inside = 4 * n_dom <= T && n_live >= 65536;       // (with a thread for every second domain or more, whole domains per thread win)
-        auto split_serial = [&](int64_t d) {
-            const int64_t a = seg_start[d], e = seg_start[d + 1], cnt = e - a;
-            if (cnt <= 0) return;
-            double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
-            for (int64_t i = a; i < e; ++i)
-                for (int k = 0; k < 3; ++k) { const double x = pos[3 * (size_t)live[i] + k]; mn[k] = std::min(mn[k], x); mx[k] = std::max(mx[k], x); }
-            int ax = 0;
-            for (int k = 1; k < 3; ++k) if (mx[k] - mn[k] > mx[ax] - mn[ax]) ax = k;
-            const int64_t half = cnt / 2;
-            // selection on contiguous (key, id) pairs: the comparator must not chase pos[] through the index array
-            std::vector<KV> kv((size_t)cnt);
-            for (int64_t i = a; i < e; ++i) kv[(size_t)(i - a)] = {pos[3 * (size_t)live[i] + ax], live[i]};
-            std::nth_element(kv.begin(), kv.begin() + half, kv.end());
-            for (int64_t i = a; i < e; ++i) {
-                const int u = kv[(size_t)(i - a)].second;
-                live[i] = u; side[u] = i - a >= half;
-                state[u] = (node[u] << 2) | ((int64_t)side[u] << 1);
+    if (bisect) {
+        // positions and the D rounds run elsewhere (csrc/nd_bisect.hip: on the device); only the graph embedding of a matrix that
+        // comes without positions is formed here
+        std::vector<double> emb;
+        bool all_rows = true;
+        if (pos_in) { for (int64_t v = 0; v < V && all_rows; ++v) all_rows = rowptr[v + 1] > rowptr[v]; }
+        else graph_embedding(V, rowptr, col, emb);
+        lap("positions");
+        const std::string err = bisect(bisect_ctx, V, D, (pos_in && all_rows) ? smooth : 0, pos_in ? nullptr : emb.data(), node.data());
+        if (!err.empty()) return err;
+    } else {
+        // ---- positions (averaged `smooth` times over the matrix neighbours: a rough surface bisects badly otherwise) ----
+        std::vector<double> pos((size_t)V * 3);
+        if (pos_in) {
+            for (int64_t i = 0; i < 3 * V; ++i) pos[i] = pos_in[i];
+            bool all_rows = true;
+            for (int64_t v = 0; v < V && all_rows; ++v) all_rows = rowptr[v + 1] > rowptr[v];
+            if (smooth > 0 && all_rows) {
+                std::vector<double> nxt((size_t)V * 3);
+                for (int it = 0; it < smooth; ++it) {
+                    parallel_for(V, 4096, [&](int64_t lo, int64_t hi) {
+                        for (int64_t v = lo; v < hi; ++v) {
+                            double a = 0, b = 0, c = 0;
+                            for (int p = rowptr[v]; p < rowptr[v + 1]; ++p) { const int w = col[p]; a += pos[3 * (size_t)w]; b += pos[3 * (size_t)w + 1]; c += pos[3 * (size_t)w + 2]; }
+                            const double inv = 1.0 / (rowptr[v + 1] - rowptr[v]);
+                            nxt[3 * v] = a * inv; nxt[3 * v + 1] = b * inv; nxt[3 * v + 2] = c * inv;
+                        }
+                    });
+                    pos.swap(nxt);
+                }
             }
-        };
-        auto split_parallel = [&](int64_t d) {
-            const int64_t a = seg_start[d], e = seg_start[d + 1], cnt = e - a;
-            if (cnt < 32768) { split_serial(d); return; }
-            const int C = (int)std::min<int64_t>(T, cnt / 8192);
-            std::vector<double> part((size_t)C * 6);
-            for (int c = 0; c < C; ++c) for (int k = 0; k < 3; ++k) { part[(size_t)c * 6 + k] = 1e300; part[(size_t)c * 6 + 3 + k] = -1e300; }
-            parallel_chunks(cnt, C, [&](int c, int64_t lo, int64_t hi) {
+        } else {
+            graph_embedding(V, rowptr, col, pos);
+        }
+        lap("positions");
+        // ---- D rounds of bisection ------------------------------------------------------------------------------------------
+        std::vector<char> fixed((size_t)V, 0), side((size_t)V, 0), endp((size_t)V, 0);
+        // (domain << 2 | side << 1 | fixed) of every vertex in ONE word: the cut detection touches one cache line per neighbour
+        std::vector<int64_t> state((size_t)V, 4);
+        std::vector<int> live((size_t)V);                 // live vertices grouped by domain
+        std::iota(live.begin(), live.end(), 0);
+        int64_t n_live = V;
+        std::vector<int64_t> seg_start;
+        std::vector<int> tmp((size_t)V);
+        // `live` holds the live vertices grouped by domain: domain d of the round owns live[seg_start[d] .. seg_start[d + 1]).
+        // A median split partitions the segment in place, so the next round's grouping is the two halves minus the separator
+        // vertices -- compacted per half with per-domain counts: every pass of a round is parallel over domains or vertices.
+        seg_start.assign(2, 0);
+        seg_start[1] = V;
+        std::vector<int64_t> next_start, keep_cnt;
+        std::vector<int> cnt0, cnt1;
+        // Rounds with fewer domains than threads run their passes parallel INSIDE a domain (the first round is one domain of V
+        // vertices); later rounds run one domain per thread. Both produce the same sets: which vertices land left of the median
+        // is decided by the (key, id) order alone, the arrangement inside `live` is irrelevant.
+        typedef std::pair<double, int> KV;
+        std::vector<KV> kv_a, kv_b;
+        constexpr int NB = 2048;                          // buckets of the parallel selection
+        std::vector<int> hist;
+        struct Piece { int64_t d, lo, hi; int n0, e0, n1, e1; int64_t w0, w1; };
+        std::vector<Piece> pieces;
+        for (int r = 0; r < D; ++r) {
+            const int64_t n_dom = (int64_t)1 << r;
+            const bool inside = 4 * n_dom <= T && n_live >= 65536;       // (with a thread for every second domain or more, whole domains per thread win)
+            auto split_serial = [&](int64_t d) {
+                const int64_t a = seg_start[d], e = seg_start[d + 1], cnt = e - a;
+                if (cnt <= 0) return;
                 double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
-                for (int64_t i = a + lo; i < a + hi; ++i)
+                for (int64_t i = a; i < e; ++i)
                     for (int k = 0; k < 3; ++k) { const double x = pos[3 * (size_t)live[i] + k]; mn[k] = std::min(mn[k], x); mx[k] = std::max(mx[k], x); }
-                for (int k = 0; k < 3; ++k) { part[(size_t)c * 6 + k] = mn[k]; part[(size_t)c * 6 + 3 + k] = mx[k]; }
-            });
-            double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
-            for (int c = 0; c < C; ++c) for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], part[(size_t)c * 6 + k]); mx[k] = std::max(mx[k], part[(size_t)c * 6 + 3 + k]); }
-            int ax = 0;
-            for (int k = 1; k < 3; ++k) if (mx[k] - mn[k] > mx[ax] - mn[ax]) ax = k;
-            const int64_t half = cnt / 2;
-            // bucket = a monotone function of the key: a smaller bucket means a smaller key, so only the median's bucket needs a
-            // real selection
-            const double lo_key = mn[ax], scale = mx[ax] > mn[ax] ? NB / (mx[ax] - mn[ax]) : 0.0;
-            auto bucket = [&](double x) { const int q = (int)((x - lo_key) * scale); return q < 0 ? 0 : q >= NB ? NB - 1 : q; };
-            if ((int64_t)kv_a.size() < cnt) { kv_a.resize((size_t)cnt); kv_b.resize((size_t)cnt); }
-            hist.assign((size_t)C * NB, 0);
-            parallel_chunks(cnt, C, [&](int c, int64_t lo, int64_t hi) {
-                int* h = hist.data() + (size_t)c * NB;
-                for (int64_t i = lo; i < hi; ++i) {
-                    const int u = live[a + i];
-                    const double x = pos[3 * (size_t)u + ax];
-                    kv_a[(size_t)i] = {x, u};
-                    ++h[bucket(x)];
-                }
-            });
-            std::vector<int64_t> total((size_t)NB, 0);
-            for (int c = 0; c < C; ++c) for (int q = 0; q < NB; ++q) total[q] += hist[(size_t)c * NB + q];
-            int bm = 0;
-            int64_t before = 0;
-            while (bm + 1 < NB && before + total[bm] <= half) { before += total[bm]; ++bm; }
-            const int64_t n_left = before, n_mid = total[bm];
-            // write offsets of every chunk's three classes (left of / in / right of the median's bucket)
-            std::vector<int64_t> off((size_t)C * 3);
-            {
-                int64_t wl = 0, wm = n_left, wr = n_left + n_mid;
-                for (int c = 0; c < C; ++c) {
-                    int64_t cl = 0, cr = 0;
-                    const int* h = hist.data() + (size_t)c * NB;
-                    for (int q = 0; q < bm; ++q) cl += h[q];
-                    for (int q = bm + 1; q < NB; ++q) cr += h[q];
-                    off[(size_t)c * 3] = wl; off[(size_t)c * 3 + 1] = wm; off[(size_t)c * 3 + 2] = wr;
-                    wl += cl; wm += h[bm]; wr += cr;
-                }
-            }
-            parallel_chunks(cnt, C, [&](int c, int64_t lo, int64_t hi) {
-                int64_t wl = off[(size_t)c * 3], wm = off[(size_t)c * 3 + 1], wr = off[(size_t)c * 3 + 2];
-                for (int64_t i = lo; i < hi; ++i) {
-                    const KV x = kv_a[(size_t)i];
-                    const int q = bucket(x.first);
-                    kv_b[(size_t)(q < bm ? wl++ : q == bm ? wm++ : wr++)] = x;
-                }
-            });
-            std::nth_element(kv_b.begin() + n_left, kv_b.begin() + half, kv_b.begin() + n_left + n_mid);
-            parallel_chunks(cnt, C, [&](int, int64_t lo, int64_t hi) {
-                for (int64_t i = lo; i < hi; ++i) {
-                    const int u = kv_b[(size_t)i].second;
-                    live[a + i] = u; side[u] = i >= half;
+                int ax = 0;
+                for (int k = 1; k < 3; ++k) if (mx[k] - mn[k] > mx[ax] - mn[ax]) ax = k;
+                const int64_t half = cnt / 2;
+                // selection on contiguous (key, id) pairs: the comparator must not chase pos[] through the index array
+                std::vector<KV> kv((size_t)cnt);
+                for (int64_t i = a; i < e; ++i) kv[(size_t)(i - a)] = {pos[3 * (size_t)live[i] + ax], live[i]};
+                std::nth_element(kv.begin(), kv.begin() + half, kv.end());
+                for (int64_t i = a; i < e; ++i) {
+                    const int u = kv[(size_t)(i - a)].second;
+                    live[i] = u; side[u] = i - a >= half;
                     state[u] = (node[u] << 2) | ((int64_t)side[u] << 1);
                 }
-            });
-        };
-        const auto tr0 = std::chrono::steady_clock::now();
-        // median split of every domain along the longest axis of its bounding box
-        if (inside) { for (int64_t d = 0; d < n_dom; ++d) split_parallel(d); }
-        else parallel_for(n_dom, 1, [&](int64_t lo, int64_t hi) { for (int64_t d = lo; d < hi; ++d) split_serial(d); });
-        const auto tr1 = std::chrono::steady_clock::now();
-        // end points of the cut edges
-        parallel_for(n_live, 4096, [&](int64_t lo, int64_t hi) {
-            for (int64_t i = lo; i < hi; ++i) {
-                const int u = live[i];
-                bool cut = false;
-                const int64_t mine = state[u];          // live vertex of domain node[u] on side side[u]
-                for (int p = rowptr[u]; p < rowptr[u + 1] && !cut; ++p) cut = (state[col[p]] ^ mine) == 2;   // same domain, live, other side
-                endp[u] = cut;
-            }
-        });
-        const auto tr2 = std::chrono::steady_clock::now();
-        // per domain: the smaller end-point set is the separator; what stays in either half moves on, in order, to the next
-        // round's grouping. The passes run over pieces of domains (a domain is one piece once there are enough domains).
-        pieces.clear();
-        {
-            const int per_dom = inside ? (int)std::max<int64_t>(1, 2 * T / n_dom) : 1;
-            for (int64_t d = 0; d < n_dom; ++d) {
-                const int64_t a = seg_start[d], e = seg_start[d + 1];
-                const int np = (int)std::max<int64_t>(1, std::min<int64_t>(per_dom, (e - a) / 4096));
-                const int64_t step = (e - a + np - 1) / np;
-                for (int q = 0; q < np; ++q) {
-                    Piece pc{d, a + q * step, std::min(e, a + (q + 1) * step), 0, 0, 0, 0, 0, 0};
-                    if (pc.lo < pc.hi || q == 0) pieces.push_back(pc);
+            };
+            auto split_parallel = [&](int64_t d) {
+                const int64_t a = seg_start[d], e = seg_start[d + 1], cnt = e - a;
+                if (cnt < 32768) { split_serial(d); return; }
+                const int C = (int)std::min<int64_t>(T, cnt / 8192);
+                std::vector<double> part((size_t)C * 6);
+                for (int c = 0; c < C; ++c) for (int k = 0; k < 3; ++k) { part[(size_t)c * 6 + k] = 1e300; part[(size_t)c * 6 + 3 + k] = -1e300; }
+                parallel_chunks(cnt, C, [&](int c, int64_t lo, int64_t hi) {
+                    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+                    for (int64_t i = a + lo; i < a + hi; ++i)
+                        for (int k = 0; k < 3; ++k) { const double x = pos[3 * (size_t)live[i] + k]; mn[k] = std::min(mn[k], x); mx[k] = std::max(mx[k], x); }
+                    for (int k = 0; k < 3; ++k) { part[(size_t)c * 6 + k] = mn[k]; part[(size_t)c * 6 + 3 + k] = mx[k]; }
+                });
+                double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+                for (int c = 0; c < C; ++c) for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], part[(size_t)c * 6 + k]); mx[k] = std::max(mx[k], part[(size_t)c * 6 + 3 + k]); }
+                int ax = 0;
+                for (int k = 1; k < 3; ++k) if (mx[k] - mn[k] > mx[ax] - mn[ax]) ax = k;
+                const int64_t half = cnt / 2;
+                // bucket = a monotone function of the key: a smaller bucket means a smaller key, so only the median's bucket needs a
+                // real selection
+                const double lo_key = mn[ax], scale = mx[ax] > mn[ax] ? NB / (mx[ax] - mn[ax]) : 0.0;
+                auto bucket = [&](double x) { const int q = (int)((x - lo_key) * scale); return q < 0 ? 0 : q >= NB ? NB - 1 : q; };
+                if ((int64_t)kv_a.size() < cnt) { kv_a.resize((size_t)cnt); kv_b.resize((size_t)cnt); }
+                hist.assign((size_t)C * NB, 0);
+                parallel_chunks(cnt, C, [&](int c, int64_t lo, int64_t hi) {
+                    int* h = hist.data() + (size_t)c * NB;
+                    for (int64_t i = lo; i < hi; ++i) {
+                        const int u = live[a + i];
+                        const double x = pos[3 * (size_t)u + ax];
+                        kv_a[(size_t)i] = {x, u};
+                        ++h[bucket(x)];
+                    }
+                });
+                std::vector<int64_t> total((size_t)NB, 0);
+                for (int c = 0; c < C; ++c) for (int q = 0; q < NB; ++q) total[q] += hist[(size_t)c * NB + q];
+                int bm = 0;
+                int64_t before = 0;
+                while (bm + 1 < NB && before + total[bm] <= half) { before += total[bm]; ++bm; }
+                const int64_t n_left = before, n_mid = total[bm];
+                // write offsets of every chunk's three classes (left of / in / right of the median's bucket)
+                std::vector<int64_t> off((size_t)C * 3);
+                {
+                    int64_t wl = 0, wm = n_left, wr = n_left + n_mid;
+                    for (int c = 0; c < C; ++c) {
+                        int64_t cl = 0, cr = 0;
+                        const int* h = hist.data() + (size_t)c * NB;
+                        for (int q = 0; q < bm; ++q) cl += h[q];
+                        for (int q = bm + 1; q < NB; ++q) cr += h[q];
+                        off[(size_t)c * 3] = wl; off[(size_t)c * 3 + 1] = wm; off[(size_t)c * 3 + 2] = wr;
+                        wl += cl; wm += h[bm]; wr += cr;
+                    }
                 }
-            }
-        }
-        const int64_t n_pieces = (int64_t)pieces.size();
-        parallel_for(n_pieces, 1, [&](int64_t lo, int64_t hi) {
-            for (int64_t q = lo; q < hi; ++q) {
-                Piece& pc = pieces[(size_t)q];
-                const int64_t a = seg_start[pc.d], half = (seg_start[pc.d + 1] - a) / 2;
-                int n0 = 0, e0 = 0, n1 = 0, e1 = 0;
-                for (int64_t i = pc.lo; i < pc.hi; ++i) {
-                    const bool ep = endp[live[i]];
-                    if (i - a >= half) { ++n1; e1 += ep; } else { ++n0; e0 += ep; }
-                }
-                pc.n0 = n0; pc.e0 = e0; pc.n1 = n1; pc.e1 = e1;
-            }
-        });
-        cnt0.assign((size_t)n_dom, 0); cnt1.assign((size_t)n_dom, 0);
-        keep_cnt.assign((size_t)2 * n_dom, 0);
-        for (const Piece& pc : pieces) { cnt0[(size_t)pc.d] += pc.e0; cnt1[(size_t)pc.d] += pc.e1; }
-        for (const Piece& pc : pieces) {
-            const bool use1 = cnt1[(size_t)pc.d] < cnt0[(size_t)pc.d];
-            keep_cnt[2 * (size_t)pc.d] += pc.n0 - (use1 ? 0 : pc.e0);
-            keep_cnt[2 * (size_t)pc.d + 1] += pc.n1 - (use1 ? pc.e1 : 0);
-        }
-        next_start.assign((size_t)2 * n_dom + 1, 0);
-        for (int64_t h = 0; h < 2 * n_dom; ++h) next_start[h + 1] = next_start[h] + keep_cnt[h];
-        {
-            std::vector<int64_t> w(next_start.begin(), next_start.end() - 1);
-            for (Piece& pc : pieces) {
-                const bool use1 = cnt1[(size_t)pc.d] < cnt0[(size_t)pc.d];
-                pc.w0 = w[2 * (size_t)pc.d]; pc.w1 = w[2 * (size_t)pc.d + 1];
-                w[2 * (size_t)pc.d] += pc.n0 - (use1 ? 0 : pc.e0);
-                w[2 * (size_t)pc.d + 1] += pc.n1 - (use1 ? pc.e1 : 0);
-            }
-        }
-        parallel_for(n_pieces, 1, [&](int64_t lo, int64_t hi) {
-            for (int64_t q = lo; q < hi; ++q) {
-                const Piece& pc = pieces[(size_t)q];
-                const int64_t a = seg_start[pc.d], half = (seg_start[pc.d + 1] - a) / 2;
-                const bool use1 = cnt1[(size_t)pc.d] < cnt0[(size_t)pc.d];
-                int64_t w0 = pc.w0, w1 = pc.w1;
-                for (int64_t i = pc.lo; i < pc.hi; ++i) {
+                parallel_chunks(cnt, C, [&](int c, int64_t lo, int64_t hi) {
+                    int64_t wl = off[(size_t)c * 3], wm = off[(size_t)c * 3 + 1], wr = off[(size_t)c * 3 + 2];
+                    for (int64_t i = lo; i < hi; ++i) {
+                        const KV x = kv_a[(size_t)i];
+                        const int q = bucket(x.first);
+                        kv_b[(size_t)(q < bm ? wl++ : q == bm ? wm++ : wr++)] = x;
+                    }
+                });
+                std::nth_element(kv_b.begin() + n_left, kv_b.begin() + half, kv_b.begin() + n_left + n_mid);
+                parallel_chunks(cnt, C, [&](int, int64_t lo, int64_t hi) {
+                    for (int64_t i = lo; i < hi; ++i) {
+                        const int u = kv_b[(size_t)i].second;
+                        live[a + i] = u; side[u] = i >= half;
+                        state[u] = (node[u] << 2) | ((int64_t)side[u] << 1);
+                    }
+                });
+            };
+            const auto tr0 = std::chrono::steady_clock::now();
+            // median split of every domain along the longest axis of its bounding box
+            if (inside) { for (int64_t d = 0; d < n_dom; ++d) split_parallel(d); }
+            else parallel_for(n_dom, 1, [&](int64_t lo, int64_t hi) { for (int64_t d = lo; d < hi; ++d) split_serial(d); });
+            const auto tr1 = std::chrono::steady_clock::now();
+            // end points of the cut edges
+            parallel_for(n_live, 4096, [&](int64_t lo, int64_t hi) {
+                for (int64_t i = lo; i < hi; ++i) {
                     const int u = live[i];
-                    const bool s1 = i - a >= half;
-                    if (endp[u] && s1 == use1) { fixed[u] = 1; state[u] |= 1; continue; }      // node[u] stays: the domain it separates
-                    tmp[(size_t)(s1 ? w1++ : w0++)] = u;
+                    bool cut = false;
+                    const int64_t mine = state[u];          // live vertex of domain node[u] on side side[u]
+                    for (int p = rowptr[u]; p < rowptr[u + 1] && !cut; ++p) cut = (state[col[p]] ^ mine) == 2;   // same domain, live, other side
+                    endp[u] = cut;
+                }
+            });
+            const auto tr2 = std::chrono::steady_clock::now();
+            // per domain: the smaller end-point set is the separator; what stays in either half moves on, in order, to the next
+            // round's grouping. The passes run over pieces of domains (a domain is one piece once there are enough domains).
+            pieces.clear();
+            {
+                const int per_dom = inside ? (int)std::max<int64_t>(1, 2 * T / n_dom) : 1;
+                for (int64_t d = 0; d < n_dom; ++d) {
+                    const int64_t a = seg_start[d], e = seg_start[d + 1];
+                    const int np = (int)std::max<int64_t>(1, std::min<int64_t>(per_dom, (e - a) / 4096));
+                    const int64_t step = (e - a + np - 1) / np;
+                    for (int q = 0; q < np; ++q) {
+                        Piece pc{d, a + q * step, std::min(e, a + (q + 1) * step), 0, 0, 0, 0, 0, 0};
+                        if (pc.lo < pc.hi || q == 0) pieces.push_back(pc);
+                    }
                 }
             }
-        });
-        n_live = next_start[2 * n_dom];
-        parallel_for(n_live, 65536, [&](int64_t lo, int64_t hi) {
-            for (int64_t i = lo; i < hi; ++i) { const int u = tmp[i]; live[i] = u; node[u] = 2 * node[u] + side[u]; }
-        });
-        seg_start.swap(next_start);
-        if (timing) {
-            const auto tr3 = std::chrono::steady_clock::now();
-            auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count() * 1e3; };
-            fprintf(stderr, "[nd_plan]   round %2d (%6lld domains%s): split %.2f ms, cut edges %.2f ms, regroup %.2f ms\n", r, (long long)n_dom, inside ? ", inside" : "",
-                    ms(tr0, tr1), ms(tr1, tr2), ms(tr2, tr3));
+            const int64_t n_pieces = (int64_t)pieces.size();
+            parallel_for(n_pieces, 1, [&](int64_t lo, int64_t hi) {
+                for (int64_t q = lo; q < hi; ++q) {
+                    Piece& pc = pieces[(size_t)q];
+                    const int64_t a = seg_start[pc.d], half = (seg_start[pc.d + 1] - a) / 2;
+                    int n0 = 0, e0 = 0, n1 = 0, e1 = 0;
+                    for (int64_t i = pc.lo; i < pc.hi; ++i) {
+                        const bool ep = endp[live[i]];
+                        if (i - a >= half) { ++n1; e1 += ep; } else { ++n0; e0 += ep; }
+                    }
+                    pc.n0 = n0; pc.e0 = e0; pc.n1 = n1; pc.e1 = e1;
+                }
+            });
+            cnt0.assign((size_t)n_dom, 0); cnt1.assign((size_t)n_dom, 0);
+            keep_cnt.assign((size_t)2 * n_dom, 0);
+            for (const Piece& pc : pieces) { cnt0[(size_t)pc.d] += pc.e0; cnt1[(size_t)pc.d] += pc.e1; }
+            for (const Piece& pc : pieces) {
+                const bool use1 = cnt1[(size_t)pc.d] < cnt0[(size_t)pc.d];
+                keep_cnt[2 * (size_t)pc.d] += pc.n0 - (use1 ? 0 : pc.e0);
+                keep_cnt[2 * (size_t)pc.d + 1] += pc.n1 - (use1 ? pc.e1 : 0);
+            }
+            next_start.assign((size_t)2 * n_dom + 1, 0);
+            for (int64_t h = 0; h < 2 * n_dom; ++h) next_start[h + 1] = next_start[h] + keep_cnt[h];
+            {
+                std::vector<int64_t> w(next_start.begin(), next_start.end() - 1);
+                for (Piece& pc : pieces) {
+                    const bool use1 = cnt1[(size_t)pc.d] < cnt0[(size_t)pc.d];
+                    pc.w0 = w[2 * (size_t)pc.d]; pc.w1 = w[2 * (size_t)pc.d + 1];
+                    w[2 * (size_t)pc.d] += pc.n0 - (use1 ? 0 : pc.e0);
+                    w[2 * (size_t)pc.d + 1] += pc.n1 - (use1 ? pc.e1 : 0);
+                }
+            }
+            parallel_for(n_pieces, 1, [&](int64_t lo, int64_t hi) {
+                for (int64_t q = lo; q < hi; ++q) {
+                    const Piece& pc = pieces[(size_t)q];
+                    const int64_t a = seg_start[pc.d], half = (seg_start[pc.d + 1] - a) / 2;
+                    const bool use1 = cnt1[(size_t)pc.d] < cnt0[(size_t)pc.d];
+                    int64_t w0 = pc.w0, w1 = pc.w1;
+                    for (int64_t i = pc.lo; i < pc.hi; ++i) {
+                        const int u = live[i];
+                        const bool s1 = i - a >= half;
+                        if (endp[u] && s1 == use1) { fixed[u] = 1; state[u] |= 1; continue; }      // node[u] stays: the domain it separates
+                        tmp[(size_t)(s1 ? w1++ : w0++)] = u;
+                    }
+                }
+            });
+            n_live = next_start[2 * n_dom];
+            parallel_for(n_live, 65536, [&](int64_t lo, int64_t hi) {
+                for (int64_t i = lo; i < hi; ++i) { const int u = tmp[i]; live[i] = u; node[u] = 2 * node[u] + side[u]; }
+            });
+            seg_start.swap(next_start);
+            if (timing) {
+                const auto tr3 = std::chrono::steady_clock::now();
+                auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count() * 1e3; };
+                fprintf(stderr, "[nd_plan]   round %2d (%6lld domains%s): split %.2f ms, cut edges %.2f ms, regroup %.2f ms\n", r, (long long)n_dom, inside ? ", inside" : "",
+                        ms(tr0, tr1), ms(tr1, tr2), ms(tr2, tr3));
+            }
         }
     }
     lap("bisection");
@@ -575,8 +594,6 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
 #include "../../include/largesteps_hip.h"
 
 namespace ls { void set_error(const char* fmt, ...); }
-
-struct ls_nd_plan { ls::NdPlan p; };
 
 extern "C" int ls_nd_plan_create(int64_t V, const int32_t* h_rowptr, const int32_t* h_col, const float* h_positions, int leaf_size,
                                  int arity, int smooth, ls_nd_plan** out) {

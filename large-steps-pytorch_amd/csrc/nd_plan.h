@@ -29,7 +29,24 @@ struct NdPlan {
 
 // rowptr / col: CSR pattern of a structurally symmetric matrix (int32, original numbering); pos: V x 3 positions (any scale;
 // only their spatial order matters), nullptr = derive pseudo-positions from graph distances. Returns "" or an error text.
+//
+// bisect: when given, the positions' smoothing and the D = nd_plan_rounds(...) rounds of bisection are done by the callee
+// (csrc/nd_bisect.hip runs them on the device): it fills node[v] = binary heap id of the domain vertex v ended in (a separator
+// vertex: the domain it separates; everything else: its leaf, an id >= 2^D). embedded: nullptr = take the caller's positions and
+// average them `smooth` times over the matrix neighbours; otherwise V x 3 doubles formed here from graph distances (smooth = 0).
+// The host's own rounds (bisect == nullptr) are what the host-only entry points and the CPU tests run, and what the device
+// rounds are checked against (tests/test_nested_gpu.py): both must produce the same node[] bit for bit.
+typedef std::string (*NdBisectFn)(void* ctx, int64_t V, int D, int smooth, const double* embedded, int64_t* node);
+int nd_plan_rounds(int64_t V, int leaf_size, int arity);
 std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, const float* pos, int leaf_size, int arity,
-                          int smooth, NdPlan& out);
+                          int smooth, NdPlan& out, NdBisectFn bisect = nullptr, void* bisect_ctx = nullptr);
+
+// The same analysis with the positions' smoothing and the bisection rounds on the device (csrc/nd_bisect.hip); the matrix pattern is
+// needed on both sides (d_*: device, h_*: host copies). d_positions may be nullptr (graph embedding, formed on the host).
+std::string nd_plan_build_device(const int32_t* d_rowptr, const int32_t* d_col, const float* d_positions, int64_t V, int64_t nnz,
+                                 const int32_t* h_rowptr, const int32_t* h_col, int leaf_size, int arity, int smooth, void* stream,
+                                 NdPlan& out);
 
 }  // namespace ls
+
+struct ls_nd_plan { ls::NdPlan p; };          // the opaque plan object of the C ABI (ls_nd_plan_create / ls_nd_plan_create_device)
