@@ -29,7 +29,8 @@ struct GemmDesc {
     const double* A; const double* B; double* C;
     int M, N, K, lda, ldb, ldc, ta, tb;          // ta / tb: the operand is stored transposed (op(A)[m][k] = A[k * lda + m])
     double alpha, beta;
-};
+    int sym, pad;                                // sym: the product (and C) is symmetric, M == N: only the tiles on and below the diagonal are
+};                                               // computed, the ones below are stored twice (C[m][n] and C[n][m]) -- half the work of the Schur updates
 
 constexpr int GT = 64, GK = 16;                  // 64 x 64 output tile per workgroup, 16-deep slices
 
@@ -38,6 +39,8 @@ __global__ __launch_bounds__(256) void k_gemm_batched(const GemmDesc* __restrict
     const int tiles_n = (d.N + GT - 1) / GT, tiles_m = (d.M + GT - 1) / GT;
     if ((int)blockIdx.x >= tiles_m * tiles_n || d.M <= 0 || d.N <= 0) return;
     const int tm = (blockIdx.x / tiles_n) * GT, tn = (blockIdx.x % tiles_n) * GT;
+    if (d.sym && tn > tm) return;
+    const bool mirror = d.sym && tn < tm;
     __shared__ double sa[GK][GT + 1], sb[GK][GT + 1];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;       // thread -> 4 x 4 outputs at (ty * 4, tx * 4)
     double acc[4][4];
@@ -79,46 +82,106 @@ __global__ __launch_bounds__(256) void k_gemm_batched(const GemmDesc* __restrict
             const int gn = tn + tx * 4 + j;
             if (gn >= d.N) continue;
             double* c = d.C + (size_t)gm * d.ldc + gn;
-            *c = d.alpha * acc[i][j] + (d.beta != 0.0 ? d.beta * *c : 0.0);
+            const double v = d.alpha * acc[i][j] + (d.beta != 0.0 ? d.beta * *c : 0.0);
+            *c = v;
+            if (mirror) d.C[(size_t)gn * d.ldc + gm] = v;
         }
     }
 }
 
-// ---- X = M^-1 for SPD M, n <= 64, one workgroup per matrix in LDS ---------------------------------------------------------------
+// ---- X = M^-1 for SPD M, n <= 128, one workgroup per matrix, the matrix in REGISTERS -------------------------------------------------
 struct InvDesc { const double* M; double* X; int n, ldm, ldx, pad; };
 
-constexpr int INV_N = 64;
+constexpr int INV_N = 128;
 
-// X = M^-1 for SPD blocks of up to 64 rows, one workgroup per block, the block resident in LDS: Gauss-Jordan sweeps in place
-// (no pivoting: the pivots of an SPD matrix are the diagonal of its Schur complements, all positive). Step k reads column k and
-// row k from a copy, so the whole n x n update is one pass between two barriers; thread (ty, tx) owns column tx of rows ty, ty + 4, ...
-__global__ __launch_bounds__(256) void k_spd_inverse_small(const InvDesc* __restrict__ descs, int* __restrict__ flag) {
+// Gauss-Jordan sweeps in place (no pivoting: the pivots of an SPD matrix are the diagonal of its Schur complements, all positive).
+// 256 threads as a 16 x 16 grid, thread (by, bx) owns the RB x RB block of rows by * RB.. and columns bx * RB.. (RB = NB / 16: 4 x 4
+// doubles for NB = 64, 8 x 8 for NB = 128), rows and columns >= n padded with zeros (they stay zero). Step k needs row k and column
+// k of the current matrix: their owners publish them to LDS at the end of step k - 1 (two buffers, by parity), so a step is ONE
+// barrier, 2 RB + 1 LDS reads and RB^2 fused multiply-adds per thread out of registers. The loop over k is blocked by RB with the
+// inner RB steps unrolled: which REGISTER holds row / column k is then known at compile time, only the owning thread is a run-time
+// test. The upper levels of the tree run these one workgroup at a time between the products of the 2 x 2 Schur recursion
+// (inverse_rec): the chain of launches, not the arithmetic, is what the factorisation waits for there -- the version with the matrix
+// in LDS took ~110 us per block (every element read and written through LDS in every step), and its 64-row limit meant one more
+// level of recursion (twice the chain).
+template <int NB>
+__global__ __launch_bounds__(256) void k_spd_inverse_reg(const InvDesc* __restrict__ descs, int* __restrict__ flag) {
+    constexpr int RB = NB / 16;
     const InvDesc d = descs[blockIdx.x];
     const int n = d.n;
     if (n <= 0) return;
-    extern __shared__ __attribute__((aligned(16))) double inv_sm[];
-    double (*a)[INV_N + 1] = reinterpret_cast<double (*)[INV_N + 1]>(inv_sm);
-    __shared__ double colk[INV_N], rowk[INV_N];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    if (tx < n)
-        for (int i = ty; i < n; i += 4) a[i][tx] = d.M[(size_t)i * d.ldm + tx];
+    __shared__ double rowb[2][NB], colb[2][NB];
+    const int bx = threadIdx.x & 15, by = threadIdx.x >> 4;
+    double a[RB][RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+#pragma unroll
+        for (int c = 0; c < RB; ++c) {
+            const int i = by * RB + r, j = bx * RB + c;
+            a[r][c] = (i < n && j < n) ? d.M[(size_t)i * d.ldm + j] : 0.0;
+        }
+    }
+    if (by == 0) {
+#pragma unroll
+        for (int c = 0; c < RB; ++c) rowb[0][bx * RB + c] = a[0][c];
+    }
+    if (bx == 0) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) colb[0][by * RB + r] = a[r][0];
+    }
     __syncthreads();
     bool bad = false;
-    for (int k = 0; k < n; ++k) {
-        if (threadIdx.x < n) { colk[threadIdx.x] = a[threadIdx.x][k]; rowk[threadIdx.x] = a[k][threadIdx.x]; }
-        __syncthreads();
-        double p = colk[k];
-        if (!(p > 0.0)) { bad = true; p = 1.0; }
-        const double ip = 1.0 / p;
-        if (tx < n) {
-            const double r = rowk[tx] * ip;
-            for (int i = ty; i < n; i += 4)
-                a[i][tx] = i == k ? (tx == k ? ip : r) : (tx == k ? -colk[i] * ip : fma(-colk[i], r, a[i][tx]));
+    for (int kb = 0; kb * RB < n; ++kb) {
+#pragma unroll
+        for (int kk = 0; kk < RB; ++kk) {
+            const int k = kb * RB + kk;
+            if (k < n) {                                      // uniform over the workgroup
+                const int cur = kk & 1, nxt = cur ^ 1;        // RB is even: the parity of k is the parity of kk
+                double p = colb[cur][k];
+                if (!(p > 0.0)) { bad = true; p = 1.0; }
+                const double ip = 1.0 / p;
+                double rr[RB], ck[RB];
+#pragma unroll
+                for (int c = 0; c < RB; ++c) rr[c] = rowb[cur][bx * RB + c] * ip;
+#pragma unroll
+                for (int r = 0; r < RB; ++r) ck[r] = colb[cur][by * RB + r];
+#pragma unroll
+                for (int r = 0; r < RB; ++r) {
+#pragma unroll
+                    for (int c = 0; c < RB; ++c) a[r][c] = fma(-ck[r], rr[c], a[r][c]);
+                }
+                if (bx == kb) {                               // column k: -colk[i] / p
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) a[r][kk] = -ck[r] * ip;
+                }
+                if (by == kb) {                               // row k: rowk[j] / p, the pivot itself 1 / p
+#pragma unroll
+                    for (int c = 0; c < RB; ++c) a[kk][c] = rr[c];
+                    if (bx == kb) a[kk][kk] = ip;
+                }
+                // row / column k + 1 of the updated matrix for the next step
+                const int kn = (kk + 1) % RB;                 // a compile-time register index once the kk loop is unrolled
+                const int ob = kk + 1 < RB ? kb : kb + 1;
+                if (by == ob) {
+#pragma unroll
+                    for (int c = 0; c < RB; ++c) rowb[nxt][bx * RB + c] = a[kn][c];
+                }
+                if (bx == ob) {
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) colb[nxt][by * RB + r] = a[r][kn];
+                }
+                __syncthreads();
+            }
         }
-        __syncthreads();
     }
-    if (tx < n)
-        for (int i = ty; i < n; i += 4) d.X[(size_t)i * d.ldx + tx] = a[i][tx];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+#pragma unroll
+        for (int c = 0; c < RB; ++c) {
+            const int i = by * RB + r, j = bx * RB + c;
+            if (i < n && j < n) d.X[(size_t)i * d.ldx + j] = a[r][c];
+        }
+    }
     if (threadIdx.x == 0 && bad) atomicExch(flag, 1);
 }
 
@@ -319,12 +382,14 @@ void inverse_small(FactorCtx& c, const std::vector<Blk>& v) {
         if ((c.err = hipMalloc((void**)&c.d_inv, c.cap_inv * sizeof(InvDesc))) != hipSuccess) return;
     }
     if ((c.err = hipMemcpyAsync(c.d_inv, live.data(), live.size() * sizeof(InvDesc), hipMemcpyHostToDevice, c.st)) != hipSuccess) return;
-    const size_t lds = INV_N * (INV_N + 1) * sizeof(double);
-    hipLaunchKernelGGL(k_spd_inverse_small, dim3((unsigned)live.size()), dim3(256), lds, c.st, c.d_inv, c.d_flag);
+    int nmax = 0;
+    for (const InvDesc& d : live) nmax = std::max(nmax, d.n);
+    if (nmax <= 64) hipLaunchKernelGGL(k_spd_inverse_reg<64>, dim3((unsigned)live.size()), dim3(256), 0, c.st, c.d_inv, c.d_flag);
+    else hipLaunchKernelGGL(k_spd_inverse_reg<128>, dim3((unsigned)live.size()), dim3(256), 0, c.st, c.d_inv, c.d_flag);
     ++c.launches;
 }
 
-// X = M^-1 for every block (SPD, any size): 2 x 2 Schur recursion `depth` times, then the in-LDS inverse. M is overwritten.
+// X = M^-1 for every block (SPD, any size): 2 x 2 Schur recursion `depth` times, then the in-register inverse. M is overwritten.
 void inverse_rec(FactorCtx& c, const std::vector<Blk>& v, int depth) {
     if (depth == 0) { inverse_small(c, v); return; }
     const size_t N = v.size();
@@ -344,7 +409,7 @@ void inverse_rec(FactorCtx& c, const std::vector<Blk>& v, int depth) {
     gemm_batched(c, g);
     for (size_t i = 0; i < N; ++i) {                                  // S = C - T B^T (in place)
         const Blk& b = v[i]; const int n1 = A[i].n, n2 = S[i].n;
-        g.push_back(GemmDesc{b.ws, b.M + (size_t)n1 * b.ldm, S[i].M, n2, n2, n1, n1, b.ldm, b.ldm, 0, 1, -1.0, 1.0});
+        g.push_back(GemmDesc{b.ws, b.M + (size_t)n1 * b.ldm, S[i].M, n2, n2, n1, n1, b.ldm, b.ldm, 0, 1, -1.0, 1.0, 1, 0});
     }
     gemm_batched(c, g);
     inverse_rec(c, S, depth - 1);                                     // X22 = S^-1
@@ -356,7 +421,7 @@ void inverse_rec(FactorCtx& c, const std::vector<Blk>& v, int depth) {
     for (size_t i = 0; i < N; ++i) {                                  // X12 = -T^T X22 ; X11 -= T^T X21
         const Blk& b = v[i]; const int n1 = A[i].n, n2 = S[i].n;
         g.push_back(GemmDesc{b.ws, S[i].X, b.X + n1, n1, n2, n2, n1, b.ldx, b.ldx, 1, 0, -1.0, 0.0});
-        g.push_back(GemmDesc{b.ws, b.X + (size_t)n1 * b.ldx, b.X, n1, n1, n2, n1, b.ldx, b.ldx, 1, 0, -1.0, 1.0});
+        g.push_back(GemmDesc{b.ws, b.X + (size_t)n1 * b.ldx, b.X, n1, n1, n2, n1, b.ldx, b.ldx, 1, 0, -1.0, 1.0, 1, 0});
     }
     gemm_batched(c, g);
 }
@@ -594,7 +659,7 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
         for (int64_t i = first; i < last; ++i) {                    // U = F_bb - W F_sb  (F_sb = F_bs^T)
             const int s = P.s[i], b = P.b[i], m = s + b;
             if (s && b) gd.push_back(GemmDesc{ws + fn[i].w_off, fronts + fn[i].f_off + (size_t)s * m, fronts + fn[i].f_off + (size_t)s * m + s,
-                                              b, b, s, s, m, m, 0, 1, -1.0, 1.0});
+                                              b, b, s, s, m, m, 0, 1, -1.0, 1.0, 1, 0});
         }
         gemm_batched(ctx, gd);
         if (!ids.empty()) {
