@@ -34,6 +34,14 @@ struct GemmDesc {
 
 constexpr int GT = 64, GK = 16;                  // 64 x 64 output tile per workgroup, 16-deep slices
 
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// The products run on the fp64 matrix instruction (v_mfma_f64_16x16x4_f64: D(16 x 16) += A(16 x 4) B(4 x 16), one double of A and
+// of B per lane: lane l holds A[l & 15][l >> 4] and B[l >> 4][l & 15]; D: 4 doubles per lane, register v = row (l >> 4) + 4 v,
+// column l & 15 -- the f64 form has its own row map, cdna_hip_programming.md "Fragment layout"). A wave owns a 32 x 32 quadrant of
+// the workgroup's tile = 2 x 2 instruction tiles: per 4-deep step four 8-byte LDS reads feed four instructions (4096 fused
+// multiply-adds). The scalar version (a 4 x 4 block per thread, 8 LDS reads per 16 multiply-adds) was bound by LDS bandwidth at
+// half the fp64 rate and reached 11-16 TFLOP/s.
 __global__ __launch_bounds__(256) void k_gemm_batched(const GemmDesc* __restrict__ descs) {
     const GemmDesc d = descs[blockIdx.y];
     const int tiles_n = (d.N + GT - 1) / GT, tiles_m = (d.M + GT - 1) / GT;
@@ -42,12 +50,14 @@ __global__ __launch_bounds__(256) void k_gemm_batched(const GemmDesc* __restrict
     if (d.sym && tn > tm) return;
     const bool mirror = d.sym && tn < tm;
     __shared__ double sa[GK][GT + 1], sb[GK][GT + 1];
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;       // thread -> 4 x 4 outputs at (ty * 4, tx * 4)
-    double acc[4][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;        // this wave's quadrant
+    const int l15 = lane & 15, l4 = lane >> 4;
+    f64x4 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+        for (int j = 0; j < 2; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
     for (int k0 = 0; k0 < d.K; k0 += GK) {
         for (int e = threadIdx.x; e < GK * GT; e += 256) {
             // A slice: (m, k); B slice: (k, n). Index order chosen per storage order so that consecutive threads read consecutive memory.
@@ -62,29 +72,31 @@ __global__ __launch_bounds__(256) void k_gemm_batched(const GemmDesc* __restrict
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < GK; ++k) {
-            double a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { a[i] = sa[k][ty * 4 + i]; b[i] = sb[k][tx * 4 + i]; }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+        for (int k4 = 0; k4 < GK; k4 += 4) {
+            const double a0 = sa[k4 + l4][wm + l15], a1 = sa[k4 + l4][wm + 16 + l15];
+            const double b0 = sb[k4 + l4][wn + l15], b1 = sb[k4 + l4][wn + 16 + l15];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int gm = tm + ty * 4 + i;
-        if (gm >= d.M) continue;
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int gn = tn + tx * 4 + j;
-            if (gn >= d.N) continue;
-            double* c = d.C + (size_t)gm * d.ldc + gn;
-            const double v = d.alpha * acc[i][j] + (d.beta != 0.0 ? d.beta * *c : 0.0);
-            *c = v;
-            if (mirror) d.C[(size_t)gn * d.ldc + gm] = v;
+        for (int v = 0; v < 4; ++v) {
+            const int gm = tm + wm + 16 * i + l4 + 4 * v;
+            if (gm >= d.M) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int gn = tn + wn + 16 * j + l15;
+                if (gn >= d.N) continue;
+                double* c = d.C + (size_t)gm * d.ldc + gn;
+                const double r = d.alpha * acc[i][j][v] + (d.beta != 0.0 ? d.beta * *c : 0.0);
+                *c = r;
+                if (mirror) d.C[(size_t)gn * d.ldc + gm] = r;
+            }
         }
     }
 }
