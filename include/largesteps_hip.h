@@ -314,12 +314,15 @@ typedef struct ls_direct_arrays {
     const int32_t* h_bnd;
 } ls_direct_arrays;
 int ls_direct_create(const ls_direct_arrays* arrays, int device, void* stream, ls_direct** out);
-/* Matrix in, solver out: symbolic analysis (host threads), numeric multifrontal factorisation in fp64 on the device with
- * hand-written kernels (csrc/nd_factor.hip), fp32 factor in the solve kernels' layouts, handle. This one call is the
+/* Matrix in, solver out: symbolic analysis (bisection rounds on the device, csrc/nd_bisect.hip; tree, fronts and index lists on
+ * host threads), numeric multifrontal factorisation in fp64 on the device with hand-written kernels (csrc/nd_factor.hip: products
+ * on the fp64 matrix instruction, SPD inverses in registers), fp32 factor in the solve kernels' layouts, handle. This one call is the
  * constructor of the reference's default solver (largesteps/solvers.py:34, CholeskySolverF(n, ii, jj, x, MatrixType.COO)).
  * d_rowptr / d_col / d_val: CSR of the symmetric positive definite matrix (DEVICE, original numbering, column-sorted rows);
- * d_positions: (V, 3) fp32 vertex positions (DEVICE) or NULL (graph-distance pseudo-positions); leaf_size 64 and arity 4 are
- * the tuned defaults; tier_levels deepest levels go into the tier layouts (-1 = chosen by the library: tree levels - 5, at least 2 and at most 4; 0 = none), sparse_leaves != 0 stores the leaves
+ * d_positions: (V, 3) fp32 vertex positions (DEVICE) or NULL (graph-distance pseudo-positions); arity 4 is the tuned default;
+ * leaf_size <= 0 = chosen by the library from V (one dense node up to 1280 vertices -- ONE launch per re-solve --, leaves of up to
+ * 1024 up to 32k vertices, 64 beyond: small systems are bound by their chain of launches, not by bytes), 64 = the large-mesh
+ * setting; tier_levels deepest levels go into the tier layouts (-1 = chosen by the library: tree levels - 5, at least 2 and at most 4, none when the leaves are larger than 128 rows; 0 = none), sparse_leaves != 0 stores the leaves
  * as packed triangle + sparse block; shard_rank / shard_count: subtree sharding (0 / 1: none; every rank factorises the whole
  * matrix, the re-solve is sharded, see ls_direct_solve_part). SYNC. Errors: LS_E_INVALID (not symmetric / not positive definite / bad arguments),
  * LS_E_WORKSPACE (fronts or factor beyond the solver's limits; or an EXPLICIT tier_levels whose subtrees do not fit a workgroup's LDS --

@@ -452,6 +452,12 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
                                 int shard_count, int device, void* stream, ls_direct** out) {
     LS_REQUIRE(out && d_rowptr && d_col && d_val && V > 0 && nnz > 0 && nnz < INT32_MAX, LS_E_INVALID, "ls_direct_factor: bad argument");
     *out = nullptr;
+    // leaf_size <= 0: picked by the size of the system. A re-solve of a small mesh is a chain of launches, ~8-11 us each however few
+    // bytes they move, so small meshes want SHALLOW trees of big dense nodes (tools/leaf_sweep.py, profiles/r03_leaf_size_sweep.txt):
+    // up to 1280 vertices ONE dense node (one launch for both sweeps: 11 us against 33-36 with leaves of 64), up to 32k vertices
+    // leaves of up to 1024 (3-4 levels, 19-43 us against 37-53); beyond that the bytes of the dense leaves cost more than the launches
+    // they save and the leaves are the 64-vertex sparse ones of the tier kernels.
+    if (leaf_size <= 0) leaf_size = V <= 1280 ? (int)V : V <= 32768 ? 1024 : 64;
     DeviceGuard g(device);
     LS_HIP(g.err);
     hipStream_t st = (hipStream_t)stream;
@@ -491,6 +497,14 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
         }
     }
     tier_levels = std::max(0, std::min(std::min(tier_levels, levels), 6));
+    if (tier_auto) {
+        // the tier walks a node with ONE workgroup (a wave per 64-row chunk): right for leaves of <= 64 vertices, 10-30x too slow for a
+        // leaf of hundreds or thousands of rows (a caller's large leaf_size; the single dense node of a very small mesh) -- those go
+        // through the level kernels, which spread a node over as many workgroups as it has row tiles
+        int leaf_max = 0;
+        for (int64_t i = P.level_off[levels - 1]; i < P.level_off[levels]; ++i) leaf_max = std::max(leaf_max, P.s[i]);
+        if (leaf_max > 128 || levels == 1) tier_levels = 0;         // (a single node: the root's launch does both sweeps)
+    }
     bool leaves_ok = tier_levels > 0 && sparse_leaves;
     for (int64_t i = P.level_off[levels - 1]; i < P.level_off[levels] && leaves_ok; ++i) leaves_ok = P.s[i] <= 64;
     // a tier the library picked itself never fails for lack of LDS: one level less until its subtrees fit a workgroup

@@ -257,7 +257,7 @@ class _NativeDirect:
         dev = csr.device
         with torch.cuda.device(dev):
             _native.check(_native.lib().ls_direct_factor(_native.ptr(csr.rowptr), _native.ptr(csr.col), _native.ptr(csr.val), csr.V, csr.nnz,
-                                                         _native.ptr(pos), int(leaf_size), int(arity), int(tier_levels), int(bool(sparse_leaves)),
+                                                         _native.ptr(pos), int(leaf_size or 0), int(arity), int(tier_levels), int(bool(sparse_leaves)),
                                                          int(shard[0]), int(shard[1]), dev.index, _native.stream_of(dev), ctypes.byref(self._h)))
         s3 = (ctypes.c_double * 3)()
         _native.check(_native.lib().ls_direct_factor_seconds(self._h, ctypes.byref(s3)))
@@ -323,7 +323,7 @@ class NestedDissectionSolver(Solver):
     positive definite, RuntimeError when the mesh does not dissect into fronts that fit the kernels.
     """
 
-    def __init__(self, M, leaf_size=64, arity=4, shard=(0, 1)):
+    def __init__(self, M, leaf_size=None, arity=4, shard=(0, 1)):
         import time
         csr = _native.csr_of(M)
         self._csr = csr
@@ -388,7 +388,7 @@ class CholeskySolver(Solver):
     other attribute is the chosen solver's.
     """
 
-    def __init__(self, M, rtol=1e-6, max_iter=10000, chebyshev=True, patch_columns=3, direct=None, leaf_size=64, arity=4):
+    def __init__(self, M, rtol=1e-6, max_iter=10000, chebyshev=True, patch_columns=3, direct=None, leaf_size=None, arity=4):
         if direct is None:
             direct = not os.environ.get("LARGESTEPS_NO_DIRECT")
         self._impl = None
@@ -398,7 +398,7 @@ class CholeskySolver(Solver):
             # one process, several devices: the subtree-sharded solver behind the unchanged call sites
             try:
                 from .distributed import MultiDeviceDirect
-                self._impl = MultiDeviceDirect(M, devices, leaf_size=leaf_size, arity=arity)
+                self._impl = MultiDeviceDirect(M, devices, leaf_size=leaf_size or 64, arity=arity)
             except (ValueError, RuntimeError) as e:
                 self.direct_error = str(e)
                 warnings.warn(f"CholeskySolver: LARGESTEPS_DEVICES={','.join(devices)} could not be used ({e}); one device instead",

@@ -361,9 +361,10 @@ def test_patch_columns_deep_plan(dev, monkeypatch, pc):
         PCGSolver(M, patch_columns=0)
 
 
+@pytest.mark.parametrize("leaf", [None, 64, 16])      # the library's choice (these meshes are small: one dense node) / the large-mesh leaves / a deep tree
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("name", ALL_MESHES)
-def test_direct_solver_all_golden_meshes(golden, dev, name, case):
+def test_direct_solver_all_golden_meshes(golden, dev, name, case, leaf):
     """The nested-dissection direct solver on every golden mesh, the degenerate ones included (non-manifold fans,
     duplicated faces, a collinear triangle with 1e6-sized cotangent weights, unreferenced vertices): either it
     factorises and matches the fp64 oracle, or CholeskySolver falls back to the iteration -- never a wrong answer."""
@@ -374,7 +375,7 @@ def test_direct_solver_all_golden_meshes(golden, dev, name, case):
     idx, val = M.indices().cpu().numpy(), M.values().cpu().numpy()
     b = np.random.default_rng(7).standard_normal((v.shape[0], 3)).astype(np.float32)
     x64 = osv.from_differential(idx[0], idx[1], val, b)
-    s = CholeskySolver(M)
+    s = CholeskySolver(M, leaf_size=leaf)
     x = s.solve(_t(b, dev)).cpu().numpy()
     assert s.method in ("nested-dissection", "iterative")
     if name not in ("collinear", "dupface") or not golden.params[case]["cotan"]:
