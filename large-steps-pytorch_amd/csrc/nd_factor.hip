@@ -352,53 +352,39 @@ namespace {
 
 struct Blk { double* M; double* X; double* ws; int n, ldm, ldx; };
 
+// The factorisation is a fixed sequence of batched launches (per level: extend-add per sibling index, the recursion of the inverse,
+// two products, the conversion) whose descriptors depend on the plan only. They are RECORDED first (host, no device call), uploaded
+// with three copies, and then launched back to back: the first version uploaded every launch's descriptors on its own (~180 small
+// copies from pageable memory) and synchronised the stream ~40 times to reuse its staging buffers -- 5-6 of its 21 ms at 1M.
+struct Cmd { int kind; size_t off; int n, gx, nmax; };        // kind: 0 product, 1 inverse, 2 extend-add, 3 convert
 struct FactorCtx {
-    hipStream_t st;
-    GemmDesc* d_gemm = nullptr; InvDesc* d_inv = nullptr;   // descriptor staging on the device
-    size_t cap_gemm = 0, cap_inv = 0;
-    int* d_flag = nullptr;
-    hipError_t err = hipSuccess;
+    std::vector<GemmDesc> gemm;
+    std::vector<InvDesc> inv;
+    std::vector<int> ids;
+    std::vector<Cmd> cmds;
     int launches = 0;
 };
 
 void gemm_batched(FactorCtx& c, std::vector<GemmDesc>& v) {
-    if (c.err != hipSuccess) return;
-    std::vector<GemmDesc> live;
+    const size_t off = c.gemm.size();
     int tiles = 0;
     for (const GemmDesc& d : v)
-        if (d.M > 0 && d.N > 0) { live.push_back(d); tiles = std::max(tiles, div_up(d.M, GT) * div_up(d.N, GT)); }
+        if (d.M > 0 && d.N > 0) { c.gemm.push_back(d); tiles = std::max(tiles, div_up(d.M, GT) * div_up(d.N, GT)); }
     v.clear();
-    if (live.empty()) return;
-    if (live.size() > c.cap_gemm) {
-        (void)hipFree(c.d_gemm);
-        c.cap_gemm = live.size() * 2;
-        if ((c.err = hipMalloc((void**)&c.d_gemm, c.cap_gemm * sizeof(GemmDesc))) != hipSuccess) return;
-    }
-    // (pageable source: the copy is staged before the call returns, the vector may go out of scope)
-    if ((c.err = hipMemcpyAsync(c.d_gemm, live.data(), live.size() * sizeof(GemmDesc), hipMemcpyHostToDevice, c.st)) != hipSuccess) return;
-    for (size_t b0 = 0; b0 < live.size(); b0 += 65535) {
-        const int nb = (int)std::min<size_t>(65535, live.size() - b0);
-        hipLaunchKernelGGL(k_gemm_batched, dim3(tiles, nb), dim3(256), 0, c.st, c.d_gemm + b0);
-    }
-    ++c.launches;
+    if (c.gemm.size() > off) c.cmds.push_back(Cmd{0, off, (int)(c.gemm.size() - off), tiles, 0});
 }
 
 void inverse_small(FactorCtx& c, const std::vector<Blk>& v) {
-    if (c.err != hipSuccess) return;
-    std::vector<InvDesc> live;
-    for (const Blk& b : v) if (b.n > 0) live.push_back(InvDesc{b.M, b.X, b.n, b.ldm, b.ldx, 0});
-    if (live.empty()) return;
-    if (live.size() > c.cap_inv) {
-        (void)hipFree(c.d_inv);
-        c.cap_inv = live.size() * 2;
-        if ((c.err = hipMalloc((void**)&c.d_inv, c.cap_inv * sizeof(InvDesc))) != hipSuccess) return;
-    }
-    if ((c.err = hipMemcpyAsync(c.d_inv, live.data(), live.size() * sizeof(InvDesc), hipMemcpyHostToDevice, c.st)) != hipSuccess) return;
+    const size_t off = c.inv.size();
     int nmax = 0;
-    for (const InvDesc& d : live) nmax = std::max(nmax, d.n);
-    if (nmax <= 64) hipLaunchKernelGGL(k_spd_inverse_reg<64>, dim3((unsigned)live.size()), dim3(256), 0, c.st, c.d_inv, c.d_flag);
-    else hipLaunchKernelGGL(k_spd_inverse_reg<128>, dim3((unsigned)live.size()), dim3(256), 0, c.st, c.d_inv, c.d_flag);
-    ++c.launches;
+    for (const Blk& b : v) if (b.n > 0) { c.inv.push_back(InvDesc{b.M, b.X, b.n, b.ldm, b.ldx, 0}); nmax = std::max(nmax, b.n); }
+    if (c.inv.size() > off) c.cmds.push_back(Cmd{1, off, (int)(c.inv.size() - off), 0, nmax});
+}
+
+void id_launch(FactorCtx& c, int kind, const std::vector<int>& ids, int gx) {
+    if (ids.empty()) return;
+    c.cmds.push_back(Cmd{kind, c.ids.size(), (int)ids.size(), gx, 0});
+    c.ids.insert(c.ids.end(), ids.begin(), ids.end());
 }
 
 // X = M^-1 for every block (SPD, any size): 2 x 2 Schur recursion `depth` times, then the in-register inverse. M is overwritten.
@@ -565,8 +551,15 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     std::vector<void*> owned, scratch;
     int rc = LS_OK;
     auto dalloc = [&](void** p, size_t bytes, bool keep, bool zero) -> bool {
+        const double ta = timing ? now_s() : 0.0;
         hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 16) + 16);
+        const double tb = timing ? now_s() : 0.0;
         if (e == hipSuccess && zero) e = hipMemsetAsync(*p, 0, std::max<size_t>(bytes, 16) + 16, st);
+        if (timing && bytes > ((size_t)256 << 20)) {
+            (void)hipStreamSynchronize(st);
+            fprintf(stderr, "[ls_direct_factor]   %.2f GB: hipMalloc %.1f ms, %s %.1f ms\n", bytes / 1073741824.0, (tb - ta) * 1e3, zero ? "zeroed in" : "no memset",
+                    (now_s() - tb) * 1e3);
+        }
         if (e != hipSuccess) { rc = hip_fail(e, "ls_direct_factor allocation", __FILE__, __LINE__); *p = nullptr; return false; }
         (keep ? owned : scratch).push_back(*p);
         return true;
@@ -576,7 +569,9 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     double *fronts = nullptr, *xs = nullptr, *ws = nullptr, *work = nullptr;
     int *d_inv = nullptr, *d_non = nullptr, *d_bnd = nullptr, *d_ppos = nullptr, *d_rowidx = nullptr, *d_ids = nullptr;
     FactorNode* d_nodes = nullptr;
-    FactorCtx ctx; ctx.st = st;
+    FactorCtx ctx;
+    int* d_flag = nullptr;
+    GemmDesc* d_gemm = nullptr; InvDesc* d_invd = nullptr;
     int64_t work_tot = 0;
     for (int i = 1; i <= n_nodes; ++i) work_tot += ((int64_t)P.s[i] * P.s[i] + 1) / 2 + 64;
     bool ok = dalloc((void**)&finv, sizeof(float) * o_finv, true, false) && dalloc((void**)&wf, sizeof(float) * o_w, true, false) &&
@@ -588,12 +583,11 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
               dalloc((void**)&ws, sizeof(double) * w_tot, false, false) && dalloc((void**)&work, sizeof(double) * work_tot, false, false) &&
               dalloc((void**)&d_inv, sizeof(int) * V, false, false) && dalloc((void**)&d_non, sizeof(int) * V, false, false) &&
               dalloc((void**)&d_bnd, sizeof(int) * P.n_bnd, false, false) && dalloc((void**)&d_ppos, sizeof(int) * P.n_bnd, false, false) &&
-              dalloc((void**)&d_rowidx, sizeof(int) * nnz, false, false) && dalloc((void**)&d_ids, sizeof(int) * (n_nodes + 1), false, false) &&
-              dalloc((void**)&d_nodes, sizeof(FactorNode) * (n_nodes + 1), false, false) && dalloc((void**)&ctx.d_flag, sizeof(int), false, true);
+              dalloc((void**)&d_rowidx, sizeof(int) * nnz, false, false) &&
+              dalloc((void**)&d_nodes, sizeof(FactorNode) * (n_nodes + 1), false, false) && dalloc((void**)&d_flag, sizeof(int), false, true);
     auto cleanup = [&](bool all) {
         (void)hipStreamSynchronize(st);
         for (void* p : scratch) (void)hipFree(p);
-        (void)hipFree(ctx.d_gemm); (void)hipFree(ctx.d_inv);
         if (all) for (void* p : owned) (void)hipFree(p);
     };
     if (!ok) { cleanup(true); return rc; }
@@ -639,13 +633,11 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     } else if (!dalloc((void**)&d_sp_ent, 16, true, true)) { cleanup(true); return rc; }
     if (e != hipSuccess) { cleanup(true); return hip_fail(e, "ls_direct_factor uploads", __FILE__, __LINE__); }
     lap("uploads");
-    // ---- numeric factorisation -------------------------------------------------------------------------------------------------------
-    hipLaunchKernelGGL(k_assemble, dim3((unsigned)div_up(nnz, 256)), dim3(256), 0, st, nnz, d_rowidx, d_col, d_val, d_inv, d_non, d_nodes, d_bnd,
-                       fronts, ctx.d_flag);
+    // ---- numeric factorisation: recorded (host), uploaded, launched back to back ---------------------------------------------------------
     std::vector<int> ids;
     std::vector<int64_t> work_off((size_t)n_nodes + 1, 0);
     { int64_t o = 0; for (int i = 1; i <= n_nodes; ++i) { work_off[i] = o; o += ((int64_t)P.s[i] * P.s[i] + 1) / 2 + 64; } }
-    for (int lv = levels - 1; lv >= 0 && ctx.err == hipSuccess && e == hipSuccess; --lv) {
+    for (int lv = levels - 1; lv >= 0; --lv) {
         const int64_t first = P.level_off[lv], last = P.level_off[lv + 1];
         if (lv + 1 < levels) {                                      // children's Schur complements, one sibling index per launch
             for (int c = 0; c < arity; ++c) {
@@ -653,14 +645,7 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
                 int bmax = 0;
                 for (int64_t ch = P.level_off[lv + 1] + c; ch < P.level_off[lv + 2]; ch += arity)
                     if (P.b[ch] > 0) { ids.push_back((int)ch); bmax = std::max(bmax, P.b[ch]); }
-                if (ids.empty()) continue;
-                h2d(d_ids, ids.data(), sizeof(int) * ids.size());
-                for (size_t b0 = 0; b0 < ids.size(); b0 += 65535) {
-                    const int nb = (int)std::min<size_t>(65535, ids.size() - b0);
-                    hipLaunchKernelGGL(k_extend_add, dim3(std::min(64, div_up((int64_t)bmax * bmax, 256)), nb), dim3(256), 0, st, d_ids + b0, nb,
-                                       d_nodes, d_ppos, fronts);
-                }
-                e = e == hipSuccess ? hipStreamSynchronize(st) : e;       // ids is reused by the next launch
+                id_launch(ctx, 2, ids, std::min(64, div_up((int64_t)bmax * bmax, 256)));
             }
         }
         int smax = 0;
@@ -688,23 +673,41 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
                                               b, b, s, s, m, m, 0, 1, -1.0, 1.0, 1, 0});
         }
         gemm_batched(ctx, gd);
-        if (!ids.empty()) {
-            h2d(d_ids, ids.data(), sizeof(int) * ids.size());
-            int64_t emax = 0;
-            for (int i : ids) emax = std::max(emax, (int64_t)P.s[i] * (P.s[i] + P.b[i]));
-            for (size_t b0 = 0; b0 < ids.size(); b0 += 65535) {
-                const int nb = (int)std::min<size_t>(65535, ids.size() - b0);
-                hipLaunchKernelGGL(k_convert, dim3(std::min(256, div_up(emax, 256)), nb), dim3(256), 0, st, d_ids + b0, d_nodes, xs, ws, finv, wf, wb, u4,
-                                   d4, tri, pu, pd);
+        int64_t emax = 0;
+        for (int i : ids) emax = std::max(emax, (int64_t)P.s[i] * (P.s[i] + P.b[i]));
+        id_launch(ctx, 3, ids, std::min(256, div_up(emax, 256)));
+    }
+    ok = dalloc((void**)&d_gemm, sizeof(GemmDesc) * ctx.gemm.size(), false, false) && dalloc((void**)&d_invd, sizeof(InvDesc) * ctx.inv.size(), false, false) &&
+         dalloc((void**)&d_ids, sizeof(int) * ctx.ids.size(), false, false);
+    if (!ok) { cleanup(true); return rc; }
+    h2d(d_gemm, ctx.gemm.data(), sizeof(GemmDesc) * ctx.gemm.size());
+    h2d(d_invd, ctx.inv.data(), sizeof(InvDesc) * ctx.inv.size());
+    h2d(d_ids, ctx.ids.data(), sizeof(int) * ctx.ids.size());
+    if (e == hipSuccess)
+        hipLaunchKernelGGL(k_assemble, dim3((unsigned)div_up(nnz, 256)), dim3(256), 0, st, nnz, d_rowidx, d_col, d_val, d_inv, d_non, d_nodes, d_bnd,
+                           fronts, d_flag);
+    for (const Cmd& c : ctx.cmds) {
+        if (e != hipSuccess) break;
+        for (int b0 = 0; b0 < c.n; b0 += 65535) {
+            const int nb = std::min(65535, c.n - b0);
+            switch (c.kind) {
+            case 0: hipLaunchKernelGGL(k_gemm_batched, dim3(c.gx, nb), dim3(256), 0, st, (const GemmDesc*)(d_gemm + c.off + b0)); break;
+            case 1:
+                if (c.nmax <= 64) hipLaunchKernelGGL(k_spd_inverse_reg<64>, dim3(nb), dim3(256), 0, st, (const InvDesc*)(d_invd + c.off + b0), d_flag);
+                else hipLaunchKernelGGL(k_spd_inverse_reg<128>, dim3(nb), dim3(256), 0, st, (const InvDesc*)(d_invd + c.off + b0), d_flag);
+                break;
+            case 2: hipLaunchKernelGGL(k_extend_add, dim3(c.gx, nb), dim3(256), 0, st, (const int*)(d_ids + c.off + b0), nb, d_nodes, d_ppos, fronts); break;
+            default:
+                hipLaunchKernelGGL(k_convert, dim3(c.gx, nb), dim3(256), 0, st, (const int*)(d_ids + c.off + b0), d_nodes, xs, ws, finv, wf, wb, u4, d4, tri, pu, pd);
             }
-            e = e == hipSuccess ? hipStreamSynchronize(st) : e;
         }
+        ++ctx.launches;
     }
     int flag = 0;
-    if (e == hipSuccess && ctx.err == hipSuccess) e = hipMemcpyAsync(&flag, ctx.d_flag, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e == hipSuccess) e = hipGetLastError();
-    if (e != hipSuccess || ctx.err != hipSuccess) { cleanup(true); return hip_fail(e != hipSuccess ? e : ctx.err, "ls_direct_factor kernels", __FILE__, __LINE__); }
+    if (e != hipSuccess) { cleanup(true); return hip_fail(e, "ls_direct_factor kernels", __FILE__, __LINE__); }
     cleanup(false);
     if (flag) {
         for (void* p : owned) (void)hipFree(p);
