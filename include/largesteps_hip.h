@@ -321,7 +321,8 @@ int ls_direct_create(const ls_direct_arrays* arrays, int device, void* stream, l
  * d_rowptr / d_col / d_val: CSR of the symmetric positive definite matrix (DEVICE, original numbering, column-sorted rows);
  * d_positions: (V, 3) fp32 vertex positions (DEVICE) or NULL (graph-distance pseudo-positions); arity 4 is the tuned default;
  * leaf_size <= 0 = chosen by the library from V (one dense node up to 1280 vertices -- ONE launch per re-solve --, leaves of up to
- * 1024 up to 32k vertices, 64 beyond: small systems are bound by their chain of launches, not by bytes), 64 = the large-mesh
+ * 1024 up to 32k vertices, 64 beyond -- 128 where that saves a tree level below 128k vertices: small systems are bound by their chain
+ * of launches, not by bytes), 64 = the large-mesh
  * setting; tier_levels deepest levels go into the tier layouts (-1 = chosen by the library: tree levels - 5, at least 2 and at most 4, none when the leaves are larger than 128 rows; 0 = none), sparse_leaves != 0 stores the leaves
  * as packed triangle + sparse block; shard_rank / shard_count: subtree sharding (0 / 1: none; every rank factorises the whole
  * matrix, the re-solve is sharded, see ls_direct_solve_part). SYNC. Errors: LS_E_INVALID (not symmetric / not positive definite / bad arguments),

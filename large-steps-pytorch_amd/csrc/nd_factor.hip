@@ -443,7 +443,13 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     // up to 1280 vertices ONE dense node (one launch for both sweeps: 11 us against 33-36 with leaves of 64), up to 32k vertices
     // leaves of up to 1024 (3-4 levels, 19-43 us against 37-53); beyond that the bytes of the dense leaves cost more than the launches
     // they save and the leaves are the 64-vertex sparse ones of the tier kernels.
-    if (leaf_size <= 0) leaf_size = V <= 1280 ? (int)V : V <= 32768 ? 1024 : 64;
+    // Between 32k and 128k vertices a tree whose depth rounds the 64-vertex leaves down to < 32 vertices (the rounds come in pairs at
+    // arity 4) is better off one level shallower with dense leaves of 65-128 rows (70k: 75 -> 69 us, 90k: 75.5 -> 70, 122k: 78 -> 76;
+    // from 490k on the sparse leaves' bytes win: 151 against 184 us).
+    if (leaf_size <= 0) {
+        leaf_size = V <= 1280 ? (int)V : V <= 32768 ? 1024 : 64;
+        if (V > 32768 && V <= 131072 && (V >> nd_plan_rounds(V, 64, arity)) < 32) leaf_size = 128;
+    }
     DeviceGuard g(device);
     LS_HIP(g.err);
     hipStream_t st = (hipStream_t)stream;
