@@ -709,20 +709,9 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
         }
         ++ctx.launches;
     }
-    int flag = 0;
-    if (e == hipSuccess) e = hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) { cleanup(true); return hip_fail(e, "ls_direct_factor kernels", __FILE__, __LINE__); }
-    cleanup(false);
-    if (flag) {
-        for (void* p : owned) (void)hipFree(p);
-        set_error(flag == 2 ? "ls_direct_factor: the matrix pattern is not symmetric" : "ls_direct_factor: a front is not positive definite");
-        return LS_E_INVALID;
-    }
-    const double t3 = now_s();
-    lap("numeric factorisation");
-    // ---- the solver handle ---------------------------------------------------------------------------------------------------------------
+    // ---- the solver handle: its tables are built on the host WHILE the device factorises (everything above is only enqueued) ------------
     ls_direct_arrays A;
     memset(&A, 0, sizeof(A));
     A.V = V; A.levels = levels; A.arity = arity; A.h_nodes = hn.data(); A.h_perm = P.perm.data(); A.h_ppos = P.ppos.data(); A.n_bnd = P.n_bnd;
@@ -732,8 +721,21 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     A.shard_rank = shard_rank; A.shard_count = shard_count;
     if (want_span) { A.d_pu = pu; A.d_pd = pd; A.h_pu_off = pu_off.data(); A.h_pd_off = pd_off.data(); A.h_bnd = P.bnd.data(); }
     rc = ls_direct_create(&A, device, stream, out);
-    if (rc != LS_OK) { for (void* p : owned) (void)hipFree(p); return rc; }
-    lap("solve tables (ls_direct_create)");
+    int flag = 0;
+    e = hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (rc != LS_OK || e != hipSuccess || flag) {
+        if (rc == LS_OK) { (void)ls_direct_destroy(*out); *out = nullptr; }       // (the handle does not own the factor arrays yet)
+        cleanup(true);
+        if (rc != LS_OK) return rc;
+        if (e != hipSuccess) return hip_fail(e, "ls_direct_factor kernels", __FILE__, __LINE__);
+        set_error(flag == 2 ? "ls_direct_factor: the matrix pattern is not symmetric" : "ls_direct_factor: a front is not positive definite");
+        return LS_E_INVALID;
+    }
+    cleanup(false);
+    const double t3 = now_s();
+    lap("numeric factorisation + solve tables (overlapped)");
     const double secs[3] = {t1 - t0, t2 - t1, t3 - t2};
     return ls_direct_adopt(*out, owned.data(), (int)owned.size(), secs);
 }
