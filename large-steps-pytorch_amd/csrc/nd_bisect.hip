@@ -22,11 +22,14 @@
 #include "common.h"
 #include "radix.h"
 #include "nd_plan.h"
+#include <chrono>
 #include <string>
 #include <vector>
 
 namespace ls {
 namespace {
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 constexpr int BI = 8;                       // list positions per thread in the regroup kernels
 constexpr int BCH = BLOCK * BI;             // list positions per workgroup
@@ -347,7 +350,10 @@ std::string ls::nd_plan_build_device(const int32_t* d_rowptr, const int32_t* d_c
                                      NdPlan& out) {
     NdBisectDevice ctx{d_rowptr, d_col, d_positions, nnz, (hipStream_t)stream};
     const float given = 0.0f;                  // "positions were given": nd_plan_build only tests the pointer, the values are read on the device
-    return nd_plan_build(V, h_rowptr, h_col, d_positions ? &given : nullptr, leaf_size, arity, smooth, out, nd_bisect_device, &ctx);
+    const double t0 = now_s();
+    const std::string err = nd_plan_build(V, h_rowptr, h_col, d_positions ? &given : nullptr, leaf_size, arity, smooth, out, nd_bisect_device, &ctx);
+    if (getenv("LS_PLAN_TIMING")) fprintf(stderr, "[nd_plan] returned (pool joined, temporaries released) %.3f s after its start\n", now_s() - t0);
+    return err;
 }
 
 extern "C" int ls_nd_plan_create_device(const int32_t* d_rowptr, const int32_t* d_col, const float* d_positions, int64_t V, int64_t nnz,
