@@ -380,13 +380,13 @@ def report_direct(args, solver, M, u, x, tv, v, f, cfg, ms, t_assemble):
         data="synthetic",
         config=dict(workload=describe(args.workload, cfg, V, nnz) + ", factor once (not timed), re-solve timed",
                     solver=(f"HIP nested-dissection multifrontal direct solver behind ls_direct_factor: {inf['levels']} tree levels, "
-                            f"symbolic analysis on host threads, fp64 factorisation with hand-written kernels (once), fp32 factor "
+                            f"symbolic analysis (bisection rounds on the device, tree and index lists on host threads), fp64 factorisation with hand-written kernels (once), fp32 factor "
                             f"{inf['factor_entries'] / 1e6:.1f} M words per solve; re-solve = {inf['launches']} launches (one per upper "
                             f"level and sweep, one per sweep for the deepest {inf['tier_levels']} levels), no atomics"),
                     method="nested-dissection", iterations=0, converged=True, rel_residual=rel_res,
                     max_abs_err_vs_v=float((x - tv).abs().max()), assemble_ms=t_assemble * 1e3,
                     factor_seconds=getattr(solver, "build_seconds", None),
-                    factor_stages_seconds=dict(symbolic_host=tm["plan_seconds"], tables_host=tm["table_seconds"], numeric_device=tm["factor_seconds"]),
+                    factor_stages_seconds=dict(symbolic_analysis=tm["plan_seconds"], layouts_host=tm["table_seconds"], numeric_device_and_solve_tables=tm["factor_seconds"]),
                     solve_bytes=solve_bytes, solve_gbs=solve_bytes / (ms * 1e-3) / 1e9,
                     solve_frac_of_8tbs=solve_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     kernel_us=dict(up_sweep=up_ms * 1e3, down_sweep=down_ms * 1e3, upper_levels_persistent=mid_ms * 1e3,

@@ -313,10 +313,13 @@ class NestedDissectionSolver(Solver):
     """
     Factor-once / re-solve direct solver (what the reference's default method does through cholespy / CHOLMOD,
     solvers.py:26-39), MI355X-native and entirely behind the C ABI (`ls_direct_factor`): geometric nested dissection of
-    the mesh on host threads (csrc/nd_plan.cpp), multifrontal numeric factorisation in fp64 on the device with
-    hand-written kernels (csrc/nd_factor.hip), and a re-solve of one launch per upper tree level and sweep plus one
+    the mesh (bisection rounds on the device, csrc/nd_bisect.hip; tree and index lists on host threads, csrc/nd_plan.cpp),
+    multifrontal numeric factorisation in fp64 on the device with hand-written kernels (csrc/nd_factor.hip), and a re-solve of one launch per upper tree level and sweep plus one
     launch per sweep for the deepest levels (csrc/direct.hip, csrc/nd_tier.h). The result is a function of b only and
     bitwise reproducible.
+
+    leaf_size=None lets the library pick the leaves from the size of the system: one dense node (ONE launch per re-solve) up
+    to 1280 vertices, shallow trees up to 32k vertices, the 64-vertex sparse leaves of the large-mesh kernels beyond.
 
     The dissection uses the vertex positions the matrix was assembled from (`compute_matrix`); a symmetric matrix built
     elsewhere gets graph-distance pseudo-positions instead. Raises ValueError when the matrix is not symmetric or not
