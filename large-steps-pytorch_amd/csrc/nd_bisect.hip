@@ -259,13 +259,22 @@ __global__ __launch_bounds__(BLOCK) void k_nodes(int64_t V, const long long* __r
 
 }  // namespace
 
-struct NdBisectDevice { const int32_t* d_rowptr; const int32_t* d_col; const float* d_pos; int64_t nnz; hipStream_t st; };
+struct NdBisectDevice {
+    const int32_t* d_rowptr; const int32_t* d_col; const float* d_pos; int64_t nnz; hipStream_t st;
+    int32_t* h_col_pending;                 // not nullptr: the host copy of the column indices is still to be made -- WHILE the rounds run
+};
 
 std::string nd_bisect_device(void* ctx, int64_t V, int D, int smooth, const double* embedded, int64_t* node) {
     const NdBisectDevice& A = *(const NdBisectDevice*)ctx;
     hipStream_t st = A.st;
     if (D > 24) return "nd_bisect_device: more than 24 bisection rounds";
-    if (D == 0) { for (int64_t v = 0; v < V; ++v) node[v] = 1; return ""; }
+    if (D == 0) {                              // one domain: nothing to split (the host still gets its copy of the pattern)
+        for (int64_t v = 0; v < V; ++v) node[v] = 1;
+        if (A.h_col_pending && (hipMemcpyAsync(A.h_col_pending, A.d_col, sizeof(int32_t) * A.nnz, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                                hipStreamSynchronize(st) != hipSuccess))
+            return "nd_bisect_device: copy of the pattern failed";
+        return "";
+    }
     const int max_dom = 1 << (D - 1), nb = div_up(V, BCH);
     const size_t nbr = (size_t)div_up(V, RS_CHUNK);
     // one allocation: positions (two copies), 3 x 2 lists, state, node, end-point flags, per-domain tables, scan scratch, sort scratch
@@ -335,6 +344,16 @@ std::string nd_bisect_device(void* ctx, int64_t V, int D, int smooth, const doub
         for (int k = 0; k < 3; ++k) { const int* t = Lc[k]; Lc[k] = Lo[k]; Lo[k] = (int*)t; }
     }
     hipLaunchKernelGGL(k_nodes, dim3(div_up(V, BLOCK)), dim3(BLOCK), 0, st, V, (const long long*)state, d_node);
+    if (A.h_col_pending) {
+        // everything above is only enqueued: the host's copy of the pattern (28 MB at 1M vertices, needed by the boundary sets after the
+        // rounds) crosses the bus on a stream of its own while the device sorts and partitions
+        hipStream_t s2 = nullptr;
+        hipError_t e = hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMemcpyAsync(A.h_col_pending, A.d_col, sizeof(int32_t) * A.nnz, hipMemcpyDeviceToHost, s2);
+        if (e == hipSuccess) e = hipStreamSynchronize(s2);
+        if (s2) (void)hipStreamDestroy(s2);
+        if (e != hipSuccess) { (void)hipStreamSynchronize(st); return "nd_bisect_device: copy of the pattern failed"; }
+    }
     if (hipMemcpyAsync(node, d_node, sizeof(long long) * V, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess ||
         hipGetLastError() != hipSuccess)
         return "nd_bisect_device: device error";
@@ -346,9 +365,16 @@ std::string nd_bisect_device(void* ctx, int64_t V, int D, int smooth, const doub
 // the whole analysis with the rounds on the device: what ls_direct_factor runs (csrc/nd_factor.hip), and -- as a plan object -- what
 // the GPU tests compare with the host-only ls_nd_plan_create
 std::string ls::nd_plan_build_device(const int32_t* d_rowptr, const int32_t* d_col, const float* d_positions, int64_t V, int64_t nnz,
-                                     const int32_t* h_rowptr, const int32_t* h_col, int leaf_size, int arity, int smooth, void* stream,
-                                     NdPlan& out) {
-    NdBisectDevice ctx{d_rowptr, d_col, d_positions, nnz, (hipStream_t)stream};
+                                     int32_t* h_rowptr, int32_t* h_col, int leaf_size, int arity, int smooth, void* stream, NdPlan& out) {
+    hipStream_t st = (hipStream_t)stream;
+    // the host's copy of the pattern: the row pointers now (the analysis looks at them first), the column indices during the device
+    // rounds -- unless there are no positions: the graph embedding walks the pattern on the host before anything else
+    if (hipMemcpyAsync(h_rowptr, d_rowptr, sizeof(int32_t) * (V + 1), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        (!d_positions && hipMemcpyAsync(h_col, d_col, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost, st) != hipSuccess) ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return "the copy of the matrix pattern to the host failed";
+    if (h_rowptr[0] != 0 || h_rowptr[V] != nnz) return "rowptr does not match nnz";
+    NdBisectDevice ctx{d_rowptr, d_col, d_positions, nnz, st, d_positions ? h_col : nullptr};
     const float given = 0.0f;                  // "positions were given": nd_plan_build only tests the pointer, the values are read on the device
     const double t0 = now_s();
     const std::string err = nd_plan_build(V, h_rowptr, h_col, d_positions ? &given : nullptr, leaf_size, arity, smooth, out, nd_bisect_device, &ctx);
@@ -365,10 +391,6 @@ extern "C" int ls_nd_plan_create_device(const int32_t* d_rowptr, const int32_t* 
     LS_HIP(g.err);
     hipStream_t st = (hipStream_t)stream;
     std::vector<int32_t> rowptr((size_t)V + 1), col((size_t)nnz);
-    LS_HIP(hipMemcpyAsync(rowptr.data(), d_rowptr, sizeof(int32_t) * (V + 1), hipMemcpyDeviceToHost, st));
-    LS_HIP(hipMemcpyAsync(col.data(), d_col, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost, st));
-    LS_HIP(hipStreamSynchronize(st));
-    LS_REQUIRE(rowptr[0] == 0 && rowptr[V] == nnz, LS_E_INVALID, "ls_nd_plan_create_device: rowptr does not match nnz");
     ls_nd_plan* h = new ls_nd_plan();
     const std::string err = nd_plan_build_device(d_rowptr, d_col, d_positions, V, nnz, rowptr.data(), col.data(), leaf_size, arity, smooth, st, h->p);
     if (!err.empty()) { delete h; set_error("%s", err.c_str()); return LS_E_INVALID; }

@@ -457,12 +457,7 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     const bool timing = getenv("LS_PLAN_TIMING") != nullptr;
     auto lap = [&](const char* what) { if (timing) { (void)hipStreamSynchronize(st); fprintf(stderr, "[ls_direct_factor] %-30s %.3f s\n", what, now_s() - t0); } };
     // ---- symbolic analysis: the bisection rounds on the device (nd_bisect.hip), the tree / fronts / index lists on the host ------------
-    std::vector<int32_t> rowptr((size_t)V + 1), col((size_t)nnz);
-    LS_HIP(hipMemcpyAsync(rowptr.data(), d_rowptr, sizeof(int32_t) * (V + 1), hipMemcpyDeviceToHost, st));
-    LS_HIP(hipMemcpyAsync(col.data(), d_col, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost, st));
-    LS_HIP(hipStreamSynchronize(st));
-    LS_REQUIRE(rowptr[0] == 0 && rowptr[V] == nnz, LS_E_INVALID, "ls_direct_factor: rowptr does not match nnz");
-    lap("matrix to the host");
+    std::vector<int32_t> rowptr((size_t)V + 1), col((size_t)nnz);          // the host's copy of the pattern, filled by the analysis
     NdPlan P;
     {
         const std::string err = nd_plan_build_device(d_rowptr, d_col, d_positions, V, nnz, rowptr.data(), col.data(), leaf_size, arity, 4, st, P);
@@ -563,7 +558,7 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
         if (e == hipSuccess && zero) e = hipMemsetAsync(*p, 0, std::max<size_t>(bytes, 16) + 16, st);
         if (timing && bytes > ((size_t)256 << 20)) {
             (void)hipStreamSynchronize(st);
-            fprintf(stderr, "[ls_direct_factor]   %.2f GB: hipMalloc %.1f ms, %s %.1f ms\n", bytes / 1073741824.0, (tb - ta) * 1e3, zero ? "zeroed in" : "no memset",
+            fprintf(stderr, "[ls_direct_factor]   %.2f GB: %s %.1f ms, %s %.1f ms\n", bytes / 1073741824.0, "hipMalloc", (tb - ta) * 1e3, zero ? "zeroed in" : "no memset",
                     (now_s() - tb) * 1e3);
         }
         if (e != hipSuccess) { rc = hip_fail(e, "ls_direct_factor allocation", __FILE__, __LINE__); *p = nullptr; return false; }

@@ -41,11 +41,11 @@ int nd_plan_rounds(int64_t V, int leaf_size, int arity);
 std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, const float* pos, int leaf_size, int arity,
                           int smooth, NdPlan& out, NdBisectFn bisect = nullptr, void* bisect_ctx = nullptr);
 
-// The same analysis with the positions' smoothing and the bisection rounds on the device (csrc/nd_bisect.hip); the matrix pattern is
-// needed on both sides (d_*: device, h_*: host copies). d_positions may be nullptr (graph embedding, formed on the host).
+// The same analysis with the positions' smoothing and the bisection rounds on the device (csrc/nd_bisect.hip). The matrix pattern is
+// needed on both sides: d_* on the device, h_rowptr (V + 1) / h_col (nnz) = the CALLER'S BUFFERS for the host copy, filled here (the
+// column indices cross the bus while the device rounds run). d_positions may be nullptr (graph embedding, formed on the host).
 std::string nd_plan_build_device(const int32_t* d_rowptr, const int32_t* d_col, const float* d_positions, int64_t V, int64_t nnz,
-                                 const int32_t* h_rowptr, const int32_t* h_col, int leaf_size, int arity, int smooth, void* stream,
-                                 NdPlan& out);
+                                 int32_t* h_rowptr, int32_t* h_col, int leaf_size, int arity, int smooth, void* stream, NdPlan& out);
 
 }  // namespace ls
 
