@@ -319,7 +319,9 @@ int ls_direct_create(const ls_direct_arrays* arrays, int device, void* stream, l
  * on the fp64 matrix instruction, SPD inverses in registers), fp32 factor in the solve kernels' layouts, handle. This one call is the
  * constructor of the reference's default solver (largesteps/solvers.py:34, CholeskySolverF(n, ii, jj, x, MatrixType.COO)).
  * d_rowptr / d_col / d_val: CSR of the symmetric positive definite matrix (DEVICE, original numbering, column-sorted rows);
- * d_positions: (V, 3) fp32 vertex positions (DEVICE) or NULL (graph-distance pseudo-positions); arity 4 is the tuned default;
+ * d_positions: (V, 3) fp32 vertex positions (DEVICE) or NULL (graph-distance pseudo-positions); arity 2 / 4 / 8 = children per tree
+ * node (1 / 2 / 3 bisection rounds per level), <= 0 = chosen by the library (8 between 12k and 300k vertices, where two tree levels
+ * less are worth more than the larger nodes cost, 4 otherwise);
  * leaf_size <= 0 = chosen by the library from V (one dense node up to 1280 vertices -- ONE launch per re-solve --, leaves of up to
  * 1024 up to 32k vertices, 64 beyond -- 128 where that saves a tree level below 128k vertices: small systems are bound by their chain
  * of launches, not by bytes), 64 = the large-mesh

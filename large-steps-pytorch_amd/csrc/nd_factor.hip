@@ -446,9 +446,22 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     // Between 32k and 128k vertices a tree whose depth rounds the 64-vertex leaves down to < 32 vertices (the rounds come in pairs at
     // arity 4) is better off one level shallower with dense leaves of 65-128 rows (70k: 75 -> 69 us, 90k: 75.5 -> 70, 122k: 78 -> 76;
     // from 490k on the sparse leaves' bytes win: 151 against 184 us).
+    // arity <= 0: picked as well. Between ~12k and ~300k vertices a tree that merges THREE bisection rounds per level (arity 8) has two
+    // levels = four launches less than the arity-4 tree and wins although its nodes are larger (16k: 27.9 against 36.5 us, 70k plane 64.8 /
+    // 68.3, the 70k and 250k configs 67.0 / 71.5 and 105.8 / 113.0, 250k plane 90.0 / 95.6); from ~490k on its extra factor entries cost
+    // more than the launches (490k: 196 against 151 us, 1M: 358 against 229).
+    if (arity <= 0) arity = (V > 12000 && V <= 300000) ? 8 : 4;
     if (leaf_size <= 0) {
-        leaf_size = V <= 1280 ? (int)V : V <= 32768 ? 1024 : 64;
-        if (V > 32768 && V <= 131072 && (V >> nd_plan_rounds(V, 64, arity)) < 32) leaf_size = 128;
+        if (arity == 8) {
+            leaf_size = V <= 1280 ? (int)V : V <= 50000 ? 1024 : 64;
+            // (the rounds come in threes: a depth that rounds the leaves down to < 12 vertices costs a whole level -- 300k: 209 us with
+            // leaves of 9 against 126 with leaves of 73)
+            if (leaf_size == 64 && (V >> nd_plan_rounds(V, 64, 8)) < 12) leaf_size = 128;
+        }
+        else {
+            leaf_size = V <= 1280 ? (int)V : V <= 32768 ? 1024 : 64;
+            if (V > 32768 && V <= 131072 && (V >> nd_plan_rounds(V, 64, arity)) < 32) leaf_size = 128;
+        }
     }
     DeviceGuard g(device);
     LS_HIP(g.err);

@@ -257,7 +257,7 @@ class _NativeDirect:
         dev = csr.device
         with torch.cuda.device(dev):
             _native.check(_native.lib().ls_direct_factor(_native.ptr(csr.rowptr), _native.ptr(csr.col), _native.ptr(csr.val), csr.V, csr.nnz,
-                                                         _native.ptr(pos), int(leaf_size or 0), int(arity), int(tier_levels), int(bool(sparse_leaves)),
+                                                         _native.ptr(pos), int(leaf_size or 0), int(arity or 0), int(tier_levels), int(bool(sparse_leaves)),
                                                          int(shard[0]), int(shard[1]), dev.index, _native.stream_of(dev), ctypes.byref(self._h)))
         s3 = (ctypes.c_double * 3)()
         _native.check(_native.lib().ls_direct_factor_seconds(self._h, ctypes.byref(s3)))
@@ -318,15 +318,16 @@ class NestedDissectionSolver(Solver):
     launch per sweep for the deepest levels (csrc/direct.hip, csrc/nd_tier.h). The result is a function of b only and
     bitwise reproducible.
 
-    leaf_size=None lets the library pick the leaves from the size of the system: one dense node (ONE launch per re-solve) up
-    to 1280 vertices, shallow trees up to 32k vertices, the 64-vertex sparse leaves of the large-mesh kernels beyond.
+    leaf_size=None / arity=None let the library pick the tree from the size of the system: one dense node (ONE launch per
+    re-solve) up to 1280 vertices, shallow trees up to 32k vertices, three bisection rounds per level (arity 8) between 12k and
+    300k vertices, the arity-4 tree with 64-vertex sparse leaves of the large-mesh kernels beyond.
 
     The dissection uses the vertex positions the matrix was assembled from (`compute_matrix`); a symmetric matrix built
     elsewhere gets graph-distance pseudo-positions instead. Raises ValueError when the matrix is not symmetric or not
     positive definite, RuntimeError when the mesh does not dissect into fronts that fit the kernels.
     """
 
-    def __init__(self, M, leaf_size=None, arity=4, shard=(0, 1)):
+    def __init__(self, M, leaf_size=None, arity=None, shard=(0, 1)):
         import time
         csr = _native.csr_of(M)
         self._csr = csr
@@ -391,7 +392,7 @@ class CholeskySolver(Solver):
     other attribute is the chosen solver's.
     """
 
-    def __init__(self, M, rtol=1e-6, max_iter=10000, chebyshev=True, patch_columns=3, direct=None, leaf_size=None, arity=4):
+    def __init__(self, M, rtol=1e-6, max_iter=10000, chebyshev=True, patch_columns=3, direct=None, leaf_size=None, arity=None):
         if direct is None:
             direct = not os.environ.get("LARGESTEPS_NO_DIRECT")
         self._impl = None
@@ -401,7 +402,7 @@ class CholeskySolver(Solver):
             # one process, several devices: the subtree-sharded solver behind the unchanged call sites
             try:
                 from .distributed import MultiDeviceDirect
-                self._impl = MultiDeviceDirect(M, devices, leaf_size=leaf_size or 64, arity=arity)
+                self._impl = MultiDeviceDirect(M, devices, leaf_size=leaf_size or 64, arity=arity or 4)
             except (ValueError, RuntimeError) as e:
                 self.direct_error = str(e)
                 warnings.warn(f"CholeskySolver: LARGESTEPS_DEVICES={','.join(devices)} could not be used ({e}); one device instead",

@@ -91,9 +91,10 @@ def test_sharded_direct_solver(tmp_path, mesh, world, k):
         assert all(int(i[0]) >= 1 and int(i[1]) > 0 for i in info)
 
 
-def test_sharded_direct_solver_at_world_eight_in_one_process():
-    """N = 8 cuts the elimination tree one level deeper than N = 2 / 4 (level 2: sixteen subtrees, two per rank; levels 0 and 1
-    replicated). Eight shard handles in ONE process stand in for the eight ranks: part 0 on each, the exchange buffers summed
+@pytest.mark.parametrize("arity,cut_level", [(4, 2), (8, 1)])
+def test_sharded_direct_solver_at_world_eight_in_one_process(arity, cut_level):
+    """N = 8 cuts the arity-4 elimination tree one level deeper than N = 2 / 4 (level 2: sixteen subtrees, two per rank; levels 0 and 1
+    replicated); the arity-8 tree is cut at level 1 (eight subtrees, one per rank, only the root replicated). Eight shard handles in ONE process stand in for the eight ranks: part 0 on each, the exchange buffers summed
     (what the all-reduce does), part 1 on each, x stitched by row ownership -- against the fp64 oracle at the solver's
     tolerance and against the unsharded solver."""
     import ctypes
@@ -111,7 +112,7 @@ def test_sharded_direct_solver_at_world_eight_in_one_process():
     x64 = osv.from_differential(idx[0], idx[1], val, b_np)
     b = torch.from_numpy(b_np).to(dev)
     lib = _native.lib()
-    ranks = [NestedDissectionSolver(M, shard=(r, world)) for r in range(world)]
+    ranks = [NestedDissectionSolver(M, leaf_size=64, arity=arity, shard=(r, world)) for r in range(world)]
     owned, per_col, cuts = [], None, set()
     for s in ranks:
         rk, cnt, cut, pc = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int64(0)
@@ -120,7 +121,7 @@ def test_sharded_direct_solver_at_world_eight_in_one_process():
                                                mask.ctypes.data_as(ctypes.c_void_p)))
         assert cnt.value == world
         owned.append(mask.astype(bool)); cuts.add(cut.value); per_col = pc.value
-    assert cuts == {2}, "eight ranks cut the arity-4 tree at level 2"
+    assert cuts == {cut_level}, "eight ranks cut the arity-4 tree at level 2, the arity-8 tree at level 1"
     assert np.array_equal(np.sum(owned, axis=0), np.ones(v.shape[0])), "ownership partitions the rows"
     ex = [torch.zeros(per_col * k, dtype=torch.float32, device=dev) for _ in ranks]
     xs = [torch.zeros_like(b) for _ in ranks]
