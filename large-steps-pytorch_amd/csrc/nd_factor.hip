@@ -453,7 +453,10 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     if (arity <= 0) arity = (V > 12000 && V <= 300000) ? 8 : 4;
     if (leaf_size <= 0) {
         if (arity == 8) {
-            leaf_size = V <= 1280 ? (int)V : V <= 50000 ? 1024 : 64;
+            // up to 36k vertices three levels of big dense nodes and no tier (16k: 28 us); up to 105k vertices four levels with dense
+            // leaves of 70-205 rows walked by the tier's leaf launch alone (40k: 43 against 52 us, 50k: 48 / 59, 70k: 57 / 65, 100k: 63 /
+            // 66); beyond, five levels with the sparse 64-vertex leaves
+            leaf_size = V <= 1280 ? (int)V : V <= 36000 ? 1024 : V <= 105000 ? 256 : 64;
             // (the rounds come in threes: a depth that rounds the leaves down to < 12 vertices costs a whole level -- 300k: 209 us with
             // leaves of 9 against 126 with leaves of 73)
             if (leaf_size == 64 && (V >> nd_plan_rounds(V, 64, 8)) < 12) leaf_size = 128;
@@ -498,12 +501,20 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     }
     tier_levels = std::max(0, std::min(std::min(tier_levels, levels), 6));
     if (tier_auto) {
-        // the tier walks a node with ONE workgroup (a wave per 64-row chunk): right for leaves of <= 64 vertices, 10-30x too slow for a
-        // leaf of hundreds or thousands of rows (a caller's large leaf_size; the single dense node of a very small mesh) -- those go
+        // the tier walks a node with ONE workgroup (a wave per 64-row chunk): right for leaves of <= 64 vertices, fine for the leaf level
+        // alone up to ~200 rows (tools/leaf_sweep.py: arity 8, 70k vertices, leaves of 137: 57 us with a tier of one level, 97 with two,
+        // 74 with none), 10-30x too slow for a leaf of many hundreds or thousands of rows (a caller's large leaf_size; the single dense node of a very small mesh) -- those go
         // through the level kernels, which spread a node over as many workgroups as it has row tiles
         int leaf_max = 0;
         for (int64_t i = P.level_off[levels - 1]; i < P.level_off[levels]; ++i) leaf_max = std::max(leaf_max, P.s[i]);
-        if (leaf_max > 128 || levels == 1) tier_levels = 0;         // (a single node: the root's launch does both sweeps)
+        const int64_t n_leaves = P.level_off[levels] - P.level_off[levels - 1];
+        if (leaf_max > 256 || levels == 1) tier_levels = 0;         // (a single node: the root's launch does both sweeps)
+        else if (leaf_max > 64) {                                   // dense leaves
+            // many leaves of up to ~220 rows in a shallow tree: the tier's leaf launch alone (64 leaves of 256 rows are better off in the
+            // level kernels: 16k vertices 28 against 37 us)
+            if (levels <= 4 && n_leaves >= 256 && leaf_max <= 224) tier_levels = std::min(tier_levels, 1);
+            else if (leaf_max > 128) tier_levels = 0;
+        }
     }
     bool leaves_ok = tier_levels > 0 && sparse_leaves;
     for (int64_t i = P.level_off[levels - 1]; i < P.level_off[levels] && leaves_ok; ++i) leaves_ok = P.s[i] <= 64;
