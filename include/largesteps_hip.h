@@ -314,6 +314,10 @@ typedef struct ls_direct_arrays {
     const int32_t* h_bnd;
 } ls_direct_arrays;
 int ls_direct_create(const ls_direct_arrays* arrays, int device, void* stream, ls_direct** out);
+/* The tree ls_direct_factor picks for a V x V system: on entry *leaf_size / *arity <= 0 mean "pick" (explicit values are kept), on return
+ * both hold what the factorisation will use. Host only (no device is touched): the rule is a table of measured crossovers
+ * (profiles/r03_leaf_size_sweep.txt), documented in DESIGN.md section 2.3. */
+int ls_direct_pick_tree(int64_t V, int* leaf_size, int* arity);
 /* Matrix in, solver out: symbolic analysis (bisection rounds on the device, csrc/nd_bisect.hip; tree, fronts and index lists on
  * host threads), numeric multifrontal factorisation in fp64 on the device with hand-written kernels (csrc/nd_factor.hip: products
  * on the fp64 matrix instruction, SPD inverses in registers), fp32 factor in the solve kernels' layouts, handle. This one call is the

@@ -433,11 +433,11 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
 int ls_direct_adopt(ls_direct* d, void* const* owned, int n_owned, const double* seconds3);
 bool direct_tier_fits(int levels, int arity, const int* s, const int* b, const int* own_start, int tier_levels, bool sparse_leaves);
 
-extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, const float* d_val, int64_t V, int64_t nnz,
-                                const float* d_positions, int leaf_size, int arity, int tier_levels, int sparse_leaves, int shard_rank,
-                                int shard_count, int device, void* stream, ls_direct** out) {
-    LS_REQUIRE(out && d_rowptr && d_col && d_val && V > 0 && nnz > 0 && nnz < INT32_MAX, LS_E_INVALID, "ls_direct_factor: bad argument");
-    *out = nullptr;
+// ---- the tree the library picks for a system of V unknowns (leaf_size <= 0 / arity <= 0 on entry = "pick"; explicit values stay) ----------
+extern "C" int ls_direct_pick_tree(int64_t V, int* leaf_size_io, int* arity_io) {
+    using namespace ls;
+    LS_REQUIRE(leaf_size_io && arity_io && V > 0, LS_E_INVALID, "ls_direct_pick_tree: bad argument");
+    int leaf_size = *leaf_size_io, arity = *arity_io;
     // leaf_size <= 0: picked by the size of the system. A re-solve of a small mesh is a chain of launches, ~8-11 us each however few
     // bytes they move, so small meshes want SHALLOW trees of big dense nodes (tools/leaf_sweep.py, profiles/r03_leaf_size_sweep.txt):
     // up to 1280 vertices ONE dense node (one launch for both sweeps: 11 us against 33-36 with leaves of 64), up to 32k vertices
@@ -466,6 +466,16 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
             if (V > 32768 && V <= 131072 && (V >> nd_plan_rounds(V, 64, arity)) < 32) leaf_size = 128;
         }
     }
+    *leaf_size_io = leaf_size; *arity_io = arity;
+    return LS_OK;
+}
+
+extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, const float* d_val, int64_t V, int64_t nnz,
+                                const float* d_positions, int leaf_size, int arity, int tier_levels, int sparse_leaves, int shard_rank,
+                                int shard_count, int device, void* stream, ls_direct** out) {
+    LS_REQUIRE(out && d_rowptr && d_col && d_val && V > 0 && nnz > 0 && nnz < INT32_MAX, LS_E_INVALID, "ls_direct_factor: bad argument");
+    *out = nullptr;
+    { const int rc_pick = ls_direct_pick_tree(V, &leaf_size, &arity); if (rc_pick) return rc_pick; }      // leaf_size / arity <= 0: picked from V
     DeviceGuard g(device);
     LS_HIP(g.err);
     hipStream_t st = (hipStream_t)stream;

@@ -157,3 +157,29 @@ def test_adam_uniform_capturable_state_dict_round_trip_keeps_an_int32_counter():
     import copy
     opt3 = copy.deepcopy(opt2)                       # __setstate__ path
     assert next(iter(opt3.state.values()))["step"].dtype == torch.int32
+
+
+def test_picked_tree_by_system_size():
+    """ls_direct_pick_tree (host only): the tree ls_direct_factor uses when leaf size / arity are left to the library -- one dense node
+    for very small systems, shallow arity-4 trees up to 12k unknowns, arity 8 between 12k and 300k (three levels / four levels with dense
+    leaves / five levels with sparse leaves), the arity-4 tree with 64-vertex leaves beyond; explicit values are kept."""
+    import ctypes
+    from largesteps import _native
+    lib = _native.lib()
+
+    def pick(V, leaf=0, arity=0):
+        l, a = ctypes.c_int(leaf), ctypes.c_int(arity)
+        _native.check(lib.ls_direct_pick_tree(V, ctypes.byref(l), ctypes.byref(a)))
+        return l.value, a.value
+
+    assert pick(4) == (4, 4) and pick(1280) == (1280, 4)
+    assert pick(1281) == (1024, 4) and pick(12000) == (1024, 4)
+    assert pick(12001) == (1024, 8) and pick(36000) == (1024, 8)
+    assert pick(36001) == (256, 8) and pick(70562) == (256, 8) and pick(105000) == (256, 8)
+    assert pick(105001) == (64, 8) and pick(249642) == (64, 8)
+    assert pick(300000) == (128, 8)                       # 64-vertex leaves would round down to 9 vertices: one level less
+    assert pick(300001) == (64, 4) and pick(1000000) == (64, 4) and pick(4000000) == (64, 4)
+    assert pick(70000, leaf=64) == (64, 8) and pick(1000000, leaf=32, arity=2) == (32, 2)
+    assert pick(70225, arity=4) == (128, 4) and pick(40000, arity=4) == (64, 4)      # the arity-4 rules for callers that fix the arity
+    with pytest.raises(Exception):
+        _native.check(lib.ls_direct_pick_tree(0, ctypes.byref(ctypes.c_int(0)), ctypes.byref(ctypes.c_int(0))))
