@@ -374,6 +374,17 @@ def report_direct(args, solver, M, u, x, tv, v, f, cfg, ms, t_assemble):
     grp_gbs = grp_bytes / (grp_ms * 1e-3) / 1e9
     traffic, traffic_n = pmc_traffic_group(grp_prefixes, args.workload)
     tm = solver.timings
+    # the constructor once more, after everything above (not timed, not used): the solver above was the FIRST one this process built and
+    # paid the process' one-off costs (kernel code objects loaded on first launch, host thread pool, fresh heap); a remesh loop pays this
+    repeat_seconds = None
+    if not args.no_extra_baselines:
+        try:
+            from largesteps.solvers import NestedDissectionSolver
+            s2 = NestedDissectionSolver(M)
+            repeat_seconds = s2.build_seconds
+            del s2
+        except Exception:
+            repeat_seconds = None
     out = dict(
         metric="from_differential_solves_per_sec", value=1e3 / ms, unit="solves/s", n_gpus=1, steps=args.steps,
         warmup=args.warmup, ms_per_step=ms, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32",
@@ -385,7 +396,7 @@ def report_direct(args, solver, M, u, x, tv, v, f, cfg, ms, t_assemble):
                             f"level and sweep, one per sweep for the deepest {inf['tier_levels']} levels), no atomics"),
                     method="nested-dissection", iterations=0, converged=True, rel_residual=rel_res,
                     max_abs_err_vs_v=float((x - tv).abs().max()), assemble_ms=t_assemble * 1e3,
-                    factor_seconds=getattr(solver, "build_seconds", None),
+                    factor_seconds=getattr(solver, "build_seconds", None), factor_seconds_second_construction=repeat_seconds,
                     factor_stages_seconds=dict(symbolic_analysis=tm["plan_seconds"], layouts_host=tm["table_seconds"], numeric_device_and_solve_tables=tm["factor_seconds"]),
                     solve_bytes=solve_bytes, solve_gbs=solve_bytes / (ms * 1e-3) / 1e9,
                     solve_frac_of_8tbs=solve_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
