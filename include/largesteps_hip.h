@@ -323,17 +323,20 @@ int ls_direct_pick_tree(int64_t V, int* leaf_size, int* arity);
  * on the fp64 matrix instruction, SPD inverses in registers), fp32 factor in the solve kernels' layouts, handle. This one call is the
  * constructor of the reference's default solver (largesteps/solvers.py:34, CholeskySolverF(n, ii, jj, x, MatrixType.COO)).
  * d_rowptr / d_col / d_val: CSR of the symmetric positive definite matrix (DEVICE, original numbering, column-sorted rows);
- * d_positions: (V, 3) fp32 vertex positions (DEVICE) or NULL (graph-distance pseudo-positions); arity 2 / 4 / 8 = children per tree
- * node (1 / 2 / 3 bisection rounds per level), <= 0 = chosen by the library (8 between 12k and 300k vertices, where two tree levels
- * less are worth more than the larger nodes cost, 4 otherwise);
- * leaf_size <= 0 = chosen by the library from V (one dense node up to 1280 vertices -- ONE launch per re-solve --, leaves of up to
- * 1024 up to 32k vertices, 64 beyond -- 128 where that saves a tree level below 128k vertices: small systems are bound by their chain
- * of launches, not by bytes), 64 = the large-mesh
- * setting; tier_levels deepest levels go into the tier layouts (-1 = chosen by the library: tree levels - 5, at least 2 and at most 4, none when the leaves are larger than 128 rows; 0 = none), sparse_leaves != 0 stores the leaves
- * as packed triangle + sparse block; shard_rank / shard_count: subtree sharding (0 / 1: none; every rank factorises the whole
- * matrix, the re-solve is sharded, see ls_direct_solve_part). SYNC. Errors: LS_E_INVALID (not symmetric / not positive definite / bad arguments),
- * LS_E_WORKSPACE (fronts or factor beyond the solver's limits; or an EXPLICIT tier_levels whose subtrees do not fit a workgroup's LDS --
- * tier_levels = -1 lowers its own choice until it fits and never fails for that reason). */
+ * d_positions: (V, 3) fp32 vertex positions (DEVICE) or NULL (graph-distance pseudo-positions);
+ * arity 2 / 4 / 8 = children per tree node (1 / 2 / 3 bisection rounds per level) and leaf_size = the largest leaf, or <= 0 = chosen
+ *   by the library from V (ls_direct_pick_tree above; small and medium systems are bound by their chain of launches, not by bytes):
+ *   one dense node up to 1280 unknowns (ONE launch per re-solve), arity 4 with leaves of up to 1024 up to 12k, arity 8 between 12k and
+ *   300k (three levels of dense nodes up to 36k, four levels with dense leaves of 70-205 rows up to 105k, five levels with 64-vertex
+ *   sparse leaves beyond), arity 4 with 64-vertex sparse leaves -- the large-mesh setting -- above 300k;
+ * tier_levels deepest levels go into the tier layouts (-1 = chosen by the library: tree levels - 5, at least 2 and at most 4; the leaf
+ *   level alone for many dense leaves of 65-224 rows in a tree of at most 4 levels; none for leaves of more than 256 rows or a single
+ *   node; 0 = none); sparse_leaves != 0 stores leaves of at most 64 rows as packed triangle + sparse block;
+ * shard_rank / shard_count: subtree sharding (0 / 1: none; every rank factorises the whole matrix, the re-solve is sharded, see
+ *   ls_direct_solve_part).
+ * SYNC. Errors: LS_E_INVALID (not symmetric / not positive definite / bad arguments), LS_E_WORKSPACE (fronts or factor beyond the
+ * solver's limits; or an EXPLICIT tier_levels whose subtrees do not fit a workgroup's LDS -- tier_levels = -1 lowers its own choice
+ * until it fits and never fails for that reason). */
 int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, const float* d_val, int64_t V, int64_t nnz,
                      const float* d_positions, int leaf_size, int arity, int tier_levels, int sparse_leaves, int shard_rank,
                      int shard_count, int device, void* stream, ls_direct** out);
