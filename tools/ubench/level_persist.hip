@@ -158,7 +158,11 @@ __global__ __launch_bounds__(64 * NW) void k_levels(Args A, const float* __restr
 // look-back scan); a tile requests its matrix rows at once, then waits for ITS PARENT NODE only (a counter of finished
 // tiles per node, agent-scope release / acquire), multiplies, stores, counts itself in. No device-wide barrier.
 struct FlowArgs { Lv lv[MAXL]; int first[MAXL + 1]; int nlv, fan; };      // first[l]: first workgroup id of level l; fan: children per node
-template <bool COH>
+// COH: 0 = acquire / release, 1 = relaxed counters + per-element coherent (atomic) accesses of the hand-over vectors, 2 = relaxed counters +
+// write-through stores / sc1 loads through raw buffer instructions (the recipe of csrc/nd_span.h, round 3)
+constexpr int FLOW_SC1 = 16 | (int)0x80000000;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t flow_rsrc(const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000); }
+template <int COH>
 __global__ __launch_bounds__(64 * NW) void k_flow(FlowArgs A, const float* __restrict__ mat, float* outs, unsigned* done, unsigned epoch) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(64 * NW) void k_flow(FlowArgs A, const float* __res
             unsigned* c = done + (size_t)(l - 1) * 4096 + parent;
             const unsigned target = epoch * (unsigned)pv.tpn;
             int spins = 0;
-            while (__hip_atomic_load(c, COH ? __ATOMIC_RELAXED : __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < 4000000) __builtin_amdgcn_s_sleep(2);
+            while (__hip_atomic_load(c, COH ? __ATOMIC_RELAXED : __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < 4000000) __builtin_amdgcn_s_sleep(COH == 2 ? 1 : 2);
             if (spins >= 4000000) done[MAXL * 4096] = 1u;
         }
         __syncthreads();
@@ -188,7 +192,8 @@ __global__ __launch_bounds__(64 * NW) void k_flow(FlowArgs A, const float* __res
 #pragma unroll
             for (int q = 0; q < K; ++q) {
                 float* src = outs + pv.out_off + ((size_t)parent * pv.S + (u % pv.S)) * K + q;
-                sm[u * K + q] = COH ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
+                if (COH == 2) sm[u * K + q] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(flow_rsrc(outs), (int)((src - outs) * 4), 0, FLOW_SC1));
+                else sm[u * K + q] = COH ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
             }
         }
     } else {
@@ -204,7 +209,8 @@ __global__ __launch_bounds__(64 * NW) void k_flow(FlowArgs A, const float* __res
 #pragma unroll
         for (int q = 0; q < K; ++q) {
             float* dst = outs + v.out_off + ((size_t)node * v.S + jw + lane) * K + q;
-            if (COH) __hip_atomic_store(dst, mine[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *dst = mine[q];
+            if (COH == 2) __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(mine[q]), flow_rsrc(outs), (int)((dst - outs) * 4), 0, FLOW_SC1);
+            else if (COH) __hip_atomic_store(dst, mine[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *dst = mine[q];
         }
     }
     if (l + 1 < A.nlv) {                       // the last level has no dependants
@@ -344,12 +350,13 @@ int main(int argc, char** argv) {
         F.first[NL] = first;
         unsigned* done; CK(hipMalloc(&done, (MAXL * 4096 + 4) * 4)); CK(hipMemset(done, 0, (MAXL * 4096 + 4) * 4));
         unsigned ep = 0;
-        for (int mode = 0; mode < 3; ++mode) {
+        for (int mode = 0; mode < 4; ++mode) {
             auto run = [&](int r) {
                 const float* m = mat + (size_t)(r % COPIES) * mat_n;
                 if (mode == 0) { for (int l = 0; l < NL; ++l) hipLaunchKernelGGL(k_flow_level, dim3(F.lv[l].tiles), dim3(64 * NW), lds, 0, F, m, outs, l); }
-                else if (mode == 1) { ++ep; hipLaunchKernelGGL(k_flow<false>, dim3(first), dim3(64 * NW), lds, 0, F, m, outs, done, ep); }
-                else { ++ep; hipLaunchKernelGGL(k_flow<true>, dim3(first), dim3(64 * NW), lds, 0, F, m, outs, done, ep); }
+                else if (mode == 1) { ++ep; hipLaunchKernelGGL(k_flow<0>, dim3(first), dim3(64 * NW), lds, 0, F, m, outs, done, ep); }
+                else if (mode == 2) { ++ep; hipLaunchKernelGGL(k_flow<1>, dim3(first), dim3(64 * NW), lds, 0, F, m, outs, done, ep); }
+                else { ++ep; hipLaunchKernelGGL(k_flow<2>, dim3(first), dim3(64 * NW), lds, 0, F, m, outs, done, ep); }
             };
             for (int r = 0; r < 5; ++r) run(r);
             CK(hipDeviceSynchronize());
@@ -363,7 +370,7 @@ int main(int argc, char** argv) {
             unsigned flag = 0; CK(hipMemcpy(&flag, done + MAXL * 4096, 4, hipMemcpyDeviceToHost));
             if (flag) printf("  A WAIT TIMED OUT\n");
             printf("flow mode %d (%s): %7.2f us per sweep of %d levels, %.0f GB/s   max diff %.3g (max |ref| %.3g)\n", mode,
-                   mode == 0 ? "one launch per level" : mode == 1 ? "ONE launch, tiles wait for their parent node (acquire / release)" : "ONE launch, tiles wait for their parent node (relaxed counters, L2-coherent vector accesses)", ms / REPS * 1e3, NL, mat_n * 4 / (ms / REPS * 1e-3) * 1e-9, diff, mx);
+                   mode == 0 ? "one launch per level" : mode == 1 ? "ONE launch, tiles wait for their parent node (acquire / release)" : mode == 2 ? "ONE launch, tiles wait for their parent node (relaxed counters, L2-coherent vector accesses)" : "ONE launch, tiles wait for their parent node (relaxed counters, write-through stores / sc1 buffer loads)", ms / REPS * 1e3, NL, mat_n * 4 / (ms / REPS * 1e-3) * 1e-9, diff, mx);
         }
     }
     {   // ---- the four subtrees below the root as four concurrent chains of launches (streams), replayed as ONE graph
