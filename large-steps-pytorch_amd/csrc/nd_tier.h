@@ -28,7 +28,10 @@
 namespace ls {
 
 constexpr int TIER_MAX_H = 6;            // tree levels one workgroup may walk
-constexpr int TIER_WAVES = 4;            // waves per tier workgroup
+#ifndef LS_TIER_WAVES
+#define LS_TIER_WAVES 4
+#endif
+constexpr int TIER_WAVES = LS_TIER_WAVES;   // waves per tier workgroup (build macro for A/B runs: 8 was measured)
 constexpr int TIER_TRI4 = 9;             // 16-byte loads per lane that hold a leaf triangle (s <= 64: 2080 floats = 520 float4)
 constexpr int TIER_SPE = 4;              // sparse entries per row prefetched to registers (longer rows: loop)
 
@@ -708,7 +711,7 @@ __device__ __forceinline__ void node_down(const TierArgs& a, const TierItem& it,
 
 // One workgroup per subtree. UP: phases run leaves -> tier root. DOWN: tier root -> leaves.
 template <int K, bool UP>
-__global__ __launch_bounds__(64 * TIER_WAVES, 4) void k_nd_tier(TierArgs a, const float* __restrict__ b_in, float* __restrict__ x_out,
+__global__ __launch_bounds__(64 * TIER_WAVES, 16 / TIER_WAVES) void k_nd_tier(TierArgs a, const float* __restrict__ b_in, float* __restrict__ x_out,
                                                               int tri_floats) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
