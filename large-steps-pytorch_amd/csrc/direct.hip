@@ -843,7 +843,7 @@ struct ls_direct {
     // bottom tier: levels [tier_root, levels) run as one launch per sweep, one workgroup per subtree (nd_tier.h)
     bool fuse_root = true;              // LS_ND_NO_FUSE_ROOT: the root keeps its up-sweep launch
     int upper_lo = 0;                   // rows [upper_lo, V) of the tree's numbering belong to the levels above the tier
-    int tier_root = 0, tier_phases = 0, tier_wgs = 0, tier_region = 0, tier_vec = 0, tier_tri = 0;
+    int tier_root = 0, tier_phases = 0, tier_wgs = 0, tier_region = 0, tier_vec = 0, tier_tri = 0, tier_waves = TIER_WAVES;
     TierItem* d_items = nullptr;
     int* pull = nullptr;                // tier up sweep: (front position - pull_base, child) -> child boundary entry, front positions of the tier's inner nodes
     int64_t pull_base = 0;
@@ -903,7 +903,7 @@ static int env_int0(const char* name, int dflt) { const char* e = getenv(name); 
 // Bottom tier (nd_tier.h): cut the subtrees rooted at level `root` into wave-sized items. Returns the LDS floats a wave
 // needs (0 = the tier does not fit), fills items / wgs.
 static size_t plan_tier(const std::vector<NodeD>& nd, const std::vector<int64_t>& level_off, int levels, int arity, int root, int64_t q_lo,
-                        int64_t q_hi, std::vector<TierItem>& items, std::vector<TierWG>& wgs, int& vec_floats, int& tri_floats) {
+                        int64_t q_hi, std::vector<TierItem>& items, std::vector<TierWG>& wgs, int& vec_floats, int& tri_floats, int waves = TIER_WAVES) {
     const int H = levels - root;
     items.clear(); wgs.assign((size_t)(q_hi - q_lo), TierWG());
     int vec_need = 0, pbuf_need = 0, leaf_need = 0, tri_cap = 0;
@@ -959,7 +959,7 @@ static size_t plan_tier(const std::vector<NodeD>& nd, const std::vector<int64_t>
                     // reduction in the padded index space of the quad-interleaved streams, parts cut at multiples of 4
                     const int rows = up ? n.b : n.s, L = up ? ((n.s + 3) & ~3) : ((n.s + 3) & ~3) + ((n.b + 3) & ~3);
                     int nparts = 1;
-                    if (!sparse && base < TIER_WAVES) nparts = std::max(1, std::min(TIER_WAVES / std::max(base, 1), L / 16));
+                    if (!sparse && base < waves) nparts = std::max(1, std::min(waves / std::max(base, 1), L / 16));
                     for (int r = 0; r < std::max(rows, 1); r += WAVE)
                         for (int pt = 0; pt < nparts; ++pt) {
                             it.row0 = r; it.r0 = (int)((int64_t)(L / 4) * pt / nparts) * 4; it.r1 = (int)((int64_t)(L / 4) * (pt + 1) / nparts) * 4;
@@ -972,7 +972,7 @@ static size_t plan_tier(const std::vector<NodeD>& nd, const std::vector<int64_t>
                 if (all_sparse) { if (up) g.up_leaf |= 1u << ph; else g.down_leaf |= 1u << ph; }
                 else if (sparse) return 0;        // a level mixing sparse and dense leaves is not supported (the caller stores all leaves alike)
                 const int n_items = (int)items.size() - off[ph];
-                if (((up ? g.up_split : g.down_split) >> ph) & 1u) pbuf_need = std::max(pbuf_need, div_up(n_items, TIER_WAVES) * 256);
+                if (((up ? g.up_split : g.down_split) >> ph) & 1u) pbuf_need = std::max(pbuf_need, div_up(n_items, waves) * 256);
             }
             off[H] = (int)items.size();
         }
@@ -1270,6 +1270,17 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
                 set_error("ls_direct_create: a tier of %d levels does not fit the kernel (LDS per wave: %zu floats)", H, region);
                 return LS_E_WORKSPACE;
             }
+            // few subtrees (<= 768 workgroups: three per CU or less): 8 waves per workgroup, two workgroups per CU, if that fits the LDS
+            // (a tier of the leaf level alone -- dense leaves of 2-4 row chunks -- does not gain: 40k vertices 44.3 against 42.7 us)
+            if (H >= 2 && (int)wgs.size() <= 768 && env_int0("LS_ND_TIER_WAVES", TIER_WAVES_WIDE) == TIER_WAVES_WIDE) {
+                std::vector<TierItem> items8;
+                std::vector<TierWG> wgs8;
+                int vec8 = 0, tri8 = 0;
+                const size_t region8 = plan_tier(nd, level_off, levels, arity, root, sub_lo * span, sub_hi * span, items8, wgs8, vec8, tri8, TIER_WAVES_WIDE);
+                if (region8 && ((region8 + 3) & ~(size_t)3) * sizeof(float) * TIER_WAVES_WIDE <= 80 * 1024) {
+                    items.swap(items8); wgs.swap(wgs8); d->tier_vec = vec8; d->tier_tri = tri8; region = region8; d->tier_waves = TIER_WAVES_WIDE;
+                }
+            }
             d->tier_root = root; d->tier_phases = H; d->tier_wgs = (int)wgs.size(); d->tier_region = (int)((region + 3) & ~(size_t)3);
         }
     }
@@ -1529,8 +1540,10 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
     LS_OPTIN(1) LS_OPTIN(2) LS_OPTIN(3) LS_OPTIN(4)
 #undef LS_OPTIN
 #define LS_OPTIN(KK)                                                                                                       \
-    (void)hipFuncSetAttribute((const void*)k_nd_tier<KK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
-    (void)hipFuncSetAttribute((const void*)k_nd_tier<KK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_nd_tier<KK, true, TIER_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
+    (void)hipFuncSetAttribute((const void*)k_nd_tier<KK, false, TIER_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+    (void)hipFuncSetAttribute((const void*)k_nd_tier<KK, true, TIER_WAVES_WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
+    (void)hipFuncSetAttribute((const void*)k_nd_tier<KK, false, TIER_WAVES_WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     LS_OPTIN(1) LS_OPTIN(2) LS_OPTIN(3) LS_OPTIN(4)
 #undef LS_OPTIN
     if (span) {
@@ -1586,7 +1599,7 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
     ta.dbg = d->profile == 2 ? d->dbg : nullptr;
     ta.ablate = d->exp_ablate; ta.stagger = d->exp_stagger;     // read once, when the handle was created
 #endif
-    const size_t tier_lds = (size_t)d->tier_region * TIER_WAVES * sizeof(float);
+    const size_t tier_lds = (size_t)d->tier_region * d->tier_waves * sizeof(float);
     int n_mark = 0;
     auto mark = [&](int lo, int hi, int sweep) -> hipError_t {        // "profile" = 3: an event in front of every launch
         if (d->profile != 3) return hipSuccess;
@@ -1618,7 +1631,8 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
         if (d->profile) LS_HIP(hipEventRecord(d->ev[0], st));
         LS_HIP(hipMemsetAsync(d->d_swords, 0, sizeof(unsigned) * 16 * (size_t)d->span_words, st));
         LS_HIP(mark(d->tier_root, d->levels - 1, 0));
-        hipLaunchKernelGGL((k_nd_tier<K, true>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
+        if (d->tier_waves == TIER_WAVES_WIDE) hipLaunchKernelGGL((k_nd_tier<K, true, TIER_WAVES_WIDE>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES_WIDE), tier_lds, st, ta, b, x, d->tier_tri);
+        else hipLaunchKernelGGL((k_nd_tier<K, true, TIER_WAVES>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
         LS_HIP(mark(0, d->tier_root - 1, 2));
         if (d->profile) LS_HIP(hipEventRecord(d->ev[1], st));
         const size_t span_lds = ((size_t)K * d->span_lcap + SPAN_WAVES * 256) * sizeof(float);
@@ -1626,9 +1640,10 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
         else if (d->arity == 2) hipLaunchKernelGGL((k_nd_span<K, 2>), dim3(d->span_grid), dim3(SPAN_THREADS), span_lds, st, sa, x);
         else hipLaunchKernelGGL((k_nd_span<K, 8>), dim3(d->span_grid), dim3(SPAN_THREADS), span_lds, st, sa, x);
         if (d->profile) LS_HIP(hipEventRecord(d->ev[2], st));
-        if (ta.dbg) ta.dbg += (size_t)d->tier_wgs * TIER_WAVES * 32;
+        if (ta.dbg) ta.dbg += (size_t)d->tier_wgs * d->tier_waves * 32;
         LS_HIP(mark(d->tier_root, d->levels - 1, 1));
-        hipLaunchKernelGGL((k_nd_tier<K, false>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
+        if (d->tier_waves == TIER_WAVES_WIDE) hipLaunchKernelGGL((k_nd_tier<K, false, TIER_WAVES_WIDE>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES_WIDE), tier_lds, st, ta, b, x, d->tier_tri);
+        else hipLaunchKernelGGL((k_nd_tier<K, false, TIER_WAVES>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
         if (d->profile) LS_HIP(hipEventRecord(d->ev[3], st));
         LS_HIP(hipGetLastError());
         LS_HIP(mark_end());
@@ -1648,7 +1663,8 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
     if (part == 0 && exch_n) LS_HIP(hipMemsetAsync(d->slots + exch_off, 0, exch_n * sizeof(float), st));
     if (d->tier_wgs) {
         LS_HIP(mark(d->tier_root, d->levels - 1, 0));
-        hipLaunchKernelGGL((k_nd_tier<K, true>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
+        if (d->tier_waves == TIER_WAVES_WIDE) hipLaunchKernelGGL((k_nd_tier<K, true, TIER_WAVES_WIDE>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES_WIDE), tier_lds, st, ta, b, x, d->tier_tri);
+        else hipLaunchKernelGGL((k_nd_tier<K, true, TIER_WAVES>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
     }
     }
     if (part == 1 && exch_n && exchange != d->slots + exch_off)
@@ -1706,10 +1722,11 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
                                d->perm, d->push_ptr, d->push_tgt, d->finv, d->wb, (const float*)d->bp, d->xb, x, p.s_cap, p.b_cap,
                                lv == 0 ? rf : RootFill{nullptr, nullptr, nullptr, nullptr});
     }
-    if (ta.dbg) ta.dbg += (size_t)d->tier_wgs * TIER_WAVES * 32;
+    if (ta.dbg) ta.dbg += (size_t)d->tier_wgs * d->tier_waves * 32;
     if (d->tier_wgs) {
         LS_HIP(mark(d->tier_root, d->levels - 1, 1));
-        hipLaunchKernelGGL((k_nd_tier<K, false>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
+        if (d->tier_waves == TIER_WAVES_WIDE) hipLaunchKernelGGL((k_nd_tier<K, false, TIER_WAVES_WIDE>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES_WIDE), tier_lds, st, ta, b, x, d->tier_tri);
+        else hipLaunchKernelGGL((k_nd_tier<K, false, TIER_WAVES>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
     }
     if (d->profile) LS_HIP(hipEventRecord(d->ev[2], st));
     LS_HIP(hipGetLastError());
@@ -1836,8 +1853,8 @@ extern "C" int ls_direct_set(ls_direct* d, const char* name, int value) {
         }
 #endif
         if (d->profile == 2 && !d->dbg && d->tier_wgs) {
-            LS_HIP(hipMalloc((void**)&d->dbg, sizeof(long long) * 2 * (size_t)d->tier_wgs * TIER_WAVES * 32));
-            LS_HIP(hipMemset(d->dbg, 0, sizeof(long long) * 2 * (size_t)d->tier_wgs * TIER_WAVES * 32));
+            LS_HIP(hipMalloc((void**)&d->dbg, sizeof(long long) * 2 * (size_t)d->tier_wgs * d->tier_waves * 32));
+            LS_HIP(hipMemset(d->dbg, 0, sizeof(long long) * 2 * (size_t)d->tier_wgs * d->tier_waves * 32));
         }
         return LS_OK;
     }
@@ -1873,7 +1890,7 @@ extern "C" int ls_direct_factor_seconds(const ls_direct* d, double* h_s3) {
 
 extern "C" int ls_direct_tier_stamps(const ls_direct* d, long long* h_out, int64_t n) {
     LS_REQUIRE(d && h_out, LS_E_INVALID, "ls_direct_tier_stamps: bad argument");
-    const int64_t have = d->dbg ? 2 * (int64_t)d->tier_wgs * TIER_WAVES * 32 : 0;
+    const int64_t have = d->dbg ? 2 * (int64_t)d->tier_wgs * d->tier_waves * 32 : 0;
     LS_REQUIRE(n <= have, LS_E_INVALID, "ls_direct_tier_stamps: %lld stamps recorded (set \"profile\" to 2 and solve first)", (long long)have);
     DeviceGuard g(d->device);
     LS_HIP(g.err);

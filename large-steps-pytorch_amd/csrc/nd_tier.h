@@ -28,10 +28,9 @@
 namespace ls {
 
 constexpr int TIER_MAX_H = 6;            // tree levels one workgroup may walk
-#ifndef LS_TIER_WAVES
-#define LS_TIER_WAVES 4
-#endif
-constexpr int TIER_WAVES = LS_TIER_WAVES;   // waves per tier workgroup (build macro for A/B runs: 8 was measured)
+constexpr int TIER_WAVES = 4;            // waves per tier workgroup: 4 (four workgroups per CU), or TIER_WAVES_WIDE for trees with few subtrees
+constexpr int TIER_WAVES_WIDE = 8;       // (<= 768 workgroups -- the arity-8 trees of 105k-300k vertices have 512: with 4 waves each that is half a
+                                         //  CU's waves; 8 waves per workgroup, two workgroups per CU: -5 %)
 constexpr int TIER_TRI4 = 9;             // 16-byte loads per lane that hold a leaf triangle (s <= 64: 2080 floats = 520 float4)
 constexpr int TIER_SPE = 4;              // sparse entries per row prefetched to registers (longer rows: loop)
 
@@ -97,7 +96,7 @@ struct TierArgs {
 #define LS_ABLATE(a, bits) ((a).ablate & (bits))
 __device__ __forceinline__ void tier_stamp(const TierArgs& a, int slot) {
     if (a.dbg && (threadIdx.x & 63) == 0)
-        a.dbg[((size_t)blockIdx.x * TIER_WAVES + (threadIdx.x >> 6)) * 32 + slot] = (long long)__builtin_amdgcn_s_memtime();
+        a.dbg[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32 + slot] = (long long)__builtin_amdgcn_s_memtime();
 }
 #else
 #define LS_ABLATE(a, bits) 0
@@ -405,12 +404,12 @@ __device__ __forceinline__ void leaf_down_compute(const TierArgs& a, const TierI
 // leaf are requested ahead (its item record and the index lists that depend on it: 5 registers). A full software pipeline
 // (next leaf's triangle in flight during the multiply, 36 more registers) was measured slower: it spilled, and the leaf
 // phase is bound by its dependent steps, not by bytes in flight.
-template <int K, bool UP>
+template <int K, bool UP, int W>
 __device__ __forceinline__ void leaf_phase(const TierArgs& a, int k0, int k1, const float* __restrict__ b_in, float* __restrict__ x_out,
                                            float* region, int tri_floats) {
     const int lane = threadIdx.x & 63;
     if (k0 >= k1) return;
-    constexpr int S = TIER_WAVES;
+    constexpr int S = W;
     tier_stamp(a, 24);
     TierItem it = rec_unpack(rec_load(a.items, k0, lane));
     int rec_n = k0 + S < k1 ? rec_load(a.items, k0 + S, lane) : 0;
@@ -710,8 +709,8 @@ __device__ __forceinline__ void node_down(const TierArgs& a, const TierItem& it,
 }
 
 // One workgroup per subtree. UP: phases run leaves -> tier root. DOWN: tier root -> leaves.
-template <int K, bool UP>
-__global__ __launch_bounds__(64 * TIER_WAVES, 16 / TIER_WAVES) void k_nd_tier(TierArgs a, const float* __restrict__ b_in, float* __restrict__ x_out,
+template <int K, bool UP, int W>
+__global__ __launch_bounds__(64 * W, 16 / W) void k_nd_tier(TierArgs a, const float* __restrict__ b_in, float* __restrict__ x_out,
                                                               int tri_floats) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -777,18 +776,18 @@ __global__ __launch_bounds__(64 * TIER_WAVES, 16 / TIER_WAVES) void k_nd_tier(Ti
             if (has_nx) rec_nx = rec_load(a.items, j0, lane);
         }
         if ((leafy >> ph) & 1u) {
-            if (!LS_ABLATE(a, 8)) leaf_phase<K, UP>(a, i0 + wave, LS_ABLATE(a, 32) ? min(i1, i0 + TIER_WAVES) : LS_ABLATE(a, 64) ? min(i1, i0 + 2 * TIER_WAVES) : i1, b_in, x_out, region, tri_floats);
+            if (!LS_ABLATE(a, 8)) leaf_phase<K, UP, W>(a, i0 + wave, LS_ABLATE(a, 32) ? min(i1, i0 + W) : LS_ABLATE(a, 64) ? min(i1, i0 + 2 * W) : i1, b_in, x_out, region, tri_floats);
         } else if (!LS_ABLATE(a, 4)) {
             int rec = (!pre_valid && i0 + wave < i1) ? rec_load(a.items, i0 + wave, lane) : 0;
             // the (last) split row chunk this wave will finish once its parts have met: record and static indices stay in
             // registers across that barrier, nothing is loaded behind it
             int head_k = -1, head_idx = 0, head_p0 = 0, head_p1 = 0;
-            for (int k = i0 + wave; k < i1; k += TIER_WAVES) {
-                const int rec_next = k + TIER_WAVES < i1 ? rec_load(a.items, k + TIER_WAVES, lane) : 0;
+            for (int k = i0 + wave; k < i1; k += W) {
+                const int rec_next = k + W < i1 ? rec_load(a.items, k + W, lane) : 0;
                 const bool first = k == i0 + wave && pre_valid;
                 const TierItem it = first ? it_pre : rec_unpack(rec);
                 rec = rec_next;
-                float* pbuf = region + a.vec_floats + ((k - i0) / TIER_WAVES) * 256;
+                float* pbuf = region + a.vec_floats + ((k - i0) / W) * 256;
                 if (!first) { if (UP) node_up_pre<K>(a, it, pre); else node_down_pre<K>(a, it, pre); }
                 if (UP) node_up<K>(a, it, pre, b_in, region, pbuf);
                 else node_down<K>(a, it, pre, x_out, region, pbuf);
@@ -799,7 +798,7 @@ __global__ __launch_bounds__(64 * TIER_WAVES, 16 / TIER_WAVES) void k_nd_tier(Ti
             if ((split >> ph) & 1u) {
                 const int rec_head = head_k >= 0 ? rec_load(a.items, head_k, lane) : 0;      // arrives while the parts meet
                 __syncthreads();
-                for (int k = i0 + wave; k < i1; k += TIER_WAVES) {
+                for (int k = i0 + wave; k < i1; k += W) {
                     const bool mine = k == head_k;
                     const TierItem it = rec_unpack(mine ? rec_head : rec_load(a.items, k, lane));
                     if (it.nparts == 1 || it.part != 0) continue;
@@ -808,7 +807,7 @@ __global__ __launch_bounds__(64 * TIER_WAVES, 16 / TIER_WAVES) void k_nd_tier(Ti
                     for (int q = 0; q < K; ++q) acc[q] = 0.0f;
                     for (int p = 0; p < it.nparts; ++p) {          // parts are consecutive items: fixed order of the sum
                         const int kp = k + p - i0;
-                        const float* pb = sm + (size_t)(kp % TIER_WAVES) * a.region_floats + a.vec_floats + (kp / TIER_WAVES) * 256;
+                        const float* pb = sm + (size_t)(kp % W) * a.region_floats + a.vec_floats + (kp / W) * 256;
 #pragma unroll
                         for (int q = 0; q < K; ++q) acc[q] += pb[lane * 4 + q];
                     }
