@@ -852,7 +852,8 @@ struct ls_direct {
     hipEvent_t busy = nullptr;          // recorded after every solve: a solve on another stream waits for it (one workspace)
     hipStream_t last_stream = nullptr;
     bool used = false;
-    std::vector<void*> owned;           // device arrays adopted from ls_direct_factor (freed with the handle)
+    std::vector<void*> owned;           // device arrays adopted from ls_direct_factor (handed to the buffer pool / freed with the handle)
+    std::vector<size_t> owned_bytes;
     // subtree sharding (one process per GPU): this handle runs the subtrees [sub_lo, sub_hi) of level `cut` and, replicated on
     // every rank, the levels above; the ranks meet once per solve in a sum over the slots of level cut - 1 (exch_f0 .. exch_f1)
     int shard_rank = 0, shard_count = 1, cut = 0;
@@ -896,7 +897,69 @@ static int pick_nw(int len, bool up_sweep = false) {
     return nw;
 }
 
-int ls_direct_adopt(ls_direct* d, void* const* owned, int n_owned, const double* seconds3);
+int ls_direct_adopt(ls_direct* d, void* const* owned, const size_t* owned_bytes, int n_owned, const double* seconds3);
+
+// ---- pool of large device buffers --------------------------------------------------------------------------------------------------
+// A remesh loop (scripts/main.py:137-169) destroys a solver and constructs one of nearly the same size again and again. The runtime gives
+// freed device memory back lazily: at 4M vertices every second or third construction of a process stalled 0.45-0.7 s inside ONE hipMalloc
+// (the 9.3 GB of fp64 fronts, or the next buffer after it: profiles/r03_run5_constructor_times.txt) -- four times the whole constructor.
+// The constructor's scratch (fronts and work arrays: 3-4 GB at 1M, 14 GB at 4M) and the handle's factor arrays therefore go back to this
+// pool instead of hipFree, and allocations of >= 64 MB take the best fit (at most 1.5x + 64 MB larger). LS_POOL_GB caps what it holds
+// (default 24 per process, 0 = no pool; oldest out first); ls_release_scratch() empties it.
+namespace ls {
+namespace {
+struct DevicePool {
+    std::mutex mu;
+    struct Entry { void* p; size_t bytes; int device; };
+    std::vector<Entry> held;
+    static size_t cap() { const char* e = getenv("LS_POOL_GB"); return (size_t)((e ? atof(e) : 24.0) * 1073741824.0); }
+};
+DevicePool g_pool;
+}  // namespace
+
+void* pool_take(int device, size_t bytes) {
+    if (bytes < POOL_FROM) return nullptr;
+    std::lock_guard<std::mutex> g(g_pool.mu);
+    int best = -1;
+    for (int i = 0; i < (int)g_pool.held.size(); ++i) {
+        const DevicePool::Entry& e = g_pool.held[(size_t)i];
+        if (e.device == device && e.bytes >= bytes && e.bytes <= bytes + bytes / 2 + POOL_FROM && (best < 0 || e.bytes < g_pool.held[(size_t)best].bytes)) best = i;
+    }
+    if (best < 0) return nullptr;
+    void* p = g_pool.held[(size_t)best].p;
+    g_pool.held.erase(g_pool.held.begin() + best);
+    return p;
+}
+
+bool pool_give(int device, void* p, size_t bytes) {
+    if (!p || bytes < POOL_FROM) return false;
+    const size_t limit = DevicePool::cap();
+    if (bytes > limit) return false;
+    std::lock_guard<std::mutex> g(g_pool.mu);
+    size_t total = bytes;
+    for (const DevicePool::Entry& e : g_pool.held) total += e.bytes;
+    while (total > limit && !g_pool.held.empty()) {                  // oldest out first
+        total -= g_pool.held.front().bytes;
+        DeviceGuard dg(g_pool.held.front().device);
+        (void)hipFree(g_pool.held.front().p);
+        g_pool.held.erase(g_pool.held.begin());
+    }
+    g_pool.held.push_back(DevicePool::Entry{p, bytes, device});
+    return true;
+}
+}  // namespace ls
+
+extern "C" int ls_release_scratch(int device) {            // device < 0: every device
+    std::lock_guard<std::mutex> g(ls::g_pool.mu);
+    for (size_t i = 0; i < ls::g_pool.held.size();) {
+        if (device < 0 || ls::g_pool.held[i].device == device) {
+            ls::DeviceGuard dg(ls::g_pool.held[i].device);
+            (void)hipFree(ls::g_pool.held[i].p);
+            ls::g_pool.held.erase(ls::g_pool.held.begin() + (long)i);
+        } else ++i;
+    }
+    return LS_OK;
+}
 
 static int env_int0(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
@@ -1575,7 +1638,9 @@ extern "C" int ls_direct_destroy(ls_direct* d) {
     (void)hipFree(d->bp4); (void)hipFree(d->xt4); (void)hipFree(d->span_dbg);
     if (d->h_sfail) (void)hipHostFree(d->h_sfail);
     if (d->busy) (void)hipEventDestroy(d->busy);
-    for (void* p : d->owned) (void)hipFree(p);
+    (void)hipDeviceSynchronize();                                   // (what hipFree did implicitly: nothing of the handle is in flight any more)
+    for (size_t i = 0; i < d->owned.size(); ++i)
+        if (!ls::pool_give(d->device, d->owned[i], i < d->owned_bytes.size() ? d->owned_bytes[i] : 0)) (void)hipFree(d->owned[i]);
     for (hipEvent_t e : d->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : d->lev) (void)hipEventDestroy(e);
     delete d;
@@ -1863,8 +1928,9 @@ extern "C" int ls_direct_set(ls_direct* d, const char* name, int value) {
     return LS_E_INVALID;
 }
 
-int ls_direct_adopt(ls_direct* d, void* const* owned, int n_owned, const double* seconds3) {
+int ls_direct_adopt(ls_direct* d, void* const* owned, const size_t* owned_bytes, int n_owned, const double* seconds3) {
     d->owned.assign(owned, owned + n_owned);
+    d->owned_bytes.assign(owned_bytes, owned_bytes + n_owned);
     for (int i = 0; i < 3; ++i) d->factor_s[i] = seconds3[i];
     return LS_OK;
 }

@@ -290,9 +290,14 @@ std::string nd_bisect_device(void* ctx, int64_t V, int D, int smooth, const doub
     const size_t o_bsum = take(sizeof(unsigned long long) * 3 * (size_t)nb);
     const size_t o_hist = take(sizeof(int) * (256 * nbr + 16)), o_offs = take(sizeof(int) * (256 * nbr + 16)),
                  o_sb = take(sizeof(int) * ((size_t)scan_blocks(256 * (int64_t)nbr) + 64));
-    char* base = nullptr;
-    if (hipMalloc(&base, off) != hipSuccess) return "nd_bisect_device: out of device memory";
-    struct Free { char* p; ~Free() { (void)hipFree(p); } } guard{base};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    char* base = (char*)pool_take(dev, off);                        // (the pool of large buffers of direct.hip: a remesh loop comes back with the same size)
+    if (!base && hipMalloc(&base, off) != hipSuccess) return "nd_bisect_device: out of device memory";
+    struct Free {
+        char* p; size_t bytes; int dev; hipStream_t st;
+        ~Free() { (void)hipStreamSynchronize(st); if (!pool_give(dev, p, bytes)) (void)hipFree(p); }
+    } guard{base, off, dev, st};
     double* pos = (double*)(base + o_pos);
     double* pos2 = (double*)(base + o_pos2);
     int* L[6];

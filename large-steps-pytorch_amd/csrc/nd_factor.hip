@@ -430,7 +430,7 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 
 // defined in direct.hip: builds the handle from plan + factor arrays and takes ownership of the device arrays
 extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* stream, ls_direct** out);
-int ls_direct_adopt(ls_direct* d, void* const* owned, int n_owned, const double* seconds3);
+int ls_direct_adopt(ls_direct* d, void* const* owned, const size_t* owned_bytes, int n_owned, const double* seconds3);
 bool direct_tier_fits(int levels, int arity, const int* s, const int* b, const int* own_start, int tier_levels, bool sparse_leaves);
 
 // ---- the tree the library picks for a system of V unknowns (leaf_size <= 0 / arity <= 0 on entry = "pick"; explicit values stay) ----------
@@ -584,19 +584,25 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     const double t2 = now_s();
     // ---- device storage ---------------------------------------------------------------------------------------------------------------
     std::vector<void*> owned, scratch;
+    std::vector<size_t> owned_bytes, scratch_bytes;
     int rc = LS_OK;
     auto dalloc = [&](void** p, size_t bytes, bool keep, bool zero) -> bool {
         const double ta = timing ? now_s() : 0.0;
-        hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 16) + 16);
+        const size_t want = std::max<size_t>(bytes, 16) + 16;
+        hipError_t e = hipSuccess;
+        *p = pool_take(device, want);                                // large buffers: from the pool the previous solver's went to (direct.hip)
+        const bool pooled = *p != nullptr;
+        if (!pooled) e = hipMalloc(p, want);
         const double tb = timing ? now_s() : 0.0;
         if (e == hipSuccess && zero) e = hipMemsetAsync(*p, 0, std::max<size_t>(bytes, 16) + 16, st);
         if (timing && bytes > ((size_t)256 << 20)) {
             (void)hipStreamSynchronize(st);
-            fprintf(stderr, "[ls_direct_factor]   %.2f GB: %s %.1f ms, %s %.1f ms\n", bytes / 1073741824.0, "hipMalloc", (tb - ta) * 1e3, zero ? "zeroed in" : "no memset",
+            fprintf(stderr, "[ls_direct_factor]   %.2f GB: %s %.1f ms, %s %.1f ms\n", bytes / 1073741824.0, pooled ? "from the pool" : "hipMalloc", (tb - ta) * 1e3, zero ? "zeroed in" : "no memset",
                     (now_s() - tb) * 1e3);
         }
         if (e != hipSuccess) { rc = hip_fail(e, "ls_direct_factor allocation", __FILE__, __LINE__); *p = nullptr; return false; }
         (keep ? owned : scratch).push_back(*p);
+        (keep ? owned_bytes : scratch_bytes).push_back(want);
         return true;
     };
     float *finv = nullptr, *wf = nullptr, *wb = nullptr, *u4 = nullptr, *d4 = nullptr, *tri = nullptr, *pu = nullptr, *pd = nullptr;
@@ -622,8 +628,12 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
               dalloc((void**)&d_nodes, sizeof(FactorNode) * (n_nodes + 1), false, false) && dalloc((void**)&d_flag, sizeof(int), false, true);
     auto cleanup = [&](bool all) {
         (void)hipStreamSynchronize(st);
-        for (void* p : scratch) (void)hipFree(p);
-        if (all) for (void* p : owned) (void)hipFree(p);
+        for (size_t i = 0; i < scratch.size(); ++i) if (!pool_give(device, scratch[i], scratch_bytes[i])) (void)hipFree(scratch[i]);
+        scratch.clear(); scratch_bytes.clear();
+        if (all) {
+            for (size_t i = 0; i < owned.size(); ++i) if (!pool_give(device, owned[i], owned_bytes[i])) (void)hipFree(owned[i]);
+            owned.clear(); owned_bytes.clear();
+        }
     };
     if (!ok) { cleanup(true); return rc; }
     lap("device allocations");
@@ -766,7 +776,7 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     const double t3 = now_s();
     lap("numeric factorisation + solve tables (overlapped)");
     const double secs[3] = {t1 - t0, t2 - t1, t3 - t2};
-    return ls_direct_adopt(*out, owned.data(), (int)owned.size(), secs);
+    return ls_direct_adopt(*out, owned.data(), owned_bytes.data(), (int)owned.size(), secs);
 }
 
 // ---- is a CSR matrix symmetric (pattern and values)? Replaces a sort-based check on the host side of the solver -------------------

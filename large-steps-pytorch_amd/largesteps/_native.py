@@ -110,6 +110,7 @@ _SIGNATURES = {
     "ls_direct_factor_seconds": (c_int, [c_void_p, ctypes.POINTER(c_double * 3)]),
     "ls_csr_is_symmetric": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_float, ctypes.POINTER(c_int), c_int, c_void_p]),
     "ls_direct_pick_tree": (c_int, [c_i64, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "ls_release_scratch": (c_int, [c_int]),
     "ls_nd_plan_create": (c_int, [c_i64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
     "ls_nd_plan_create_device": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_int, c_int, c_int, c_int, c_void_p, ctypes.POINTER(c_void_p)]),
     "ls_nd_plan_destroy": (c_int, [c_void_p]),

@@ -309,6 +309,14 @@ class _NativeDirect:
         return [dict(ms=ms[i], words=words[i], levels=(lo[i], hi[i]), sweep=("up", "down", "both")[sw[i]]) for i in range(n.value)]
 
 
+def release_scratch(device=None):
+    """Free the large device buffers the direct solver keeps between constructions (constructor scratch and the factor arrays of destroyed
+    solvers: 4 GB at 1M vertices, up to LS_POOL_GB = 24 GB; see ls_release_scratch in include/largesteps_hip.h).
+    device: a torch device / index, or None for every device."""
+    idx = -1 if device is None else (device.index if isinstance(device, torch.device) else int(device))
+    _native.check(_native.lib().ls_release_scratch(-1 if idx is None else idx))
+
+
 class NestedDissectionSolver(Solver):
     """
     Factor-once / re-solve direct solver (what the reference's default method does through cholespy / CHOLMOD,

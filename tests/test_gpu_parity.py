@@ -1120,3 +1120,38 @@ def test_nearly_symmetric_foreign_matrix_and_in_place_values(golden, dev):
     M.values().mul_(2.0)
     t1 = _native.csr_transposed(csr)
     assert t1 is not t0 and torch.allclose(t1.val.sum(), 2.0 * t0.val.sum())
+
+
+@pytest.mark.gpu
+def test_buffer_pool_between_constructions(dev):
+    """The direct solver hands its large device buffers to a pool instead of freeing them (a remesh loop constructs a solver of nearly the
+    same size again and again): constructions that reuse pooled buffers give the same answers as fresh ones, ls_release_scratch returns
+    the memory, and a size change in between does not confuse the best-fit rule."""
+    import gc
+    from largesteps import synthetic
+    from largesteps.geometry import compute_matrix
+    from largesteps.parameterize import to_differential
+    from largesteps.solvers import NestedDissectionSolver, release_scratch
+    release_scratch()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    answers = []
+    for n in (330, 300, 330, 350, 330):
+        v, f = synthetic.plane(n)
+        tv, tf = _t(v, dev), _t(f, dev)
+        M = compute_matrix(tv, tf, 20.0)
+        u = to_differential(M, tv)
+        s = NestedDissectionSolver(M)
+        x = s.solve(u)
+        assert float((x - tv).abs().max()) <= 2e-5
+        if n == 330:
+            answers.append(x.clone())
+        del s, x, u, M, tv, tf
+        gc.collect()
+    assert torch.equal(answers[0], answers[1]) and torch.equal(answers[0], answers[2])
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    held, _ = torch.cuda.mem_get_info()
+    release_scratch(dev)
+    freed, _ = torch.cuda.mem_get_info()
+    assert freed > held + (64 << 20), "the pool held buffers of the destroyed solvers and released them"
+    assert freed >= free0 - (64 << 20), "nothing of the five constructions is left on the device"
