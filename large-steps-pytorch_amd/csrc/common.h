@@ -45,9 +45,10 @@ struct DeviceGuard {  // every entry point pins the device itself: no thread-loc
 
 inline int div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // direct.hip: a small per-device pool of LARGE device buffers (>= 64 MB) that the direct solver's constructor and destructor hand back
-// instead of hipFree -- see ls_release_scratch in the header. take: a pooled buffer of at least `bytes` (and not much more) or nullptr;
+// instead of hipFree -- see ls_release_scratch in the header. take: a pooled buffer of at least `bytes` (and not much more; *capacity = its real size,
+// to be handed back to give) or nullptr;
 // give: false when the pool did not take the buffer (the caller frees it). The buffer must be idle (its stream synchronised).
-void* pool_take(int device, size_t bytes);
+void* pool_take(int device, size_t bytes, size_t* capacity);
 bool pool_give(int device, void* p, size_t bytes);
 constexpr size_t POOL_FROM = (size_t)64 << 20;
 // assemble.hip: out[0 .. n] = exclusive scan of the int32 in[0 .. n), out[n] = total; bsum: scan_blocks(n) + 1 ints of scratch

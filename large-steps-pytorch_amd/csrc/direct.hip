@@ -917,7 +917,7 @@ struct DevicePool {
 DevicePool g_pool;
 }  // namespace
 
-void* pool_take(int device, size_t bytes) {
+void* pool_take(int device, size_t bytes, size_t* capacity) {
     if (bytes < POOL_FROM) return nullptr;
     std::lock_guard<std::mutex> g(g_pool.mu);
     int best = -1;
@@ -927,6 +927,7 @@ void* pool_take(int device, size_t bytes) {
     }
     if (best < 0) return nullptr;
     void* p = g_pool.held[(size_t)best].p;
+    if (capacity) *capacity = g_pool.held[(size_t)best].bytes;
     g_pool.held.erase(g_pool.held.begin() + best);
     return p;
 }

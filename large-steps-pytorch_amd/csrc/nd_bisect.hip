@@ -292,12 +292,13 @@ std::string nd_bisect_device(void* ctx, int64_t V, int D, int smooth, const doub
                  o_sb = take(sizeof(int) * ((size_t)scan_blocks(256 * (int64_t)nbr) + 64));
     int dev = 0;
     (void)hipGetDevice(&dev);
-    char* base = (char*)pool_take(dev, off);                        // (the pool of large buffers of direct.hip: a remesh loop comes back with the same size)
+    size_t cap = off;
+    char* base = (char*)pool_take(dev, off, &cap);                  // (the pool of large buffers of direct.hip: a remesh loop comes back with the same size)
     if (!base && hipMalloc(&base, off) != hipSuccess) return "nd_bisect_device: out of device memory";
     struct Free {
         char* p; size_t bytes; int dev; hipStream_t st;
         ~Free() { (void)hipStreamSynchronize(st); if (!pool_give(dev, p, bytes)) (void)hipFree(p); }
-    } guard{base, off, dev, st};
+    } guard{base, cap, dev, st};
     double* pos = (double*)(base + o_pos);
     double* pos2 = (double*)(base + o_pos2);
     int* L[6];

@@ -590,7 +590,8 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
         const double ta = timing ? now_s() : 0.0;
         const size_t want = std::max<size_t>(bytes, 16) + 16;
         hipError_t e = hipSuccess;
-        *p = pool_take(device, want);                                // large buffers: from the pool the previous solver's went to (direct.hip)
+        size_t cap = want;
+        *p = pool_take(device, want, &cap);                          // large buffers: from the pool the previous solver's went to (direct.hip)
         const bool pooled = *p != nullptr;
         if (!pooled) e = hipMalloc(p, want);
         const double tb = timing ? now_s() : 0.0;
@@ -602,7 +603,7 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
         }
         if (e != hipSuccess) { rc = hip_fail(e, "ls_direct_factor allocation", __FILE__, __LINE__); *p = nullptr; return false; }
         (keep ? owned : scratch).push_back(*p);
-        (keep ? owned_bytes : scratch_bytes).push_back(want);
+        (keep ? owned_bytes : scratch_bytes).push_back(cap);
         return true;
     };
     float *finv = nullptr, *wf = nullptr, *wb = nullptr, *u4 = nullptr, *d4 = nullptr, *tri = nullptr, *pu = nullptr, *pd = nullptr;
