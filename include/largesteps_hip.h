@@ -255,6 +255,26 @@ int ls_nd_plan_create(int64_t V, const int32_t* h_rowptr, const int32_t* h_col, 
  * to ls_nd_plan_create on the same input -- the GPU tests compare the two. SYNC. */
 int ls_nd_plan_create_device(const int32_t* d_rowptr, const int32_t* d_col, const float* d_positions, int64_t V, int64_t nnz,
                              int leaf_size, int arity, int smooth, int device, void* stream, ls_nd_plan** out);
+/* How the cutting direction of a domain is chosen (replaces the graph-based fill-reducing ordering CHOLMOD runs behind the reference's
+ * constructor, largesteps/solvers.py:34 -- which does not depend on how the surface lies in space):
+ *   LS_ND_ORDER_LONGEST (0)  median cut along the longest axis of the domain's bounding box in the embedding (positions, or graph
+ *                            distances without positions) -- what ls_nd_plan_create / ls_nd_plan_create_device run;
+ *   LS_ND_ORDER_MINSEP  (1)  every domain tries the three position axes AND three graph distances and takes the thinnest separator
+ *                            (host threads): a surface that is folded or rolled up in space, or shells inside each other, dissect
+ *                            like the flat sheet (a cutting plane crosses every layer, a level set of a graph distance crosses one);
+ *   LS_ND_ORDER_AUTO   (-1)  LONGEST first; if its separators are thicker than a surface's should be (spread > 1.3, below), MINSEP
+ *                            too, and the plan with fewer factor numbers -- what ls_direct_factor runs (environment LS_ND_ORDER
+ *                            overrides, LS_ND_SUSPECT moves the threshold).
+ * ls_nd_plan_quality / ls_direct_plan_quality: the rule that built the plan, factor numbers per vertex (sum over the nodes of
+ * s^2 + 2 s b, / V), spread = sum of s^2 over the inner nodes / (A x sum of their subtrees' vertex counts) with A = (sum_{j < log2
+ * arity} 2^(j/2))^2 -- ~0.7 on a flat sheet at ANY size, 1.0-1.2 on closed surfaces, 1.4 on a sheet folded once, 5-75 on scrolls --,
+ * and the factor numbers per vertex of the plan AUTO built and did not take (0: it built one). Any pointer may be NULL. Host only. */
+#define LS_ND_ORDER_AUTO (-1)
+#define LS_ND_ORDER_LONGEST 0
+#define LS_ND_ORDER_MINSEP 1
+int ls_nd_plan_create_ordered(int64_t V, const int32_t* h_rowptr, const int32_t* h_col, const float* h_positions, int leaf_size,
+                              int arity, int smooth, int ordering, ls_nd_plan** out);
+int ls_nd_plan_quality(const ls_nd_plan* p, int* h_ordering, double* h_words_per_vertex, double* h_spread, double* h_words_other);
 int ls_nd_plan_destroy(ls_nd_plan* p);
 int ls_nd_plan_info(const ls_nd_plan* p, int* levels, int* arity, int* n_nodes, int64_t* n_bnd, int64_t* n_front, double* seconds);
 /* copies out: perm (V), s / b / own_start / parent (n_nodes + 1 each, node ids are 1-based), bnd / ppos / push_tgt (n_bnd),
@@ -358,6 +378,8 @@ int ls_direct_level_words(const ls_direct* d, int cap, int64_t* h_up, int64_t* h
  * Any pointer may be NULL. */
 int ls_direct_launch_profile(const ls_direct* d, int cap, int* h_n, double* h_ms, int64_t* h_words, int32_t* h_level_lo,
                              int32_t* h_level_hi, int32_t* h_sweep);
+/* the dissection behind a handle made by ls_direct_factor (see ls_nd_plan_quality) */
+int ls_direct_plan_quality(const ls_direct* d, int* h_ordering, double* h_words_per_vertex, double* h_spread, double* h_words_other);
 /* seconds of the three constructor stages of a handle made by ls_direct_factor: symbolic analysis, layout tables, numeric */
 int ls_direct_factor_seconds(const ls_direct* d, double* h_s3);
 /* SYNC: *h_symmetric = 1 iff every stored entry (r, c, v) has a stored mirror (c, r, v') with |v - v'| <= tol */

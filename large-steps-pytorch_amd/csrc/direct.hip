@@ -873,6 +873,7 @@ struct ls_direct {
     int exp_ablate = 0, exp_stagger = 0;            // -DLS_ND_EXPERIMENTS builds only (LS_ND_ABLATE / LS_ND_STAGGER at creation)
     long long* span_dbg = nullptr;
     double factor_s[3] = {0, 0, 0};     // ls_direct_factor: symbolic analysis, layout / sparse tables, numeric factorisation
+    double plan_q[4] = {0, 0, 0, 0};    // ls_direct_factor: the dissection's ordering rule, factor numbers per vertex, spread, the other plan's numbers (nd_plan.h)
     std::vector<LevelPlan> plan;
     int64_t factor_entries = 0, words_up = 0, words_down = 0;    // 4-byte words of factor data per solve / per sweep
     int profile = 0;
@@ -1929,10 +1930,20 @@ extern "C" int ls_direct_set(ls_direct* d, const char* name, int value) {
     return LS_E_INVALID;
 }
 
-int ls_direct_adopt(ls_direct* d, void* const* owned, const size_t* owned_bytes, int n_owned, const double* seconds3) {
+int ls_direct_adopt(ls_direct* d, void* const* owned, const size_t* owned_bytes, int n_owned, const double* seconds3, const double* quality4) {
     d->owned.assign(owned, owned + n_owned);
     d->owned_bytes.assign(owned_bytes, owned_bytes + n_owned);
     for (int i = 0; i < 3; ++i) d->factor_s[i] = seconds3[i];
+    for (int i = 0; i < 4; ++i) d->plan_q[i] = quality4[i];
+    return LS_OK;
+}
+
+extern "C" int ls_direct_plan_quality(const ls_direct* d, int* h_ordering, double* h_words_per_vertex, double* h_spread, double* h_words_other) {
+    LS_REQUIRE(d, LS_E_INVALID, "ls_direct_plan_quality: bad argument");
+    if (h_ordering) *h_ordering = (int)d->plan_q[0];
+    if (h_words_per_vertex) *h_words_per_vertex = d->plan_q[1];
+    if (h_spread) *h_spread = d->plan_q[2];
+    if (h_words_other) *h_words_other = d->plan_q[3];
     return LS_OK;
 }
 

@@ -371,21 +371,51 @@ std::string nd_bisect_device(void* ctx, int64_t V, int D, int smooth, const doub
 // the whole analysis with the rounds on the device: what ls_direct_factor runs (csrc/nd_factor.hip), and -- as a plan object -- what
 // the GPU tests compare with the host-only ls_nd_plan_create
 std::string ls::nd_plan_build_device(const int32_t* d_rowptr, const int32_t* d_col, const float* d_positions, int64_t V, int64_t nnz,
-                                     int32_t* h_rowptr, int32_t* h_col, int leaf_size, int arity, int smooth, void* stream, NdPlan& out) {
+                                     int32_t* h_rowptr, int32_t* h_col, int leaf_size, int arity, int smooth, void* stream, NdPlan& out,
+                                     int ordering) {
     hipStream_t st = (hipStream_t)stream;
     // the host's copy of the pattern: the row pointers now (the analysis looks at them first), the column indices during the device
     // rounds -- unless there are no positions: the graph embedding walks the pattern on the host before anything else
+    const bool host_rounds = ordering == ND_ORDER_MINSEP;             // every domain tries six directions: host threads (nd_plan.cpp)
     if (hipMemcpyAsync(h_rowptr, d_rowptr, sizeof(int32_t) * (V + 1), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        (!d_positions && hipMemcpyAsync(h_col, d_col, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost, st) != hipSuccess) ||
+        ((!d_positions || host_rounds) && hipMemcpyAsync(h_col, d_col, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost, st) != hipSuccess) ||
         hipStreamSynchronize(st) != hipSuccess)
         return "the copy of the matrix pattern to the host failed";
     if (h_rowptr[0] != 0 || h_rowptr[V] != nnz) return "rowptr does not match nnz";
+    std::vector<float> h_pos;
+    auto fetch_positions = [&]() -> bool {
+        if (!d_positions) return true;
+        h_pos.resize((size_t)V * 3);
+        return hipMemcpyAsync(h_pos.data(), d_positions, sizeof(float) * 3 * V, hipMemcpyDeviceToHost, st) == hipSuccess &&
+               hipStreamSynchronize(st) == hipSuccess;
+    };
+    const double t0 = now_s();
+    const bool timing = getenv("LS_PLAN_TIMING") != nullptr;
+    if (host_rounds) {
+        if (!fetch_positions()) return "the copy of the positions to the host failed";
+        return nd_plan_build(V, h_rowptr, h_col, d_positions ? h_pos.data() : nullptr, leaf_size, arity, smooth, out, nullptr, nullptr, ND_ORDER_MINSEP);
+    }
     NdBisectDevice ctx{d_rowptr, d_col, d_positions, nnz, st, d_positions ? h_col : nullptr};
     const float given = 0.0f;                  // "positions were given": nd_plan_build only tests the pointer, the values are read on the device
-    const double t0 = now_s();
-    const std::string err = nd_plan_build(V, h_rowptr, h_col, d_positions ? &given : nullptr, leaf_size, arity, smooth, out, nd_bisect_device, &ctx);
-    if (getenv("LS_PLAN_TIMING")) fprintf(stderr, "[nd_plan] returned (pool joined, temporaries released) %.3f s after its start\n", now_s() - t0);
-    return err;
+    std::string err = nd_plan_build(V, h_rowptr, h_col, d_positions ? &given : nullptr, leaf_size, arity, smooth, out, nd_bisect_device, &ctx);
+    if (timing) fprintf(stderr, "[nd_plan] returned (pool joined, temporaries released) %.3f s after its start; %.1f factor numbers per vertex, spread %.2f\n",
+                        now_s() - t0, out.words_per_vertex, out.spread);
+    if (!err.empty() || ordering != ND_ORDER_AUTO || out.spread <= nd_plan_suspect()) return err;
+    // Separators thicker than a surface's should be: the cutting planes cross several layers of a surface that is folded or rolled up
+    // in space (or several components that lie inside each other). The rounds are run again on the host with graph distances among the
+    // candidate directions; the cheaper plan is kept. Costs a few tenths of a second at 1M vertices -- against a factor that is
+    // 1.5-30 x larger, or no factor at all (fronts beyond the solver's limit).
+    if (!fetch_positions()) return "";
+    NdPlan B;
+    err = nd_plan_build(V, h_rowptr, h_col, d_positions ? h_pos.data() : nullptr, leaf_size, arity, smooth, B, nullptr, nullptr, ND_ORDER_MINSEP);
+    if (timing) fprintf(stderr, "[nd_plan] suspect dissection: tried graph distances as well: %.1f factor numbers per vertex, spread %.2f (%s), %.3f s after the start\n",
+                        B.words_per_vertex, B.spread, err.empty() ? (B.words_per_vertex < out.words_per_vertex ? "taken" : "not taken") : err.c_str(), now_s() - t0);
+    if (!err.empty()) return "";
+    const double seconds = out.seconds + B.seconds;
+    if (B.words_per_vertex < out.words_per_vertex) { B.words_other = out.words_per_vertex; out = std::move(B); }
+    else out.words_other = B.words_per_vertex;
+    out.seconds = seconds;
+    return "";
 }
 
 extern "C" int ls_nd_plan_create_device(const int32_t* d_rowptr, const int32_t* d_col, const float* d_positions, int64_t V, int64_t nnz,

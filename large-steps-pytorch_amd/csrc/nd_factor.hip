@@ -430,7 +430,7 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 
 // defined in direct.hip: builds the handle from plan + factor arrays and takes ownership of the device arrays
 extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* stream, ls_direct** out);
-int ls_direct_adopt(ls_direct* d, void* const* owned, const size_t* owned_bytes, int n_owned, const double* seconds3);
+int ls_direct_adopt(ls_direct* d, void* const* owned, const size_t* owned_bytes, int n_owned, const double* seconds3, const double* quality4);
 bool direct_tier_fits(int levels, int arity, const int* s, const int* b, const int* own_start, int tier_levels, bool sparse_leaves);
 
 // ---- the tree the library picks for a system of V unknowns (leaf_size <= 0 / arity <= 0 on entry = "pick"; explicit values stay) ----------
@@ -486,7 +486,12 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     std::vector<int32_t> rowptr((size_t)V + 1), col((size_t)nnz);          // the host's copy of the pattern, filled by the analysis
     NdPlan P;
     {
-        const std::string err = nd_plan_build_device(d_rowptr, d_col, d_positions, V, nnz, rowptr.data(), col.data(), leaf_size, arity, 4, st, P);
+        // how the cutting directions are chosen: ND_ORDER_AUTO (nd_plan.h) unless the environment says otherwise (LS_ND_ORDER = 0: always
+        // the longest axis of the embedding, 1: always the thinnest of six trial separators on host threads -- 5-10 % fewer factor
+        // numbers on rough scans for a constructor of tenths of a second)
+        const char* oe = getenv("LS_ND_ORDER");
+        const int ordering = oe ? std::max(-1, std::min(1, atoi(oe))) : ND_ORDER_AUTO;
+        const std::string err = nd_plan_build_device(d_rowptr, d_col, d_positions, V, nnz, rowptr.data(), col.data(), leaf_size, arity, 4, st, P, ordering);
         LS_REQUIRE(err.empty(), LS_E_INVALID, "%s", err.c_str());
     }
     const double t1 = now_s();
@@ -777,7 +782,8 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     const double t3 = now_s();
     lap("numeric factorisation + solve tables (overlapped)");
     const double secs[3] = {t1 - t0, t2 - t1, t3 - t2};
-    return ls_direct_adopt(*out, owned.data(), owned_bytes.data(), (int)owned.size(), secs);
+    const double quality[4] = {(double)P.ordering, P.words_per_vertex, P.spread, P.words_other};
+    return ls_direct_adopt(*out, owned.data(), owned_bytes.data(), (int)owned.size(), secs, quality);
 }
 
 // ---- is a CSR matrix symmetric (pattern and values)? Replaces a sort-based check on the host side of the solver -------------------

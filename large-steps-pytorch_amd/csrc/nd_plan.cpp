@@ -184,7 +184,7 @@ int nd_plan_rounds(int64_t V, int leaf_size, int arity) {
 }
 
 std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, const float* pos_in, int leaf_size, int arity,
-                          int smooth, NdPlan& P, NdBisectFn bisect, void* bisect_ctx) {
+                          int smooth, NdPlan& P, NdBisectFn bisect, void* bisect_ctx, int ordering) {
     const auto t_start = std::chrono::steady_clock::now();
     const bool timing = getenv("LS_PLAN_TIMING") != nullptr;
     auto lap = [&](const char* what) { if (timing) fprintf(stderr, "[nd_plan] %-28s %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count()); };
@@ -211,28 +211,44 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
         const std::string err = bisect(bisect_ctx, V, D, (pos_in && all_rows) ? smooth : 0, pos_in ? nullptr : emb.data(), node.data());
         if (!err.empty()) return err;
     } else {
-        // ---- positions (averaged `smooth` times over the matrix neighbours: a rough surface bisects badly otherwise) ----
-        std::vector<double> pos((size_t)V * 3);
-        if (pos_in) {
-            for (int64_t i = 0; i < 3 * V; ++i) pos[i] = pos_in[i];
-            bool all_rows = true;
-            for (int64_t v = 0; v < V && all_rows; ++v) all_rows = rowptr[v + 1] > rowptr[v];
-            if (smooth > 0 && all_rows) {
-                std::vector<double> nxt((size_t)V * 3);
-                for (int it = 0; it < smooth; ++it) {
-                    parallel_for(V, 4096, [&](int64_t lo, int64_t hi) {
-                        for (int64_t v = lo; v < hi; ++v) {
-                            double a = 0, b = 0, c = 0;
-                            for (int p = rowptr[v]; p < rowptr[v + 1]; ++p) { const int w = col[p]; a += pos[3 * (size_t)w]; b += pos[3 * (size_t)w + 1]; c += pos[3 * (size_t)w + 2]; }
-                            const double inv = 1.0 / (rowptr[v + 1] - rowptr[v]);
-                            nxt[3 * v] = a * inv; nxt[3 * v + 1] = b * inv; nxt[3 * v + 2] = c * inv;
-                        }
-                    });
-                    pos.swap(nxt);
-                }
+        // ---- coordinates: NA candidate axes per vertex. Axes 0-2: the caller's positions (averaged `smooth` times over the matrix
+        // neighbours: a rough surface bisects badly otherwise) or, without positions, the graph-distance embedding. ordering ==
+        // ND_ORDER_MINSEP with positions: axes 3-5 = the graph-distance embedding as well -- a surface that is folded or rolled up
+        // in space (cloth, a scroll, two shells close to each other) has layers that are neighbours in space and not on the
+        // surface; a cutting plane then crosses every layer, a level set of a graph distance crosses one.
+        const bool minsep = ordering == ND_ORDER_MINSEP;
+        const int NA = (minsep && pos_in) ? 6 : 3;
+        std::vector<double> pos((size_t)V * NA);
+        auto smooth_axes = [&](int a0, int passes) {          // axes a0 .. a0 + 2, sums in CSR order (the device rounds repeat this to the letter)
+            std::vector<double> nxt((size_t)V * 3);
+            for (int it = 0; it < passes; ++it) {
+                parallel_for(V, 4096, [&](int64_t lo, int64_t hi) {
+                    for (int64_t v = lo; v < hi; ++v) {
+                        double a = 0, b = 0, c = 0;
+                        for (int p = rowptr[v]; p < rowptr[v + 1]; ++p) { const size_t w = (size_t)col[p] * NA + a0; a += pos[w]; b += pos[w + 1]; c += pos[w + 2]; }
+                        const double inv = 1.0 / (rowptr[v + 1] - rowptr[v]);
+                        nxt[3 * v] = a * inv; nxt[3 * v + 1] = b * inv; nxt[3 * v + 2] = c * inv;
+                    }
+                });
+                parallel_for(V, 65536, [&](int64_t lo, int64_t hi) {
+                    for (int64_t v = lo; v < hi; ++v) for (int k = 0; k < 3; ++k) pos[(size_t)v * NA + a0 + k] = nxt[3 * v + k];
+                });
             }
-        } else {
-            graph_embedding(V, rowptr, col, pos);
+        };
+        bool all_rows = true;
+        for (int64_t v = 0; v < V && all_rows; ++v) all_rows = rowptr[v + 1] > rowptr[v];
+        if (pos_in) {
+            for (int64_t v = 0; v < V; ++v) for (int k = 0; k < 3; ++k) pos[(size_t)v * NA + k] = pos_in[3 * v + k];
+            if (smooth > 0 && all_rows) smooth_axes(0, smooth);
+        }
+        if (!pos_in || NA == 6) {
+            std::vector<double> emb;
+            graph_embedding(V, rowptr, col, emb);
+            const int a0 = pos_in ? 3 : 0;
+            for (int64_t v = 0; v < V; ++v) for (int k = 0; k < 3; ++k) pos[(size_t)v * NA + a0 + k] = emb[3 * v + k];
+            // integer distances tie by the thousand: a median inside a level set would be cut by vertex id. Averaging makes the
+            // level sets smooth curves (only with ND_ORDER_MINSEP: the plain embedding stays what the device rounds are pinned to)
+            if (minsep && smooth > 0 && all_rows) smooth_axes(a0, smooth);
         }
         lap("positions");
         // ---- D rounds of bisection ------------------------------------------------------------------------------------------
@@ -258,6 +274,8 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
         std::vector<KV> kv_a, kv_b;
         constexpr int NB = 2048;                          // buckets of the parallel selection
         std::vector<int> hist;
+        std::vector<int> pick, trial;                     // ND_ORDER_MINSEP: split axis per domain, separator size per (domain, axis)
+        std::vector<std::vector<char>> cside;             // ... the side of every vertex under each candidate axis
         struct Piece { int64_t d, lo, hi; int n0, e0, n1, e1; int64_t w0, w1; };
         std::vector<Piece> pieces;
         for (int r = 0; r < D; ++r) {
@@ -268,13 +286,14 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
                 if (cnt <= 0) return;
                 double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
                 for (int64_t i = a; i < e; ++i)
-                    for (int k = 0; k < 3; ++k) { const double x = pos[3 * (size_t)live[i] + k]; mn[k] = std::min(mn[k], x); mx[k] = std::max(mx[k], x); }
+                    for (int k = 0; k < 3; ++k) { const double x = pos[(size_t)NA * live[i] + k]; mn[k] = std::min(mn[k], x); mx[k] = std::max(mx[k], x); }
                 int ax = 0;
                 for (int k = 1; k < 3; ++k) if (mx[k] - mn[k] > mx[ax] - mn[ax]) ax = k;
+                if (minsep) ax = pick[(size_t)d];
                 const int64_t half = cnt / 2;
                 // selection on contiguous (key, id) pairs: the comparator must not chase pos[] through the index array
                 std::vector<KV> kv((size_t)cnt);
-                for (int64_t i = a; i < e; ++i) kv[(size_t)(i - a)] = {pos[3 * (size_t)live[i] + ax], live[i]};
+                for (int64_t i = a; i < e; ++i) kv[(size_t)(i - a)] = {pos[(size_t)NA * live[i] + ax], live[i]};
                 std::nth_element(kv.begin(), kv.begin() + half, kv.end());
                 for (int64_t i = a; i < e; ++i) {
                     const int u = kv[(size_t)(i - a)].second;
@@ -286,18 +305,19 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
                 const int64_t a = seg_start[d], e = seg_start[d + 1], cnt = e - a;
                 if (cnt < 32768) { split_serial(d); return; }
                 const int C = (int)std::min<int64_t>(T, cnt / 8192);
-                std::vector<double> part((size_t)C * 6);
-                for (int c = 0; c < C; ++c) for (int k = 0; k < 3; ++k) { part[(size_t)c * 6 + k] = 1e300; part[(size_t)c * 6 + 3 + k] = -1e300; }
+                std::vector<double> part((size_t)C * 12);
+                for (int c = 0; c < C; ++c) for (int k = 0; k < 6; ++k) { part[(size_t)c * 12 + k] = 1e300; part[(size_t)c * 12 + 6 + k] = -1e300; }
                 parallel_chunks(cnt, C, [&](int c, int64_t lo, int64_t hi) {
-                    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+                    double mn[6] = {1e300, 1e300, 1e300, 1e300, 1e300, 1e300}, mx[6] = {-1e300, -1e300, -1e300, -1e300, -1e300, -1e300};
                     for (int64_t i = a + lo; i < a + hi; ++i)
-                        for (int k = 0; k < 3; ++k) { const double x = pos[3 * (size_t)live[i] + k]; mn[k] = std::min(mn[k], x); mx[k] = std::max(mx[k], x); }
-                    for (int k = 0; k < 3; ++k) { part[(size_t)c * 6 + k] = mn[k]; part[(size_t)c * 6 + 3 + k] = mx[k]; }
+                        for (int k = 0; k < NA; ++k) { const double x = pos[(size_t)NA * live[i] + k]; mn[k] = std::min(mn[k], x); mx[k] = std::max(mx[k], x); }
+                    for (int k = 0; k < NA; ++k) { part[(size_t)c * 12 + k] = mn[k]; part[(size_t)c * 12 + 6 + k] = mx[k]; }
                 });
-                double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
-                for (int c = 0; c < C; ++c) for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], part[(size_t)c * 6 + k]); mx[k] = std::max(mx[k], part[(size_t)c * 6 + 3 + k]); }
+                double mn[6] = {1e300, 1e300, 1e300, 1e300, 1e300, 1e300}, mx[6] = {-1e300, -1e300, -1e300, -1e300, -1e300, -1e300};
+                for (int c = 0; c < C; ++c) for (int k = 0; k < NA; ++k) { mn[k] = std::min(mn[k], part[(size_t)c * 12 + k]); mx[k] = std::max(mx[k], part[(size_t)c * 12 + 6 + k]); }
                 int ax = 0;
                 for (int k = 1; k < 3; ++k) if (mx[k] - mn[k] > mx[ax] - mn[ax]) ax = k;
+                if (minsep) ax = pick[(size_t)d];
                 const int64_t half = cnt / 2;
                 // bucket = a monotone function of the key: a smaller bucket means a smaller key, so only the median's bucket needs a
                 // real selection
@@ -309,7 +329,7 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
                     int* h = hist.data() + (size_t)c * NB;
                     for (int64_t i = lo; i < hi; ++i) {
                         const int u = live[a + i];
-                        const double x = pos[3 * (size_t)u + ax];
+                        const double x = pos[(size_t)NA * u + ax];
                         kv_a[(size_t)i] = {x, u};
                         ++h[bucket(x)];
                     }
@@ -351,7 +371,50 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
                 });
             };
             const auto tr0 = std::chrono::steady_clock::now();
-            // median split of every domain along the longest axis of its bounding box
+            if (minsep) {
+                // every candidate axis of every domain is TRIED: median split along it, count the end points of the cut edges on
+                // either side; the axis whose smaller end-point set is smallest wins (ties: the lower axis -- positions before
+                // graph distances). Tasks = (domain, axis); a task's sides live in that axis' own array.
+                pick.assign((size_t)n_dom, 0);
+                trial.assign((size_t)n_dom * NA, 0);
+                if (cside.empty()) cside.assign((size_t)NA, std::vector<char>((size_t)V, 0));
+                parallel_for(n_dom * NA, 1, [&](int64_t lo, int64_t hi) {
+                    std::vector<KV> kv;
+                    for (int64_t t = lo; t < hi; ++t) {
+                        const int64_t d = t / NA;
+                        const int ax = (int)(t % NA);
+                        const int64_t a = seg_start[d], e = seg_start[d + 1], cnt = e - a, half = cnt / 2;
+                        if (cnt <= 0) continue;
+                        kv.resize((size_t)cnt);
+                        double lo_k = 1e300, hi_k = -1e300;
+                        for (int64_t i = a; i < e; ++i) {
+                            const double x = pos[(size_t)NA * live[i] + ax];
+                            kv[(size_t)(i - a)] = {x, live[i]};
+                            lo_k = std::min(lo_k, x); hi_k = std::max(hi_k, x);
+                        }
+                        if (!(hi_k > lo_k) && cnt > 1) { trial[(size_t)t] = INT32_MAX; continue; }      // a constant axis orders by vertex id: never
+                        std::nth_element(kv.begin(), kv.begin() + half, kv.end());
+                        char* cs = cside[(size_t)ax].data();
+                        for (int64_t i = 0; i < cnt; ++i) cs[kv[(size_t)i].second] = i >= half;
+                        int e0 = 0, e1 = 0;
+                        for (int64_t i = a; i < e; ++i) {
+                            const int u = live[i];
+                            const int64_t nu = node[u];
+                            const char su = cs[u];
+                            bool cut = false;
+                            for (int p = rowptr[u]; p < rowptr[u + 1] && !cut; ++p) { const int w = col[p]; cut = node[w] == nu && !fixed[w] && cs[w] != su; }
+                            if (cut) { if (su) ++e1; else ++e0; }
+                        }
+                        trial[(size_t)t] = std::min(e0, e1);
+                    }
+                });
+                for (int64_t d = 0; d < n_dom; ++d) {
+                    int best = 0;
+                    for (int k = 1; k < NA; ++k) if (trial[(size_t)d * NA + k] < trial[(size_t)d * NA + best]) best = k;
+                    pick[(size_t)d] = best;
+                }
+            }
+            // median split of every domain along the longest axis of its bounding box (ND_ORDER_MINSEP: along the axis picked above)
             if (inside) { for (int64_t d = 0; d < n_dom; ++d) split_parallel(d); }
             else parallel_for(n_dom, 1, [&](int64_t lo, int64_t hi) { for (int64_t d = lo; d < hi; ++d) split_serial(d); });
             const auto tr1 = std::chrono::steady_clock::now();
@@ -584,7 +647,46 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
         }
     });
     lap("push lists");
+    P.ordering = (bisect || ordering != ND_ORDER_MINSEP) ? ND_ORDER_LONGEST : ND_ORDER_MINSEP;
+    nd_plan_quality(P);
+    lap("quality");
     P.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    return "";
+}
+
+void nd_plan_quality(NdPlan& P) {
+    const int n = P.n_nodes;
+    double words = 0.0;
+    for (int i = 1; i <= n; ++i) words += (double)P.s[i] * P.s[i] + 2.0 * P.s[i] * P.b[i];
+    P.words_per_vertex = P.V > 0 ? words / (double)P.V : 0.0;
+    std::vector<double> sub((size_t)n + 1, 0.0);
+    for (int i = n; i >= 1; --i) { sub[i] += P.s[i]; if (i > 1) sub[P.parent[i]] += sub[i]; }
+    const int m = P.arity == 2 ? 1 : P.arity == 4 ? 2 : 3;
+    double a = 0.0;
+    for (int j = 0; j < m; ++j) a += std::sqrt((double)(1 << j));
+    double s2 = 0.0, nv = 0.0;
+    const int64_t n_inner = P.levels > 1 ? P.level_off[P.levels - 1] - 1 : 0;
+    for (int64_t i = 1; i <= n_inner; ++i) { s2 += (double)P.s[i] * P.s[i]; nv += sub[i]; }
+    P.spread = nv > 0.0 ? s2 / (a * a * nv) : 0.0;
+}
+
+double nd_plan_suspect() {
+    const char* e = getenv("LS_ND_SUSPECT");
+    const double v = e ? atof(e) : 1.3;
+    return v > 0.0 ? v : 1.3;
+}
+
+std::string nd_plan_build_auto(int64_t V, const int32_t* rowptr, const int32_t* col, const float* pos, int leaf_size, int arity,
+                               int smooth, NdPlan& out) {
+    std::string err = nd_plan_build(V, rowptr, col, pos, leaf_size, arity, smooth, out, nullptr, nullptr, ND_ORDER_LONGEST);
+    if (!err.empty() || out.spread <= nd_plan_suspect()) return err;
+    NdPlan B;
+    err = nd_plan_build(V, rowptr, col, pos, leaf_size, arity, smooth, B, nullptr, nullptr, ND_ORDER_MINSEP);
+    if (!err.empty()) return "";                     // the first plan stands
+    const double seconds = out.seconds + B.seconds;
+    if (B.words_per_vertex < out.words_per_vertex) { B.words_other = out.words_per_vertex; out = std::move(B); }
+    else out.words_other = B.words_per_vertex;
+    out.seconds = seconds;
     return "";
 }
 
@@ -603,6 +705,29 @@ extern "C" int ls_nd_plan_create(int64_t V, const int32_t* h_rowptr, const int32
     const std::string err = ls::nd_plan_build(V, h_rowptr, h_col, h_positions, leaf_size, arity, smooth, h->p);
     if (!err.empty()) { delete h; ls::set_error("%s", err.c_str()); return LS_E_INVALID; }
     *out = h;
+    return LS_OK;
+}
+
+extern "C" int ls_nd_plan_create_ordered(int64_t V, const int32_t* h_rowptr, const int32_t* h_col, const float* h_positions, int leaf_size,
+                                         int arity, int smooth, int ordering, ls_nd_plan** out) {
+    if (!out || !h_rowptr || !h_col) { ls::set_error("ls_nd_plan_create_ordered: null argument"); return LS_E_INVALID; }
+    *out = nullptr;
+    if (ordering < ls::ND_ORDER_AUTO || ordering > ls::ND_ORDER_MINSEP) { ls::set_error("ls_nd_plan_create_ordered: ordering must be -1, 0 or 1"); return LS_E_INVALID; }
+    ls_nd_plan* h = new ls_nd_plan();
+    const std::string err = ordering == ls::ND_ORDER_AUTO
+        ? ls::nd_plan_build_auto(V, h_rowptr, h_col, h_positions, leaf_size, arity, smooth, h->p)
+        : ls::nd_plan_build(V, h_rowptr, h_col, h_positions, leaf_size, arity, smooth, h->p, nullptr, nullptr, ordering);
+    if (!err.empty()) { delete h; ls::set_error("%s", err.c_str()); return LS_E_INVALID; }
+    *out = h;
+    return LS_OK;
+}
+
+extern "C" int ls_nd_plan_quality(const ls_nd_plan* h, int* ordering, double* words_per_vertex, double* spread, double* words_other) {
+    if (!h) { ls::set_error("ls_nd_plan_quality: null handle"); return LS_E_INVALID; }
+    if (ordering) *ordering = h->p.ordering;
+    if (words_per_vertex) *words_per_vertex = h->p.words_per_vertex;
+    if (spread) *spread = h->p.spread;
+    if (words_other) *words_other = h->p.words_other;
     return LS_OK;
 }
 

@@ -25,6 +25,13 @@ struct NdPlan {
     std::vector<int> push_ptr, push_tgt;                     // CSR: front position -> the children's boundary entries that are this vertex
     int64_t n_bnd = 0, n_front = 0;
     double seconds = 0.0;
+    // quality of the dissection (nd_plan_quality): factor numbers per vertex, sum over the nodes of s^2 + 2 s b; `spread` = sum of
+    // s^2 over the inner nodes / (A x sum of their subtrees' vertex counts), A = (sum_{j < log2 arity} 2^(j/2))^2 -- the squared
+    // separator size per vertex of the domain it separates, scale free: ~0.7 on a flat sheet at any size, 1.0-1.2 on closed
+    // surfaces, 1.4+ when a cutting plane crosses several layers of a folded surface. ordering = the ND_ORDER_* that built the
+    // plan; words_other = words_per_vertex of the plan the automatic choice built and did NOT take (0: it built only one).
+    int ordering = 0;
+    double words_per_vertex = 0.0, spread = 0.0, words_other = 0.0;
 };
 
 // rowptr / col: CSR pattern of a structurally symmetric matrix (int32, original numbering); pos: V x 3 positions (any scale;
@@ -36,16 +43,32 @@ struct NdPlan {
 // average them `smooth` times over the matrix neighbours; otherwise V x 3 doubles formed here from graph distances (smooth = 0).
 // The host's own rounds (bisect == nullptr) are what the host-only entry points and the CPU tests run, and what the device
 // rounds are checked against (tests/test_nested_gpu.py): both must produce the same node[] bit for bit.
+// How a domain's cutting direction is chosen (the `ordering` argument below):
+//   ND_ORDER_LONGEST  median cut along the longest axis of the domain's bounding box in the embedding it is given (the caller's
+//                     positions, or graph distances when there are none): what the device rounds run, a few milliseconds
+//   ND_ORDER_MINSEP   every domain TRIES six directions -- the three position axes and three graph distances (level sets of a
+//                     graph distance do not care how the surface lies in space) -- and takes the thinnest separator. Host rounds.
+//   ND_ORDER_AUTO     LONGEST first; when its separators are thicker than a surface's should be (NdPlan::spread above
+//                     nd_plan_suspect(), 1.3), MINSEP as well, and the cheaper plan of the two.
+// CHOLMOD's ordering behind the reference's constructor (largesteps/solvers.py:34) is graph based and has no such dependence on
+// the embedding; ND_ORDER_AUTO is what ls_direct_factor runs.
+enum { ND_ORDER_AUTO = -1, ND_ORDER_LONGEST = 0, ND_ORDER_MINSEP = 1 };
+double nd_plan_suspect();                                    // the threshold on NdPlan::spread (environment LS_ND_SUSPECT)
 typedef std::string (*NdBisectFn)(void* ctx, int64_t V, int D, int smooth, const double* embedded, int64_t* node);
 int nd_plan_rounds(int64_t V, int leaf_size, int arity);
 std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, const float* pos, int leaf_size, int arity,
-                          int smooth, NdPlan& out, NdBisectFn bisect = nullptr, void* bisect_ctx = nullptr);
+                          int smooth, NdPlan& out, NdBisectFn bisect = nullptr, void* bisect_ctx = nullptr, int ordering = ND_ORDER_LONGEST);
+void nd_plan_quality(NdPlan& P);                             // fills words_per_vertex and spread
+// ND_ORDER_AUTO on the host: `pos` are real host positions (or nullptr)
+std::string nd_plan_build_auto(int64_t V, const int32_t* rowptr, const int32_t* col, const float* pos, int leaf_size, int arity,
+                               int smooth, NdPlan& out);
 
 // The same analysis with the positions' smoothing and the bisection rounds on the device (csrc/nd_bisect.hip). The matrix pattern is
 // needed on both sides: d_* on the device, h_rowptr (V + 1) / h_col (nnz) = the CALLER'S BUFFERS for the host copy, filled here (the
 // column indices cross the bus while the device rounds run). d_positions may be nullptr (graph embedding, formed on the host).
 std::string nd_plan_build_device(const int32_t* d_rowptr, const int32_t* d_col, const float* d_positions, int64_t V, int64_t nnz,
-                                 int32_t* h_rowptr, int32_t* h_col, int leaf_size, int arity, int smooth, void* stream, NdPlan& out);
+                                 int32_t* h_rowptr, int32_t* h_col, int leaf_size, int arity, int smooth, void* stream, NdPlan& out,
+                                 int ordering = ND_ORDER_LONGEST);
 
 }  // namespace ls
 

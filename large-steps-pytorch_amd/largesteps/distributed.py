@@ -544,7 +544,7 @@ class MultiDeviceDirect:
     device and solve, so this mode pays from a few million vertices on (a 1M-vertex solve is 0.24 ms on ONE device); the
     one-process-per-GPU form (`ShardedDirect` under torchrun) has no such overhead."""
 
-    def __init__(self, M, devices, leaf_size=64, arity=4):
+    def __init__(self, M, devices, leaf_size=None, arity=None):
         from .solvers import _NativeDirect
         csr = _native.csr_of(M)
         if not _native.is_symmetric(csr):

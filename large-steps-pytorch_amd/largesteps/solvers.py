@@ -263,6 +263,11 @@ class _NativeDirect:
         _native.check(_native.lib().ls_direct_factor_seconds(self._h, ctypes.byref(s3)))
         self.timings = dict(plan_seconds=s3[0], table_seconds=s3[1], factor_seconds=s3[2])
         self.tier_levels = int(tier_levels)
+        o, w, sp, wo = ctypes.c_int(0), ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0)
+        _native.check(_native.lib().ls_direct_plan_quality(self._h, ctypes.byref(o), ctypes.byref(w), ctypes.byref(sp), ctypes.byref(wo)))
+        # how the dissection's cutting directions were chosen and what it costs (include/largesteps_hip.h, ls_nd_plan_quality)
+        self.plan_quality = dict(ordering="trial-cuts" if o.value == 1 else "longest-axis", words_per_vertex=w.value, spread=sp.value,
+                                 words_per_vertex_other=wo.value)
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -331,7 +336,10 @@ class NestedDissectionSolver(Solver):
     300k vertices, the arity-4 tree with 64-vertex sparse leaves of the large-mesh kernels beyond.
 
     The dissection uses the vertex positions the matrix was assembled from (`compute_matrix`); a symmetric matrix built
-    elsewhere gets graph-distance pseudo-positions instead. Raises ValueError when the matrix is not symmetric or not
+    elsewhere gets graph-distance pseudo-positions instead. A surface that is folded or rolled up in space (cloth, a scroll, shells
+    inside each other) is recognised by its thick separators and dissected again with graph distances among the cutting directions
+    (`plan_quality['ordering'] == 'trial-cuts'`; LS_ND_ORDER=1 asks for that always: 5-10 % fewer factor numbers on rough scans
+    for a constructor of tenths of a second). Raises ValueError when the matrix is not symmetric or not
     positive definite, RuntimeError when the mesh does not dissect into fronts that fit the kernels.
     """
 
@@ -350,6 +358,7 @@ class NestedDissectionSolver(Solver):
         torch.cuda.synchronize(csr.device)
         self.build_seconds = time.perf_counter() - t0
         self.timings = self._direct.timings
+        self.plan_quality = self._direct.plan_quality
 
     def solve(self, b, backward=False):
         _native.require_device(b, "b")
@@ -410,7 +419,7 @@ class CholeskySolver(Solver):
             # one process, several devices: the subtree-sharded solver behind the unchanged call sites
             try:
                 from .distributed import MultiDeviceDirect
-                self._impl = MultiDeviceDirect(M, devices, leaf_size=leaf_size or 64, arity=arity or 4)
+                self._impl = MultiDeviceDirect(M, devices, leaf_size=leaf_size, arity=arity)      # None: the tree ls_direct_pick_tree picks, as on one device
             except (ValueError, RuntimeError) as e:
                 self.direct_error = str(e)
                 warnings.warn(f"CholeskySolver: LARGESTEPS_DEVICES={','.join(devices)} could not be used ({e}); one device instead",

@@ -13,7 +13,7 @@ and the oracle.
 """
 import numpy as np
 
-__all__ = ["plane", "icosphere", "perturb", "config_mesh", "CONFIGS"]
+__all__ = ["plane", "icosphere", "perturb", "config_mesh", "CONFIGS", "folded_sheet", "scroll", "shells"]
 
 
 def plane(n, dtype=np.float32, index_dtype=np.int64):
@@ -107,6 +107,29 @@ def perturb(v, radial=0.0, tangential=0.0, edge=None, seed=0):
         d -= (d * nrm).sum(1, keepdims=True) * nrm
         v64 = v64 + tangential * edge * d
     return v64.astype(v.dtype)
+
+
+# Surfaces that are folded in space: layers that are neighbours in space and far apart on the surface (cloth, ears, coils). The
+# connectivity is the plane's / the sphere's; only the embedding differs -- what a fill-reducing ordering must not depend on.
+def folded_sheet(n, gap=1e-3, dtype=np.float32):
+    """plane(n) folded once along x = 1/2, the two layers `gap` apart."""
+    v, f = plane(n, dtype=np.float64)
+    x = v[:, 0]
+    return np.stack([np.where(x < 0.5, x, 1.0 - x), v[:, 1], np.where(x < 0.5, 0.0, gap)], 1).astype(dtype), f
+
+
+def scroll(n, turns, dtype=np.float32):
+    """plane(n) rolled up around the y axis: x -> (r cos 2 pi T x, y, r sin 2 pi T x), r = 0.2 + 0.8 x."""
+    v, f = plane(n, dtype=np.float64)
+    x = v[:, 0]
+    r = 0.2 + 0.8 * x
+    return np.stack([r * np.cos(2 * np.pi * turns * x), v[:, 1], r * np.sin(2 * np.pi * turns * x)], 1).astype(dtype), f
+
+
+def shells(n, gap=1e-3, dtype=np.float32):
+    """two concentric icosphere(n) shells, radii 1 and 1 + gap (two components)."""
+    v, f = icosphere(n, dtype=np.float64)
+    return np.concatenate([v, v * (1.0 + gap)]).astype(dtype), np.concatenate([f, f + v.shape[0]])
 
 
 # BASELINE.json configs -> stand-in meshes (SURVEY.md §8 table)

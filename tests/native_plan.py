@@ -9,7 +9,9 @@ from largesteps import _native
 from nd_plan_statement import NDPlan
 
 
-def native_plan(rowptr, col, positions, leaf_size=64, arity=4, smooth=4):
+def native_plan(rowptr, col, positions, leaf_size=64, arity=4, smooth=4, ordering=0):
+    """ordering: 0 longest axis of the embedding (ls_nd_plan_create), 1 thinnest of six trial separators, -1 the automatic choice
+    (ls_nd_plan_create_ordered); the plan carries .ordering / .words_per_vertex / .spread / .words_other (ls_nd_plan_quality)."""
     lib = _native.lib()
     rowptr32 = np.ascontiguousarray(rowptr, dtype=np.int32)
     col32 = np.ascontiguousarray(col, dtype=np.int32)
@@ -17,12 +19,17 @@ def native_plan(rowptr, col, positions, leaf_size=64, arity=4, smooth=4):
     pos = None if positions is None else np.ascontiguousarray(positions, dtype=np.float32)
     as_p = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)   # noqa: E731
     h = ctypes.c_void_p()
-    _native.check(lib.ls_nd_plan_create(V, as_p(rowptr32), as_p(col32), as_p(pos), leaf_size, arity, smooth, ctypes.byref(h)))
+    if ordering == 0:
+        _native.check(lib.ls_nd_plan_create(V, as_p(rowptr32), as_p(col32), as_p(pos), leaf_size, arity, smooth, ctypes.byref(h)))
+    else:
+        _native.check(lib.ls_nd_plan_create_ordered(V, as_p(rowptr32), as_p(col32), as_p(pos), leaf_size, arity, smooth, ordering, ctypes.byref(h)))
     try:
         lv, ar, nn = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         nb, nf, sec = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_double()
         _native.check(lib.ls_nd_plan_info(h, lv, ar, nn, nb, nf, sec))
         n = nn.value
+        q_ord, q_w, q_s, q_o = ctypes.c_int(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _native.check(lib.ls_nd_plan_quality(h, q_ord, q_w, q_s, q_o))
         perm = np.zeros(V, np.int32)
         s, b, own_start, parent = (np.zeros(n + 1, np.int32) for _ in range(4))
         bnd, ppos, push_tgt = (np.zeros(nb.value, np.int32) for _ in range(3))
@@ -35,6 +42,7 @@ def native_plan(rowptr, col, positions, leaf_size=64, arity=4, smooth=4):
     p.V, p.levels, p.arity, p.n_nodes = V, lv.value, ar.value, n
     p.D = p.levels - 1
     p.seconds = sec.value
+    p.ordering, p.words_per_vertex, p.spread, p.words_other = q_ord.value, q_w.value, q_s.value, q_o.value
     p.level_off = np.array([1 + (p.arity ** l - 1) // (p.arity - 1) for l in range(p.levels + 1)], dtype=np.int64)
     p.level_of = np.zeros(n + 1, np.int64)
     p.child_ix = np.zeros(n + 1, np.int64)

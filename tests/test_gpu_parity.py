@@ -641,6 +641,48 @@ def test_configs_vs_oracle(dev, cfg, chol_path):
     assert chol.method == ("nested-dissection" if chol_path == "direct" else "iterative"), chol.direct_error
 
 
+_FLAT_WORDS = {}
+
+
+def _flat_sheet_words(dev):
+    """factor numbers per vertex of the flat 500 x 500 sheet with the tree the library picks at that size"""
+    if "w" not in _FLAT_WORDS:
+        from largesteps.geometry import compute_matrix
+        from largesteps.solvers import NestedDissectionSolver
+        from largesteps import synthetic
+        v, f = synthetic.plane(500)
+        flat = NestedDissectionSolver(compute_matrix(_t(v, dev), _t(f, dev), 19.0))
+        assert flat.plan_quality["ordering"] == "longest-axis" and flat.plan_quality["words_per_vertex_other"] == 0.0
+        _FLAT_WORDS["w"] = flat.plan_quality["words_per_vertex"]
+    return _FLAT_WORDS["w"]
+
+
+@pytest.mark.parametrize("cot", [False, True])
+@pytest.mark.parametrize("mesh", ["folded", "scroll3", "scroll10", "shells"])
+def test_folded_surfaces_vs_oracle(dev, mesh, cot):
+    """250k-vertex surfaces whose layers are neighbours in space and far apart on the surface (a sheet folded once, rolled up 3 and
+    10 times, two shells 1e-3 apart): the default solver must stay the direct one -- cutting planes alone give fronts of up to 19 500
+    rows there, beyond the solver's limit -- with a factor within 1.3x of the flat sheet's, and match the fp64 direct solve."""
+    from largesteps.geometry import compute_matrix
+    from largesteps.parameterize import from_differential
+    from largesteps import parameterize, synthetic
+    v, f = {"folded": lambda: synthetic.folded_sheet(500), "scroll3": lambda: synthetic.scroll(500, 3),
+            "scroll10": lambda: synthetic.scroll(500, 10), "shells": lambda: synthetic.shells(112)}[mesh]()
+    tv, tf = _t(v, dev), _t(f, dev)
+    M = compute_matrix(tv, tf, 0.0, alpha=0.95, cotan=True) if cot else compute_matrix(tv, tf, 19.0)
+    idx, val = M.indices().cpu().numpy(), M.values().cpu().numpy()
+    direct = osv.DirectSolver(idx[0], idx[1], val, v.shape[0])
+    rhs = np.random.default_rng(2).standard_normal(v.shape).astype(np.float32)
+    x64 = direct.solve(rhs)
+    x = from_differential(M, _t(rhs, dev), "Cholesky").cpu().numpy()
+    assert np.abs(x - x64).max() <= 1e-4 * np.abs(x64).max(), (mesh, cot)
+    chol = parameterize._cache[(id(M), "Cholesky")][0]
+    assert chol.method == "nested-dissection", chol.direct_error
+    q = chol.plan_quality
+    assert q["ordering"] == "trial-cuts" and q["spread"] < 1.0 and q["words_per_vertex_other"] > 1.3 * q["words_per_vertex"], q
+    assert q["words_per_vertex"] <= 1.3 * _flat_sheet_words(dev), (q, _flat_sheet_words(dev))
+
+
 def _config_system(cfg, dev):
     from largesteps.geometry import compute_matrix
     from largesteps import synthetic
