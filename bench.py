@@ -64,7 +64,23 @@ def algorithmic_bytes(V, nnz, k, iters, method="pcg", implicit_values=False):
     return dict(k1=b_spmv, k2=b_k2, k3=b_k3, iter=b_iter, solve=(4 * k + 1) * 4 * V + iters * b_iter)
 
 
-PMC_FILE = "r03_pmc_traffic.json"
+def _newest_pmc_file():
+    """the newest committed PMC summary (profiles/rNN_pmc_traffic.json, written by tools/pmc_summary.py from the --pmc passes)"""
+    import glob
+    names = sorted(os.path.basename(p) for p in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    return names[-1] if names else "r03_pmc_traffic.json"
+
+
+PMC_FILE = _newest_pmc_file()
+
+
+def direct_group_prefixes(persistent=False):
+    """kernel-name prefixes of the launch group the direct solver's `roofline` is quoted on (tools/pmc_summary.py keys the PMC file by
+    the full kernel name, template arguments included: the prefixes stop BEFORE the arguments that vary with the tree -- the tier
+    kernel is k_nd_tier<K, UP, WAVES>). tests/test_bench_model.py resolves them against the committed PMC file."""
+    if persistent:
+        return ("ls::k_nd_tier<3", "ls::k_nd_span<3")
+    return ("ls::k_nd_down", "ls::k_nd_tier<3, false")
 
 
 def _pmc_doc(workload):
@@ -127,7 +143,9 @@ def cpu_baseline(v, f, cfg, u_np, seconds_cap=120.0):
 
 def describe(workload, cfg, V, nnz):
     """one-line description of a synthetic config (largesteps.synthetic.CONFIGS)"""
-    mesh = {"cfg4_plane1m": "1000x1000 plane", "cfg5_plane4m": "2000x2000 plane"}.get(workload, "noisy geodesic sphere (stand-in mesh)")
+    mesh = {"cfg4_plane1m": "1000x1000 plane", "cfg5_plane4m": "2000x2000 plane", "scroll250k": "500x500 sheet rolled up 3 turns",
+            "scroll10_250k": "500x500 sheet rolled up 10 turns", "folded250k": "500x500 sheet folded once, layers 1e-3 apart",
+            "shells250k": "two concentric geodesic spheres 1e-3 apart"}.get(workload, "noisy geodesic sphere (stand-in mesh)")
     if cfg["alpha"] is not None:
         mat = f"M=(1-{cfg['alpha']:g})I+{cfg['alpha']:g}*L_{'cot' if cfg['cotan'] else 'uniform'}"
     else:
@@ -348,8 +366,15 @@ def report_direct(args, solver, M, u, x, tv, v, f, cfg, ms, t_assemble):
         for row, r in zip(table, lp):
             row["us"] += r["ms"] * 1e3 / n_prof
     solver.set_option("profile", 0)
+    # the vectors' share of a launch: per sweep the b / b' / x rows of its levels' vertices and the boundary vectors of their nodes
+    # (the per-sweep total below, 4k (2V + 3 n_bnd) + 4V, split by level: ls_direct_level_rows)
+    lv_rows, lv_bnd = solver.level_rows()
     for row in table:
-        row["tb_per_s"] = row["factor_bytes"] / (row["us"] * 1e-6) / 1e12 if row["us"] > 0 else None
+        lo, hi = row["levels"]
+        nv, nb_ = sum(lv_rows[max(lo, 0):hi + 1]), sum(lv_bnd[max(lo, 0):hi + 1])
+        row["vector_bytes"] = (2 if row["sweep"] == "both" else 1) * (4 * 3 * (2 * nv + 3 * nb_) + 4 * nv)
+        row["bytes"] = row["factor_bytes"] + row["vector_bytes"]
+        row["tb_per_s"] = row["bytes"] / (row["us"] * 1e-6) / 1e12 if row["us"] > 0 else None
         row["frac_of_8tbs"] = row["tb_per_s"] / 8.0 if row["tb_per_s"] else None
     persistent = inf["launches"] == 3 and len(table) == 3        # tier up / persistent upper-level launch / tier down
     n_down = sum(1 for r in table if r["sweep"] == "down")
@@ -365,12 +390,12 @@ def report_direct(args, solver, M, u, x, tv, v, f, cfg, ms, t_assemble):
     rel_res = [float(a / b) for a, b in zip(r.norm(dim=0).tolist(), u.norm(dim=0).tolist())]
     if persistent:          # the sweeps are not separate launch groups: the whole solve is the group
         grp_bytes, grp_ms, grp_n, grp_name = solve_bytes, up_ms + mid_ms + down_ms, 3, "whole solve: k_nd_tier<3, true> + k_nd_span<3, 4> + k_nd_tier<3, false>"
-        grp_prefixes = ("ls::k_nd_tier<3", "ls::k_nd_span<3")
+        grp_prefixes = direct_group_prefixes(True)
     else:
         grp_bytes, grp_ms, grp_n = down_bytes, down_ms, n_down
         grp_name = (f"down sweep: k_nd_down_b<3> x {n_down - 1} + k_nd_tier<3, false> ({n_down} launches: x_s = Finv b'_s - W^T x_bnd "
                     f"per upper tree level, then the deepest {inf['tier_levels']} levels in one launch)")
-        grp_prefixes = ("ls::k_nd_down", "ls::k_nd_tier<3, false>")
+        grp_prefixes = direct_group_prefixes(False)
     grp_gbs = grp_bytes / (grp_ms * 1e-3) / 1e9
     traffic, traffic_n = pmc_traffic_group(grp_prefixes, args.workload)
     tm = solver.timings
@@ -396,6 +421,7 @@ def report_direct(args, solver, M, u, x, tv, v, f, cfg, ms, t_assemble):
                             f"level and sweep, one per sweep for the deepest {inf['tier_levels']} levels), no atomics"),
                     method="nested-dissection", iterations=0, converged=True, rel_residual=rel_res,
                     max_abs_err_vs_v=float((x - tv).abs().max()), assemble_ms=t_assemble * 1e3,
+                    dissection=getattr(solver, "plan_quality", None),
                     factor_seconds=getattr(solver, "build_seconds", None), factor_seconds_second_construction=repeat_seconds,
                     factor_stages_seconds=dict(symbolic_analysis=tm["plan_seconds"], layouts_host=tm["table_seconds"], numeric_device_and_solve_tables=tm["factor_seconds"]),
                     solve_bytes=solve_bytes, solve_gbs=solve_bytes / (ms * 1e-3) / 1e9,

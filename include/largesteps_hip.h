@@ -373,6 +373,9 @@ int ls_direct_shape(const ls_direct* d, int* h_levels, int* h_arity, int* h_tier
 /* 4-byte words of factor data each tree level reads in the up / the down sweep (h_up, h_down: `cap` entries, level 0 = root;
  * the sparse leaves' lists are counted with the last level). Host only. */
 int ls_direct_level_words(const ls_direct* d, int cap, int64_t* h_up, int64_t* h_down);
+/* own rows (vertices) and boundary entries of each tree level (level 0 = root): what the vectors a level's launch moves are made
+ * of -- per sweep b / b' / x rows of its vertices and the boundary vectors of its nodes. Host only. */
+int ls_direct_level_rows(const ls_direct* d, int cap, int64_t* h_rows, int64_t* h_bnd);
 /* After a solve with "profile" = 3 (an event in front of every launch; the solve synchronises): number of launches and, for
  * the first `cap` of them, duration in ms, factor words read, tree levels [lo, hi] covered, sweep (0 up, 1 down, 2 both).
  * Any pointer may be NULL. */

@@ -56,7 +56,11 @@ __device__ __forceinline__ Tile load_tile(const Tile* __restrict__ tiles, int id
 #ifndef LS_ND_UNROLL
 #define LS_ND_UNROLL 32       // (8: 17.1 / 17.1 us for the two row-per-lane up levels of a 1M-vertex solve, 16: 19.9 / 19.3, 32: 16.6 / 16.0)
 #endif
-constexpr int ND_UNROLL = LS_ND_UNROLL;   // independent matrix loads in flight per lane (row-per-lane kernels)
+// independent matrix loads in flight per lane of the row-per-lane kernels. Both kernels are compiled for 1024 threads (128 VGPRs):
+// 32 was measured on k_nd_up<3> and fits there (K = 4: 8); k_nd_down keeps TWO such batches (Finv and W^T) and stays at the 8 it
+// has always fitted with -- at 32 it spilled 42-114 registers to scratch (round 3). tests/test_abi_and_host.py reads the spill
+// counts of every kernel out of the built library.
+template <int K> struct NdUnroll { static constexpr int up = K <= 3 ? LS_ND_UNROLL : (LS_ND_UNROLL > 8 ? 8 : LS_ND_UNROLL), down = 8; };
 #ifndef LS_ND_ROWS
 #define LS_ND_ROWS 2
 #endif
@@ -182,7 +186,7 @@ __device__ __forceinline__ void push_down(const int* __restrict__ push_tgt, int 
 
 // ---- a row per lane ---------------------------------------------------------------------------------------------
 // acc += sum_{u in [u0, u1)} col[u * stride] * sv[u * K + q]; the first ND_UNROLL values were prefetched
-template <int K>
+template <int K, int ND_UNROLL>
 __device__ __forceinline__ void dot_strided(const float* __restrict__ col, size_t stride, int u0, int u1,
                                             const float* __restrict__ sv, const float (&pre)[ND_UNROLL], float (&acc)[K]) {
 #pragma unroll
@@ -210,6 +214,7 @@ __device__ __forceinline__ void dot_strided(const float* __restrict__ col, size_
     }
 }
 
+template <int ND_UNROLL>
 __device__ __forceinline__ void prefetch_strided(const float* __restrict__ col, size_t stride, int u0, int u1, float (&pre)[ND_UNROLL]) {
 #pragma unroll
     for (int e = 0; e < ND_UNROLL; ++e) pre[e] = (u0 + e < u1) ? col[(size_t)(u0 + e) * stride] : 0.0f;
@@ -252,7 +257,7 @@ __global__ __launch_bounds__(1024) void k_nd_up(const Tile* __restrict__ tiles, 
     const bool row = i < b;
     // everything that does not depend on this level's arithmetic is requested up front
     const float* __restrict__ col = wf + t.w_off + (row ? i : 0);
-    float pre[ND_UNROLL];
+    float pre[NdUnroll<K>::up];
     prefetch_strided(col, (size_t)b, j0, row ? j1 : j0, pre);
     int pp = 0;
     float pass[K];
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(1024) void k_nd_down(const Tile* __restrict__ tiles
     const float* __restrict__ fcol = finv + t.finv_off + (row ? j : 0);
     const float* __restrict__ wcol = wb + t.w_off + (row ? j : 0);
     const int f0 = min(t0, s), f1 = min(t1, s), g0 = max(t0, s) - s, g1 = max(t1, s) - s;   // Finv part, W part
-    float pre_f[ND_UNROLL], pre_w[ND_UNROLL];
+    float pre_f[NdUnroll<K>::down], pre_w[NdUnroll<K>::down];
     prefetch_strided(fcol, (size_t)s, f0, row ? f1 : f0, pre_f);
     prefetch_strided(wcol, (size_t)s, g0, row ? g1 : g0, pre_w);
     int p0 = 0, p1 = 0;
@@ -730,7 +735,7 @@ __global__ __launch_bounds__(64) void k_nd_up_p(const PackedTile* __restrict__ t
     const NodeP d = t.d[g];
     const int i = lane - t.row0[g];
     const float* __restrict__ col = wf + d.w_off + (row ? i : 0);
-    float pre[ND_UNROLL];
+    float pre[LS_ND_UNROLL];
     prefetch_strided(col, (size_t)d.b, 0, row ? d.s : 0, pre);
     int pp = 0;
     float pass[K];
@@ -771,7 +776,7 @@ __global__ __launch_bounds__(64) void k_nd_down_p(const PackedTile* __restrict__
     const int j = lane - t.row0[g];
     const float* __restrict__ fcol = finv + d.finv_off + (row ? j : 0);
     const float* __restrict__ wcol = wb + d.w_off + (row ? j : 0);
-    float pre_f[ND_UNROLL], pre_w[ND_UNROLL];
+    float pre_f[LS_ND_UNROLL], pre_w[LS_ND_UNROLL];            // (a 64-thread workgroup: registers are plentiful here)
     prefetch_strided(fcol, (size_t)d.s, 0, row ? d.s : 0, pre_f);
     prefetch_strided(wcol, (size_t)d.s, 0, row ? d.b : 0, pre_w);
     int p0 = 0, p1 = 0;
@@ -815,7 +820,12 @@ __global__ __launch_bounds__(64) void k_nd_down_p(const PackedTile* __restrict__
 
 }  // namespace ls
 #include "nd_tier.h"
+// The levels above the tier as ONE persistent launch (tree-local barriers, write-through hand-offs, register prefetch) were built and
+// measured in round 3: 166-207 us against 103-120 us for nine launches at 1M vertices. It is an experiment:
+// the kernel, its layouts and its planner exist only in -DLS_ND_EXPERIMENTS builds (tools/build/liblargesteps_hip_exp.so).
+#ifdef LS_ND_EXPERIMENTS
 #include "nd_span.h"
+#endif
 namespace ls {
 
 // down tiles of a level: compute tiles, then forward tiles
@@ -862,8 +872,12 @@ struct ls_direct {
     // the levels above the tier as ONE persistent launch (nd_span.h); off: one launch per level and sweep (the kernels above)
     bool span_ok = false, span_on = false;
     const float *pu = nullptr, *pd = nullptr;                    // caller's arrays (layouts of nd_span.h)
+#ifdef LS_ND_EXPERIMENTS
     SpanJob* d_sjobs = nullptr;
     SpanSync* d_ssync = nullptr;
+#else
+    void *d_sjobs = nullptr, *d_ssync = nullptr;                 // (never allocated in the product)
+#endif
     unsigned* d_swords = nullptr;
     unsigned* h_sfail = nullptr;        // host-mapped: a wait of the persistent launch timed out
     int* d_bnd = nullptr;
@@ -884,6 +898,7 @@ struct ls_direct {
     std::vector<LaunchMeta> lmeta;
     std::vector<double> launch_ms;
     std::vector<int64_t> lvl_up, lvl_down;            // 4-byte words of factor data per tree level and sweep
+    std::vector<int64_t> lvl_rows, lvl_bnd;           // own rows / boundary entries per tree level (the vectors' share of a launch's bytes)
     double prof_ms[3] = {0, 0, 0};     // up sweep, down sweep, 0 (last profiled solve)
 };
 
@@ -1073,6 +1088,7 @@ bool direct_tier_fits(int levels, int arity, const int* s, const int* b, const i
     return region && region * sizeof(float) * TIER_WAVES <= 150 * 1024;
 }
 
+#ifdef LS_ND_EXPERIMENTS
 // The levels above the tier as phases of one persistent launch (nd_span.h): workgroup ranges per node (a node's range is the
 // union of its children's), every workgroup's jobs per phase, and the arrival counters / release flags between the phases.
 struct SpanPlan { std::vector<SpanJob> jobs; std::vector<SpanSync> sync; int phases = 0, grid = 0, lcap = 0, words = 0; };
@@ -1201,6 +1217,7 @@ static bool plan_span(const std::vector<NodeDesc>& nodes, const std::vector<int6
     sp.phases = P; sp.grid = G; sp.lcap = (lcap + 3) & ~3; sp.words = std::max(words, 1);
     return true;
 }
+#endif
 
 extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* stream, ls_direct** out) {
     LS_REQUIRE(A && out, LS_E_INVALID, "ls_direct_create: null argument");
@@ -1267,8 +1284,9 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
         fe += up_w + down_w; fe_up += up_w; fe_down += down_w;
         int lv = 0;
         while (lv + 1 < levels && i >= level_off[lv + 1]) ++lv;
-        if (d->lvl_up.empty()) { d->lvl_up.assign((size_t)levels, 0); d->lvl_down.assign((size_t)levels, 0); }
+        if (d->lvl_up.empty()) { d->lvl_up.assign((size_t)levels, 0); d->lvl_down.assign((size_t)levels, 0); d->lvl_rows.assign((size_t)levels, 0); d->lvl_bnd.assign((size_t)levels, 0); }
         d->lvl_up[(size_t)lv] += up_w; d->lvl_down[(size_t)lv] += down_w;
+        d->lvl_rows[(size_t)lv] += n.s; d->lvl_bnd[(size_t)lv] += n.b;
     }
     fe += 2 * A->n_sp_ent + A->n_sp_ptr;        // each CSR list is read by one sweep (8-byte entries, 4-byte pointers)
     fe_up += A->n_sp_ent + A->n_sp_ptr / 2; fe_down += A->n_sp_ent + A->n_sp_ptr - A->n_sp_ptr / 2;
@@ -1535,6 +1553,7 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
                 if (lv < cut ? rank == 0 : active(i, lv))
                     for (int r = 0; r < nodes[i].s; ++r) d->owned_rows[(size_t)h_perm[nodes[i].own_start + r]] = 1;
     }
+#ifdef LS_ND_EXPERIMENTS
     // the levels above the tier as one persistent launch (nd_span.h): needs the caller's pu / pd layouts and the boundary ids
     SpanPlan sp;
     bool span = A->d_pu && A->d_pd && A->h_pu_off && A->h_pd_off && A->h_bnd && n_ranks == 1 && d->tier_root >= 1 && d->tier_wgs > 0 && !getenv("LS_ND_NO_SPAN");
@@ -1561,6 +1580,9 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
         span = span && plan_span(nodes, level_off, d->tier_root, levels, arity, A->h_pu_off, A->h_pd_off, std::min(G, cus), sp);
         if (span && ((size_t)d->kmax * sp.lcap + SPAN_WAVES * 256) * sizeof(float) > 150 * 1024) span = false;
     }
+#else
+    const bool span = false;
+#endif
     int rc = LS_OK;
     auto up = [&](auto** dst, const auto* src, size_t n) -> int {
         LS_HIP(hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(**dst)));
@@ -1573,12 +1595,18 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
         !(rc = up(&d->push_tgt, h_push_tgt, (size_t)n_bnd)) && !(rc = up(&d->mask, mask.data(), mask.size())) &&
         !(rc = up(&d->d_items, items.data(), items.size())) && !(rc = up(&d->pull, pull.data(), pull.size())) &&
         !(rc = up(&d->d_wgs, wgs.data(), wgs.size())) &&
+#ifdef LS_ND_EXPERIMENTS
         (!span || (!(rc = up(&d->d_sjobs, sp.jobs.data(), sp.jobs.size())) && !(rc = up(&d->d_ssync, sp.sync.data(), sp.sync.size())) &&
-                   !(rc = up(&d->d_bnd, A->h_bnd, (size_t)n_bnd))))) {
+                   !(rc = up(&d->d_bnd, A->h_bnd, (size_t)n_bnd))))
+#else
+        true
+#endif
+        ) {
         hipError_t e = hipMalloc((void**)&d->bp, sizeof(float) * (size_t)V * d->kmax);
         if (e == hipSuccess) e = hipMalloc((void**)&d->braw, sizeof(float) * (size_t)V * d->kmax);
         if (e == hipSuccess) e = hipMalloc((void**)&d->slots, sizeof(float) * (size_t)n_front * arity * d->kmax);
         if (e == hipSuccess) e = hipMalloc((void**)&d->xb, sizeof(float) * (size_t)std::max<int64_t>(n_bnd, 1) * d->kmax);
+#ifdef LS_ND_EXPERIMENTS
         if (e == hipSuccess && span) {
             const size_t up_rows = (size_t)(V - d->upper_lo);
             const size_t n_pf = d->tier_root < levels ? (size_t)nodes[level_off[d->tier_root]].front_off : (size_t)n_front;
@@ -1589,6 +1617,7 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
             if (e == hipSuccess) e = hipHostMalloc((void**)&d->h_sfail, sizeof(unsigned), hipHostMallocMapped);
             if (e == hipSuccess) *d->h_sfail = 0u;
         }
+#endif
         if (e == hipSuccess) e = hipEventCreateWithFlags(&d->busy, hipEventDisableTiming);
         if (e == hipSuccess) e = hipStreamSynchronize(st);      // the host vectors above go out of scope
         if (e != hipSuccess) rc = hip_fail(e, "ls_direct_create allocations", __FILE__, __LINE__);
@@ -1611,6 +1640,7 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
     (void)hipFuncSetAttribute((const void*)k_nd_tier<KK, false, TIER_WAVES_WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     LS_OPTIN(1) LS_OPTIN(2) LS_OPTIN(3) LS_OPTIN(4)
 #undef LS_OPTIN
+#ifdef LS_ND_EXPERIMENTS
     if (span) {
         d->pu = A->d_pu; d->pd = A->d_pd;
         d->span_phases = sp.phases; d->span_grid = sp.grid; d->span_lcap = sp.lcap; d->span_words = sp.words;
@@ -1626,6 +1656,9 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
         LS_OPTIN(1) LS_OPTIN(2) LS_OPTIN(3) LS_OPTIN(4)
 #undef LS_OPTIN
     }
+#else
+    (void)span;
+#endif
     *out = d;
     return LS_OK;
 }
@@ -1684,6 +1717,7 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
         for (int i = 0; i < n_mark && r == hipSuccess; ++i) { float ms = 0; r = hipEventElapsedTime(&ms, d->lev[(size_t)i], d->lev[(size_t)i + 1]); d->launch_ms[(size_t)i] = ms; }
         return r;
     };
+#ifdef LS_ND_EXPERIMENTS
     if (d->span_ok && d->span_on && part == -1) {
         // tier up -> every level above the tier, both sweeps, as ONE persistent launch -> tier down
         SpanArgs sa;
@@ -1724,6 +1758,7 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
         }
         return LS_OK;
     }
+#endif
     const size_t exch_off = (size_t)d->exch_f0 * d->arity * K, exch_n = (size_t)(d->exch_f1 - d->exch_f0) * d->arity * K;
     if (part != 1) {
     if (d->profile) LS_HIP(hipEventRecord(d->ev[0], st));
@@ -1925,7 +1960,16 @@ extern "C" int ls_direct_set(ls_direct* d, const char* name, int value) {
         }
         return LS_OK;
     }
-    if (!strcmp(name, "persist")) { d->span_on = d->span_ok && value != 0; return LS_OK; }
+    if (!strcmp(name, "persist")) {
+#ifdef LS_ND_EXPERIMENTS
+        d->span_on = d->span_ok && value != 0;
+        return LS_OK;
+#else
+        LS_REQUIRE(value == 0, LS_E_INVALID, "ls_direct_set: the persistent upper-level launch exists only in -DLS_ND_EXPERIMENTS builds of the library "
+                                             "(measured slower than one launch per level: DESIGN.md section 2.3c)");
+        return LS_OK;
+#endif
+    }
     set_error("ls_direct_set: unknown option '%s'", name);
     return LS_E_INVALID;
 }
@@ -1981,6 +2025,15 @@ extern "C" int ls_direct_level_words(const ls_direct* d, int cap, int64_t* h_up,
     for (int lv = 0; lv < cap && lv < d->levels; ++lv) {
         if (h_up) h_up[lv] = lv < (int)d->lvl_up.size() ? d->lvl_up[(size_t)lv] : 0;
         if (h_down) h_down[lv] = lv < (int)d->lvl_down.size() ? d->lvl_down[(size_t)lv] : 0;
+    }
+    return LS_OK;
+}
+
+extern "C" int ls_direct_level_rows(const ls_direct* d, int cap, int64_t* h_rows, int64_t* h_bnd) {
+    LS_REQUIRE(d && cap >= 0, LS_E_INVALID, "ls_direct_level_rows: bad argument");
+    for (int lv = 0; lv < cap && lv < d->levels; ++lv) {
+        if (h_rows) h_rows[lv] = lv < (int)d->lvl_rows.size() ? d->lvl_rows[(size_t)lv] : 0;
+        if (h_bnd) h_bnd[lv] = lv < (int)d->lvl_bnd.size() ? d->lvl_bnd[(size_t)lv] : 0;
     }
     return LS_OK;
 }

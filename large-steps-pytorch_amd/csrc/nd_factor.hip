@@ -544,7 +544,12 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     std::vector<int64_t> hn((size_t)(n_nodes + 1) * LS_DIRECT_NODE_COLS, 0);
     int64_t f_tot = 0, x_tot = 0, w_tot = 0, o_finv = 0, o_w = 0, o_d4 = 0, o_u4 = 0, o_tri = 0, o_pu = 0, o_pd = 0;
     // the levels above the tier also get the layouts of the persistent upper-level launch (nd_span.h); unsharded handles only
+    // (experiments builds only, and only when asked for: the layouts double the upper levels' factor memory)
+#ifdef LS_ND_EXPERIMENTS
     const bool want_span = tier_levels > 0 && tier_root >= 1 && shard_count <= 1 && !getenv("LS_ND_NO_SPAN");
+#else
+    const bool want_span = false;
+#endif
     std::vector<int64_t> pu_off((size_t)n_nodes + 1, -1), pd_off((size_t)n_nodes + 1, -1);
     for (int i = 1; i <= n_nodes; ++i) {
         FactorNode& n = fn[i];

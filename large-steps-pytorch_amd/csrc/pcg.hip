@@ -524,6 +524,10 @@ template <> struct LdsVec<2> { typedef float2 T; };
 template <> struct LdsVec<3> { struct T { float x, y, z; }; };
 template <> struct LdsVec<4> { typedef float4 T; };
 
+// the packed neighbour ids are unpacked where they are used: hipcc otherwise hoists the 64 shifts / masks of a thread's 8 rows out of
+// the step loop and keeps both halves of every register resident (+32 VGPRs: the 1024-thread forms then spilled to scratch)
+__device__ __forceinline__ unsigned in_loop(unsigned v) { asm volatile("" : "+v"(v)); return v; }
+
 template <int K, int PATCH_BS, int PATCH_RPT>
 __global__ __launch_bounds__(PATCH_BS) void k_patch_cheb(const int* __restrict__ table, const int* __restrict__ ghost_gid,
                                                          const unsigned short* __restrict__ cols16, const float* __restrict__ diag,
@@ -591,15 +595,23 @@ __global__ __launch_bounds__(PATCH_BS) void k_patch_cheb(const int* __restrict__
 #pragma unroll
                 for (int q = 0; q < K; ++q) sum[q] = 0.0f;
                 if (NW > 0) {
-                    slot_t g8[NW > 0 ? NW : 1];
+                    // gathers in batches of GB slots: all NW at once (8 x K registers on top of the 8 rows' resident b, diagonal and
+                    // ids) spilled 16-37 registers to scratch in the 1024-thread form for K >= 3; the sum's order is unchanged
+                    constexpr int GB = (K >= 3 && PATCH_BS == 1024) ? 4 : (NW > 0 ? NW : 1);
 #pragma unroll
-                    for (int e = 0; e < NW; ++e)        // padding ids point at the zero slot: no branch needed
-                        g8[e] = cur[(e & 1) ? (nb[j][e >> 1] >> 16) : (nb[j][e >> 1] & 0xffffu)];
+                    for (int e0 = 0; e0 < NW; e0 += GB) {
+                        slot_t g8[GB];
 #pragma unroll
-                    for (int e = 0; e < NW; ++e) {
-                        const float* f = reinterpret_cast<const float*>(&g8[e]);
+                        for (int e = e0; e < e0 + GB; ++e)        // padding ids point at the zero slot: no branch needed
+                            if (e < NW) { const unsigned pk = in_loop(nb[j][e >> 1]); g8[e - e0] = cur[(e & 1) ? (pk >> 16) : (pk & 0xffffu)]; }
 #pragma unroll
-                        for (int q = 0; q < K; ++q) sum[q] += f[q];
+                        for (int e = e0; e < e0 + GB; ++e) {
+                            if (e < NW) {
+                                const float* f = reinterpret_cast<const float*>(&g8[e - e0]);
+#pragma unroll
+                                for (int q = 0; q < K; ++q) sum[q] += f[q];
+                            }
+                        }
                     }
                 } else {
                     const unsigned short* __restrict__ cr = cols16 + oc + r;

@@ -93,6 +93,7 @@ _SIGNATURES = {
     "ls_patch_plan_info": (c_int, [c_void_p] + [ctypes.POINTER(c_int)] * 5 + [ctypes.POINTER(c_i64)] * 3 + [ctypes.POINTER(ctypes.c_double)]),
     "ls_patch_plan_arrays": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ls_direct_level_words": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "ls_direct_level_rows": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "ls_direct_exchange_region": (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_i64)]),
     "ls_dist_unique_id": (c_int, [c_void_p]),
     "ls_dist_create": (c_int, [c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),

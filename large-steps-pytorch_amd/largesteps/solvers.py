@@ -304,6 +304,13 @@ class _NativeDirect:
         _native.check(_native.lib().ls_direct_level_words(self._h, n, up, down))
         return list(up), list(down)
 
+    def level_rows(self):
+        """own rows (vertices) and boundary entries per tree level, level 0 = root"""
+        n = self.info()["levels"]
+        rows, bnd = (ctypes.c_int64 * n)(), (ctypes.c_int64 * n)()
+        _native.check(_native.lib().ls_direct_level_rows(self._h, n, rows, bnd))
+        return list(rows), list(bnd)
+
     def launch_profile(self):
         """Launches of the last solve run with set_option("profile", 3): dicts of ms, factor words, levels (lo, hi), sweep."""
         n = ctypes.c_int(0)
@@ -390,6 +397,9 @@ class NestedDissectionSolver(Solver):
 
     def level_words(self):
         return self._direct.level_words()
+
+    def level_rows(self):
+        return self._direct.level_rows()
 
     def launch_profile(self):
         return self._direct.launch_profile()

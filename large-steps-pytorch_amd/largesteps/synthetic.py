@@ -139,6 +139,11 @@ CONFIGS = {
     "cfg3_dragon250k": dict(kind="icosphere", n=158, radial=0.05, tangential=0.25, lambda_=None, alpha=0.95, cotan=True),
     "cfg4_plane1m": dict(kind="plane", n=1000, lambda_=50.0, alpha=None, cotan=False),
     "cfg5_plane4m": dict(kind="plane", n=2000, lambda_=50.0, alpha=None, cotan=False),
+    # not BASELINE.json configs: surfaces folded in space (bench.py --workload ..., tests): the plane's connectivity, another embedding
+    "scroll250k": dict(kind="scroll", n=500, turns=3, lambda_=19.0, alpha=None, cotan=False),
+    "scroll10_250k": dict(kind="scroll", n=500, turns=10, lambda_=19.0, alpha=None, cotan=False),
+    "folded250k": dict(kind="folded", n=500, lambda_=19.0, alpha=None, cotan=False),
+    "shells250k": dict(kind="shells", n=112, lambda_=19.0, alpha=None, cotan=False),
 }
 
 
@@ -147,6 +152,12 @@ def config_mesh(name):
     c = dict(CONFIGS[name])
     if c["kind"] == "plane":
         v, f = plane(c["n"])
+    elif c["kind"] == "scroll":
+        v, f = scroll(c["n"], c["turns"])
+    elif c["kind"] == "folded":
+        v, f = folded_sheet(c["n"])
+    elif c["kind"] == "shells":
+        v, f = shells(c["n"])
     else:
         v, f = icosphere(c["n"])
         if c.get("radial") or c.get("tangential"):

@@ -66,3 +66,31 @@ def test_committed_profiles_are_consistent():
     assert abs(r["achieved"] - r["bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) <= 1e-6 * r["achieved"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+
+
+def test_roofline_group_resolves_in_the_committed_pmc_file():
+    """`roofline.traffic` is looked up by kernel-name PREFIX in the committed PMC summary: a template argument added to a kernel
+    (k_nd_tier<K, UP> became <K, UP, WAVES>) once made the lookup silently drop the group's largest kernel. Every prefix of the
+    group must resolve, the launches must be in the ratio one solve has (n - 1 level launches : 1 tier launch), and the traffic the
+    line would print must not be BELOW the algorithmic bytes of the committed bench line."""
+    import glob
+    b = load_bench()
+    with open(os.path.join(ROOT, "profiles", b.PMC_FILE)) as fh:
+        doc = json.load(fh)
+    assert doc["workload"] == b.WORKLOAD
+    per_prefix = {}
+    for p in b.direct_group_prefixes(False):
+        hits = {k: v for k, v in doc["kernels"].items() if k.startswith(p)}
+        assert hits, f"no kernel of {b.PMC_FILE} starts with {p!r}"
+        per_prefix[p] = sum(v["dispatches"] for v in hits.values())
+    levels, tier = per_prefix["ls::k_nd_down"], per_prefix["ls::k_nd_tier<3, false"]
+    # the up-sweep tier kernel must not be caught by the down-sweep prefix
+    assert not any(k.startswith("ls::k_nd_tier<3, false") and "true" in k for k in doc["kernels"])
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", b.PMC_FILE[:3] + "_*bench_direct*.json")))
+    d = json.loads([ln for ln in open(lines[-1]).read().splitlines() if ln.startswith("{")][-1])
+    n_down = d["config"]["kernel_us"]["down_launches"]
+    assert tier > 0 and levels == (n_down - 1) * tier, (levels, tier, n_down)
+    traffic, n = b.pmc_traffic_group(b.direct_group_prefixes(False), b.WORKLOAD)
+    assert n == levels + tier
+    assert traffic >= 0.9 * d["roofline"]["bytes_per_launch"], (traffic, d["roofline"]["bytes_per_launch"])
+    assert traffic <= 1.5 * d["roofline"]["bytes_per_launch"]
