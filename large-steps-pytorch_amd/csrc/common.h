@@ -50,6 +50,7 @@ inline int div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // give: false when the pool did not take the buffer (the caller frees it). The buffer must be idle (its stream synchronised).
 void* pool_take(int device, size_t bytes, size_t* capacity);
 bool pool_give(int device, void* p, size_t bytes);
+hipError_t pool_alloc(int device, void** p, size_t bytes);      // hipMalloc; out of memory: the pool of `device` is emptied and the call repeated once
 constexpr size_t POOL_FROM = (size_t)64 << 20;
 // assemble.hip: out[0 .. n] = exclusive scan of the int32 in[0 .. n), out[n] = total; bsum: scan_blocks(n) + 1 ints of scratch
 int exclusive_scan(const int* in, int64_t n, int* out, int* bsum, hipStream_t st);

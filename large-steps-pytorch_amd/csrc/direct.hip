@@ -920,15 +920,26 @@ int ls_direct_adopt(ls_direct* d, void* const* owned, const size_t* owned_bytes,
 // freed device memory back lazily: at 4M vertices every second or third construction of a process stalled 0.45-0.7 s inside ONE hipMalloc
 // (the 9.3 GB of fp64 fronts, or the next buffer after it: profiles/r03_run5_constructor_times.txt) -- four times the whole constructor.
 // The constructor's scratch (fronts and work arrays: 3-4 GB at 1M, 14 GB at 4M) and the handle's factor arrays therefore go back to this
-// pool instead of hipFree, and allocations of >= 64 MB take the best fit (at most 1.5x + 64 MB larger). LS_POOL_GB caps what it holds
-// (default 24 per process, 0 = no pool; oldest out first); ls_release_scratch() empties it.
+// pool instead of hipFree, and allocations of >= 64 MB take the best fit (at most 1.5x + 64 MB larger). What the pool may hold is
+// bounded PER DEVICE: LS_POOL_GB (default 16, 0 = no pool) and never more than a quarter of the device's memory (torch's caching
+// allocator cannot see or reclaim what sits here); oldest out first. An allocation of the library that fails empties the pool of its
+// device and is tried once more (pool_alloc below), ls_release_scratch() empties it on request, and the Python layer calls that when
+// torch itself runs out of memory (largesteps.solvers.release_scratch).
 namespace ls {
 namespace {
 struct DevicePool {
     std::mutex mu;
     struct Entry { void* p; size_t bytes; int device; };
     std::vector<Entry> held;
-    static size_t cap() { const char* e = getenv("LS_POOL_GB"); return (size_t)((e ? atof(e) : 24.0) * 1073741824.0); }
+    static size_t cap(int device) {              // bytes the pool may hold on one device
+        const char* e = getenv("LS_POOL_GB");
+        double gb = e ? atof(e) : 16.0;
+        if (!(gb > 0.0)) return 0;
+        size_t free_b = 0, total_b = 0;
+        DeviceGuard dg(device);
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) gb = std::min(gb, (double)total_b / 4.0 / 1073741824.0);
+        return (size_t)(gb * 1073741824.0);
+    }
 };
 DevicePool g_pool;
 }  // namespace
@@ -950,19 +961,30 @@ void* pool_take(int device, size_t bytes, size_t* capacity) {
 
 bool pool_give(int device, void* p, size_t bytes) {
     if (!p || bytes < POOL_FROM) return false;
-    const size_t limit = DevicePool::cap();
+    const size_t limit = DevicePool::cap(device);
     if (bytes > limit) return false;
     std::lock_guard<std::mutex> g(g_pool.mu);
     size_t total = bytes;
-    for (const DevicePool::Entry& e : g_pool.held) total += e.bytes;
-    while (total > limit && !g_pool.held.empty()) {                  // oldest out first
-        total -= g_pool.held.front().bytes;
-        DeviceGuard dg(g_pool.held.front().device);
-        (void)hipFree(g_pool.held.front().p);
-        g_pool.held.erase(g_pool.held.begin());
+    for (const DevicePool::Entry& e : g_pool.held) if (e.device == device) total += e.bytes;
+    for (size_t i = 0; total > limit && i < g_pool.held.size();) {    // this device's oldest out first
+        if (g_pool.held[i].device != device) { ++i; continue; }
+        total -= g_pool.held[i].bytes;
+        DeviceGuard dg(device);
+        (void)hipFree(g_pool.held[i].p);
+        g_pool.held.erase(g_pool.held.begin() + (long)i);
     }
     g_pool.held.push_back(DevicePool::Entry{p, bytes, device});
     return true;
+}
+
+// hipMalloc that gives the pool's memory back before it gives up: a remesh to a size outside the pool's fit window, or a torch /
+// renderer allocation next to a full pool, must not fail for memory the library is only keeping warm
+hipError_t pool_alloc(int device, void** p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipErrorOutOfMemory && e != hipErrorMemoryAllocation) return e;
+    (void)hipGetLastError();
+    (void)ls_release_scratch(device);
+    return hipMalloc(p, bytes);
 }
 }  // namespace ls
 
@@ -1585,7 +1607,7 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
 #endif
     int rc = LS_OK;
     auto up = [&](auto** dst, const auto* src, size_t n) -> int {
-        LS_HIP(hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(**dst)));
+        LS_HIP(pool_alloc(device, (void**)dst, std::max<size_t>(n, 1) * sizeof(**dst)));
         if (n) LS_HIP(hipMemcpyAsync(*dst, src, n * sizeof(**dst), hipMemcpyHostToDevice, st));
         return LS_OK;
     };
@@ -1602,10 +1624,10 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
         true
 #endif
         ) {
-        hipError_t e = hipMalloc((void**)&d->bp, sizeof(float) * (size_t)V * d->kmax);
-        if (e == hipSuccess) e = hipMalloc((void**)&d->braw, sizeof(float) * (size_t)V * d->kmax);
-        if (e == hipSuccess) e = hipMalloc((void**)&d->slots, sizeof(float) * (size_t)n_front * arity * d->kmax);
-        if (e == hipSuccess) e = hipMalloc((void**)&d->xb, sizeof(float) * (size_t)std::max<int64_t>(n_bnd, 1) * d->kmax);
+        hipError_t e = pool_alloc(device, (void**)&d->bp, sizeof(float) * (size_t)V * d->kmax);
+        if (e == hipSuccess) e = pool_alloc(device, (void**)&d->braw, sizeof(float) * (size_t)V * d->kmax);
+        if (e == hipSuccess) e = pool_alloc(device, (void**)&d->slots, sizeof(float) * (size_t)n_front * arity * d->kmax);
+        if (e == hipSuccess) e = pool_alloc(device, (void**)&d->xb, sizeof(float) * (size_t)std::max<int64_t>(n_bnd, 1) * d->kmax);
 #ifdef LS_ND_EXPERIMENTS
         if (e == hipSuccess && span) {
             const size_t up_rows = (size_t)(V - d->upper_lo);

@@ -294,7 +294,7 @@ std::string nd_bisect_device(void* ctx, int64_t V, int D, int smooth, const doub
     (void)hipGetDevice(&dev);
     size_t cap = off;
     char* base = (char*)pool_take(dev, off, &cap);                  // (the pool of large buffers of direct.hip: a remesh loop comes back with the same size)
-    if (!base && hipMalloc(&base, off) != hipSuccess) return "nd_bisect_device: out of device memory";
+    if (!base && pool_alloc(dev, (void**)&base, off) != hipSuccess) return "nd_bisect_device: out of device memory";
     struct Free {
         char* p; size_t bytes; int dev; hipStream_t st;
         ~Free() { (void)hipStreamSynchronize(st); if (!pool_give(dev, p, bytes)) (void)hipFree(p); }

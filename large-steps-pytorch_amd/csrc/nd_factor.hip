@@ -603,7 +603,7 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
         size_t cap = want;
         *p = pool_take(device, want, &cap);                          // large buffers: from the pool the previous solver's went to (direct.hip)
         const bool pooled = *p != nullptr;
-        if (!pooled) e = hipMalloc(p, want);
+        if (!pooled) e = pool_alloc(device, p, want);                // (out of memory: the pool is emptied and the call repeated once)
         const double tb = timing ? now_s() : 0.0;
         if (e == hipSuccess && zero) e = hipMemsetAsync(*p, 0, std::max<size_t>(bytes, 16) + 16, st);
         if (timing && bytes > ((size_t)256 << 20)) {

@@ -189,6 +189,9 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
     const bool timing = getenv("LS_PLAN_TIMING") != nullptr;
     auto lap = [&](const char* what) { if (timing) fprintf(stderr, "[nd_plan] %-28s %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count()); };
     if (V <= 0 || V >= INT32_MAX) return "nd_plan_build: bad vertex count";
+    // (with `bisect` the column indices are still on their way from the device -- see nd_plan_build_device -- and were bounds-checked when
+    // the matrix was made: a coalesced torch tensor / ls_assemble_*; the host-only entry points take arbitrary arrays)
+    if (!bisect) { if (const char* bad = csr_pattern_problem(V, rowptr, col, pos_in)) return std::string("nd_plan_build: ") + bad; }
     if (arity != 2 && arity != 4 && arity != 8) return "nd_plan_build: arity must be 2, 4 or 8";
     if (leaf_size < 1) return "nd_plan_build: leaf_size must be positive";
     Pool pool(n_threads());

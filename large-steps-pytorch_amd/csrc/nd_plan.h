@@ -5,6 +5,7 @@
 // This is the factorisation-time half of what the reference gets from cholespy / CHOLMOD's analysis phase
 // (largesteps/solvers.py:34, `CholeskySolverF(n, ii, jj, x, MatrixType.COO)`).
 #pragma once
+#include <limits.h>
 #include <stdint.h>
 #include <string>
 #include <vector>
@@ -71,5 +72,19 @@ std::string nd_plan_build_device(const int32_t* d_rowptr, const int32_t* d_col, 
                                  int ordering = ND_ORDER_LONGEST);
 
 }  // namespace ls
+
+// Shared by the host-side planners (nd_plan.cpp, patch_plan.cpp, shard_plan.cpp): a CSR pattern they index arrays with must be checked
+// ONCE up front -- a malformed matrix would otherwise write out of bounds in native code where the numpy statements raised IndexError,
+// and a NaN coordinate breaks the strict weak order of nth_element / sort. Returns nullptr or what is wrong.
+inline const char* csr_pattern_problem(int64_t V, const int32_t* rowptr, const int32_t* col, const float* positions = nullptr) {
+    if (V < 0 || V >= INT32_MAX) return "bad vertex count";
+    if (rowptr[0] != 0) return "rowptr[0] != 0";
+    for (int64_t v = 0; v < V; ++v) if (rowptr[v + 1] < rowptr[v]) return "rowptr is not monotone";
+    const int64_t nnz = rowptr[V];
+    for (int64_t e = 0; e < nnz; ++e) if (col[e] < 0 || col[e] >= V) return "a column index is out of range";
+    if (positions)
+        for (int64_t i = 0; i < 3 * V; ++i) if (!(positions[i] - positions[i] == 0.0f)) return "a position is not finite";
+    return nullptr;
+}
 
 struct ls_nd_plan { ls::NdPlan p; };          // the opaque plan object of the C ABI (ls_nd_plan_create / ls_nd_plan_create_device)

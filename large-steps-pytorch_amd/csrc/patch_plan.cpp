@@ -25,6 +25,7 @@
 #include <thread>
 #include <vector>
 #include "../../include/largesteps_hip.h"
+#include "nd_plan.h"
 
 namespace ls { void set_error(const char* fmt, ...); }
 
@@ -91,8 +92,10 @@ extern "C" int ls_patch_plan_create(int64_t V, const int32_t* h_rowptr, const in
         return LS_E_INVALID;
     }
     *out = nullptr;
+    if (const char* bad = csr_pattern_problem(V, h_rowptr, h_col, h_positions)) { ls::set_error("ls_patch_plan_create: %s", bad); return LS_E_INVALID; }
     const auto t_begin = std::chrono::steady_clock::now();
-    const int threads = n_threads();
+    // (two V-sized marker arrays per thread below: 32 threads at 4M vertices would hold 1 GB of host memory for markers alone)
+    const int threads = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads(), std::max<int64_t>(1, ((int64_t)256 << 20) / (8 * std::max<int64_t>(V, 1)))));
     // ---- 2^m equal patches by recursive coordinate bisection (median along the longest axis of every box) ---------------------------
     int levels = 0;
     while ((V + (1ll << levels) - 1) / (1ll << levels) > patch_size) ++levels;

@@ -13,6 +13,7 @@
 #include <thread>
 #include <vector>
 #include "../../include/largesteps_hip.h"
+#include "nd_plan.h"
 
 namespace ls { void set_error(const char* fmt, ...); }
 
@@ -65,6 +66,7 @@ struct ls_shard_plan {
 
 extern "C" int ls_shard_layer_sizes(int64_t V, const int32_t* h_rowptr, const int32_t* h_col, int64_t lo, int64_t hi, int depth, int64_t* h_sizes) {
     if (!h_rowptr || !h_col || !h_sizes || V <= 0 || lo < 0 || hi > V || lo > hi || depth < 1) { ls::set_error("ls_shard_layer_sizes: bad argument"); return LS_E_INVALID; }
+    if (const char* bad = csr_pattern_problem(V, h_rowptr, h_col)) { ls::set_error("ls_shard_layer_sizes: %s", bad); return LS_E_INVALID; }
     std::vector<unsigned char> seen;
     std::vector<std::vector<int32_t>> layers;
     layers_of(V, h_rowptr, h_col, lo, hi, depth, seen, layers);
@@ -79,6 +81,7 @@ extern "C" int ls_shard_plan_create(int64_t V, const int32_t* h_rowptr, const in
     if (P < 1 || rank < 0 || rank >= P) { ls::set_error("invalid rank %d of %d", rank, P); return LS_E_INVALID; }
     if ((int64_t)P > std::max<int64_t>(V, 1)) { ls::set_error("cannot cut %lld vertices into %d non-empty blocks", (long long)V, P); return LS_E_INVALID; }
     if (depth < 1) { ls::set_error("halo depth must be >= 1"); return LS_E_INVALID; }
+    if (const char* bad = csr_pattern_problem(V, h_rowptr, h_col)) { ls::set_error("ls_shard_plan_create: %s", bad); return LS_E_INVALID; }
     ls_shard_plan* s = new ls_shard_plan();
     s->rank = rank; s->P = P; s->depth = depth; s->lo = bound(V, P, rank); s->hi = bound(V, P, rank + 1);
     // every rank's ghost groups (mine for the local matrix and the receive list, the others' for the send lists)

@@ -469,35 +469,71 @@ class ShardedDirect:
             return
         self._comm = h
         # never trust an untested transport with the job: one solve through each path, same right-hand side on every rank; the
-        # exchange sum is exact (one non-zero contributor per entry), so the two results must be IDENTICAL on this rank's rows
-        good = 1
-        try:
-            gen = torch.Generator(device="cpu").manual_seed(1234)
-            bt = torch.randn((self.V, 3), generator=gen, dtype=torch.float32).to(self.device)
-            xa = self.solve(bt)
-            self._comm = ctypes.c_void_p(None)
-            xb = self.solve(bt)
-            torch.cuda.synchronize(self.device)
-            good = int(torch.equal(xa[self.owned], xb[self.owned]))
-        except Exception:
-            good = 0
-        self._comm = h
-        ok = torch.tensor([good], dtype=torch.int32, device=self.device)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
-        if int(ok.item()) == 0:
+        # exchange sum is exact (one non-zero contributor per entry), so the two results must be IDENTICAL on this rank's rows.
+        # Every rank runs the SAME sequence of collectives whatever happens locally: success is agreed on (all-reduce MIN) after each
+        # step separately, and a step that contains a collective is only entered when every rank got through the step before it -- a
+        # rank that raised in one solve must not leave its peers waiting inside the other solve's all-reduce.
+        def agreed(flag):
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+            return int(t.item()) == 1
+
+        def give_up():
             lib.ls_dist_destroy(h)
             self._comm = ctypes.c_void_p(None)
-            return
+
+        gen = torch.Generator(device="cpu").manual_seed(1234)
+        bt = torch.randn((self.V, 3), generator=gen, dtype=torch.float32).to(self.device)
+        xa = xb = None
+        self._comm = ctypes.c_void_p(None)
+        try:                                         # step 1: the torch.distributed path (what the job falls back to)
+            xb = self.solve(bt)
+            torch.cuda.synchronize(self.device)
+            fine = True
+        except Exception:
+            fine = False
+        if not agreed(fine):
+            return give_up()
+        try:                                         # step 2: this rank's local half of a native solve (no collective inside)
+            probe = torch.zeros_like(bt)
+            region, n_region = ctypes.c_void_p(None), ctypes.c_int64(0)
+            with torch.cuda.device(self.device):
+                _native.check(lib.ls_direct_exchange_region(self.local._direct._h, 3, ctypes.byref(region), ctypes.byref(n_region)))
+                _native.check(lib.ls_direct_solve_part(self.local._direct._h, _native.ptr(bt), _native.ptr(probe), 3, 0, region,
+                                                       _native.stream_of(self.device)))
+            torch.cuda.synchronize(self.device)
+            fine = True
+        except Exception:
+            fine = False
+        if not agreed(fine):
+            return give_up()
+        self._comm = h
+        try:                                         # step 3: the native solve (part 0 -> RCCL all-reduce in place -> part 1)
+            xa = self.solve(bt)
+            torch.cuda.synchronize(self.device)
+            fine = bool(torch.equal(xa[self.owned], xb[self.owned]))
+        except Exception:
+            fine = False
+        if not agreed(fine):
+            return give_up()
         self.last_info["collective"] = "ls_dist (RCCL, in place, on the solve's stream)"
 
-    def __del__(self):
+    def close(self):
+        """Destroy the library's communicator (collective-free: ncclCommDestroy of this rank's handle). Call it before the process group
+        goes away; __del__ only does it while the interpreter is still alive."""
         c = getattr(self, "_comm", None)
         if c is not None and c.value:
             try:
                 _native.lib().ls_dist_destroy(c)
             except Exception:
                 pass
-            self._comm = None
+        self._comm = ctypes.c_void_p(None)
+
+    def __del__(self):
+        import sys
+        if sys is None or sys.is_finalizing():        # interpreter shutdown: ncclCommDestroy may block on peers that are already gone
+            return
+        self.close()
 
     def info(self):
         return self.local.info()

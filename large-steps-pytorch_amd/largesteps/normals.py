@@ -123,18 +123,26 @@ def _on(dev):
 # id of the running backward call (torch._C._current_graph_task_id): the face-normal node only takes what was left for it
 # in the same call, so a backward that stops at the face normals cannot leak into a later one.
 class _PairTag:
-    __slots__ = ("verts", "verts_version", "faces", "faces_version", "fn", "fn_version", "norms", "pending", "__weakref__")
+    __slots__ = ("verts", "verts_version", "faces", "faces_version", "fn", "fn_version", "norms", "pending", "node", "__weakref__")
 
     def __init__(self, verts, faces, norms):
         self.verts, self.verts_version = weakref.ref(verts), verts._version
         self.faces, self.faces_version = weakref.ref(faces), faces._version
         self.fn, self.fn_version = None, 0
+        self.node = None               # weak reference to the face-normal autograd node that produced the tagged tensor (None: no graph)
         self.norms = norms
         self.pending = {}              # id(ctx of a vertex-normal node) -> (graph task, g_raw, gN)
 
     def matches(self, verts, faces, fn):
         return (self.verts() is verts and self.verts_version == verts._version and self.faces() is faces
                 and self.faces_version == faces._version and self.fn is not None and self.fn() is fn and self.fn_version == fn._version)
+
+    def produced_by_live_node(self, fn):
+        """True iff `fn` still hangs on the face-normal node that made it: only then will that node run in a backward pass and finish
+        what the vertex-normal node hands to it. Face normals computed under no_grad() and switched to requires_grad afterwards (or
+        detached in place) match by identity and version and have NO such node -- the hand-over would be dropped silently."""
+        node = self.node() if self.node is not None else None
+        return node is not None and fn.grad_fn is node
 
 
 _graph_task_id = getattr(torch._C, "_current_graph_task_id", None)
@@ -192,7 +200,8 @@ class _FaceNormals(Function):
 
 class _VertexNormals(Function):
     @staticmethod
-    def forward(ctx, verts, faces, face_normals, tag):
+    def forward(ctx, verts, faces, face_normals, tag, can_defer=False):
+        ctx.can_defer = bool(can_defer)
         v, f, vptr, vcorner = _prep(verts, faces)
         F, V, dev = f.shape[0], v.shape[0], v.device
         _native.require_device(face_normals, "face_normals")
@@ -222,7 +231,7 @@ class _VertexNormals(Function):
     @staticmethod
     def backward(ctx, g):
         if not (ctx.needs_input_grad[0] or ctx.needs_input_grad[2]):
-            return None, None, None, None
+            return None, None, None, None, None
         g = g.contiguous().to(torch.float32)
         lib = _native.lib()
         tag = ctx.tag
@@ -236,7 +245,8 @@ class _VertexNormals(Function):
             task = _graph_task_id() if _graph_task_id is not None else -1
             # the face-normal node runs later in this backward call exactly when its output needs a gradient here and the
             # vertices need one: then it finishes the job (one corner buffer). Otherwise both halves run now.
-            defer = task >= 0 and ctx.needs_input_grad[0] and ctx.needs_input_grad[2]
+            # (and only if the face normals really hang on that node: ctx.can_defer, decided in compute_vertex_normals)
+            defer = task >= 0 and ctx.needs_input_grad[0] and ctx.needs_input_grad[2] and ctx.can_defer
             with _on(dev):
                 _native.check(lib.ls_normals_pair_backward_faces(_native.ptr(v), _native.ptr(f), f.element_size(), F, V, _native.ptr(raw),
                                                                  _native.ptr(tag.norms), _native.ptr(g), _native.ptr(g_raw), _native.ptr(gN),
@@ -244,7 +254,7 @@ class _VertexNormals(Function):
                                                                  _native.stream_of(dev)))
                 if defer:
                     tag.pending[id(ctx)] = (task, g_raw, gN)
-                    return None, None, gfn, None
+                    return None, None, gfn, None, None
                 gv = None
                 if ctx.needs_input_grad[0]:
                     gv = torch.empty_like(v)
@@ -252,7 +262,7 @@ class _VertexNormals(Function):
                                                                      _native.ptr(vcorner), _native.ptr(tag.norms), _native.ptr(g_raw),
                                                                      _native.ptr(gN), _native.ptr(None), _native.ptr(gv), _native.ptr(ws),
                                                                      ws.numel(), dev.index, _native.stream_of(dev)))
-            return gv, None, (gfn if ctx.needs_input_grad[2] else None), None
+            return gv, None, (gfn if ctx.needs_input_grad[2] else None), None, None
         v, f, fn, raw, norms, vptr, vcorner = ctx.saved_tensors
         F, V, dev = f.shape[0], v.shape[0], v.device
         gv = torch.empty_like(v)
@@ -264,7 +274,7 @@ class _VertexNormals(Function):
                                                          _native.ptr(raw), _native.ptr(norms), _native.ptr(g), _native.ptr(gv),
                                                          _native.ptr(gfn), _native.ptr(ws), ws.numel(), dev.index,
                                                          _native.stream_of(dev)))
-        return (gv if ctx.needs_input_grad[0] else None), None, (gfn if ctx.needs_input_grad[2] else None), None
+        return (gv if ctx.needs_input_grad[0] else None), None, (gfn if ctx.needs_input_grad[2] else None), None, None
 
 
 def compute_face_normals(verts, faces):
@@ -282,6 +292,7 @@ def compute_face_normals(verts, faces):
     tag, _handoff.tag = getattr(_handoff, "tag", None), None
     if tag is not None:                            # tag the result: compute_vertex_normals recognises the pair by it
         tag.fn, tag.fn_version = weakref.ref(fn), fn._version
+        tag.node = weakref.ref(fn.grad_fn) if fn.grad_fn is not None else None
         fn._largesteps_pair = tag
     return fn
 
@@ -302,4 +313,4 @@ def compute_vertex_normals(verts, faces, face_normals):
     tag = getattr(face_normals, "_largesteps_pair", None)
     if tag is not None and not (tag.matches(verts, faces, face_normals) and os.environ.get("LARGESTEPS_NORMALS_PAIR", "1") != "0"):
         tag = None
-    return _VertexNormals.apply(verts, faces, face_normals, tag)
+    return _VertexNormals.apply(verts, faces, face_normals, tag, tag is not None and tag.produced_by_live_node(face_normals))

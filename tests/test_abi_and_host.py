@@ -202,3 +202,37 @@ def test_no_kernel_of_the_product_library_spills():
     assert not bad, f"kernels with (spilled VGPRs, scratch bytes): {bad}"
     # the experiment of round 3 (one persistent launch for the upper levels, nd_span.h) is not in the product
     assert not any("k_nd_span" in n for n in ks)
+
+
+def test_host_planners_refuse_malformed_patterns():
+    """The native planners index arrays with the caller's column ids: a malformed CSR pattern or a NaN position must come back as
+    LS_E_INVALID with a message, not as an out-of-bounds write (the numpy statements they replaced raised IndexError)."""
+    import ctypes
+    import numpy as np
+    from largesteps import _native
+    lib = _native.lib()
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)      # noqa: E731
+    rowptr = np.array([0, 2, 4, 6], np.int32)
+    good = np.array([0, 1, 0, 1, 1, 2], np.int32)
+    pos = np.zeros((3, 3), np.float32)
+    diag = np.ones(3, np.float32)
+    val = np.ones(6, np.float32)
+    cases = [(rowptr, np.array([0, 1, 0, 7, 1, 2], np.int32), pos, "column index"),
+             (rowptr, np.array([0, -1, 0, 1, 1, 2], np.int32), pos, "column index"),
+             (np.array([0, 4, 2, 6], np.int32), good, pos, "monotone"),
+             (np.array([1, 2, 4, 6], np.int32), good, pos, "rowptr[0]")]
+    bad_pos = pos.copy()
+    bad_pos[1, 2] = np.nan
+    for rp, col, ps, what in cases + [(rowptr, good, bad_pos, "finite")]:
+        h = ctypes.c_void_p()
+        assert lib.ls_nd_plan_create(3, p(rp), p(col), p(ps), 2, 2, 0, ctypes.byref(h)) == _native.LS_E_INVALID and what in _native.last_error()
+        assert lib.ls_patch_plan_create(3, p(rp), p(col), p(diag), p(ps), 2, 2, 100, 1, 100, ctypes.byref(h)) == _native.LS_E_INVALID
+        assert what in _native.last_error()
+    for rp, col, ps, what in cases:
+        h = ctypes.c_void_p()
+        assert lib.ls_shard_plan_create(3, p(rp), p(col), p(val), 1, 0, 1, ctypes.byref(h)) == _native.LS_E_INVALID and what in _native.last_error()
+        sizes = np.zeros(1, np.int64)
+        assert lib.ls_shard_layer_sizes(3, p(rp), p(col), 0, 1, 1, p(sizes)) == _native.LS_E_INVALID and what in _native.last_error()
+    h = ctypes.c_void_p()
+    assert lib.ls_nd_plan_create(3, p(rowptr), p(good), p(pos), 2, 2, 0, ctypes.byref(h)) == 0
+    lib.ls_nd_plan_destroy(h)

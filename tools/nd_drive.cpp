@@ -112,6 +112,12 @@ int main(int argc, char** argv) {
                 printf("    sum of the launches (with an event between each two) %.1f us\n", tot);
             }
         }
+        {   // FNV-1a over the solution's bytes: variant builds of the library must agree bit for bit
+            unsigned long long hsh = 1469598103934665603ull;
+            const unsigned char* pb = (const unsigned char*)x.data();
+            for (size_t i = 0; i < x.size() * 4; ++i) { hsh ^= pb[i]; hsh *= 1099511628211ull; }
+            printf("solution hash %016llx\n", hsh);
+        }
         printf("persist %d: %2d launches  %8.2f us per solve   max |x - x*| %.2e   ||b - M x|| / ||b|| %.2e   events: first part %.1f us, last part %.1f us, middle %.1f us\n",
                mode, launches, ms / solves * 1e3, err, sqrt(res / bn), acc[0] * 1e3, acc[1] * 1e3, acc[2] * 1e3);
     }
