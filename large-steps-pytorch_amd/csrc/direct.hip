@@ -1010,7 +1010,12 @@ static size_t plan_tier(const std::vector<NodeD>& nd, const std::vector<int64_t>
     items.clear(); wgs.assign((size_t)(q_hi - q_lo), TierWG());
     int vec_need = 0, pbuf_need = 0, leaf_need = 0, tri_cap = 0;
     for (int64_t i = level_off[levels - 1]; i < level_off[levels]; ++i)
-        if (nd[i].flags & NODE_SPARSE) tri_cap = std::max(tri_cap, (nd[i].s * (nd[i].s + 1) / 2 + 3) & ~3);
+        if (nd[i].flags & NODE_SPARSE) {
+            // the LDS triangle area holds whole 16-column chunks: the mat-vec reads element (j, c) of the LAST chunk for every c up to
+            // 16 ceil(s / 16) - 1 (columns >= s meet zero vector entries; nd_tier.h, tri_chunk)
+            const int sc = (nd[i].s + 15) & ~15;
+            tri_cap = std::max(tri_cap, (sc * (sc + 1) / 2 + 3) & ~3);
+        }
     tri_floats = tri_cap;
     for (int64_t q = q_lo; q < q_hi; ++q) {
         TierWG& g = wgs[(size_t)(q - q_lo)];

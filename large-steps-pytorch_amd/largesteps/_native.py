@@ -213,6 +213,13 @@ def stream_of(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def raw_stream(device):
+    """the current stream of `device` as a plain integer (ctypes converts it for a c_void_p argument)"""
+    if _raw_stream is not None and device.index is not None:
+        return _raw_stream(device.index)
+    return torch.cuda.current_stream(device).cuda_stream
+
+
 def ptr(t):
     """Raw device pointer of a tensor (NULL for None / empty tensors)."""
     return ctypes.c_void_p(t.data_ptr() if t is not None else 0)

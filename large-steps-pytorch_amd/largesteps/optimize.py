@@ -75,14 +75,13 @@ class AdamUniform(torch.optim.Optimizer):
                     step = state["step"]
                     if not (torch.is_tensor(step) and step.dtype == torch.int32 and step.numel() >= 2 and step.device == dev):
                         raise TypeError("AdamUniform(capturable=True): state['step'] must be an int32 tensor of two elements on the parameter's device")
-                    with torch.cuda.device(dev):
-                        _native.check(lib.ls_adam_uniform_step_device(_native.ptr(p.data), _native.ptr(grad), _native.ptr(state["g1"]),
-                                                                      _native.ptr(state["g2"]), p.numel(), float(lr), float(b1), float(b2),
-                                                                      _native.ptr(state["step"]), _native.ptr(_scratch_for(dev)), dev.index,
-                                                                      _native.stream_of(dev)))
+                    # (no torch.cuda.device context: the native call selects `dev` itself)
+                    _native.check(lib.ls_adam_uniform_step_device(_native.ptr(p.data), _native.ptr(grad), _native.ptr(state["g1"]),
+                                                                  _native.ptr(state["g2"]), p.numel(), float(lr), float(b1), float(b2),
+                                                                  _native.ptr(state["step"]), _native.ptr(_scratch_for(dev)), dev.index,
+                                                                  _native.stream_of(dev)))
                     continue
-                with torch.cuda.device(dev):
-                    _native.check(lib.ls_adam_uniform_step(_native.ptr(p.data), _native.ptr(grad), _native.ptr(state["g1"]),
-                                                           _native.ptr(state["g2"]), p.numel(), float(lr), float(b1), float(b2),
-                                                           int(state["step"]), _native.ptr(_scratch_for(dev)), dev.index,
-                                                           _native.stream_of(dev)))
+                _native.check(lib.ls_adam_uniform_step(_native.ptr(p.data), _native.ptr(grad), _native.ptr(state["g1"]),
+                                                       _native.ptr(state["g2"]), p.numel(), float(lr), float(b1), float(b2),
+                                                       int(state["step"]), _native.ptr(_scratch_for(dev)), dev.index,
+                                                       _native.stream_of(dev)))

@@ -263,6 +263,7 @@ class _NativeDirect:
         _native.check(_native.lib().ls_direct_factor_seconds(self._h, ctypes.byref(s3)))
         self.timings = dict(plan_seconds=s3[0], table_seconds=s3[1], factor_seconds=s3[2])
         self.tier_levels = int(tier_levels)
+        self._solve = _native.lib().ls_direct_solve
         o, w, sp, wo = ctypes.c_int(0), ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0)
         _native.check(_native.lib().ls_direct_plan_quality(self._h, ctypes.byref(o), ctypes.byref(w), ctypes.byref(sp), ctypes.byref(wo)))
         # how the dissection's cutting directions were chosen and what it costs (include/largesteps_hip.h, ls_nd_plan_quality)
@@ -279,8 +280,11 @@ class _NativeDirect:
             self._h = None
 
     def solve(self, b, x):
-        with torch.cuda.device(self.device):
-            _native.check(_native.lib().ls_direct_solve(self._h, _native.ptr(b), _native.ptr(x), b.shape[1], _native.stream_of(self.device)))
+        # (no torch.cuda.device context here: ls_direct_solve selects the handle's device itself, and the stream is looked up for that
+        #  device by index -- the context manager cost more host time than the call at the reference's mesh sizes)
+        rc = self._solve(self._h, b.data_ptr(), x.data_ptr(), b.shape[1], _native.raw_stream(self.device))
+        if rc:
+            _native.check(rc)
 
     def set_option(self, name, value):
         _native.check(_native.lib().ls_direct_set(self._h, name.encode(), int(value)))
@@ -329,6 +333,9 @@ def release_scratch(device=None):
     device: a torch device / index, or None for every device."""
     idx = -1 if device is None else (device.index if isinstance(device, torch.device) else int(device))
     _native.check(_native.lib().ls_release_scratch(-1 if idx is None else idx))
+
+
+_DIRECT_INFO = dict(iterations=0, converged=True, method="nested-dissection")      # (what every direct solve reports: one shared object)
 
 
 class NestedDissectionSolver(Solver):
@@ -380,15 +387,15 @@ class NestedDissectionSolver(Solver):
         squeeze = b.dim() == 1
         b32 = (b.detach().unsqueeze(1) if squeeze else b.detach()).contiguous()
         x = torch.empty_like(b32)
-        for c0 in range(0, b32.shape[1], _KMAX):
-            c1 = min(b32.shape[1], c0 + _KMAX)
-            if c0 == 0 and c1 == b32.shape[1]:
-                self._direct.solve(b32, x)
-            else:
+        if b32.shape[1] <= _KMAX:                        # the common case (k = 3 coordinates): one native call, no column loop
+            self._direct.solve(b32, x)
+        else:
+            for c0 in range(0, b32.shape[1], _KMAX):
+                c1 = min(b32.shape[1], c0 + _KMAX)
                 xb = torch.empty((b32.shape[0], c1 - c0), dtype=torch.float32, device=b32.device)
                 self._direct.solve(b32[:, c0:c1].contiguous(), xb)
                 x[:, c0:c1] = xb
-        self.last_info = dict(iterations=0, converged=True, method="nested-dissection")
+        self.last_info = _DIRECT_INFO
         return x.squeeze(1) if squeeze else x
 
     def set_option(self, name, value):

@@ -964,6 +964,17 @@ def test_optimisation_step_as_a_captured_graph(dev):
     # an eager solve after the replays still works (the handle's event was never recorded inside the capture)
     x = from_differential(M, u.detach(), "Cholesky")
     assert torch.isfinite(x).all()
+    # the same through the public helper (largesteps.capture.CapturedStep: warm-up on a side stream, capture, replay): the caller's
+    # loop keeps its shape -- `loss = step()` per iteration -- and its tensors (u is updated in place by the optimiser)
+    from largesteps.capture import CapturedStep
+    u2 = u0.clone().requires_grad_(True)
+    opt2 = AdamUniform([u2], 1e-2, capturable=True)
+    cs = CapturedStep(lambda: step(u2, opt2), warmup=2)
+    for _ in range(4):
+        loss = cs()
+    torch.cuda.synchronize(dev)
+    assert cs.steps_run == 6 and int(opt2.state[u2]["step"][0]) == 6 and torch.isfinite(loss).all()
+    assert torch.equal(u2.detach(), u.detach()), "the same graph of the same kernels: bitwise the same parameters"
 
 
 # ---------------------------------------------------------------------------------------------------

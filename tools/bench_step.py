@@ -43,17 +43,11 @@ for _ in range(steps): l = step(u, opt)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
 print(f"{workload}: {dt*1e3:.3f} ms per optimisation step, eager (forward solve + normals + loss + backward incl. adjoint solve + AdamUniform), loss {float(l):.3e}")
 
+from largesteps.capture import CapturedStep
 u, opt = make(True)
-side = torch.cuda.Stream()
-side.wait_stream(torch.cuda.current_stream())
-with torch.cuda.stream(side):
-    for _ in range(3): step(u, opt)
-torch.cuda.current_stream().wait_stream(side)
-g = torch.cuda.CUDAGraph()
-with torch.cuda.graph(g):
-    loss = step(u, opt)
-for _ in range(3): g.replay()
+cs = CapturedStep(lambda: step(u, opt), warmup=3)            # largesteps/capture.py: warm-up on a side stream, capture, replay
+for _ in range(3): loss = cs()
 torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(steps): g.replay()
+for _ in range(steps): loss = cs()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
-print(f"{workload}: {dt*1e3:.3f} ms per optimisation step, captured graph replay, loss {float(loss):.3e}")
+print(f"{workload}: {dt*1e3:.3f} ms per optimisation step, captured graph replay (largesteps.capture.CapturedStep), loss {float(loss):.3e}")
