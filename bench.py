@@ -441,8 +441,10 @@ def report_direct(args, solver, M, u, x, tv, v, f, cfg, ms, t_assemble):
                       traffic_source=(f"profiles/{PMC_FILE}: FETCH_SIZE x 2 + WRITE_SIZE of separate rocprofv3 --pmc passes of this command, "
                                       f"mean over the {traffic_n} launches of the SAME kernel group, per launch like bytes_per_launch; "
                                       f"NOT measured in this run") if traffic is not None else None,
-                      note="latency bound, not bandwidth bound: every upper tree level is one dependent launch (T_stream + ~4.5 us of launch "
-                           "boundary, first-byte latency and reduction tail), the tier kernels are bound by dependent round trips per phase"),
+                      note="every upper tree level is one dependent launch (T_stream + ~4.5 us of launch boundary, first-byte latency and "
+                           "reduction tail); inside the tier launches the leaf rounds stream at ~5.5 TB/s counted in HBM-side bytes (round 4: "
+                           "per-wave clock stamps, DESIGN.md section 2.3), the tier's loss against that rate is its start (three dependent "
+                           "round trips and the burst of 4096 first triangles) and its two dense levels"),
     )
     if not args.no_cpu_baseline:
         base, x_oracle = cpu_baseline(v, f, cfg, u.cpu().numpy())

@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256) void k_dedup_faces(const IdxT* __restrict__ fa
 
 extern "C" int ls_remove_duplicates_workspace_bytes(int64_t V, size_t* h_bytes) {
     LS_REQUIRE(h_bytes && V >= 0, LS_E_INVALID, "ls_remove_duplicates_workspace_bytes: bad argument");
-    const size_t nb = (size_t)div_up(std::max<int64_t>(V, 1), RS_CHUNK);
+    const size_t nb = (size_t)div_up(std::max<int64_t>(V, 1), rs_chunk(V));
     // order a / b, flags, uid (V + 1), histogram + its scan (256 nb + 1 each), scan block sums
     *h_bytes = sizeof(int) * ((size_t)V * 4 + 16 + 2 * (256 * nb + 16) + (size_t)div_up(std::max<int64_t>(std::max<int64_t>(V, 256 * (int64_t)nb), 1), SCAN_CHUNK) + 64) + 256;
     return LS_OK;
@@ -557,7 +557,7 @@ extern "C" int ls_remove_duplicates(const float* verts, int64_t V, const void* f
     LS_HIP(g.err);
     hipStream_t st = (hipStream_t)stream;
     if (V == 0) { LS_REQUIRE(F == 0, LS_E_INDEX, "ls_remove_duplicates: faces without vertices"); return LS_OK; }
-    const int nb = div_up(V, RS_CHUNK);
+    const int nb = div_up(V, rs_chunk(V));
     int* w = (int*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     int* ord_a = w;
     int* ord_b = ord_a + V;
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(256) void k_invert_order(const int* __restrict__ or
 }  // namespace ls
 
 static size_t argsort_ws_ints(int64_t n, int64_t nkeys) {
-    const size_t nb = (size_t)div_up(std::max<int64_t>(n, 1), RS_CHUNK);
+    const size_t nb = (size_t)div_up(std::max<int64_t>(n, 1), rs_chunk(n));
     return (size_t)n * 3 + (size_t)nkeys + 64 + 2 * (256 * nb + 16) + (size_t)div_up(std::max<int64_t>(std::max<int64_t>(std::max<int64_t>(n, nkeys), 256 * (int64_t)nb), 1), SCAN_CHUNK) + 64;
 }
 
@@ -649,7 +649,7 @@ extern "C" int ls_csr_transpose(const int32_t* rowptr, const int32_t* col, const
     DeviceGuard g(device);
     LS_HIP(g.err);
     hipStream_t st = (hipStream_t)stream;
-    const size_t nb = (size_t)div_up(std::max<int64_t>(nnz, 1), RS_CHUNK);
+    const size_t nb = (size_t)div_up(std::max<int64_t>(nnz, 1), rs_chunk(nnz));
     int* w = (int*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     int *ord_a = w, *ord_b = ord_a + nnz, *cnt = ord_b + nnz;          // cnt: V + 1 (last = range flag)
     int *hist = cnt + V + 16 + nnz, *offs = hist + 256 * nb + 16, *bsum = offs + 256 * nb + 16;
@@ -691,7 +691,7 @@ extern "C" int ls_corner_ranks(const void* faces, int idx_bytes, int64_t F, int6
     LS_HIP(g.err);
     hipStream_t st = (hipStream_t)stream;
     const int64_t n = 3 * F;
-    const size_t nb = (size_t)div_up(std::max<int64_t>(n, 1), RS_CHUNK);
+    const size_t nb = (size_t)div_up(std::max<int64_t>(n, 1), rs_chunk(n));
     int* w = (int*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     int *ord_a = w, *ord_b = ord_a + n, *cnt = ord_b + n;
     int *hist = cnt + V + 16 + n, *offs = hist + 256 * nb + 16, *bsum = offs + 256 * nb + 16;

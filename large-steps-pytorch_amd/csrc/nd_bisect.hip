@@ -276,7 +276,7 @@ std::string nd_bisect_device(void* ctx, int64_t V, int D, int smooth, const doub
         return "";
     }
     const int max_dom = 1 << (D - 1), nb = div_up(V, BCH);
-    const size_t nbr = (size_t)div_up(V, RS_CHUNK);
+    const size_t nbr = (size_t)div_up(V, rs_chunk(V));
     // one allocation: positions (two copies), 3 x 2 lists, state, node, end-point flags, per-domain tables, scan scratch, sort scratch
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };

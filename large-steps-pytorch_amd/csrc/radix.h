@@ -7,7 +7,11 @@
 
 namespace ls {
 
-constexpr int RS_CHUNK = 4096;      // elements per workgroup (histogram: 256 threads; scatter: one wave)
+// elements per workgroup (histogram: 256 threads; scatter: ONE wave walks them 64 at a time, in order -- a serial chain of dependent
+// gathers whose length is the chunk, whatever the input's size): the chunk follows the input so that small sorts still fill the chip
+// (round 4, tools/time_dedup.py: remove_duplicates of the 250k config's soup 1.36 -> 0.94 ms, 70k 1.10 -> 0.53 ms with 1024 instead of
+// 4096; the 6M-row soup of the 1M config is best at 4096: 3.15 against 3.56 ms). Workspace formulas use the same function.
+__host__ __device__ constexpr int rs_chunk(int64_t n) { return n > ((int64_t)4 << 20) ? 4096 : n > ((int64_t)2 << 20) ? 2048 : 1024; }
 
 // order-preserving map of a float to uint32; -0.0 is folded into +0.0 first (torch compares values)
 __device__ __forceinline__ unsigned key_of(float x) {
@@ -31,6 +35,7 @@ __global__ __launch_bounds__(256) void k_rs_hist(Key key, const int* __restrict_
     __shared__ int h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
+    const int RS_CHUNK = rs_chunk(n);
     const int64_t base = (int64_t)blockIdx.x * RS_CHUNK;
     for (int e = threadIdx.x; e < RS_CHUNK && base + e < n; e += 256) atomicAdd(&h[key.digit(order ? order[base + e] : (int)(base + e), pass)], 1);
     __syncthreads();
@@ -44,6 +49,7 @@ __global__ __launch_bounds__(64) void k_rs_scatter(Key key, const int* __restric
     const int lane = threadIdx.x;
     for (int d = lane; d < 256; d += 64) run[d] = offs[(size_t)d * nblocks + blockIdx.x];
     __syncthreads();
+    const int RS_CHUNK = rs_chunk(n);
     const int64_t base = (int64_t)blockIdx.x * RS_CHUNK;
     const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
     for (int t = 0; t < RS_CHUNK && base + t < n; t += 64) {
@@ -86,7 +92,7 @@ struct KeyF64 {
 // order = the ids 0..n-1 sorted stably by `passes` key bytes; tmp: n ints; hist / offs: 256 nb + 16 ints each; returns where the result is
 template <typename Key>
 static inline int radix_argsort(Key key, int64_t n, int passes, int* ord_a, int* ord_b, int* hist, int* offs, int* bsum, hipStream_t st, const int** result) {
-    const int nb = ls::div_up(n, ls::RS_CHUNK);
+    const int nb = ls::div_up(n, ls::rs_chunk(n));
     const int* src = nullptr;                  // pass 0 reads the identity order
     int* dst = ord_a;
     for (int pass = 0; pass < passes; ++pass) {

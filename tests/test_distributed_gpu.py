@@ -218,3 +218,40 @@ def test_rccl_process_group_initialises():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "rccl ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_line_of_a_multi_process_run(world):
+    """`bench.py --gpus N` exactly as the driver launches it (torch.distributed.run, one process per rank, 127.0.0.1), in loopback on the
+    one GPU (LS_DIST_LOOPBACK=1: every rank on cuda:0, gloo transport): rank 0 must print ONE JSON line with the keys the driver parses,
+    for the subtree-sharded direct solver, with the sharded answer correct. (The first SCALE record can only be taken on an 8-GPU node;
+    this keeps the command from failing there for a reason a 1-GPU box could have shown.)"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, LS_DIST_LOOPBACK="1", LS_POOL_GB="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
+           "--workload", "cfg2_bunny70k"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["metric"] == "from_differential_solves_per_sec" and d["n_gpus"] == world and d["steps"] == 3 and d["warmup"] == 1
+    assert d["scaling"] == "strong" and d["higher_is_better"] is True and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
+    c = d["config"]
+    assert "cfg2_bunny70k" in c["workload"] and f"over {world} ranks" in c["workload"] and c["method"] == "nested-dissection"
+    assert c["max_abs_err_vs_v"] <= 1e-4, c["max_abs_err_vs_v"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 * world and abs(rf["frac"] - rf["achieved"] / rf["peak"]) <= 1e-9

@@ -38,5 +38,24 @@ for N in (1, 2, 4, 8):
         for _ in range(n): solve()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / n * 1e3
-        print(f"{workload}: rank {r} of {N}: {ms * 1e3:7.1f} us of kernels per solve (cut level {cut.value}, exchange {per_col.value * 3 * 4 / 1024:.0f} KiB, tier workgroups {s.info()['tier_workgroups']})", flush=True)
+        # where the time goes: an event in front of every launch ("profile" 3; the events add ~1 us per launch) -- the levels ABOVE the cut
+        # run on every rank alike (replicated), the rest is the rank's own share
+        s.set_option("profile", 3)
+        rep_us = own_us = 0.0
+        rows = []
+        for part in ((None,) if N == 1 else (0, 1)):
+            if part is None:
+                _native.check(lib.ls_direct_solve(h, _native.ptr(u), _native.ptr(x), 3, st))
+            else:
+                _native.check(lib.ls_direct_solve_part(h, _native.ptr(u), _native.ptr(x), 3, part, _native.ptr(ex), st))
+            for row in s.launch_profile():
+                rows.append(row)
+                if N > 1 and row["levels"][1] < cut.value:
+                    rep_us += row["ms"] * 1e3
+                else:
+                    own_us += row["ms"] * 1e3
+        s.set_option("profile", 0)
+        inf = s.info()
+        print(f"{workload}: rank {r} of {N}: {ms * 1e3:7.1f} us of kernels per solve (cut level {cut.value}, exchange {per_col.value * 3 * 4 / 1024:.0f} KiB, "
+              f"tier workgroups {inf['tier_workgroups']}, {len(rows)} launches; by events: levels above the cut {rep_us:6.1f} us, own subtrees {own_us:6.1f} us)", flush=True)
         del s
