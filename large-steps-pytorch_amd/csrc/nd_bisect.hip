@@ -372,7 +372,7 @@ std::string nd_bisect_device(void* ctx, int64_t V, int D, int smooth, const doub
 // the GPU tests compare with the host-only ls_nd_plan_create
 std::string ls::nd_plan_build_device(const int32_t* d_rowptr, const int32_t* d_col, const float* d_positions, int64_t V, int64_t nnz,
                                      int32_t* h_rowptr, int32_t* h_col, int leaf_size, int arity, int smooth, void* stream, NdPlan& out,
-                                     int ordering) {
+                                     int ordering, bool defer_push_lists) {
     hipStream_t st = (hipStream_t)stream;
     // the host's copy of the pattern: the row pointers now (the analysis looks at them first), the column indices during the device
     // rounds -- unless there are no positions: the graph embedding walks the pattern on the host before anything else
@@ -393,11 +393,12 @@ std::string ls::nd_plan_build_device(const int32_t* d_rowptr, const int32_t* d_c
     const bool timing = getenv("LS_PLAN_TIMING") != nullptr;
     if (host_rounds) {
         if (!fetch_positions()) return "the copy of the positions to the host failed";
-        return nd_plan_build(V, h_rowptr, h_col, d_positions ? h_pos.data() : nullptr, leaf_size, arity, smooth, out, nullptr, nullptr, ND_ORDER_MINSEP);
+        return nd_plan_build(V, h_rowptr, h_col, d_positions ? h_pos.data() : nullptr, leaf_size, arity, smooth, out, nullptr, nullptr, ND_ORDER_MINSEP, defer_push_lists);
     }
     NdBisectDevice ctx{d_rowptr, d_col, d_positions, nnz, st, d_positions ? h_col : nullptr};
     const float given = 0.0f;                  // "positions were given": nd_plan_build only tests the pointer, the values are read on the device
-    std::string err = nd_plan_build(V, h_rowptr, h_col, d_positions ? &given : nullptr, leaf_size, arity, smooth, out, nd_bisect_device, &ctx);
+    std::string err = nd_plan_build(V, h_rowptr, h_col, d_positions ? &given : nullptr, leaf_size, arity, smooth, out, nd_bisect_device, &ctx, ND_ORDER_LONGEST,
+                                    defer_push_lists);
     if (timing) fprintf(stderr, "[nd_plan] returned (pool joined, temporaries released) %.3f s after its start; %.1f factor numbers per vertex, spread %.2f\n",
                         now_s() - t0, out.words_per_vertex, out.spread);
     if (!err.empty() || ordering != ND_ORDER_AUTO || out.spread <= nd_plan_suspect()) return err;
@@ -407,7 +408,7 @@ std::string ls::nd_plan_build_device(const int32_t* d_rowptr, const int32_t* d_c
     // 1.5-30 x larger, or no factor at all (fronts beyond the solver's limit).
     if (!fetch_positions()) return "";
     NdPlan B;
-    err = nd_plan_build(V, h_rowptr, h_col, d_positions ? h_pos.data() : nullptr, leaf_size, arity, smooth, B, nullptr, nullptr, ND_ORDER_MINSEP);
+    err = nd_plan_build(V, h_rowptr, h_col, d_positions ? h_pos.data() : nullptr, leaf_size, arity, smooth, B, nullptr, nullptr, ND_ORDER_MINSEP, defer_push_lists);
     if (timing) fprintf(stderr, "[nd_plan] suspect dissection: tried graph distances as well: %.1f factor numbers per vertex, spread %.2f (%s), %.3f s after the start\n",
                         B.words_per_vertex, B.spread, err.empty() ? (B.words_per_vertex < out.words_per_vertex ? "taken" : "not taken") : err.c_str(), now_s() - t0);
     if (!err.empty()) return "";

@@ -491,7 +491,8 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
         // numbers on rough scans for a constructor of tenths of a second)
         const char* oe = getenv("LS_ND_ORDER");
         const int ordering = oe ? std::max(-1, std::min(1, atoi(oe))) : ND_ORDER_AUTO;
-        const std::string err = nd_plan_build_device(d_rowptr, d_col, d_positions, V, nnz, rowptr.data(), col.data(), leaf_size, arity, 4, st, P, ordering);
+        const std::string err = nd_plan_build_device(d_rowptr, d_col, d_positions, V, nnz, rowptr.data(), col.data(), leaf_size, arity, 4, st, P, ordering,
+                                                     /* defer_push_lists = */ true);
         LS_REQUIRE(err.empty(), LS_E_INVALID, "%s", err.c_str());
     }
     const double t1 = now_s();
@@ -762,6 +763,7 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) { cleanup(true); return hip_fail(e, "ls_direct_factor kernels", __FILE__, __LINE__); }
     // ---- the solver handle: its tables are built on the host WHILE the device factorises (everything above is only enqueued) ------------
+    nd_plan_push_lists(P);          // (left out of the analysis: only the solve needs them)
     ls_direct_arrays A;
     memset(&A, 0, sizeof(A));
     A.V = V; A.levels = levels; A.arity = arity; A.h_nodes = hn.data(); A.h_perm = P.perm.data(); A.h_ppos = P.ppos.data(); A.n_bnd = P.n_bnd;

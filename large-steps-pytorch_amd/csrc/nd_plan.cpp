@@ -184,7 +184,7 @@ int nd_plan_rounds(int64_t V, int leaf_size, int arity) {
 }
 
 std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, const float* pos_in, int leaf_size, int arity,
-                          int smooth, NdPlan& P, NdBisectFn bisect, void* bisect_ctx, int ordering) {
+                          int smooth, NdPlan& P, NdBisectFn bisect, void* bisect_ctx, int ordering, bool defer_push_lists) {
     const auto t_start = std::chrono::steady_clock::now();
     const bool timing = getenv("LS_PLAN_TIMING") != nullptr;
     auto lap = [&](const char* what) { if (timing) fprintf(stderr, "[nd_plan] %-28s %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count()); };
@@ -624,7 +624,24 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
     if (bad) return "nd_plan_build: separator property violated (the matrix pattern is not symmetric?)";
     if (P.b[1] != 0) return "nd_plan_build: the root has a boundary";
     lap("parent positions");
-    // ---- push lists of the down sweep: front position -> boundary entries of the children that are this vertex -------------
+    if (!defer_push_lists) {
+        nd_plan_push_lists(P);
+        lap("push lists");
+    }
+    P.ordering = (bisect || ordering != ND_ORDER_MINSEP) ? ND_ORDER_LONGEST : ND_ORDER_MINSEP;
+    nd_plan_quality(P);
+    lap("quality");
+    P.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    return "";
+}
+
+// ---- push lists of the down sweep: front position -> boundary entries of the children that are this vertex. Needed by the solve
+// only, not by the factorisation: ls_direct_factor builds them while the device factorises (defer_push_lists) ---------------------------
+void nd_plan_push_lists(NdPlan& P) {
+    if (!P.push_ptr.empty()) return;
+    const int levels = P.levels, arity = P.arity;
+    Pool* own = nullptr;
+    if (!g_pool) { own = new Pool(n_threads()); g_pool = own; }
     P.push_ptr.assign((size_t)P.n_front + 1, 0);
     P.push_tgt.resize((size_t)P.n_bnd);
     // a parent's front positions receive entries from its own children only: counts and fills run parent by parent
@@ -649,12 +666,7 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
                 for (int k = 0; k < P.b[i]; ++k) P.push_tgt[(size_t)cur[(size_t)P.ppos[(size_t)P.bnd_off[i] + k]]++] = (int)(P.bnd_off[i] + k);
         }
     });
-    lap("push lists");
-    P.ordering = (bisect || ordering != ND_ORDER_MINSEP) ? ND_ORDER_LONGEST : ND_ORDER_MINSEP;
-    nd_plan_quality(P);
-    lap("quality");
-    P.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
-    return "";
+    if (own) { g_pool = nullptr; delete own; }
 }
 
 void nd_plan_quality(NdPlan& P) {

@@ -58,7 +58,11 @@ double nd_plan_suspect();                                    // the threshold on
 typedef std::string (*NdBisectFn)(void* ctx, int64_t V, int D, int smooth, const double* embedded, int64_t* node);
 int nd_plan_rounds(int64_t V, int leaf_size, int arity);
 std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, const float* pos, int leaf_size, int arity,
-                          int smooth, NdPlan& out, NdBisectFn bisect = nullptr, void* bisect_ctx = nullptr, int ordering = ND_ORDER_LONGEST);
+                          int smooth, NdPlan& out, NdBisectFn bisect = nullptr, void* bisect_ctx = nullptr, int ordering = ND_ORDER_LONGEST,
+                          bool defer_push_lists = false);
+// the push lists of the down sweep (push_ptr / push_tgt): the last stage of nd_plan_build, or -- with defer_push_lists -- called by
+// ls_direct_factor while the device factorises (the factorisation does not need them: ~3 ms off the constructor's critical path at 1M)
+void nd_plan_push_lists(NdPlan& P);
 void nd_plan_quality(NdPlan& P);                             // fills words_per_vertex and spread
 // ND_ORDER_AUTO on the host: `pos` are real host positions (or nullptr)
 std::string nd_plan_build_auto(int64_t V, const int32_t* rowptr, const int32_t* col, const float* pos, int leaf_size, int arity,
@@ -69,7 +73,7 @@ std::string nd_plan_build_auto(int64_t V, const int32_t* rowptr, const int32_t* 
 // column indices cross the bus while the device rounds run). d_positions may be nullptr (graph embedding, formed on the host).
 std::string nd_plan_build_device(const int32_t* d_rowptr, const int32_t* d_col, const float* d_positions, int64_t V, int64_t nnz,
                                  int32_t* h_rowptr, int32_t* h_col, int leaf_size, int arity, int smooth, void* stream, NdPlan& out,
-                                 int ordering = ND_ORDER_LONGEST);
+                                 int ordering = ND_ORDER_LONGEST, bool defer_push_lists = false);
 
 }  // namespace ls
 
