@@ -666,6 +666,31 @@ def test_folded_surfaces_vs_oracle(dev, mesh, cot):
     assert q["words_per_vertex"] <= 1.3 * _flat_sheet_words(dev), (q, _flat_sheet_words(dev))
 
 
+@pytest.mark.parametrize("name", ["torus", "helicoid", "collapsed", "graded", "swarm", "spike"])
+def test_meshes_that_mislead_cutting_planes_vs_oracle(dev, name):
+    """tests/test_ordering_cpu.py's hard meshes (a tube, a spiral staircase, all vertices in one point, graded density, closed surfaces
+    inside each other, a spike) through `'Cholesky'` on the device: the direct solver, with the trial-cut plan where the automatic
+    choice took it, against the fp64 direct solve. (Uniform Laplacian: it does not look at the positions, the dissection does.)"""
+    from largesteps.geometry import compute_matrix
+    from largesteps.parameterize import from_differential
+    from largesteps import parameterize
+    from test_ordering_cpu import _hard_mesh
+    v, f = _hard_mesh(name)
+    v = np.asarray(v, dtype=np.float32)
+    tv, tf = _t(v, dev), _t(np.asarray(f, dtype=np.int64), dev)
+    M = compute_matrix(tv, tf, 25.0)
+    idx, val = M.indices().cpu().numpy(), M.values().cpu().numpy()
+    rhs = np.random.default_rng(4).standard_normal(v.shape).astype(np.float32)
+    x64 = osv.from_differential(idx[0], idx[1], val, rhs)
+    x = from_differential(M, _t(rhs, dev), "Cholesky").cpu().numpy()
+    assert np.abs(x - x64).max() <= 1e-4 * np.abs(x64).max(), name
+    chol = parameterize._cache[(id(M), "Cholesky")][0]
+    assert chol.method == "nested-dissection", chol.direct_error
+    assert chol.plan_quality["spread"] <= 1.3, chol.plan_quality
+    if name in ("helicoid", "collapsed", "swarm"):
+        assert chol.plan_quality["ordering"] == "trial-cuts", chol.plan_quality
+
+
 def _config_system(cfg, dev):
     from largesteps.geometry import compute_matrix
     from largesteps import synthetic

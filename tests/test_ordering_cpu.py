@@ -143,3 +143,51 @@ def test_threshold_and_bad_arguments(monkeypatch):
     rc = _native.lib().ls_nd_plan_create_ordered(v.shape[0], rp32.ctypes.data_as(ctypes.c_void_p), c32.ctypes.data_as(ctypes.c_void_p), None,
                                                  64, 4, 4, 7, ctypes.byref(h))
     assert rc == _native.LS_E_INVALID and "ordering" in _native.last_error()
+
+
+def _grid_faces(nx, ny, wrapx=False, wrapy=False):
+    X, Y = (nx if wrapx else nx - 1), (ny if wrapy else ny - 1)
+    x, y = np.meshgrid(np.arange(X), np.arange(Y), indexing="xy")
+    x, y = x.ravel(), y.ravel()
+    i00, i10, i01, i11 = y * nx + x, y * nx + (x + 1) % nx, ((y + 1) % ny) * nx + x, ((y + 1) % ny) * nx + (x + 1) % nx
+    return np.concatenate([np.stack([i00, i10, i11], 1), np.stack([i00, i11, i01], 1)])
+
+
+def _hard_mesh(name, n=160):
+    u, v = np.meshgrid(np.arange(n) / n, np.arange(n) / n, indexing="xy")
+    u, v = u.ravel(), v.ravel()
+    if name == "torus":                  # a cutting plane crosses the tube twice
+        return np.stack([(1 + 0.3 * np.cos(2 * np.pi * v)) * np.cos(2 * np.pi * u), (1 + 0.3 * np.cos(2 * np.pi * v)) * np.sin(2 * np.pi * u),
+                         0.3 * np.sin(2 * np.pi * v)], 1), _grid_faces(n, n, True, True)
+    if name == "helicoid":               # a spiral staircase of 8 turns, 0.05 high: every plane through the axis crosses 8 layers
+        return np.stack([(0.2 + 0.8 * v) * np.cos(16 * np.pi * u), (0.2 + 0.8 * v) * np.sin(16 * np.pi * u), 0.05 * u], 1), _grid_faces(n, n)
+    if name == "collapsed":              # every vertex at the origin (a mesh before its first step)
+        return np.zeros((n * n, 3)), _grid_faces(n, n)
+    if name == "graded":                 # vertex density varying by orders of magnitude: bounding boxes say nothing about vertex counts
+        return np.stack([u ** 4, v ** 4, 0 * u], 1), _grid_faces(n, n)
+    if name == "swarm":                  # 60 closed surfaces scattered inside each other
+        sv, sf = synthetic.icosphere(6)
+        rng = np.random.default_rng(0)
+        return (np.concatenate([sv * rng.uniform(0.5, 1.5) + rng.normal(0, 0.3, 3) for _ in range(60)]),
+                np.concatenate([sf + k * sv.shape[0] for k in range(60)]))
+    sv, sf = synthetic.icosphere(50)     # "spike": a sphere with a long thin spike pulled out of a cap
+    sp = sv.astype(np.float64).copy()
+    cap = sp[:, 2] > 0.95
+    sp[cap, 2] += (sp[cap, 2] - 0.95) * 400.0
+    return sp, sf
+
+
+@pytest.mark.parametrize("name", ["torus", "helicoid", "collapsed", "graded", "swarm", "spike"])
+def test_automatic_choice_on_meshes_that_mislead_cutting_planes(name):
+    """Surfaces on which the positions mislead a cutting plane for OTHER reasons than folds: a tube cut twice, a spiral staircase, a
+    mesh whose vertices all sit in one point, graded density, closed surfaces scattered inside each other, a long spike. Whatever the
+    reason, the automatic choice must end within 1.25x of the better of the two pure embeddings and with ordinary separators."""
+    v, f = _hard_mesh(name)
+    v = np.asarray(v, dtype=np.float32)
+    rowptr, col = pattern(f, v.shape[0])
+    axis = native_plan(rowptr, col, v, 64, 4, ordering=0)
+    graph = native_plan(rowptr, col, None, 64, 4, ordering=0)
+    auto = native_plan(rowptr, col, v, 64, 4, ordering=-1)
+    assert auto.words_per_vertex <= 1.25 * min(axis.words_per_vertex, graph.words_per_vertex), (auto.words_per_vertex, axis.words_per_vertex, graph.words_per_vertex)
+    assert auto.words_per_vertex <= axis.words_per_vertex and auto.spread <= 1.3
+    assert int((auto.s + auto.b).max()) <= 8000            # the direct solver's front limit
