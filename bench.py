@@ -401,10 +401,14 @@ def report_direct(args, solver, M, u, x, tv, v, f, cfg, ms, t_assemble):
     tm = solver.timings
     # the constructor once more, after everything above (not timed, not used): the solver above was the FIRST one this process built and
     # paid the process' one-off costs (kernel code objects loaded on first launch, host thread pool, fresh heap); a remesh loop pays this
+    # cycle (scripts/main.py:137-169: the old matrix and its solver are gone when the new one is built): the measured solver is closed first,
+    # so that -- as in that loop -- its factor arrays are in the library's pool when the next construction asks for them
     repeat_seconds = None
     if not args.no_extra_baselines:
         try:
             from largesteps.solvers import NestedDissectionSolver
+            if hasattr(solver, "close"):
+                solver.close()
             s2 = NestedDissectionSolver(M)
             repeat_seconds = s2.build_seconds
             del s2

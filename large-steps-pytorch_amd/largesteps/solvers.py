@@ -270,16 +270,23 @@ class _NativeDirect:
         self.plan_quality = dict(ordering="trial-cuts" if o.value == 1 else "longest-axis", words_per_vertex=w.value, spread=sp.value,
                                  words_per_vertex_other=wo.value)
 
-    def __del__(self):
+    def close(self):
+        """Destroy the native handle now (its factor arrays go to the library's buffer pool, where the next construction of a similar size
+        finds them); idempotent. Solving with a closed solver raises."""
         h = getattr(self, "_h", None)
         if h is not None and h.value:
             try:
                 _native.lib().ls_direct_destroy(h)
-            except Exception:
+            except Exception:      # interpreter shutdown: module globals may already be gone
                 pass
-            self._h = None
+        self._h = ctypes.c_void_p(None)
+
+    def __del__(self):
+        self.close()
 
     def solve(self, b, x):
+        if not self._h.value:
+            raise RuntimeError("this solver was closed")
         # (no torch.cuda.device context here: ls_direct_solve selects the handle's device itself, and the stream is looked up for that
         #  device by index -- the context manager cost more host time than the call at the reference's mesh sizes)
         rc = self._solve(self._h, b.data_ptr(), x.data_ptr(), b.shape[1], _native.raw_stream(self.device))
@@ -400,6 +407,11 @@ class NestedDissectionSolver(Solver):
 
     def set_option(self, name, value):
         self._direct.set_option(name, value)
+
+    def close(self):
+        """Free the factor now instead of when the object dies (a remesh loop that keeps the old solver alive while it builds the next one
+        pays for both at once)."""
+        self._direct.close()
 
     def info(self):
         return self._direct.info()
