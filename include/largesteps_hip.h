@@ -364,7 +364,7 @@ int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, const float*
  * at 4M --, the analysis' scratch, a destroyed handle's factor arrays) in a per-process pool instead of freeing them: a remesh loop
  * (scripts/main.py:137-169) destroys a solver and constructs one of nearly the same size again and again, and the runtime gives freed
  * memory back lazily -- at the 4M size every second or third construction stalled 0.45-0.7 s inside one hipMalloc. The pool holds at most
- * LS_POOL_GB per device (environment, default 16; 0 = no pool; oldest out first) and never more than a quarter of the device's memory. An
+ * LS_POOL_GB per device (environment, default 24; 0 = no pool; oldest out first) and never more than a quarter of the device's memory. An
  * allocation of the library that fails for lack of memory empties the pool of its device and is repeated once. This call frees what the
  * pool holds (device < 0: on every device) -- for callers whose OWN allocator ran out (torch's caching allocator cannot see the pool). */
 int ls_release_scratch(int device);

@@ -921,7 +921,7 @@ int ls_direct_adopt(ls_direct* d, void* const* owned, const size_t* owned_bytes,
 // (the 9.3 GB of fp64 fronts, or the next buffer after it: profiles/r03_run5_constructor_times.txt) -- four times the whole constructor.
 // The constructor's scratch (fronts and work arrays: 3-4 GB at 1M, 14 GB at 4M) and the handle's factor arrays therefore go back to this
 // pool instead of hipFree, and allocations of >= 64 MB take the best fit (at most 1.5x + 64 MB larger). What the pool may hold is
-// bounded PER DEVICE: LS_POOL_GB (default 16, 0 = no pool) and never more than a quarter of the device's memory (torch's caching
+// bounded PER DEVICE: LS_POOL_GB (default 24, 0 = no pool) and never more than a quarter of the device's memory (torch's caching
 // allocator cannot see or reclaim what sits here); oldest out first. An allocation of the library that fails empties the pool of its
 // device and is tried once more (pool_alloc below), ls_release_scratch() empties it on request, and the Python layer calls that when
 // torch itself runs out of memory (largesteps.solvers.release_scratch).
@@ -933,7 +933,7 @@ struct DevicePool {
     std::vector<Entry> held;
     static size_t cap(int device) {              // bytes the pool may hold on one device
         const char* e = getenv("LS_POOL_GB");
-        double gb = e ? atof(e) : 16.0;
+        double gb = e ? atof(e) : 24.0;        // (a 4M-vertex construction leaves 14 GB of scratch + 2.4 GB of factor: with 16 the fronts were evicted every time)
         if (!(gb > 0.0)) return 0;
         size_t free_b = 0, total_b = 0;
         DeviceGuard dg(device);

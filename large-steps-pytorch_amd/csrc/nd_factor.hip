@@ -32,7 +32,10 @@ struct GemmDesc {
     int sym, pad;                                // sym: the product (and C) is symmetric, M == N: only the tiles on and below the diagonal are
 };                                               // computed, the ones below are stored twice (C[m][n] and C[n][m]) -- half the work of the Schur updates
 
-constexpr int GT = 64, GK = 16;                  // 64 x 64 output tile per workgroup, 16-deep slices
+#ifndef LS_GEMM_GK
+#define LS_GEMM_GK 16          // (32 was measured too, with the prefetch below: 5.3 against 5.0 ms of products per 1M construction, and 3x slower at 4M)
+#endif
+constexpr int GT = 64, GK = LS_GEMM_GK;          // 64 x 64 output tile per workgroup, GK-deep slices
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
@@ -42,6 +45,10 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 // the workgroup's tile = 2 x 2 instruction tiles: per 4-deep step four 8-byte LDS reads feed four instructions (4096 fused
 // multiply-adds). The scalar version (a 4 x 4 block per thread, 8 LDS reads per 16 multiply-adds) was bound by LDS bandwidth at
 // half the fp64 rate and reached 11-16 TFLOP/s.
+// Round 4: the NEXT slice is requested into registers before the current one is multiplied (the top levels' products are single
+// matrices of a few hundred tiles -- one workgroup per CU: with the loads of a slice issued, waited for and only then multiplied,
+// every 16-deep slice cost a memory round trip): 9.1 -> 5.0 ms of products per construction at 1M vertices (118 launches; the largest
+// 366 -> 276 us), constructor 0.039-0.042 -> 0.030-0.032 s (profiles/r04_gemm_prefetch.txt).
 __global__ __launch_bounds__(256) void k_gemm_batched(const GemmDesc* __restrict__ descs) {
     const GemmDesc d = descs[blockIdx.y];
     const int tiles_n = (d.N + GT - 1) / GT, tiles_m = (d.M + GT - 1) / GT;
@@ -58,19 +65,37 @@ __global__ __launch_bounds__(256) void k_gemm_batched(const GemmDesc* __restrict
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < d.K; k0 += GK) {
-        for (int e = threadIdx.x; e < GK * GT; e += 256) {
-            // A slice: (m, k); B slice: (k, n). Index order chosen per storage order so that consecutive threads read consecutive memory.
+    constexpr int PER = GK * GT / 256;                             // elements of either slice per thread
+    double ra[PER], rb[PER];
+    // element e of a slice: A (m, k), B (k, n); the index order follows the storage order so that consecutive threads read consecutive memory
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int t = 0; t < PER; ++t) {
+            const int e = threadIdx.x + t * 256;
             int m, k;
             if (d.ta) { m = e % GT; k = e / GT; } else { k = e % GK; m = e / GK; }
             const int gm = tm + m, gk = k0 + k;
-            sa[k][m] = (gm < d.M && gk < d.K) ? (d.ta ? d.A[(size_t)gk * d.lda + gm] : d.A[(size_t)gm * d.lda + gk]) : 0.0;
+            ra[t] = (gm < d.M && gk < d.K) ? (d.ta ? d.A[(size_t)gk * d.lda + gm] : d.A[(size_t)gm * d.lda + gk]) : 0.0;
             int n, kk;
             if (d.tb) { kk = e % GK; n = e / GK; } else { n = e % GT; kk = e / GT; }
             const int gn = tn + n, gk2 = k0 + kk;
-            sb[kk][n] = (gn < d.N && gk2 < d.K) ? (d.tb ? d.B[(size_t)gn * d.ldb + gk2] : d.B[(size_t)gk2 * d.ldb + gn]) : 0.0;
+            rb[t] = (gn < d.N && gk2 < d.K) ? (d.tb ? d.B[(size_t)gn * d.ldb + gk2] : d.B[(size_t)gk2 * d.ldb + gn]) : 0.0;
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < d.K; k0 += GK) {
+#pragma unroll
+        for (int t = 0; t < PER; ++t) {
+            const int e = threadIdx.x + t * 256;
+            int m, k;
+            if (d.ta) { m = e % GT; k = e / GT; } else { k = e % GK; m = e / GK; }
+            sa[k][m] = ra[t];
+            int n, kk;
+            if (d.tb) { kk = e % GK; n = e / GK; } else { n = e % GT; kk = e / GT; }
+            sb[kk][n] = rb[t];
         }
         __syncthreads();
+        if (k0 + GK < d.K) fetch(k0 + GK);                          // in flight while this slice is multiplied
 #pragma unroll
         for (int k4 = 0; k4 < GK; k4 += 4) {
             const double a0 = sa[k4 + l4][wm + l15], a1 = sa[k4 + l4][wm + 16 + l15];

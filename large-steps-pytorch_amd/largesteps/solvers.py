@@ -334,7 +334,7 @@ class _NativeDirect:
 
 def release_scratch(device=None):
     """Free the large device buffers the direct solver keeps between constructions (constructor scratch and the factor arrays of destroyed
-    solvers: 4 GB at 1M vertices; per device at most LS_POOL_GB = 16 GB and a quarter of the device's memory; see ls_release_scratch in
+    solvers: 4 GB at 1M vertices; per device at most LS_POOL_GB = 24 GB and a quarter of the device's memory; see ls_release_scratch in
     include/largesteps_hip.h). The library does this itself when one of ITS allocations fails; torch's caching allocator cannot see these
     buffers, so a caller that catches torch.cuda.OutOfMemoryError should call this (and torch.cuda.empty_cache()) before it retries.
     device: a torch device / index, or None for every device."""
