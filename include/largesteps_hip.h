@@ -354,6 +354,9 @@ int ls_direct_pick_tree(int64_t V, int* leaf_size, int* arity);
  *   node; 0 = none); sparse_leaves != 0 stores leaves of at most 64 rows as packed triangle + sparse block;
  * shard_rank / shard_count: subtree sharding (0 / 1: none; every rank factorises the whole matrix, the re-solve is sharded, see
  *   ls_direct_solve_part).
+ * The host half of the analysis runs on a pool of threads (environment LS_PLAN_THREADS, default 32, at most the host's cores divided
+ * by LOCAL_WORLD_SIZE) that is created by the first call and kept, asleep, for the life of the process; a call made while another
+ * thread's call holds the pool, or from a forked child, uses threads of its own.
  * SYNC. Errors: LS_E_INVALID (not symmetric / not positive definite / bad arguments), LS_E_WORKSPACE (fronts or factor beyond the
  * solver's limits; or an EXPLICIT tier_levels whose subtrees do not fit a workgroup's LDS -- tier_levels = -1 lowers its own choice
  * until it fits and never fails for that reason). */

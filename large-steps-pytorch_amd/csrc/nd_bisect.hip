@@ -427,7 +427,7 @@ extern "C" int ls_nd_plan_create_device(const int32_t* d_rowptr, const int32_t* 
     DeviceGuard g(device);
     LS_HIP(g.err);
     hipStream_t st = (hipStream_t)stream;
-    std::vector<int32_t> rowptr((size_t)V + 1), col((size_t)nnz);
+    uvec<int32_t> rowptr((size_t)V + 1), col((size_t)nnz);
     ls_nd_plan* h = new ls_nd_plan();
     const std::string err = nd_plan_build_device(d_rowptr, d_col, d_positions, V, nnz, rowptr.data(), col.data(), leaf_size, arity, smooth, st, h->p);
     if (!err.empty()) { delete h; set_error("%s", err.c_str()); return LS_E_INVALID; }

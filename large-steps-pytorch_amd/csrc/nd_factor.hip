@@ -18,6 +18,7 @@
 #include <string.h>
 #include <string>
 #include <thread>
+#include <sys/resource.h>
 #include <vector>
 
 namespace ls {
@@ -506,9 +507,11 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     hipStream_t st = (hipStream_t)stream;
     const double t0 = now_s();
     const bool timing = getenv("LS_PLAN_TIMING") != nullptr;
-    auto lap = [&](const char* what) { if (timing) { (void)hipStreamSynchronize(st); fprintf(stderr, "[ls_direct_factor] %-30s %.3f s\n", what, now_s() - t0); } };
+    auto faults = [] { struct rusage u; getrusage(RUSAGE_SELF, &u); return (long)u.ru_minflt; };
+    const long f0 = timing ? faults() : 0;
+    auto lap = [&](const char* what) { if (timing) { (void)hipStreamSynchronize(st); fprintf(stderr, "[ls_direct_factor] %-30s %.3f s  (%ld page faults so far)\n", what, now_s() - t0, faults() - f0); } };
     // ---- symbolic analysis: the bisection rounds on the device (nd_bisect.hip), the tree / fronts / index lists on the host ------------
-    std::vector<int32_t> rowptr((size_t)V + 1), col((size_t)nnz);          // the host's copy of the pattern, filled by the analysis
+    uvec<int32_t> rowptr((size_t)V + 1), col((size_t)nnz);                 // the host's copy of the pattern, filled by the analysis (not zeroed first: 32 MB at 1M)
     NdPlan P;
     {
         // how the cutting directions are chosen: ND_ORDER_AUTO (nd_plan.h) unless the environment says otherwise (LS_ND_ORDER = 0: always

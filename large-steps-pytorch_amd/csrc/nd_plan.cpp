@@ -12,6 +12,8 @@
 #include <mutex>
 #include <numeric>
 #include <thread>
+#include <unistd.h>
+#include <sys/resource.h>
 
 namespace ls {
 namespace {
@@ -29,11 +31,12 @@ int n_threads() {          // read at every build: tests compare the one-thread 
     return std::max(1, std::min(want, hw > 0 ? hw : 1));
 }
 
-// A pool of host threads that lives for one nd_plan_build call: a round of the bisection issues a handful of short parallel
-// passes, and creating 32 threads for each of them costs more than the passes themselves.
+// A pool of host threads: a round of the bisection issues a handful of short parallel passes, and creating 32 threads for each of
+// them costs more than the passes themselves. One pool is kept for the life of the process (PoolLease below): creating and joining
+// its threads cost every nd_plan_build call 1-2 ms of the ~19 ms a 1M-vertex analysis takes.
 class Pool {
 public:
-    explicit Pool(int threads) {
+    explicit Pool(int threads) : limit_(std::max(1, threads)) {
         for (int t = 1; t < threads; ++t) th_.emplace_back([this] { worker(); });
     }
     ~Pool() {
@@ -41,12 +44,14 @@ public:
         cv_.notify_all();
         for (auto& t : th_) t.join();
     }
-    int size() const { return (int)th_.size() + 1; }
+    int size() const { return limit_; }                       // threads a pass may count on (<= capacity())
+    int capacity() const { return (int)th_.size() + 1; }
+    void set_limit(int threads) { limit_ = std::max(1, std::min(threads, capacity())); }
     // fn(chunk, begin, end) for `chunks` contiguous pieces of [0, n); the calling thread takes part
     void run(int64_t n, int chunks, const std::function<void(int, int64_t, int64_t)>& fn) {
         if (n <= 0) return;
         chunks = (int)std::max<int64_t>(1, std::min<int64_t>(chunks, n));
-        if (chunks == 1 || th_.empty()) {
+        if (chunks == 1 || th_.empty() || limit_ == 1) {
             const int64_t step = (n + chunks - 1) / chunks;
             for (int c = 0; c < chunks; ++c) { const int64_t lo = c * step, hi = std::min(n, lo + step); if (lo < hi) fn(c, lo, hi); }
             return;
@@ -97,10 +102,41 @@ private:
     int64_t n_ = 0, step_ = 0;
     int chunks_ = 0, next_ = 0, pending_ = 0;
     uint64_t gen_ = 0;
+    int limit_ = 1;
     bool stop_ = false;
 };
 
 thread_local Pool* g_pool = nullptr;      // the pool of the nd_plan_build call running on this thread
+
+// The process-wide pool when nobody else is using it (two threads that analyse two matrices at the same moment -- one per device of
+// a multi-device solver -- : the second one gets a pool of its own, as every call did before). The shared pool is never destroyed: its
+// threads sleep on a condition variable between calls and end with the process; a forked child (which has none of the parent's
+// threads) notices the changed process id and starts its own.
+std::mutex g_shared_m;
+Pool* g_shared = nullptr;
+long g_shared_pid = 0;
+bool g_shared_busy = false;
+struct PoolLease {
+    Pool* pool = nullptr;
+    bool shared = false;
+    explicit PoolLease(int threads) {
+        {
+            std::lock_guard<std::mutex> lk(g_shared_m);
+            if (g_shared && g_shared_pid != (long)getpid()) { g_shared = nullptr; g_shared_busy = false; }      // after fork(): the old object is left alone
+            if (!g_shared_busy) {
+                if (g_shared && g_shared->capacity() < threads) { delete g_shared; g_shared = nullptr; }
+                if (!g_shared) { g_shared = new Pool(threads); g_shared_pid = (long)getpid(); }
+                g_shared_busy = true; shared = true; pool = g_shared;
+            }
+        }
+        if (shared) pool->set_limit(threads); else pool = new Pool(threads);
+    }
+    ~PoolLease() {
+        if (!shared) { delete pool; return; }
+        std::lock_guard<std::mutex> lk(g_shared_m);
+        if (pool == g_shared) g_shared_busy = false;
+    }
+};
 
 // body(begin, end) over [0, n) in contiguous chunks of at least `grain`
 void parallel_for(int64_t n, int64_t grain, const std::function<void(int64_t, int64_t)>& body) {
@@ -187,14 +223,17 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
                           int smooth, NdPlan& P, NdBisectFn bisect, void* bisect_ctx, int ordering, bool defer_push_lists) {
     const auto t_start = std::chrono::steady_clock::now();
     const bool timing = getenv("LS_PLAN_TIMING") != nullptr;
-    auto lap = [&](const char* what) { if (timing) fprintf(stderr, "[nd_plan] %-28s %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count()); };
+    auto faults = [] { struct rusage u; getrusage(RUSAGE_SELF, &u); return (long)u.ru_minflt; };
+    const long f_start = timing ? faults() : 0;
+    auto lap = [&](const char* what) { if (timing) fprintf(stderr, "[nd_plan] %-28s %.3f s  (%ld page faults so far)\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(), faults() - f_start); };
     if (V <= 0 || V >= INT32_MAX) return "nd_plan_build: bad vertex count";
     // (with `bisect` the column indices are still on their way from the device -- see nd_plan_build_device -- and were bounds-checked when
     // the matrix was made: a coalesced torch tensor / ls_assemble_*; the host-only entry points take arbitrary arrays)
     if (!bisect) { if (const char* bad = csr_pattern_problem(V, rowptr, col, pos_in)) return std::string("nd_plan_build: ") + bad; }
     if (arity != 2 && arity != 4 && arity != 8) return "nd_plan_build: arity must be 2, 4 or 8";
     if (leaf_size < 1) return "nd_plan_build: leaf_size must be positive";
-    Pool pool(n_threads());
+    PoolLease lease(n_threads());
+    Pool& pool = *lease.pool;
     struct PoolScope { PoolScope(Pool* p) { g_pool = p; } ~PoolScope() { g_pool = nullptr; } } pool_scope(&pool);
     const int T = pool.size();
     const int m = arity == 2 ? 1 : arity == 4 ? 2 : 3;
@@ -202,13 +241,18 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
     while ((V >> D) > leaf_size) ++D;
     D = (D + m - 1) / m * m;
     if (D > 40) return "nd_plan_build: tree too deep";
-    std::vector<int64_t> node((size_t)V, 1);          // binary heap id of the domain a vertex lives in / became a separator of
+    uvec<int64_t> node((size_t)V);                    // binary heap id of the domain a vertex lives in / became a separator of
+    if (!bisect) std::fill(node.begin(), node.end(), (int64_t)1);
     if (bisect) {
         // positions and the D rounds run elsewhere (csrc/nd_bisect.hip: on the device); only the graph embedding of a matrix that
         // comes without positions is formed here
         std::vector<double> emb;
         bool all_rows = true;
-        if (pos_in) { for (int64_t v = 0; v < V && all_rows; ++v) all_rows = rowptr[v + 1] > rowptr[v]; }
+        if (pos_in) {
+            std::atomic<bool> empty_row(false);
+            parallel_for(V, 65536, [&](int64_t lo, int64_t hi) { for (int64_t v = lo; v < hi; ++v) if (rowptr[v + 1] <= rowptr[v]) { empty_row = true; break; } });
+            all_rows = !empty_row;
+        }
         else graph_embedding(V, rowptr, col, emb);
         lap("positions");
         const std::string err = bisect(bisect_ctx, V, D, (pos_in && all_rows) ? smooth : 0, pos_in ? nullptr : emb.data(), node.data());
@@ -524,7 +568,7 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
             P.level_of[i] = l;
             if (l) { P.parent[i] = (int)(P.level_off[l - 1] + (i - P.level_off[l]) / arity); P.child_ix[i] = (int)((i - P.level_off[l]) % arity); }
         }
-    std::vector<int> node_id((size_t)V);
+    uvec<int> node_id((size_t)V);
     parallel_for(V, 65536, [&](int64_t lo, int64_t hi) {
         for (int64_t v = lo; v < hi; ++v) {
             const int64_t h = node[v];
@@ -566,40 +610,54 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
     }
     lap("ordering");
     // ---- boundary sets, deepest level first (a node's set needs its children's) ------------------------------------------------
-    std::vector<std::vector<int>> bset((size_t)n_nodes + 1);
+    // Sets live in per-(level, chunk) arenas -- one growing array per thread and level instead of one heap block per node (21845
+    // of them at 1M vertices, allocated and freed by 32 threads at once); a level's arenas no longer move once the level is done,
+    // which is when the parents read them.
+    struct Span { const int* p = nullptr; int n = 0; };
+    std::vector<Span> bset((size_t)n_nodes + 1);
+    std::vector<std::vector<uvec<int>>> arena((size_t)levels);
     std::atomic<bool> bad(false);
     for (int l = levels - 1; l >= 1; --l) {
         const int64_t first = P.level_off[l], cnt = P.level_off[l + 1] - first;
-        parallel_for(cnt, 1, [&](int64_t lo, int64_t hi) {
+        const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(T, cnt));
+        arena[l].resize((size_t)chunks);
+        parallel_chunks(cnt, chunks, [&](int c, int64_t lo, int64_t hi) {
+            uvec<int>& A = arena[l][c];
+            std::vector<int64_t> at((size_t)(hi - lo) + 1, 0);
             for (int64_t k = lo; k < hi; ++k) {
                 const int64_t i = first + k;
-                std::vector<int>& B = bset[i];
+                const size_t a0 = A.size();
                 const int o = P.own_start[i], oe = o + P.s[i];
                 for (int nw = o; nw < oe; ++nw) {
                     const int v = P.perm[nw];
-                    for (int p = rowptr[v]; p < rowptr[v + 1]; ++p) { const int c = P.inv[col[p]]; if (c >= oe) B.push_back(c); }
+                    for (int p = rowptr[v]; p < rowptr[v + 1]; ++p) { const int w = P.inv[col[p]]; if (w >= oe) A.push_back(w); }
                 }
                 if (l + 1 < levels)
-                    for (int c = 0; c < arity; ++c) {
-                        const int64_t ch = P.level_off[l + 1] + (i - first) * arity + c;
-                        for (int w : bset[ch]) if (w >= oe) B.push_back(w);
+                    for (int ch = 0; ch < arity; ++ch) {
+                        const Span& S = bset[P.level_off[l + 1] + (i - first) * arity + ch];
+                        for (int e = 0; e < S.n; ++e) if (S.p[e] >= oe) A.push_back(S.p[e]);
                     }
-                std::sort(B.begin(), B.end());
-                B.erase(std::unique(B.begin(), B.end()), B.end());
+                std::sort(A.begin() + a0, A.end());
+                A.erase(std::unique(A.begin() + a0, A.end()), A.end());
+                at[(size_t)(k - lo) + 1] = (int64_t)A.size();
+            }
+            for (int64_t k = lo; k < hi; ++k) {
+                Span& S = bset[first + k];
+                S.p = A.data() + at[(size_t)(k - lo)]; S.n = (int)(at[(size_t)(k - lo) + 1] - at[(size_t)(k - lo)]);
             }
         });
     }
     lap("boundary sets");
     P.bnd_off.assign((size_t)n_nodes + 2, 0); P.front_off.assign((size_t)n_nodes + 2, 0);
     for (int i = 1; i <= n_nodes; ++i) {
-        P.b[i] = (int)bset[i].size();
+        P.b[i] = bset[i].n;
         P.bnd_off[i + 1] = P.bnd_off[i] + P.b[i];
         P.front_off[i + 1] = P.front_off[i] + P.s[i] + P.b[i];
     }
     P.bnd_off[1] = 0; P.front_off[1] = 0;
     P.n_bnd = P.bnd_off[n_nodes + 1]; P.n_front = P.front_off[n_nodes + 1];
     if (P.n_bnd >= INT32_MAX || P.n_front * arity >= INT32_MAX) return "nd_plan_build: plan exceeds int32 offsets";
-    P.bnd.resize((size_t)P.n_bnd); P.ppos.assign((size_t)P.n_bnd, 0);
+    P.bnd.resize((size_t)P.n_bnd); P.ppos.resize((size_t)P.n_bnd);
     // position of every boundary vertex in its parent's front [own | boundary]
     parallel_for(n_nodes, 64, [&](int64_t lo, int64_t hi) {
         for (int64_t k = lo; k < hi; ++k) {
@@ -607,15 +665,15 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
             if (i < 2) continue;
             const int par = P.parent[i];
             const int po = P.own_start[par], pe = po + P.s[par];
-            const std::vector<int>& PB = bset[par];
+            const Span PB = bset[par];
             for (int k = 0; k < P.b[i]; ++k) {
-                const int w = bset[i][k];
+                const int w = bset[i].p[k];
                 P.bnd[(size_t)P.bnd_off[i] + k] = w;
                 int pp;
                 if (w < pe) { if (w < po) bad = true; pp = w - po; }
                 else {
-                    const auto it = std::lower_bound(PB.begin(), PB.end(), w);
-                    if (it == PB.end() || *it != w) { bad = true; pp = 0; } else pp = P.s[par] + (int)(it - PB.begin());
+                    const int* it = std::lower_bound(PB.p, PB.p + PB.n, w);
+                    if (it == PB.p + PB.n || *it != w) { bad = true; pp = 0; } else pp = P.s[par] + (int)(it - PB.p);
                 }
                 P.ppos[(size_t)P.bnd_off[i] + k] = pp;
             }
@@ -640,8 +698,8 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
 void nd_plan_push_lists(NdPlan& P) {
     if (!P.push_ptr.empty()) return;
     const int levels = P.levels, arity = P.arity;
-    Pool* own = nullptr;
-    if (!g_pool) { own = new Pool(n_threads()); g_pool = own; }
+    PoolLease* own = nullptr;
+    if (!g_pool) { own = new PoolLease(n_threads()); g_pool = own->pool; }
     P.push_ptr.assign((size_t)P.n_front + 1, 0);
     P.push_tgt.resize((size_t)P.n_bnd);
     // a parent's front positions receive entries from its own children only: counts and fills run parent by parent
@@ -764,7 +822,7 @@ extern "C" int ls_nd_plan_arrays(const ls_nd_plan* h, int32_t* perm, int32_t* s,
                                  int32_t* bnd, int32_t* ppos, int32_t* push_ptr, int32_t* push_tgt) {
     if (!h) { ls::set_error("ls_nd_plan_arrays: null handle"); return LS_E_INVALID; }
     const ls::NdPlan& p = h->p;
-    auto cp = [](int32_t* dst, const std::vector<int>& src) { if (dst) std::copy(src.begin(), src.end(), dst); };
+    auto cp = [](int32_t* dst, const auto& src) { if (dst) std::copy(src.begin(), src.end(), dst); };
     cp(perm, p.perm); cp(s, p.s); cp(b, p.b); cp(own_start, p.own_start); cp(parent, p.parent);
     cp(bnd, p.bnd); cp(ppos, p.ppos); cp(push_ptr, p.push_ptr); cp(push_tgt, p.push_tgt);
     return LS_OK;

@@ -12,6 +12,22 @@
 
 namespace ls {
 
+// std::vector whose resize(n) leaves the new elements uninitialised: the analysis overwrites every entry of its large arrays (4-28 MB
+// each at 1M vertices), and zero-filling them first costs the constructor milliseconds. (assign(n, v) and resize(n, v) still fill.)
+template <class T>
+struct NoInitAlloc {
+    typedef T value_type;
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U>&) {}
+    T* allocate(size_t n) { return static_cast<T*>(::operator new(n * sizeof(T))); }
+    void deallocate(T* p, size_t) { ::operator delete(p); }
+    template <class U> void construct(U* p) { ::new ((void*)p) U; }
+    template <class U, class A0, class... A> void construct(U* p, A0&& a0, A&&... a) { ::new ((void*)p) U(static_cast<A0&&>(a0), static_cast<A&&>(a)...); }
+    template <class U> bool operator==(const NoInitAlloc<U>&) const { return true; }
+    template <class U> bool operator!=(const NoInitAlloc<U>&) const { return false; }
+};
+template <class T> using uvec = std::vector<T, NoInitAlloc<T>>;
+
 struct NdPlan {
     int64_t V = 0;
     int levels = 0, arity = 4, n_nodes = 0, rounds = 0;      // rounds = bisection rounds D (levels = D / log2(arity) + 1)
@@ -19,11 +35,11 @@ struct NdPlan {
     std::vector<int> parent, level_of, child_ix;             // per node id (slot 0 unused)
     std::vector<int> s, b, own_start;                        // own block size, boundary size, first new vertex id
     std::vector<int64_t> bnd_off, front_off;                 // prefix sums of b and of s + b
-    std::vector<int> perm, inv;                              // perm[new] = old, inv[old] = new
-    std::vector<int> node_of_new;                            // node id of every new vertex id
-    std::vector<int> bnd;                                    // concatenated boundary lists (new vertex ids, ascending per node)
-    std::vector<int> ppos;                                   // position of every boundary entry in the PARENT's front [own | boundary]
-    std::vector<int> push_ptr, push_tgt;                     // CSR: front position -> the children's boundary entries that are this vertex
+    uvec<int> perm, inv;                                     // perm[new] = old, inv[old] = new
+    uvec<int> node_of_new;                                   // node id of every new vertex id
+    uvec<int> bnd;                                           // concatenated boundary lists (new vertex ids, ascending per node)
+    uvec<int> ppos;                                          // position of every boundary entry in the PARENT's front [own | boundary]
+    uvec<int> push_ptr, push_tgt;                            // CSR: front position -> the children's boundary entries that are this vertex
     int64_t n_bnd = 0, n_front = 0;
     double seconds = 0.0;
     // quality of the dissection (nd_plan_quality): factor numbers per vertex, sum over the nodes of s^2 + 2 s b; `spread` = sum of

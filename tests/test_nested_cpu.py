@@ -324,3 +324,59 @@ def test_native_plan_is_independent_of_the_thread_count(with_pos, monkeypatch):
     for q in plans[1:]:
         for name in ("perm", "s", "b", "own_start", "bnd", "ppos", "push_ptr", "push_tgt"):
             assert np.array_equal(getattr(a, name), getattr(q, name)), name
+
+
+def test_native_plans_built_at_the_same_moment():
+    """The analysis keeps ONE pool of host threads for the life of the process (csrc/nd_plan.cpp, PoolLease): a second analysis that
+    starts while the first one holds it (a multi-device solver builds one plan per device from its own thread; ctypes releases the
+    GIL) gets a pool of its own. Both must produce the plan a lone call produces, call after call."""
+    import threading
+    from native_plan import native_plan
+    meshes = []
+    for n in (120, 90):
+        v, f = synthetic.plane(n)
+        r, rowptr, c, val = csr_of(v, f, lambda_=5.0)
+        meshes.append((rowptr, c, v))
+    alone = [native_plan(rp, c, v, leaf_size=32, arity=4) for rp, c, v in meshes]
+    for rep in range(3):
+        got = [None, None]
+
+        def work(i):
+            rp, c, v = meshes[i]
+            got[i] = native_plan(rp, c, v, leaf_size=32, arity=4)
+
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        for a, q in zip(alone, got):
+            for name in ("perm", "s", "b", "own_start", "bnd", "ppos", "push_ptr", "push_tgt"):
+                assert np.array_equal(getattr(a, name), getattr(q, name)), name
+
+
+def test_native_plan_in_a_forked_child():
+    """A forked child has none of the parent's threads: the process-wide pool of the parent must not be waited for there."""
+    import os
+    from native_plan import native_plan
+    v, f = synthetic.plane(100)
+    r, rowptr, c, val = csr_of(v, f, lambda_=5.0)
+    a = native_plan(rowptr, c, v, leaf_size=32, arity=4)           # the parent's pool exists now
+    rd, wr = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        ok = b"0"
+        try:
+            q = native_plan(rowptr, c, v, leaf_size=32, arity=4)
+            ok = b"1" if np.array_equal(a.perm, q.perm) and np.array_equal(a.bnd, q.bnd) else b"0"
+        finally:
+            os.write(wr, ok)
+            os._exit(0)
+    os.close(wr)
+    import select
+    ready, _, _ = select.select([rd], [], [], 60.0)
+    if not ready:
+        os.kill(pid, 9)
+    os.waitpid(pid, 0)
+    assert ready, "the child hung in the analysis"
+    assert os.read(rd, 1) == b"1"
