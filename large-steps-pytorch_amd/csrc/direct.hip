@@ -18,6 +18,7 @@
 //     k_nd_up_p / k_nd_down_p  tiny nodes: up to 8 consecutive nodes share a wave (lane -> (node, row))
 #include "common.h"
 #include <vector>
+#include <chrono>
 #include <algorithm>
 #include <string.h>
 #include <mutex>
@@ -926,6 +927,21 @@ int ls_direct_adopt(ls_direct* d, void* const* owned, const size_t* owned_bytes,
 // device and is tried once more (pool_alloc below), ls_release_scratch() empties it on request, and the Python layer calls that when
 // torch itself runs out of memory (largesteps.solvers.release_scratch).
 namespace ls {
+// Two non-blocking streams per device for work that must not queue behind the caller's stream: which = 0 the handle's tables go up
+// while that stream factorises; which = 1 the fp32 conversion of a finished tree level runs beside the chain of small launches of
+// the level above (two streams: the uploads must not queue behind conversions that wait for the factorisation either).
+// Created on first use, kept for the life of the process. Ordering against the caller's stream is always by events.
+hipStream_t side_stream(int device, int which) {
+    static std::mutex mu;
+    static hipStream_t streams[64][2] = {{nullptr, nullptr}};
+    if (device < 0 || device >= 64 || which < 0 || which > 1) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!streams[device][which]) {
+        DeviceGuard dg(device);
+        if (dg.err != hipSuccess || hipStreamCreateWithFlags(&streams[device][which], hipStreamNonBlocking) != hipSuccess) streams[device][which] = nullptr;
+    }
+    return streams[device][which];
+}
 namespace {
 struct DevicePool {
     std::mutex mu;
@@ -1268,6 +1284,9 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
     DeviceGuard g(device);
     LS_HIP(g.err);
     hipStream_t st = (hipStream_t)stream;
+    const bool timing = getenv("LS_PLAN_TIMING") != nullptr;          // host clock only, no synchronisation: where the handle's construction spends its time
+    const auto t_create = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (timing) fprintf(stderr, "[ls_direct_create] %-28s %.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create).count()); };
     ls_direct* d = new ls_direct();
     d->device = device; d->levels = levels; d->arity = arity; d->n_nodes = n_nodes; d->V = V; d->n_bnd = n_bnd; d->n_front = n_front;
     d->finv = A->d_finv; d->wf = A->d_wf; d->wb = A->d_wb;
@@ -1611,9 +1630,15 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
     const bool span = false;
 #endif
     int rc = LS_OK;
+    lap("tables built (host)");
+    // The tables go up on a stream of their own: `st` is busy with the factorisation when ls_direct_factor calls this (a copy from
+    // pageable memory queued behind it kept the HOST waiting until the last kernel was done, and ~50 MB of index lists then crossed
+    // the bus one after the other while the device idled: 3.5 of the 28 ms of a 1M-vertex construction). `st` waits for them through an event.
+    hipStream_t su = side_stream(device, 0);
+    LS_REQUIRE(su, LS_E_STATE, "ls_direct_create: no side stream on this device");
     auto up = [&](auto** dst, const auto* src, size_t n) -> int {
         LS_HIP(pool_alloc(device, (void**)dst, std::max<size_t>(n, 1) * sizeof(**dst)));
-        if (n) LS_HIP(hipMemcpyAsync(*dst, src, n * sizeof(**dst), hipMemcpyHostToDevice, st));
+        if (n) LS_HIP(hipMemcpyAsync(*dst, src, n * sizeof(**dst), hipMemcpyHostToDevice, su));
         return LS_OK;
     };
     if (!(rc = up(&d->tiles, tiles.data(), tiles.size())) && !(rc = up(&d->ptiles, ptiles.data(), ptiles.size())) &&
@@ -1646,7 +1671,11 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
         }
 #endif
         if (e == hipSuccess) e = hipEventCreateWithFlags(&d->busy, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);      // the host vectors above go out of scope
+        lap("uploads enqueued, vectors allocated");
+        if (e == hipSuccess) e = hipEventRecord(d->busy, su);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, d->busy, 0);      // whatever follows on the caller's stream sees the tables
+        if (e == hipSuccess) e = hipStreamSynchronize(su);               // the host vectors above go out of scope
+        lap("uploads done");
         if (e != hipSuccess) rc = hip_fail(e, "ls_direct_create allocations", __FILE__, __LINE__);
     }
     if (rc != LS_OK) { ls_direct_destroy(d); return rc; }
@@ -1686,6 +1715,7 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
 #else
     (void)span;
 #endif
+    lap("kernel attributes set");
     *out = d;
     return LS_OK;
 }

@@ -457,6 +457,7 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 // defined in direct.hip: builds the handle from plan + factor arrays and takes ownership of the device arrays
 extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* stream, ls_direct** out);
 int ls_direct_adopt(ls_direct* d, void* const* owned, const size_t* owned_bytes, int n_owned, const double* seconds3, const double* quality4);
+namespace ls { hipStream_t side_stream(int device, int which); }
 bool direct_tier_fits(int levels, int arity, const int* s, const int* b, const int* own_start, int tier_levels, bool sparse_leaves);
 
 // ---- the tree the library picks for a system of V unknowns (leaf_size <= 0 / arity <= 0 on entry = "pick"; explicit values stay) ----------
@@ -771,8 +772,21 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     if (e == hipSuccess)
         hipLaunchKernelGGL(k_assemble, dim3((unsigned)div_up(nnz, 256)), dim3(256), 0, st, nnz, d_rowidx, d_col, d_val, d_inv, d_non, d_nodes, d_bnd,
                            fronts, d_flag);
+    // The fp32 conversion of a finished level runs on the side stream, beside the next level's chain of small launches (the upper levels
+    // are inverses of one workgroup and products of a few tiles: the chip is nearly empty there, and the conversions were 1.0 of the
+    // 10.6 ms of kernels of a 1M-vertex factorisation). Events order it: after its level's products, before the stream's end.
+    hipStream_t sc = side_stream(device, 1);
+    std::vector<hipEvent_t> evs;
     for (const Cmd& c : ctx.cmds) {
         if (e != hipSuccess) break;
+        hipStream_t sk = st;
+        if (c.kind == 3 && sc) {
+            hipEvent_t ev = nullptr;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+                evs.push_back(ev);
+                if (hipEventRecord(ev, st) == hipSuccess && hipStreamWaitEvent(sc, ev, 0) == hipSuccess) sk = sc;
+            }
+        }
         for (int b0 = 0; b0 < c.n; b0 += 65535) {
             const int nb = std::min(65535, c.n - b0);
             switch (c.kind) {
@@ -783,15 +797,25 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
                 break;
             case 2: hipLaunchKernelGGL(k_extend_add, dim3(c.gx, nb), dim3(256), 0, st, (const int*)(d_ids + c.off + b0), nb, d_nodes, d_ppos, fronts); break;
             default:
-                hipLaunchKernelGGL(k_convert, dim3(c.gx, nb), dim3(256), 0, st, (const int*)(d_ids + c.off + b0), d_nodes, xs, ws, finv, wf, wb, u4, d4, tri, pu, pd);
+                hipLaunchKernelGGL(k_convert, dim3(c.gx, nb), dim3(256), 0, sk, (const int*)(d_ids + c.off + b0), d_nodes, xs, ws, finv, wf, wb, u4, d4, tri, pu, pd);
             }
         }
         ++ctx.launches;
     }
+    if (sc && !evs.empty()) {                                  // join: the caller's stream continues after the last conversion
+        hipEvent_t ev = nullptr;
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (ev) evs.push_back(ev);
+        if (e == hipSuccess) e = hipEventRecord(ev, sc);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, ev, 0);
+    }
+    struct EventGuard { std::vector<hipEvent_t>& v; ~EventGuard() { for (hipEvent_t x : v) (void)hipEventDestroy(x); } } ev_guard{evs};
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) { cleanup(true); return hip_fail(e, "ls_direct_factor kernels", __FILE__, __LINE__); }
     // ---- the solver handle: its tables are built on the host WHILE the device factorises (everything above is only enqueued) ------------
+    if (timing) fprintf(stderr, "[ls_direct_factor]   %d launches enqueued %.3f s (host clock)\n", ctx.launches, now_s() - t0);
     nd_plan_push_lists(P);          // (left out of the analysis: only the solve needs them)
+    if (timing) fprintf(stderr, "[ls_direct_factor]   push lists built %.3f s (host clock)\n", now_s() - t0);
     ls_direct_arrays A;
     memset(&A, 0, sizeof(A));
     A.V = V; A.levels = levels; A.arity = arity; A.h_nodes = hn.data(); A.h_perm = P.perm.data(); A.h_ppos = P.ppos.data(); A.n_bnd = P.n_bnd;
