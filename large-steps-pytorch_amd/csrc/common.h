@@ -44,14 +44,15 @@ struct DeviceGuard {  // every entry point pins the device itself: no thread-loc
 };
 
 inline int div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
-// direct.hip: a small per-device pool of LARGE device buffers (>= 64 MB) that the direct solver's constructor and destructor hand back
-// instead of hipFree -- see ls_release_scratch in the header. take: a pooled buffer of at least `bytes` (and not much more; *capacity = its real size,
+// direct.hip: a per-device pool of device buffers (>= 256 KB) that the direct solver's constructor and destructor hand back instead of
+// hipFree -- see ls_release_scratch in the header. (Round 4: the threshold was 64 MB; a 1M-vertex construction also makes ~40 allocations of
+// 1-30 MB -- index lists, tables, vectors -- whose hipMalloc / hipFree pairs cost the remesh loop milliseconds.) take: a pooled buffer of at least `bytes` (and not much more; *capacity = its real size,
 // to be handed back to give) or nullptr;
 // give: false when the pool did not take the buffer (the caller frees it). The buffer must be idle (its stream synchronised).
 void* pool_take(int device, size_t bytes, size_t* capacity);
 bool pool_give(int device, void* p, size_t bytes);
 hipError_t pool_alloc(int device, void** p, size_t bytes);      // hipMalloc; out of memory: the pool of `device` is emptied and the call repeated once
-constexpr size_t POOL_FROM = (size_t)64 << 20;
+constexpr size_t POOL_FROM = (size_t)256 << 10, POOL_SLACK = (size_t)1 << 20;      // smallest pooled buffer; a taken buffer is at most 1.5 x the request + POOL_SLACK
 // assemble.hip: out[0 .. n] = exclusive scan of the int32 in[0 .. n), out[n] = total; bsum: scan_blocks(n) + 1 ints of scratch
 int exclusive_scan(const int* in, int64_t n, int* out, int* bsum, hipStream_t st);
 inline int64_t scan_blocks(int64_t n) { return (n + 2047) / 2048; }

@@ -863,6 +863,7 @@ struct ls_direct {
     hipEvent_t busy = nullptr;          // recorded after every solve: a solve on another stream waits for it (one workspace)
     hipStream_t last_stream = nullptr;
     bool used = false;
+    std::vector<std::pair<void*, size_t>> tables;      // index tables and vectors of the handle (pool_take / pool_alloc in ls_direct_create; back to the pool with the handle)
     std::vector<void*> owned;           // device arrays adopted from ls_direct_factor (handed to the buffer pool / freed with the handle)
     std::vector<size_t> owned_bytes;
     // subtree sharding (one process per GPU): this handle runs the subtrees [sub_lo, sub_hi) of level `cut` and, replicated on
@@ -966,7 +967,7 @@ void* pool_take(int device, size_t bytes, size_t* capacity) {
     int best = -1;
     for (int i = 0; i < (int)g_pool.held.size(); ++i) {
         const DevicePool::Entry& e = g_pool.held[(size_t)i];
-        if (e.device == device && e.bytes >= bytes && e.bytes <= bytes + bytes / 2 + POOL_FROM && (best < 0 || e.bytes < g_pool.held[(size_t)best].bytes)) best = i;
+        if (e.device == device && e.bytes >= bytes && e.bytes <= bytes + bytes / 2 + POOL_SLACK && (best < 0 || e.bytes < g_pool.held[(size_t)best].bytes)) best = i;
     }
     if (best < 0) return nullptr;
     void* p = g_pool.held[(size_t)best].p;
@@ -982,8 +983,11 @@ bool pool_give(int device, void* p, size_t bytes) {
     std::lock_guard<std::mutex> g(g_pool.mu);
     size_t total = bytes;
     for (const DevicePool::Entry& e : g_pool.held) if (e.device == device) total += e.bytes;
-    for (size_t i = 0; total > limit && i < g_pool.held.size();) {    // this device's oldest out first
+    size_t count = 1;
+    for (const DevicePool::Entry& e : g_pool.held) if (e.device == device) ++count;
+    for (size_t i = 0; (total > limit || count > 512) && i < g_pool.held.size();) {    // this device's oldest out first
         if (g_pool.held[i].device != device) { ++i; continue; }
+        --count;
         total -= g_pool.held[i].bytes;
         DeviceGuard dg(device);
         (void)hipFree(g_pool.held[i].p);
@@ -1636,8 +1640,15 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
     // the bus one after the other while the device idled: 3.5 of the 28 ms of a 1M-vertex construction). `st` waits for them through an event.
     hipStream_t su = side_stream(device, 0);
     LS_REQUIRE(su, LS_E_STATE, "ls_direct_create: no side stream on this device");
+    auto table = [&](void** dst, size_t bytes) -> hipError_t {          // from the pool when a destroyed handle left one of this size there
+        size_t cap = bytes;
+        *dst = pool_take(device, bytes, &cap);
+        if (!*dst) { const hipError_t e = pool_alloc(device, dst, bytes); if (e != hipSuccess) return e; }
+        d->tables.emplace_back(*dst, cap);
+        return hipSuccess;
+    };
     auto up = [&](auto** dst, const auto* src, size_t n) -> int {
-        LS_HIP(pool_alloc(device, (void**)dst, std::max<size_t>(n, 1) * sizeof(**dst)));
+        LS_HIP(table((void**)dst, std::max<size_t>(n, 1) * sizeof(**dst)));
         if (n) LS_HIP(hipMemcpyAsync(*dst, src, n * sizeof(**dst), hipMemcpyHostToDevice, su));
         return LS_OK;
     };
@@ -1654,10 +1665,10 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
         true
 #endif
         ) {
-        hipError_t e = pool_alloc(device, (void**)&d->bp, sizeof(float) * (size_t)V * d->kmax);
-        if (e == hipSuccess) e = pool_alloc(device, (void**)&d->braw, sizeof(float) * (size_t)V * d->kmax);
-        if (e == hipSuccess) e = pool_alloc(device, (void**)&d->slots, sizeof(float) * (size_t)n_front * arity * d->kmax);
-        if (e == hipSuccess) e = pool_alloc(device, (void**)&d->xb, sizeof(float) * (size_t)std::max<int64_t>(n_bnd, 1) * d->kmax);
+        hipError_t e = table((void**)&d->bp, sizeof(float) * (size_t)V * d->kmax);
+        if (e == hipSuccess) e = table((void**)&d->braw, sizeof(float) * (size_t)V * d->kmax);
+        if (e == hipSuccess) e = table((void**)&d->slots, sizeof(float) * (size_t)n_front * arity * d->kmax);
+        if (e == hipSuccess) e = table((void**)&d->xb, sizeof(float) * (size_t)std::max<int64_t>(n_bnd, 1) * d->kmax);
 #ifdef LS_ND_EXPERIMENTS
         if (e == hipSuccess && span) {
             const size_t up_rows = (size_t)(V - d->upper_lo);
@@ -1723,14 +1734,13 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
 extern "C" int ls_direct_destroy(ls_direct* d) {
     if (!d) return LS_OK;
     DeviceGuard g(d->device);
-    (void)hipFree(d->tiles); (void)hipFree(d->ptiles); (void)hipFree(d->perm); (void)hipFree(d->ppos); (void)hipFree(d->push_ptr); (void)hipFree(d->push_tgt);
-    (void)hipFree(d->mask); (void)hipFree(d->bp); (void)hipFree(d->braw); (void)hipFree(d->slots); (void)hipFree(d->xb);
-    (void)hipFree(d->d_items); (void)hipFree(d->d_wgs); (void)hipFree(d->dbg); (void)hipFree(d->pull);
-    (void)hipFree(d->d_sjobs); (void)hipFree(d->d_ssync); (void)hipFree(d->d_swords); (void)hipFree(d->d_bnd); (void)hipFree(d->pslots);
+    (void)hipFree(d->dbg); (void)hipFree(d->d_swords); (void)hipFree(d->pslots);
     (void)hipFree(d->bp4); (void)hipFree(d->xt4); (void)hipFree(d->span_dbg);
     if (d->h_sfail) (void)hipHostFree(d->h_sfail);
     if (d->busy) (void)hipEventDestroy(d->busy);
     (void)hipDeviceSynchronize();                                   // (what hipFree did implicitly: nothing of the handle is in flight any more)
+    for (const auto& t : d->tables)                                 // tiles, perm, ppos, push lists, mask, items, pull, wgs, span jobs; bp, braw, slots, xb
+        if (!ls::pool_give(d->device, t.first, t.second)) (void)hipFree(t.first);
     for (size_t i = 0; i < d->owned.size(); ++i)
         if (!ls::pool_give(d->device, d->owned[i], i < d->owned_bytes.size() ? d->owned_bytes[i] : 0)) (void)hipFree(d->owned[i]);
     for (hipEvent_t e : d->ev) (void)hipEventDestroy(e);
