@@ -363,8 +363,8 @@ int ls_direct_pick_tree(int64_t V, int* leaf_size, int* arity);
 int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, const float* d_val, int64_t V, int64_t nnz,
                      const float* d_positions, int leaf_size, int arity, int tier_levels, int sparse_leaves, int shard_rank,
                      int shard_count, int device, void* stream, ls_direct** out);
-/* The direct solver keeps its LARGE device buffers (>= 64 MB: the constructor's fp64 fronts and work arrays -- 3-4 GB at 1M vertices, 14 GB
- * at 4M --, the analysis' scratch, a destroyed handle's factor arrays) in a per-process pool instead of freeing them: a remesh loop
+/* The direct solver keeps its device buffers (>= 256 KB: the constructor's fp64 fronts and work arrays -- 3-4 GB at 1M vertices, 14 GB
+ * at 4M --, the analysis' scratch, a destroyed handle's factor arrays, index tables and vectors) in a per-process pool instead of freeing them: a remesh loop
  * (scripts/main.py:137-169) destroys a solver and constructs one of nearly the same size again and again, and the runtime gives freed
  * memory back lazily -- at the 4M size every second or third construction stalled 0.45-0.7 s inside one hipMalloc. The pool holds at most
  * LS_POOL_GB per device (environment, default 24; 0 = no pool; oldest out first) and never more than a quarter of the device's memory. An
