@@ -353,6 +353,17 @@ __global__ __launch_bounds__(1024) void k_nd_down(const Tile* __restrict__ tiles
     }
 }
 
+#ifdef LS_ND_EXPERIMENTS
+// timing experiments of the lanes-along-the-reduction level kernels (wrong results; environment LS_ND_ABLATE, read when a handle is made):
+//   1 no vector loads (zeros staged)   2 only the first batch of matrix rows   4 no epilogue (no stores, no hand-down)   8 no matrix loads at all
+//   16 the down sweep reads its W rows from the array the UP sweep has just read (same sizes and offsets, wrong values): what a factor
+//      layout shared by both sweeps would find in the Infinity Cache around the root
+__device__ int g_nd_ablate = 0;
+__device__ const float* g_nd_alias = nullptr;
+#define ND_ABLATE(bit) ((g_nd_ablate & (bit)) != 0)
+#else
+#define ND_ABLATE(bit) false
+#endif
 // ---- lanes along the reduction ----------------------------------------------------------------------------------
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_sum_step(float v) {
@@ -510,16 +521,23 @@ __global__ __launch_bounds__(64 * ND_BW) void k_nd_down_b(const Tile* __restrict
     const int jw = t.row0 + w * ND_ROWS * chunks;
     const int wrows = max(0, min(ND_ROWS * chunks, s - jw));
     const float* __restrict__ frow = finv + t.finv_off + (size_t)jw * s;
+#ifdef LS_ND_EXPERIMENTS
+    const float* __restrict__ wrow = (ND_ABLATE(16) && g_nd_alias && t.s >= 400 ? g_nd_alias : wf) + t.w_off + (size_t)jw * b;   // (1M plane: levels 1-2, whose up launches read wb)
+#else
     const float* __restrict__ wrow = wf + t.w_off + (size_t)jw * b;
+#endif
     f4u first_f[ND_ROWS][ND_E], first_w[ND_ROWS][ND_E];
-    rows_load(frow, (size_t)s, min(wrows, ND_ROWS), s, 0, first_f);          // in flight while the vectors are staged
-    rows_load(wrow, (size_t)b, min(wrows, ND_ROWS), b, 0, first_w);
+    rows_load(frow, (size_t)s, ND_ABLATE(8) ? 0 : min(wrows, ND_ROWS), s, 0, first_f);          // in flight while the vectors are staged
+    rows_load(wrow, (size_t)b, ND_ABLATE(8) ? 0 : min(wrows, ND_ROWS), b, 0, first_w);
     int p0 = 0, p1 = 0;
     size_t g = 0;
     if (lane < wrows) {
         g = (size_t)perm[t.own_start + jw + lane];
         if (!t.leaf) { p0 = push_ptr[t.front_off + jw + lane]; p1 = push_ptr[t.front_off + jw + lane + 1]; }
     }
+    if (ND_ABLATE(1)) {
+        for (int u = threadIdx.x; u < (s + b) * K; u += blockDim.x) sm[u < s * K ? u : (size_t)s_cap * K + (u - s * K)] = 0.0f;
+    } else {
     if (rf.slots && t.pfront_off < 0) root_bprime<K>(t, rf, sb);
     else
     for (int u = threadIdx.x; u < s; u += blockDim.x) {
@@ -529,6 +547,7 @@ __global__ __launch_bounds__(64 * ND_BW) void k_nd_down_b(const Tile* __restrict
     for (int i = threadIdx.x; i < b; i += blockDim.x) {
 #pragma unroll
         for (int q = 0; q < K; ++q) sx[i * K + q] = -xb[(size_t)(t.bnd_off + i) * K + q];
+    }
     }
     __syncthreads();
     float mine[K];
@@ -545,16 +564,20 @@ __global__ __launch_bounds__(64 * ND_BW) void k_nd_down_b(const Tile* __restrict
         }
         const float* __restrict__ fc = frow + (size_t)c * ND_ROWS * s;
         const float* __restrict__ wc = wrow + (size_t)c * ND_ROWS * b;
-        if (c) { rows_load(fc, (size_t)s, nrows, s, 0, first_f); rows_load(wc, (size_t)b, nrows, b, 0, first_w); }
-        dot_rows<K>(fc, (size_t)s, nrows, s, sb, first_f, acc);
-        dot_rows<K>(wc, (size_t)b, nrows, b, sx, first_w, acc);
+        if (c && !ND_ABLATE(8)) { rows_load(fc, (size_t)s, nrows, s, 0, first_f); rows_load(wc, (size_t)b, nrows, b, 0, first_w); }
+        const bool short_loop = ND_ABLATE(2) || ND_ABLATE(8);
+        dot_rows<K>(fc, (size_t)s, nrows, short_loop ? min(s, 256 * ND_E) : s, sb, first_f, acc);
+        dot_rows<K>(wc, (size_t)b, nrows, short_loop ? min(b, 256 * ND_E) : b, sx, first_w, acc);
         rows_to_lanes<K>(acc, c * ND_ROWS, mine);
     }
-    if (lane < wrows) {
+    if (lane < wrows && !ND_ABLATE(4)) {
 #pragma unroll
         for (int q = 0; q < K; ++q) x_out[g * K + q] = mine[q];
         push_down<K>(push_tgt, p0, p1, xb, mine);
     }
+#ifdef LS_ND_EXPERIMENTS
+    if (ND_ABLATE(4) && mine[0] == 123.456f) x_out[0] = mine[0];         // (keeps the products alive)
+#endif
 }
 
 // ---- small nodes (the lower tree levels): the node's whole matrix staged in LDS ------------------------------------
@@ -1727,6 +1750,10 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
     (void)span;
 #endif
     lap("kernel attributes set");
+#ifdef LS_ND_EXPERIMENTS
+    { const int ab = env_int0("LS_ND_ABLATE", 0); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_nd_ablate), &ab, sizeof(int));
+      const float* alias = d->wb; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_nd_alias), &alias, sizeof(alias)); }
+#endif
     *out = d;
     return LS_OK;
 }
