@@ -50,7 +50,12 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 // matrices of a few hundred tiles -- one workgroup per CU: with the loads of a slice issued, waited for and only then multiplied,
 // every 16-deep slice cost a memory round trip): 9.1 -> 5.0 ms of products per construction at 1M vertices (118 launches; the largest
 // 366 -> 276 us), constructor 0.039-0.042 -> 0.030-0.032 s (profiles/r04_gemm_prefetch.txt).
+// TT = 64: the tile above. TT = 32 (a wave owns a 16 x 16 quadrant, ONE instruction per 4-deep step): for launches of a few tiles -- the 2 x 2
+// Schur recursion of the top levels multiplies blocks of 125-500 rows one launch after the other, 4-64 tiles of 64 x 64 on 256 CUs; with
+// quarter tiles four times as many workgroups share the work and a launch takes a third of the time (same sums in the same order: bit-identical).
+template <int TT>
 __global__ __launch_bounds__(256) void k_gemm_batched(const GemmDesc* __restrict__ descs) {
+    constexpr int GT = TT, MI = TT / 32;                           // (shadows the 64 of the host side) instruction tiles per quadrant side
     const GemmDesc d = descs[blockIdx.y];
     const int tiles_n = (d.N + GT - 1) / GT, tiles_m = (d.M + GT - 1) / GT;
     if ((int)blockIdx.x >= tiles_m * tiles_n || d.M <= 0 || d.N <= 0) return;
@@ -59,13 +64,13 @@ __global__ __launch_bounds__(256) void k_gemm_batched(const GemmDesc* __restrict
     const bool mirror = d.sym && tn < tm;
     __shared__ double sa[GK][GT + 1], sb[GK][GT + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;        // this wave's quadrant
+    const int wm = (wave >> 1) * (GT / 2), wn = (wave & 1) * (GT / 2);        // this wave's quadrant
     const int l15 = lane & 15, l4 = lane >> 4;
-    f64x4 acc[2][2];
+    f64x4 acc[MI][MI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < MI; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
     constexpr int PER = GK * GT / 256;                             // elements of either slice per thread
     double ra[PER], rb[PER];
     // element e of a slice: A (m, k), B (k, n); the index order follows the storage order so that consecutive threads read consecutive memory
@@ -99,23 +104,24 @@ __global__ __launch_bounds__(256) void k_gemm_batched(const GemmDesc* __restrict
         if (k0 + GK < d.K) fetch(k0 + GK);                          // in flight while this slice is multiplied
 #pragma unroll
         for (int k4 = 0; k4 < GK; k4 += 4) {
-            const double a0 = sa[k4 + l4][wm + l15], a1 = sa[k4 + l4][wm + 16 + l15];
-            const double b0 = sb[k4 + l4][wn + l15], b1 = sb[k4 + l4][wn + 16 + l15];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+            double av[MI], bv[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) { av[i] = sa[k4 + l4][wm + 16 * i + l15]; bv[i] = sb[k4 + l4][wn + 16 * i + l15]; }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < MI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int gm = tm + wm + 16 * i + l4 + 4 * v;
             if (gm >= d.M) continue;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < MI; ++j) {
                 const int gn = tn + wn + 16 * j + l15;
                 if (gn >= d.N) continue;
                 double* c = d.C + (size_t)gm * d.ldc + gn;
@@ -393,11 +399,20 @@ struct FactorCtx {
 
 void gemm_batched(FactorCtx& c, std::vector<GemmDesc>& v) {
     const size_t off = c.gemm.size();
-    int tiles = 0;
+    int tiles = 0, tiles32 = 0;
+    int64_t all = 0;
     for (const GemmDesc& d : v)
-        if (d.M > 0 && d.N > 0) { c.gemm.push_back(d); tiles = std::max(tiles, div_up(d.M, GT) * div_up(d.N, GT)); }
+        if (d.M > 0 && d.N > 0) {
+            c.gemm.push_back(d);
+            const int t64 = div_up(d.M, GT) * div_up(d.N, GT);
+            tiles = std::max(tiles, t64); tiles32 = std::max(tiles32, div_up(d.M, 32) * div_up(d.N, 32));
+            all += d.sym ? (t64 + div_up(d.M, GT)) / 2 : t64;
+        }
     v.clear();
-    if (c.gemm.size() > off) c.cmds.push_back(Cmd{0, off, (int)(c.gemm.size() - off), tiles, 0});
+    // fewer 64 x 64 tiles than half the chip's CUs in the whole launch: quarter tiles (Cmd::nmax carries the tile size of a product)
+    static const int small = [] { const char* e = getenv("LS_GEMM_SMALL_TILES"); return e ? atoi(e) : 128; }();
+    const bool quarter = all < small;
+    if (c.gemm.size() > off) c.cmds.push_back(Cmd{0, off, (int)(c.gemm.size() - off), quarter ? tiles32 : tiles, quarter ? 32 : 64});
 }
 
 void inverse_small(FactorCtx& c, const std::vector<Blk>& v) {
@@ -790,7 +805,10 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
         for (int b0 = 0; b0 < c.n; b0 += 65535) {
             const int nb = std::min(65535, c.n - b0);
             switch (c.kind) {
-            case 0: hipLaunchKernelGGL(k_gemm_batched, dim3(c.gx, nb), dim3(256), 0, st, (const GemmDesc*)(d_gemm + c.off + b0)); break;
+            case 0:
+                if (c.nmax == 32) hipLaunchKernelGGL(k_gemm_batched<32>, dim3(c.gx, nb), dim3(256), 0, st, (const GemmDesc*)(d_gemm + c.off + b0));
+                else hipLaunchKernelGGL(k_gemm_batched<64>, dim3(c.gx, nb), dim3(256), 0, st, (const GemmDesc*)(d_gemm + c.off + b0));
+                break;
             case 1:
                 if (c.nmax <= 64) hipLaunchKernelGGL(k_spd_inverse_reg<64>, dim3(nb), dim3(256), 0, st, (const InvDesc*)(d_invd + c.off + b0), d_flag);
                 else hipLaunchKernelGGL(k_spd_inverse_reg<128>, dim3(nb), dim3(256), 0, st, (const InvDesc*)(d_invd + c.off + b0), d_flag);
