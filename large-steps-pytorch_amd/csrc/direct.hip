@@ -975,9 +975,21 @@ struct DevicePool {
         const char* e = getenv("LS_POOL_GB");
         double gb = e ? atof(e) : 24.0;        // (a 4M-vertex construction leaves 14 GB of scratch + 2.4 GB of factor: with 16 the fronts were evicted every time)
         if (!(gb > 0.0)) return 0;
-        size_t free_b = 0, total_b = 0;
-        DeviceGuard dg(device);
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) gb = std::min(gb, (double)total_b / 4.0 / 1073741824.0);
+        // the device's memory size is asked for once (hipMemGetInfo is a driver call, and every buffer handed back comes through here:
+        // ~40 per construction since the small arrays are pooled too)
+        static std::mutex mu;
+        static double total_gb[64];
+        double t = 0.0;
+        if (device >= 0 && device < 64) {
+            std::lock_guard<std::mutex> lk(mu);
+            if (total_gb[device] == 0.0) {
+                size_t free_b = 0, total_b = 0;
+                DeviceGuard dg(device);
+                total_gb[device] = (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) ? (double)total_b / 1073741824.0 : -1.0;
+            }
+            t = total_gb[device];
+        }
+        if (t > 0.0) gb = std::min(gb, t / 4.0);
         return (size_t)(gb * 1073741824.0);
     }
 };

@@ -1197,8 +1197,18 @@ def test_buffer_pool_between_constructions(dev):
     from largesteps.geometry import compute_matrix
     from largesteps.parameterize import to_differential
     from largesteps.solvers import NestedDissectionSolver, release_scratch
+    # one small round first: what the runtime allocates ONCE per process (code objects of the library's and of torch's kernels, side
+    # streams) is not the pool's -- as the first GPU test of a process this test saw ~200 MB of it after its reference reading
+    v, f = synthetic.plane(40)
+    tv, tf = _t(v, dev), _t(f, dev)
+    M = compute_matrix(tv, tf, 20.0)
+    s = NestedDissectionSolver(M)
+    x = s.solve(to_differential(M, tv))
+    assert float((x - tv).abs().max()) <= 2e-5 and torch.equal(x, x.clone())
+    del s, x, M, tv, tf
+    gc.collect()
     release_scratch()
-    torch.cuda.synchronize()
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
     free0, _ = torch.cuda.mem_get_info()
     answers = []
     for n in (330, 300, 330, 350, 330):
