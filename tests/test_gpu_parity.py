@@ -1235,3 +1235,19 @@ def test_buffer_pool_between_constructions(dev):
     freed, _ = torch.cuda.mem_get_info()
     assert freed > held + (64 << 20), "the pool held buffers of the destroyed solvers and released them"
     assert freed >= free0 - (64 << 20), "nothing of the five constructions is left on the device"
+
+
+def test_many_constructions_in_one_process(dev):
+    """The remesh loop of the reference (scripts/main.py:137-169) makes and drops a solver every few hundred steps for as long as the optimisation
+    runs. tools/soak_constructor.py does that 150 times in a process of its own -- sizes in random order, up to three solvers alive at once, solves
+    on two streams, handles closed explicitly or by the collector, the buffer pool released now and then -- and checks every solve; what the
+    constructor keeps per process (thread pool, side streams, pooled buffers: DESIGN.md section 2.3) must neither mix up two solvers' arrays
+    nor leave memory behind."""
+    import re
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_constructor.py"), "150", "5"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    m = re.search(r"worst \|x - v\| ([0-9.e+-]+), device memory left behind since iteration 10: (-?[0-9.]+) MB", r.stdout)
+    assert m, r.stdout[-500:]
+    assert float(m.group(1)) <= 5e-5 and float(m.group(2)) <= 64.0, r.stdout[-300:]
