@@ -1251,3 +1251,7 @@ def test_many_constructions_in_one_process(dev):
     m = re.search(r"worst \|x - v\| ([0-9.e+-]+), device memory left behind since iteration 10: (-?[0-9.]+) MB", r.stdout)
     assert m, r.stdout[-500:]
     assert float(m.group(1)) <= 5e-5 and float(m.group(2)) <= 64.0, r.stdout[-300:]
+    # and from two host threads at the same time (the library releases no lock to Python, ctypes releases the GIL: the two threads' analyses --
+    # one on the process-wide thread pool, one on its own --, factorisations and table uploads overlap; side streams and pools are shared)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_threads.py"), "60"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "failures: none" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
