@@ -139,8 +139,8 @@ struct InvDesc { const double* M; double* X; int n, ldm, ldx, pad; };
 constexpr int INV_N = 128;
 
 // Gauss-Jordan sweeps in place (no pivoting: the pivots of an SPD matrix are the diagonal of its Schur complements, all positive).
-// 256 threads as a 16 x 16 grid, thread (by, bx) owns the RB x RB block of rows by * RB.. and columns bx * RB.. (RB = NB / 16: 4 x 4
-// doubles for NB = 64, 8 x 8 for NB = 128), rows and columns >= n padded with zeros (they stay zero). Step k needs row k and column
+// G x G threads, thread (by, bx) owns the RB x RB block of rows by * RB.. and columns bx * RB.. (RB = NB / G: 4 x 4 doubles in both
+// forms: 16 x 16 threads for NB = 64, 32 x 32 for NB = 128), rows and columns >= n padded with zeros (they stay zero). Step k needs row k and column
 // k of the current matrix: their owners publish them to LDS at the end of step k - 1 (two buffers, by parity), so a step is ONE
 // barrier, 2 RB + 1 LDS reads and RB^2 fused multiply-adds per thread out of registers. The loop over k is blocked by RB with the
 // inner RB steps unrolled: which REGISTER holds row / column k is then known at compile time, only the owning thread is a run-time
@@ -148,14 +148,18 @@ constexpr int INV_N = 128;
 // (inverse_rec): the chain of launches, not the arithmetic, is what the factorisation waits for there -- the version with the matrix
 // in LDS took ~110 us per block (every element read and written through LDS in every step), and its 64-row limit meant one more
 // level of recursion (twice the chain).
-template <int NB>
-__global__ __launch_bounds__(256) void k_spd_inverse_reg(const InvDesc* __restrict__ descs, int* __restrict__ flag) {
-    constexpr int RB = NB / 16;
+// Round 4: the 128-row form of the CHAIN (launches of up to 64 blocks) runs 32 x 32 threads with 4 x 4 doubles each instead of 16 x 16 with 8 x 8: a lone wave per SIMD issues the
+// straight-line code of a step at ~12 cycles per instruction (tools/ubench/fp64_rate.hip, spd_inverse.hip: it waits for its instruction
+// fetches, not for the fp64 pipe), four waves per SIMD hide that: 80 -> 69 us per block, the same sums in the same order.
+template <int NB, int G>
+__global__ __launch_bounds__(G * G) void k_spd_inverse_reg(const InvDesc* __restrict__ descs, int* __restrict__ flag) {
+    constexpr int RB = NB / G;
+    static_assert(RB % 2 == 0, "the parity of k is the parity of kk");
     const InvDesc d = descs[blockIdx.x];
     const int n = d.n;
     if (n <= 0) return;
     __shared__ double rowb[2][NB], colb[2][NB];
-    const int bx = threadIdx.x & 15, by = threadIdx.x >> 4;
+    const int bx = threadIdx.x % G, by = threadIdx.x / G;
     double a[RB][RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
@@ -810,8 +814,9 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
                 else hipLaunchKernelGGL(k_gemm_batched<64>, dim3(c.gx, nb), dim3(256), 0, st, (const GemmDesc*)(d_gemm + c.off + b0));
                 break;
             case 1:
-                if (c.nmax <= 64) hipLaunchKernelGGL(k_spd_inverse_reg<64>, dim3(nb), dim3(256), 0, st, (const InvDesc*)(d_invd + c.off + b0), d_flag);
-                else hipLaunchKernelGGL(k_spd_inverse_reg<128>, dim3(nb), dim3(256), 0, st, (const InvDesc*)(d_invd + c.off + b0), d_flag);
+                if (c.nmax <= 64) hipLaunchKernelGGL((k_spd_inverse_reg<64, 16>), dim3(nb), dim3(256), 0, st, (const InvDesc*)(d_invd + c.off + b0), d_flag);
+                else if (nb <= 64) hipLaunchKernelGGL((k_spd_inverse_reg<128, 32>), dim3(nb), dim3(1024), 0, st, (const InvDesc*)(d_invd + c.off + b0), d_flag);
+                else hipLaunchKernelGGL((k_spd_inverse_reg<128, 16>), dim3(nb), dim3(256), 0, st, (const InvDesc*)(d_invd + c.off + b0), d_flag);   // a block per CU and more: 256 blocks 132 us, with 1024 threads 197
                 break;
             case 2: hipLaunchKernelGGL(k_extend_add, dim3(c.gx, nb), dim3(256), 0, st, (const int*)(d_ids + c.off + b0), nb, d_nodes, d_ppos, fronts); break;
             default:
