@@ -410,9 +410,18 @@ __device__ __forceinline__ void rows_fma(const f4u (&a)[ND_ROWS][ND_E], int len,
     for (int e = 0; e < ND_E; ++e) {
         const int t = t0 + (e * 64 + lane) * 4;
         if (t < len) {
+            // the lane's 4 consecutive vector entries = 4 K floats = K aligned 16-byte reads (t is a multiple of 4 and the vector starts on a
+            // 16-byte boundary; the last quad may reach up to 3 entries past len: inside the workgroup's LDS, never used). With a test per
+            // element the compiler read dword by dword at a lane stride of 12 K bytes: 4-way bank conflicts, 68 % of the kernel's LDS cycles
+            // (SQ_LDS_BANK_CONFLICT, profiles/r04_pmc_sq_counters.txt).
+            typedef float f4a __attribute__((ext_vector_type(4)));
             float v[4 * K];
+            const f4a* __restrict__ pv = reinterpret_cast<const f4a*>(sv + (size_t)t * K);
 #pragma unroll
-            for (int q = 0; q < 4 * K; ++q) v[q] = (t + q / K < len) ? sv[t * K + q] : 0.0f;
+            for (int i = 0; i < K; ++i) {
+                const f4a w = pv[i];
+                v[4 * i] = w[0]; v[4 * i + 1] = w[1]; v[4 * i + 2] = w[2]; v[4 * i + 3] = w[3];
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if (t + c < len) {
@@ -512,7 +521,7 @@ __global__ __launch_bounds__(64 * ND_BW) void k_nd_down_b(const Tile* __restrict
                                                           int s_cap, int b_cap, int chunks, RootFill rf) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sb = sm;
-    float* sx = sm + (size_t)s_cap * K;
+    float* sx = sm + (((size_t)s_cap * K + 3) & ~(size_t)3);      // (16-byte aligned: rows_fma reads the vectors in quads)
     const Tile t = load_tile(tiles, blockIdx.x);
     if (t.forward == 2) return;                 // padding of the XCD-aware tile order
     if (t.forward) { forward_rows<K>(t, push_ptr, push_tgt, xb); return; }
@@ -536,7 +545,7 @@ __global__ __launch_bounds__(64 * ND_BW) void k_nd_down_b(const Tile* __restrict
         if (!t.leaf) { p0 = push_ptr[t.front_off + jw + lane]; p1 = push_ptr[t.front_off + jw + lane + 1]; }
     }
     if (ND_ABLATE(1)) {
-        for (int u = threadIdx.x; u < (s + b) * K; u += blockDim.x) sm[u < s * K ? u : (size_t)s_cap * K + (u - s * K)] = 0.0f;
+        for (int u = threadIdx.x; u < (s + b) * K; u += blockDim.x) (u < s * K ? sb[u] : sx[u - s * K]) = 0.0f;
     } else {
     if (rf.slots && t.pfront_off < 0) root_bprime<K>(t, rf, sb);
     else
@@ -1895,7 +1904,7 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
             hipLaunchKernelGGL(k_nd_up_s<K>, dim3(p.up_tiles), dim3(WAVE * p.up_nw), ((size_t)p.s_cap * p.b_cap + (size_t)p.s_cap * K) * sizeof(float), st,
                                d->tiles + p.up_first, up_perm, d->mask, d->ppos, d->wf, up_b, d->bp, d->slots, p.s_cap, p.b_cap);
         else if (p.up_b)
-            hipLaunchKernelGGL(k_nd_up_b<K>, dim3(p.up_tiles), dim3(WAVE * p.up_nw), (size_t)p.s_cap * K * sizeof(float), st, d->tiles + p.up_first,
+            hipLaunchKernelGGL(k_nd_up_b<K>, dim3(p.up_tiles), dim3(WAVE * p.up_nw), ((size_t)p.s_cap * K + 16) * sizeof(float), st, d->tiles + p.up_first,
                                up_perm, d->mask, d->ppos, d->wb, up_b, d->bp, d->slots, p.s_cap, p.up_chunks);
         else
             hipLaunchKernelGGL(k_nd_up<K>, dim3(p.up_tiles), dim3(WAVE * p.up_nw), ((size_t)p.s_cap + (size_t)(p.up_nw - 1) * WAVE) * K * sizeof(float),
@@ -1921,7 +1930,7 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
                                ((size_t)p.s_cap * (p.s_cap + p.b_cap) + (size_t)(p.s_cap + p.b_cap) * K) * sizeof(float), st, d->tiles + p.down_first,
                                d->perm, d->push_ptr, d->push_tgt, d->finv, d->wb, (const float*)d->bp, d->xb, x, p.s_cap, p.b_cap);
         else if (p.down_b)
-            hipLaunchKernelGGL(k_nd_down_b<K>, dim3(p.down_tiles), dim3(WAVE * p.down_nw), ((size_t)p.s_cap + p.b_cap) * K * sizeof(float), st,
+            hipLaunchKernelGGL(k_nd_down_b<K>, dim3(p.down_tiles), dim3(WAVE * p.down_nw), (((size_t)p.s_cap + p.b_cap) * K + 32) * sizeof(float), st,
                                d->tiles + p.down_first, d->perm, d->push_ptr, d->push_tgt, d->finv, d->wf, (const float*)d->bp, d->xb, x,
                                p.s_cap, p.b_cap, p.down_chunks, lv == 0 ? rf : RootFill{nullptr, nullptr, nullptr, nullptr});
         else
