@@ -539,8 +539,8 @@ __global__ __launch_bounds__(256) void k_dedup_faces(const IdxT* __restrict__ fa
 extern "C" int ls_remove_duplicates_workspace_bytes(int64_t V, size_t* h_bytes) {
     LS_REQUIRE(h_bytes && V >= 0, LS_E_INVALID, "ls_remove_duplicates_workspace_bytes: bad argument");
     const size_t nb = (size_t)div_up(std::max<int64_t>(V, 1), rs_chunk(V));
-    // order a / b, flags, uid (V + 1), histogram + its scan (256 nb + 1 each), scan block sums
-    *h_bytes = sizeof(int) * ((size_t)V * 4 + 16 + 2 * (256 * nb + 16) + (size_t)div_up(std::max<int64_t>(std::max<int64_t>(V, 256 * (int64_t)nb), 1), SCAN_CHUNK) + 64) + 256;
+    // order a / b, flags, uid (V + 1), carried keys a / b, histogram + its scan (256 nb + 1 each), scan block sums
+    *h_bytes = sizeof(int) * ((size_t)V * 6 + 16 + 2 * (256 * nb + 16) + (size_t)div_up(std::max<int64_t>(std::max<int64_t>(V, 256 * (int64_t)nb), 1), SCAN_CHUNK) + 64) + 256;
     return LS_OK;
 }
 
@@ -563,13 +563,15 @@ extern "C" int ls_remove_duplicates(const float* verts, int64_t V, const void* f
     int* ord_b = ord_a + V;
     int* flag = ord_b + V;
     int* uid = flag + V;                       // V + 1
-    int* hist = uid + V + 16;                  // 256 nb
+    unsigned* keys_a = (unsigned*)(uid + V + 16);
+    unsigned* keys_b = keys_a + V;
+    int* hist = (int*)(keys_b + V);            // 256 nb
     int* offs = hist + 256 * (size_t)nb + 16;  // 256 nb + 1
     int* bsum = offs + 256 * (size_t)nb + 16;
     const int* src = nullptr;
     {
-        KeyVerts key{verts};
-        const int rc0 = radix_argsort(key, V, 12, ord_a, ord_b, hist, offs, bsum, st, &src);
+        KeyVerts key{verts};                   // three 32-bit key words (z, y, x), each gathered once and carried through its four byte passes
+        const int rc0 = radix_argsort_words(key, V, 3, ord_a, ord_b, keys_a, keys_b, hist, offs, bsum, st, &src);
         if (rc0) return rc0;
     }
     const int vg = div_up(V, 256);

@@ -288,6 +288,7 @@ std::string nd_bisect_device(void* ctx, int64_t V, int D, int smooth, const doub
     const size_t o_ax = take(sizeof(int) * max_dom), o_half = take(sizeof(int) * max_dom), o_ecnt = take(sizeof(int) * 2 * (size_t)max_dom),
                  o_use1 = take(sizeof(int) * max_dom), o_b0 = take(sizeof(int) * max_dom), o_b1 = take(sizeof(int) * max_dom);
     const size_t o_bsum = take(sizeof(unsigned long long) * 3 * (size_t)nb);
+    const size_t o_keys = take(sizeof(unsigned) * 2 * (size_t)V);            // carried key words of the coordinate sorts
     const size_t o_hist = take(sizeof(int) * (256 * nbr + 16)), o_offs = take(sizeof(int) * (256 * nbr + 16)),
                  o_sb = take(sizeof(int) * ((size_t)scan_blocks(256 * (int64_t)nbr) + 64));
     int dev = 0;
@@ -321,7 +322,8 @@ std::string nd_bisect_device(void* ctx, int64_t V, int D, int smooth, const doub
     int* Lo[3];
     for (int k = 0; k < 3; ++k) {
         const int* res = nullptr;
-        const int rc = radix_argsort(KeyF64{pos, k}, V, 8, L[2 * k], L[2 * k + 1], (int*)(base + o_hist), (int*)(base + o_offs), (int*)(base + o_sb), st, &res);
+        const int rc = radix_argsort_words(KeyF64{pos, k}, V, 2, L[2 * k], L[2 * k + 1], (unsigned*)(base + o_keys), (unsigned*)(base + o_keys) + V, (int*)(base + o_hist),
+                                           (int*)(base + o_offs), (int*)(base + o_sb), st, &res);
         if (rc) return "nd_bisect_device: sort failed";
         Lc[k] = res;
         Lo[k] = res == L[2 * k] ? L[2 * k + 1] : L[2 * k];
