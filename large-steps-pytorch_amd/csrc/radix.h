@@ -29,6 +29,7 @@ struct KeyVerts {
 struct KeyInt {
     const int* keys;
     __device__ __forceinline__ unsigned digit(int row, int pass) const { return ((unsigned)keys[row] >> (8 * pass)) & 255u; }
+    __device__ __forceinline__ unsigned word(int row, int) const { return (unsigned)keys[row]; }
 };
 
 // lanes of the wave that hold the same digit as this lane (eight ballots); `ok` = the lane takes part
@@ -232,10 +233,11 @@ static inline int radix_argsort(Key key, int64_t n, int passes, int* ord_a, int*
     return LS_OK;
 }
 
-// the same order (bit for bit) by `words` 32-bit key words, keys carried; keys_a / keys_b: n unsigned each
+// the same order (bit for bit) by `words` 32-bit key words, keys carried; keys_a / keys_b: n unsigned each; last_bytes: byte passes of the LAST word
+// (keys known to be small: fewer passes)
 template <typename Key>
 static inline int radix_argsort_words(Key key, int64_t n, int words, int* ord_a, int* ord_b, unsigned* keys_a, unsigned* keys_b, int* hist, int* offs, int* bsum,
-                                      hipStream_t st, const int** result) {
+                                      hipStream_t st, const int** result, int last_bytes = 4) {
     const int nb = ls::div_up(n, ls::rs_chunk(n));
     const int* src = nullptr;                  // word 0 is loaded in the identity order
     int* dst = ord_a;
@@ -243,12 +245,13 @@ static inline int radix_argsort_words(Key key, int64_t n, int words, int* ord_a,
         hipLaunchKernelGGL(ls::k_rs_load<Key>, dim3(ls::div_up(n, 256)), dim3(256), 0, st, key, src, n, w, keys_a);
         unsigned* kin = keys_a;
         unsigned* kout = keys_b;
-        for (int byte = 0; byte < 4; ++byte) {
+        const int nbytes = w + 1 == words ? last_bytes : 4;
+        for (int byte = 0; byte < nbytes; ++byte) {
             hipLaunchKernelGGL(ls::k_rs_hist32<0>, dim3(nb), dim3(256), 0, st, (const unsigned*)kin, n, 8 * byte, nb, hist);
             int rc = ls::exclusive_scan(hist, 256 * (int64_t)nb, offs, bsum, st);
             if (rc) return rc;
             hipLaunchKernelGGL(ls::k_rs_scatter32<0>, dim3(nb), dim3(64), 0, st, (const unsigned*)kin, src, n, 8 * byte, nb, (const int*)offs,
-                               byte < 3 ? kout : (unsigned*)nullptr, dst);
+                               byte + 1 < nbytes ? kout : (unsigned*)nullptr, dst);
             src = dst;
             dst = (dst == ord_a) ? ord_b : ord_a;
             std::swap(kin, kout);
