@@ -2,7 +2,7 @@
 # full GPU pass of round 4 on the final state: everything DESIGN.md / BASELINE.md quote from profiles/r04_run1_*
 set -u
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/full_r04_5; rm -rf $O; mkdir -p $O/pmc
+O=gpurun_out/full_r04_6; rm -rf $O; mkdir -p $O/pmc
 export TMPDIR=/tmp
 ( timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -30 ) > $O/pytest.log 2>&1
 ( timeout 200 python -c "import __graft_entry__ as g; g.smoke()" ) > $O/smoke.log 2>&1
