@@ -321,17 +321,6 @@ typedef struct ls_direct_arrays {
     const void* d_sp_ent;          /* {float value; int32 index} pairs */
     int64_t n_sp_ptr, n_sp_ent;    /* lengths of the two sparse-leaf arrays (accounting only) */
     int32_t shard_rank, shard_count;   /* subtree sharding over `shard_count` processes (0 or 1: none), see ls_direct_solve_part */
-    /* Optional (all NULL: the levels above the tier run as one launch per level and sweep): the same factor of the levels above
-     * the tier in the layouts of the persistent upper-level launch (csrc/nd_span.h), rows 16-byte aligned and zero padded
-     * (s4 / b4 = s / b rounded up to 4), offsets (floats, multiples of 4) per node id in h_pu_off / h_pd_off (n_nodes + 1):
-     *     d_pu[pu_off + i * s4 + j] = W[i][j]                                   (i < b)
-     *     d_pd[pd_off + j * (s4 + b4) + t] = [F_ss^-1 (s4 columns) | W^T][j][t]  (j < s)
-     * and h_bnd (n_bnd): the tree-numbering vertex id of every boundary entry. */
-    const float* d_pu;
-    const float* d_pd;
-    const int64_t* h_pu_off;
-    const int64_t* h_pd_off;
-    const int32_t* h_bnd;
 } ls_direct_arrays;
 int ls_direct_create(const ls_direct_arrays* arrays, int device, void* stream, ls_direct** out);
 /* The tree ls_direct_factor picks for a V x V system: on entry *leaf_size / *arity <= 0 mean "pick" (explicit values are kept), on return
@@ -425,25 +414,17 @@ int ls_dist_unique_id(void* h_id128);
 int ls_dist_create(const void* h_id128, int rank, int world, int device, ls_dist** out);
 int ls_dist_destroy(ls_dist* c);
 int ls_dist_allreduce_sum(ls_dist* c, float* d_buf, int64_t n, void* stream);
+/* what the RCCL communicator itself reports (ncclCommUserRank / ncclCommCount), not what the caller passed to ls_dist_create */
+int ls_dist_info(const ls_dist* c, int* h_rank, int* h_world);
 int ls_dist_direct_solve(ls_dist* c, ls_direct* d, const float* b, float* x, int k, void* stream);
 /* knobs: "profile" (1: the next solves time the up sweep and the down sweep with HIP events and synchronise; 3: an event in
- * front of every launch, read back by ls_direct_launch_profile; 2: the
- * tier kernels also record shader-clock stamps per wave, read back by ls_direct_tier_stamps -- experiments builds only);
- * "persist" (1 / 0: the levels above the tier as one persistent launch, csrc/nd_span.h, or one launch per level and sweep;
- * default 0 -- measured slower on the MI355X; environment LS_ND_PERSIST=1 at creation turns it on where the
- * handle has the layouts for it) */
+ * front of every launch, read back by ls_direct_launch_profile);
+ * "nt" (cache policy of the read-once factor streams: 1 non-temporal loads, 0 default policy, -1 the library's rule -- non-temporal
+ * once the factor exceeds what the 256 MB Infinity Cache keeps from solve to solve; results are bit-identical either way) */
 int ls_direct_set(ls_direct* d, const char* name, int value);
 /* host-only: 4-byte words of factor data one solve reads, kernel launches per solve, {up sweep, down sweep, 0} ms of the
  * last profiled solve (any pointer may be NULL) */
 int ls_direct_info(const ls_direct* d, int64_t* h_factor_entries, int* h_launches, double* h_ms3);
-/* SYNC, profiling only ("profile" = 2): 32 stamps per wave of the last up-sweep tier launch (tier workgroups x 4 waves),
- * then the same for the down sweep: [0] start, [1 + 2p] / [2 + 2p] work of phase p done / its barrier passed,
- * [16 + r] the wave's r-th leaf done. h_out: n int64 values, n <= 2 x workgroups x 4 x 32. */
-int ls_direct_tier_stamps(const ls_direct* d, long long* h_out, int64_t n);
-/* the same for the persistent upper-level launch (csrc/nd_span.h): workgroups x phases x 8 stamps (0 phase entered, 1 wait
- * over, 2 vector in LDS, 3 products done, 4 jobs done, 5 stores drained, 6 arrived, 7 next phase requested); h_workgroups /
- * h_phases (may be NULL) always receive the launch's shape (0 x 0: the handle has no such launch); h_out may be NULL. */
-int ls_direct_span_stamps(const ls_direct* d, long long* h_out, int64_t n, int* h_workgroups, int* h_phases);
 
 /* ---- remove_duplicates (reference scripts/geometry.py:3-11) --------------------------------------
  * unique_verts = the distinct rows of verts ((V, 3) fp32) in lexicographic order of their VALUES (-0.0 == 0.0), exactly what

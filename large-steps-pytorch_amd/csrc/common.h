@@ -62,6 +62,34 @@ inline int64_t scan_blocks(int64_t n) { return (n + 2047) / 2048; }
 
 template <int K> struct Vec { float v[K]; };   // K interleaved right-hand-side columns of one vertex (4-byte aligned)
 
+// Read-once factor streams. A solve reads every word of the dense factor blocks exactly once per sweep, while the vectors, slot
+// records and index lists next to them are re-read by neighbouring tiles and by the next launch. When the factor does not fit the
+// 256 MB Infinity Cache anyway, its loads carry the non-temporal policy (global_load ... nt: the line is not kept behind the read) and
+// stop evicting what IS re-used: 1M vertices 214 -> 199 us per solve, 4M 722 -> 705 (profiles/r05_nt_policy.txt). Below that size the
+// whole factor stays cache resident from solve to solve and nt costs 5-15 %: the policy is a template parameter the handle picks
+// (ls_direct_create). The leaves' packed triangles never carry it: both sweeps read the same triangle.
+template <bool NT, typename T>
+__device__ __forceinline__ T ld_stream(const T* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+typedef float ls_f4v __attribute__((ext_vector_type(4)));
+typedef float ls_f2v __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ float2 ld_stream2(const float2* p) {
+    if constexpr (NT) {
+        const ls_f2v v = __builtin_nontemporal_load(reinterpret_cast<const ls_f2v*>(p));
+        return make_float2(v[0], v[1]);
+    } else return *p;
+}
+template <bool NT>
+__device__ __forceinline__ float4 ld_stream4(const float4* p) {
+    if constexpr (NT) {
+        const ls_f4v v = __builtin_nontemporal_load(reinterpret_cast<const ls_f4v*>(p));
+        return make_float4(v[0], v[1], v[2], v[3]);
+    } else return *p;
+}
+
 // ---- DPP wave reductions ---------------------------------------------------------------------------
 // __shfl_down lowers to ds_bpermute (an LDS-crossbar round trip, ~100+ cycles per dependent step); a
 // 6-step fp64 butterfly per value made the dot-product hand-off of the PCG kernels cost ~4 us per launch

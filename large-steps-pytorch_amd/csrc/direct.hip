@@ -187,7 +187,7 @@ __device__ __forceinline__ void push_down(const int* __restrict__ push_tgt, int 
 
 // ---- a row per lane ---------------------------------------------------------------------------------------------
 // acc += sum_{u in [u0, u1)} col[u * stride] * sv[u * K + q]; the first ND_UNROLL values were prefetched
-template <int K, int ND_UNROLL>
+template <int K, bool NT, int ND_UNROLL>
 __device__ __forceinline__ void dot_strided(const float* __restrict__ col, size_t stride, int u0, int u1,
                                             const float* __restrict__ sv, const float (&pre)[ND_UNROLL], float (&acc)[K]) {
 #pragma unroll
@@ -201,7 +201,7 @@ __device__ __forceinline__ void dot_strided(const float* __restrict__ col, size_
     for (; u + ND_UNROLL <= u1; u += ND_UNROLL) {
         float a[ND_UNROLL];
 #pragma unroll
-        for (int e = 0; e < ND_UNROLL; ++e) a[e] = col[(size_t)(u + e) * stride];
+        for (int e = 0; e < ND_UNROLL; ++e) a[e] = ld_stream<NT>(col + (size_t)(u + e) * stride);
 #pragma unroll
         for (int e = 0; e < ND_UNROLL; ++e) {
 #pragma unroll
@@ -209,16 +209,16 @@ __device__ __forceinline__ void dot_strided(const float* __restrict__ col, size_
         }
     }
     for (; u < u1; ++u) {
-        const float a = col[(size_t)u * stride];
+        const float a = ld_stream<NT>(col + (size_t)u * stride);
 #pragma unroll
         for (int q = 0; q < K; ++q) acc[q] = fmaf(a, sv[u * K + q], acc[q]);
     }
 }
 
-template <int ND_UNROLL>
+template <bool NT, int ND_UNROLL>
 __device__ __forceinline__ void prefetch_strided(const float* __restrict__ col, size_t stride, int u0, int u1, float (&pre)[ND_UNROLL]) {
 #pragma unroll
-    for (int e = 0; e < ND_UNROLL; ++e) pre[e] = (u0 + e < u1) ? col[(size_t)(u0 + e) * stride] : 0.0f;
+    for (int e = 0; e < ND_UNROLL; ++e) pre[e] = (u0 + e < u1) ? ld_stream<NT>(col + (size_t)(u0 + e) * stride) : 0.0f;
 }
 
 // sum of acc over the NW waves of the workgroup, result in wave 0 (red: (NW-1) * 64 * K floats)
@@ -241,7 +241,7 @@ __device__ __forceinline__ void reduce_waves(float (&acc)[K], float* __restrict_
 
 // Up sweep, one tree level:  b'_s = b_s - (slots at own_i)  [stored for the down sweep];
 //                            upd_i = W_i b'_s + (slots at bnd_i)  -> the parent's slots
-template <int K>
+template <int K, bool NT>
 __global__ __launch_bounds__(1024) void k_nd_up(const Tile* __restrict__ tiles, const int* __restrict__ perm,
                                                 const unsigned char* __restrict__ mask, const int* __restrict__ ppos,
                                                 const float* __restrict__ wf, const float* __restrict__ b_in,
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(1024) void k_nd_up(const Tile* __restrict__ tiles, 
     // everything that does not depend on this level's arithmetic is requested up front
     const float* __restrict__ col = wf + t.w_off + (row ? i : 0);
     float pre[NdUnroll<K>::up];
-    prefetch_strided(col, (size_t)b, j0, row ? j1 : j0, pre);
+    prefetch_strided<NT>(col, (size_t)b, j0, row ? j1 : j0, pre);
     int pp = 0;
     float pass[K];
 #pragma unroll
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(1024) void k_nd_up(const Tile* __restrict__ tiles, 
     float acc[K];
 #pragma unroll
     for (int q = 0; q < K; ++q) acc[q] = 0.0f;
-    if (row) dot_strided<K>(col, (size_t)b, j0, j1, sb, pre, acc);
+    if (row) dot_strided<K, NT>(col, (size_t)b, j0, j1, sb, pre, acc);
     reduce_waves<K>(acc, red);
     if (w == 0 && row) {
         const size_t dst = ((size_t)(t.pfront_off + pp) * t.arity + t.cix) * K;
@@ -297,7 +297,7 @@ __device__ __forceinline__ void forward_rows(const Tile& t, const int* __restric
 }
 
 // Down sweep, one tree level:  x_s = Finv_i b'_s - W_i^T xb_i;  x leaves in the caller's numbering and is pushed down
-template <int K>
+template <int K, bool NT>
 __global__ __launch_bounds__(1024) void k_nd_down(const Tile* __restrict__ tiles, const int* __restrict__ perm,
                                                   const int* __restrict__ push_ptr, const int* __restrict__ push_tgt,
                                                   const float* __restrict__ finv, const float* __restrict__ wb,
@@ -319,8 +319,8 @@ __global__ __launch_bounds__(1024) void k_nd_down(const Tile* __restrict__ tiles
     const float* __restrict__ wcol = wb + t.w_off + (row ? j : 0);
     const int f0 = min(t0, s), f1 = min(t1, s), g0 = max(t0, s) - s, g1 = max(t1, s) - s;   // Finv part, W part
     float pre_f[NdUnroll<K>::down], pre_w[NdUnroll<K>::down];
-    prefetch_strided(fcol, (size_t)s, f0, row ? f1 : f0, pre_f);
-    prefetch_strided(wcol, (size_t)s, g0, row ? g1 : g0, pre_w);
+    prefetch_strided<NT>(fcol, (size_t)s, f0, row ? f1 : f0, pre_f);
+    prefetch_strided<NT>(wcol, (size_t)s, g0, row ? g1 : g0, pre_w);
     int p0 = 0, p1 = 0;
     size_t g = 0;
     if (w == 0 && row) {
@@ -342,8 +342,8 @@ __global__ __launch_bounds__(1024) void k_nd_down(const Tile* __restrict__ tiles
 #pragma unroll
     for (int q = 0; q < K; ++q) acc[q] = 0.0f;
     if (row) {
-        dot_strided<K>(fcol, (size_t)s, f0, f1, sb, pre_f, acc);
-        dot_strided<K>(wcol, (size_t)s, g0, g1, sx, pre_w, acc);
+        dot_strided<K, NT>(fcol, (size_t)s, f0, f1, sb, pre_f, acc);
+        dot_strided<K, NT>(wcol, (size_t)s, g0, g1, sx, pre_w, acc);
     }
     reduce_waves<K>(acc, red);
     if (w == 0 && row) {
@@ -353,17 +353,6 @@ __global__ __launch_bounds__(1024) void k_nd_down(const Tile* __restrict__ tiles
     }
 }
 
-#ifdef LS_ND_EXPERIMENTS
-// timing experiments of the lanes-along-the-reduction level kernels (wrong results; environment LS_ND_ABLATE, read when a handle is made):
-//   1 no vector loads (zeros staged)   2 only the first batch of matrix rows   4 no epilogue (no stores, no hand-down)   8 no matrix loads at all
-//   16 the down sweep reads its W rows from the array the UP sweep has just read (same sizes and offsets, wrong values): what a factor
-//      layout shared by both sweeps would find in the Infinity Cache around the root
-__device__ int g_nd_ablate = 0;
-__device__ const float* g_nd_alias = nullptr;
-#define ND_ABLATE(bit) ((g_nd_ablate & (bit)) != 0)
-#else
-#define ND_ABLATE(bit) false
-#endif
 // ---- lanes along the reduction ----------------------------------------------------------------------------------
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_sum_step(float v) {
@@ -389,6 +378,7 @@ __device__ __forceinline__ float wave_sum63(float v) {
 #endif
 constexpr int ND_E = LS_ND_E;
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+template <bool NT>
 __device__ __forceinline__ void rows_load(const float* __restrict__ base, size_t stride_rows, int nrows, int len, int t0,
                                           f4u (&a)[ND_ROWS][ND_E]) {
     const int lane = threadIdx.x & 63;
@@ -398,7 +388,9 @@ __device__ __forceinline__ void rows_load(const float* __restrict__ base, size_t
         for (int e = 0; e < ND_E; ++e) {
             const int t = t0 + (e * 64 + lane) * 4;        // (the last quad of a row may reach 12 bytes into the next row /
             f4u z = {0.f, 0.f, 0.f, 0.f};                  //  the array's slack: those components are never used)
-            a[r][e] = (r < nrows && t < len) ? *reinterpret_cast<const f4u*>(base + (size_t)r * stride_rows + t) : z;
+            const f4u* p = reinterpret_cast<const f4u*>(base + (size_t)r * stride_rows + t);
+            if constexpr (NT) a[r][e] = (r < nrows && t < len) ? __builtin_nontemporal_load(p) : z;
+            else a[r][e] = (r < nrows && t < len) ? *p : z;
         }
     }
 }
@@ -436,13 +428,13 @@ __device__ __forceinline__ void rows_fma(const f4u (&a)[ND_ROWS][ND_E], int len,
     }
 }
 // acc[r][q] += sum_t row_r[t] * sv[t*K+q]; `first` holds the already loaded batch t0 = 0
-template <int K>
+template <int K, bool NT>
 __device__ __forceinline__ void dot_rows(const float* __restrict__ base, size_t stride_rows, int nrows, int len,
                                          const float* __restrict__ sv, const f4u (&first)[ND_ROWS][ND_E], float (&acc)[ND_ROWS][K]) {
     rows_fma<K>(first, len, 0, sv, acc);
     for (int t0 = 256 * ND_E; t0 < len; t0 += 256 * ND_E) {
         f4u a[ND_ROWS][ND_E];
-        rows_load(base, stride_rows, nrows, len, t0, a);
+        rows_load<NT>(base, stride_rows, nrows, len, t0, a);
         rows_fma<K>(a, len, t0, sv, acc);
     }
 }
@@ -461,7 +453,7 @@ __device__ __forceinline__ void rows_to_lanes(const float (&acc)[ND_ROWS][K], in
     }
 }
 
-template <int K>
+template <int K, bool NT>
 __global__ __launch_bounds__(64 * ND_BW) void k_nd_up_b(const Tile* __restrict__ tiles, const int* __restrict__ perm,
                                                         const unsigned char* __restrict__ mask, const int* __restrict__ ppos,
                                                         const float* __restrict__ wb, const float* __restrict__ b_in,
@@ -477,7 +469,7 @@ __global__ __launch_bounds__(64 * ND_BW) void k_nd_up_b(const Tile* __restrict__
     const int wrows = max(0, min(ND_ROWS * chunks, b - iw));
     const float* __restrict__ wrow = wb + t.w_off + (size_t)iw * s;
     f4u first[ND_ROWS][ND_E];
-    rows_load(wrow, (size_t)s, min(wrows, ND_ROWS), s, 0, first);   // in flight while b' is assembled
+    rows_load<NT>(wrow, (size_t)s, min(wrows, ND_ROWS), s, 0, first);   // in flight while b' is assembled
     // per-row epilogue data (lane r of the wave serves row iw + r), requested before anything else
     int pp = 0;
     float pass[K];
@@ -502,8 +494,8 @@ __global__ __launch_bounds__(64 * ND_BW) void k_nd_up_b(const Tile* __restrict__
             for (int q = 0; q < K; ++q) acc[r][q] = 0.0f;
         }
         const float* __restrict__ rowc = wrow + (size_t)c * ND_ROWS * s;
-        if (c) rows_load(rowc, (size_t)s, nrows, s, 0, first);
-        dot_rows<K>(rowc, (size_t)s, nrows, s, sb, first, acc);
+        if (c) rows_load<NT>(rowc, (size_t)s, nrows, s, 0, first);
+        dot_rows<K, NT>(rowc, (size_t)s, nrows, s, sb, first, acc);
         rows_to_lanes<K>(acc, c * ND_ROWS, mine);
     }
     if (lane < wrows) {
@@ -513,7 +505,7 @@ __global__ __launch_bounds__(64 * ND_BW) void k_nd_up_b(const Tile* __restrict__
     }
 }
 
-template <int K>
+template <int K, bool NT>
 __global__ __launch_bounds__(64 * ND_BW) void k_nd_down_b(const Tile* __restrict__ tiles, const int* __restrict__ perm,
                                                           const int* __restrict__ push_ptr, const int* __restrict__ push_tgt,
                                                           const float* __restrict__ finv, const float* __restrict__ wf,
@@ -530,23 +522,16 @@ __global__ __launch_bounds__(64 * ND_BW) void k_nd_down_b(const Tile* __restrict
     const int jw = t.row0 + w * ND_ROWS * chunks;
     const int wrows = max(0, min(ND_ROWS * chunks, s - jw));
     const float* __restrict__ frow = finv + t.finv_off + (size_t)jw * s;
-#ifdef LS_ND_EXPERIMENTS
-    const float* __restrict__ wrow = (ND_ABLATE(16) && g_nd_alias && t.s >= 400 ? g_nd_alias : wf) + t.w_off + (size_t)jw * b;   // (1M plane: levels 1-2, whose up launches read wb)
-#else
     const float* __restrict__ wrow = wf + t.w_off + (size_t)jw * b;
-#endif
     f4u first_f[ND_ROWS][ND_E], first_w[ND_ROWS][ND_E];
-    rows_load(frow, (size_t)s, ND_ABLATE(8) ? 0 : min(wrows, ND_ROWS), s, 0, first_f);          // in flight while the vectors are staged
-    rows_load(wrow, (size_t)b, ND_ABLATE(8) ? 0 : min(wrows, ND_ROWS), b, 0, first_w);
+    rows_load<NT>(frow, (size_t)s, min(wrows, ND_ROWS), s, 0, first_f);          // in flight while the vectors are staged
+    rows_load<NT>(wrow, (size_t)b, min(wrows, ND_ROWS), b, 0, first_w);
     int p0 = 0, p1 = 0;
     size_t g = 0;
     if (lane < wrows) {
         g = (size_t)perm[t.own_start + jw + lane];
         if (!t.leaf) { p0 = push_ptr[t.front_off + jw + lane]; p1 = push_ptr[t.front_off + jw + lane + 1]; }
     }
-    if (ND_ABLATE(1)) {
-        for (int u = threadIdx.x; u < (s + b) * K; u += blockDim.x) (u < s * K ? sb[u] : sx[u - s * K]) = 0.0f;
-    } else {
     if (rf.slots && t.pfront_off < 0) root_bprime<K>(t, rf, sb);
     else
     for (int u = threadIdx.x; u < s; u += blockDim.x) {
@@ -556,7 +541,6 @@ __global__ __launch_bounds__(64 * ND_BW) void k_nd_down_b(const Tile* __restrict
     for (int i = threadIdx.x; i < b; i += blockDim.x) {
 #pragma unroll
         for (int q = 0; q < K; ++q) sx[i * K + q] = -xb[(size_t)(t.bnd_off + i) * K + q];
-    }
     }
     __syncthreads();
     float mine[K];
@@ -573,20 +557,16 @@ __global__ __launch_bounds__(64 * ND_BW) void k_nd_down_b(const Tile* __restrict
         }
         const float* __restrict__ fc = frow + (size_t)c * ND_ROWS * s;
         const float* __restrict__ wc = wrow + (size_t)c * ND_ROWS * b;
-        if (c && !ND_ABLATE(8)) { rows_load(fc, (size_t)s, nrows, s, 0, first_f); rows_load(wc, (size_t)b, nrows, b, 0, first_w); }
-        const bool short_loop = ND_ABLATE(2) || ND_ABLATE(8);
-        dot_rows<K>(fc, (size_t)s, nrows, short_loop ? min(s, 256 * ND_E) : s, sb, first_f, acc);
-        dot_rows<K>(wc, (size_t)b, nrows, short_loop ? min(b, 256 * ND_E) : b, sx, first_w, acc);
+        if (c) { rows_load<NT>(fc, (size_t)s, nrows, s, 0, first_f); rows_load<NT>(wc, (size_t)b, nrows, b, 0, first_w); }
+        dot_rows<K, NT>(fc, (size_t)s, nrows, s, sb, first_f, acc);
+        dot_rows<K, NT>(wc, (size_t)b, nrows, b, sx, first_w, acc);
         rows_to_lanes<K>(acc, c * ND_ROWS, mine);
     }
-    if (lane < wrows && !ND_ABLATE(4)) {
+    if (lane < wrows) {
 #pragma unroll
         for (int q = 0; q < K; ++q) x_out[g * K + q] = mine[q];
         push_down<K>(push_tgt, p0, p1, xb, mine);
     }
-#ifdef LS_ND_EXPERIMENTS
-    if (ND_ABLATE(4) && mine[0] == 123.456f) x_out[0] = mine[0];         // (keeps the products alive)
-#endif
 }
 
 // ---- small nodes (the lower tree levels): the node's whole matrix staged in LDS ------------------------------------
@@ -769,7 +749,7 @@ __global__ __launch_bounds__(64) void k_nd_up_p(const PackedTile* __restrict__ t
     const int i = lane - t.row0[g];
     const float* __restrict__ col = wf + d.w_off + (row ? i : 0);
     float pre[LS_ND_UNROLL];
-    prefetch_strided(col, (size_t)d.b, 0, row ? d.s : 0, pre);
+    prefetch_strided<false>(col, (size_t)d.b, 0, row ? d.s : 0, pre);
     int pp = 0;
     float pass[K];
 #pragma unroll
@@ -786,7 +766,7 @@ __global__ __launch_bounds__(64) void k_nd_up_p(const PackedTile* __restrict__ t
         float acc[K];
 #pragma unroll
         for (int q = 0; q < K; ++q) acc[q] = 0.0f;
-        dot_strided<K>(col, (size_t)d.b, 0, d.s, sb + (size_t)t.sb0[g] * K, pre, acc);
+        dot_strided<K, false>(col, (size_t)d.b, 0, d.s, sb + (size_t)t.sb0[g] * K, pre, acc);
         const size_t dst = ((size_t)(d.pfront_off + pp) * t.arity + d.cix) * K;
 #pragma unroll
         for (int q = 0; q < K; ++q) slots[dst + q] = acc[q] + pass[q];
@@ -810,8 +790,8 @@ __global__ __launch_bounds__(64) void k_nd_down_p(const PackedTile* __restrict__
     const float* __restrict__ fcol = finv + d.finv_off + (row ? j : 0);
     const float* __restrict__ wcol = wb + d.w_off + (row ? j : 0);
     float pre_f[LS_ND_UNROLL], pre_w[LS_ND_UNROLL];            // (a 64-thread workgroup: registers are plentiful here)
-    prefetch_strided(fcol, (size_t)d.s, 0, row ? d.s : 0, pre_f);
-    prefetch_strided(wcol, (size_t)d.s, 0, row ? d.b : 0, pre_w);
+    prefetch_strided<false>(fcol, (size_t)d.s, 0, row ? d.s : 0, pre_f);
+    prefetch_strided<false>(wcol, (size_t)d.s, 0, row ? d.b : 0, pre_w);
     int p0 = 0, p1 = 0;
     size_t gx = 0;
     if (row) {
@@ -843,8 +823,8 @@ __global__ __launch_bounds__(64) void k_nd_down_p(const PackedTile* __restrict__
         float acc[K];
 #pragma unroll
         for (int q = 0; q < K; ++q) acc[q] = 0.0f;
-        dot_strided<K>(fcol, (size_t)d.s, 0, d.s, sb + (size_t)t.sb0[g] * K, pre_f, acc);
-        dot_strided<K>(wcol, (size_t)d.s, 0, d.b, sx + (size_t)t.sx0[g] * K, pre_w, acc);
+        dot_strided<K, false>(fcol, (size_t)d.s, 0, d.s, sb + (size_t)t.sb0[g] * K, pre_f, acc);
+        dot_strided<K, false>(wcol, (size_t)d.s, 0, d.b, sx + (size_t)t.sx0[g] * K, pre_w, acc);
 #pragma unroll
         for (int q = 0; q < K; ++q) x_out[gx * K + q] = acc[q];
         push_down<K>(push_tgt, p0, p1, xb, acc);
@@ -853,12 +833,8 @@ __global__ __launch_bounds__(64) void k_nd_down_p(const PackedTile* __restrict__
 
 }  // namespace ls
 #include "nd_tier.h"
-// The levels above the tier as ONE persistent launch (tree-local barriers, write-through hand-offs, register prefetch) were built and
-// measured in round 3: 166-207 us against 103-120 us for nine launches at 1M vertices. It is an experiment:
-// the kernel, its layouts and its planner exist only in -DLS_ND_EXPERIMENTS builds (tools/build/liblargesteps_hip_exp.so).
-#ifdef LS_ND_EXPERIMENTS
-#include "nd_span.h"
-#endif
+// (The levels above the tier as ONE persistent launch -- tree-local barriers, write-through hand-offs, register prefetch -- were built
+// and measured in round 3: 166-207 us against 103-120 us for nine launches at 1M vertices. Archived: tools/archive/lab/.)
 namespace ls {
 
 // down tiles of a level: compute tiles, then forward tiles
@@ -891,7 +867,6 @@ struct ls_direct {
     int* pull = nullptr;                // tier up sweep: (front position - pull_base, child) -> child boundary entry, front positions of the tier's inner nodes
     int64_t pull_base = 0;
     TierWG* d_wgs = nullptr;
-    long long* dbg = nullptr;           // profile = 2: per-wave clock stamps of the tier kernels (2 x tier_wgs x TIER_WAVES x 32)
     hipEvent_t busy = nullptr;          // recorded after every solve: a solve on another stream waits for it (one workspace)
     hipStream_t last_stream = nullptr;
     bool used = false;
@@ -903,23 +878,9 @@ struct ls_direct {
     int shard_rank = 0, shard_count = 1, cut = 0;
     int64_t exch_f0 = 0, exch_f1 = 0;
     std::vector<unsigned char> owned_rows;    // caller's numbering: 1 = this rank is the designated owner of the row's x
-    // the levels above the tier as ONE persistent launch (nd_span.h); off: one launch per level and sweep (the kernels above)
-    bool span_ok = false, span_on = false;
-    const float *pu = nullptr, *pd = nullptr;                    // caller's arrays (layouts of nd_span.h)
-#ifdef LS_ND_EXPERIMENTS
-    SpanJob* d_sjobs = nullptr;
-    SpanSync* d_ssync = nullptr;
-#else
-    void *d_sjobs = nullptr, *d_ssync = nullptr;                 // (never allocated in the product)
-#endif
-    unsigned* d_swords = nullptr;
-    unsigned* h_sfail = nullptr;        // host-mapped: a wait of the persistent launch timed out
-    int* d_bnd = nullptr;
-    float *pslots = nullptr, *bp4 = nullptr, *xt4 = nullptr;
-    int span_phases = 0, span_grid = 0, span_lcap = 0, span_words = 0;
     int tier_xcd = 1;                   // LS_ND_XCD=0 at creation: plain workgroup -> subtree order in the tier kernels
-    int exp_ablate = 0, exp_stagger = 0;            // -DLS_ND_EXPERIMENTS builds only (LS_ND_ABLATE / LS_ND_STAGGER at creation)
-    long long* span_dbg = nullptr;
+    // cache policy of the read-once factor streams (common.h, ld_stream): non-temporal when the factor cannot stay cache resident anyway
+    bool nt_levels = false, nt_tier = false, nt_rule[2] = {false, false};
     double factor_s[3] = {0, 0, 0};     // ls_direct_factor: symbolic analysis, layout / sparse tables, numeric factorisation
     double plan_q[4] = {0, 0, 0, 0};    // ls_direct_factor: the dissection's ordering rule, factor numbers per vertex, spread, the other plan's numbers (nd_plan.h)
     std::vector<LevelPlan> plan;
@@ -1179,136 +1140,6 @@ bool direct_tier_fits(int levels, int arity, const int* s, const int* b, const i
     return region && region * sizeof(float) * TIER_WAVES <= 150 * 1024;
 }
 
-#ifdef LS_ND_EXPERIMENTS
-// The levels above the tier as phases of one persistent launch (nd_span.h): workgroup ranges per node (a node's range is the
-// union of its children's), every workgroup's jobs per phase, and the arrival counters / release flags between the phases.
-struct SpanPlan { std::vector<SpanJob> jobs; std::vector<SpanSync> sync; int phases = 0, grid = 0, lcap = 0, words = 0; };
-static bool plan_span(const std::vector<NodeDesc>& nodes, const std::vector<int64_t>& level_off, int T, int levels, int arity,
-                      const int64_t* pu_off, const int64_t* pd_off, int G, SpanPlan& sp) {
-    if (T < 1 || G < 1) return false;
-    const int64_t n_upper = level_off[T] - 1;
-    auto s4 = [](int x) { return (x + 3) & ~3; };
-    // weights: fp32 words of a subtree's upper levels
-    std::vector<double> wt((size_t)n_upper + 2, 0.0);
-    for (int lv = T - 1; lv >= 0; --lv)
-        for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i) {
-            const NodeDesc& n = nodes[i];
-            double w = (double)n.b * s4(n.s) + (double)n.s * (s4(n.s) + s4(n.b));
-            if (lv + 1 < T) for (int c = 0; c < arity; ++c) w += wt[(size_t)(level_off[lv + 1] + (i - level_off[lv]) * arity + c)];
-            wt[(size_t)i] = w;
-        }
-    std::vector<int> g0((size_t)n_upper + 2, 0), g1((size_t)n_upper + 2, 0);
-    g0[1] = 0; g1[1] = G;
-    for (int lv = 0; lv + 1 < T; ++lv)
-        for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i) {
-            const int lo = g0[(size_t)i], sz = g1[(size_t)i] - lo;
-            const int64_t c0 = level_off[lv + 1] + (i - level_off[lv]) * arity;
-            int nz = 0;
-            double tot = 0.0;
-            for (int c = 0; c < arity; ++c) if (wt[(size_t)(c0 + c)] > 0.0) { ++nz; tot += wt[(size_t)(c0 + c)]; }
-            std::vector<int> cnt((size_t)arity, 0);
-            if (nz && sz >= nz) {           // at least one workgroup per working child, the rest in proportion (largest remainders)
-                const int left = sz - nz;
-                std::vector<double> rem((size_t)arity, -1.0);
-                int given = 0;
-                for (int c = 0; c < arity; ++c) if (wt[(size_t)(c0 + c)] > 0.0) {
-                    const double share = (double)left * wt[(size_t)(c0 + c)] / tot;
-                    cnt[(size_t)c] = 1 + (int)share; rem[(size_t)c] = share - (int)share; given += (int)share;
-                }
-                for (int r = left - given; r > 0; --r) {      // r < nz: every child gets at most one of the remaining workgroups
-                    int best = -1;
-                    for (int c = 0; c < arity; ++c) if (rem[(size_t)c] >= 0.0 && (best < 0 || rem[(size_t)c] > rem[(size_t)best])) best = c;
-                    if (best < 0) break;
-                    ++cnt[(size_t)best]; rem[(size_t)best] = -1.0;
-                }
-                int at = lo;
-                for (int c = 0; c < arity; ++c) {
-                    g0[(size_t)(c0 + c)] = std::min(at, lo + sz - 1);
-                    g1[(size_t)(c0 + c)] = cnt[(size_t)c] ? at + cnt[(size_t)c] : g0[(size_t)(c0 + c)] + 1;
-                    at += cnt[(size_t)c];
-                }
-            } else {                        // fewer workgroups than working children: they share
-                int k = 0;
-                for (int c = 0; c < arity; ++c) {
-                    const int g = lo + (nz ? (int)((int64_t)k * sz / nz) : 0);
-                    g0[(size_t)(c0 + c)] = g; g1[(size_t)(c0 + c)] = g + 1;
-                    if (wt[(size_t)(c0 + c)] > 0.0) ++k;
-                }
-            }
-        }
-    // phases: up(T-1) .. up(1), root, down(1) .. down(T-1)
-    const int P = 2 * (T - 1) + 1;
-    std::vector<std::vector<SpanJob>> jb((size_t)P * G);
-    int lcap = 4;
-    auto add_jobs = [&](int ph, int kind, int lv) {
-        for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i) {
-            const NodeDesc& n = nodes[i];
-            if (n.s == 0 && n.b == 0) continue;
-            const int lo = g0[(size_t)i], z = g1[(size_t)i] - lo;
-            const int rows = kind == SPAN_UP ? n.b : n.s;
-            const int last = lv == T - 1, leaf = lv + 1 >= levels;
-            const int keep = kind == SPAN_UP ? n.s : (kind == SPAN_DOWN && last && !leaf) ? n.b : 0;     // positions whose b' is stored / whose x is forwarded
-            for (int k = 0; k < z; ++k) {
-                SpanJob j;
-                memset(&j, 0, sizeof(j));
-                j.kind = kind; j.s = n.s; j.b = n.b; j.own_start = n.own_start; j.bnd_off = n.bnd_off; j.front_off = n.front_off;
-                j.pfront_off = i > 1 ? nodes[n.parent].front_off : -1; j.cix = lv ? (int)((i - level_off[lv]) % arity) : 0;
-                j.flags = (leaf ? SPAN_F_LEAF : 0) | ((last && !leaf) ? (SPAN_F_CHTIER | SPAN_F_LAST) : 0);
-                j.row0 = (int)((int64_t)rows * k / z); j.nrows = (int)((int64_t)rows * (k + 1) / z) - j.row0;
-                j.v0 = (int)((int64_t)keep * k / z); j.v1 = (int)((int64_t)keep * (k + 1) / z);
-                j.s4 = s4(n.s); j.len = kind == SPAN_UP ? s4(n.s) : s4(n.s) + s4(n.b);
-                j.mat_off = kind == SPAN_UP ? pu_off[i] : pd_off[i];
-                if (j.nrows == 0 && j.v1 == j.v0) continue;
-                lcap = std::max(lcap, j.len);
-                jb[(size_t)ph * G + lo + k].push_back(j);
-            }
-        }
-    };
-    int ph = 0;
-    for (int lv = T - 1; lv >= 1; --lv) add_jobs(ph++, SPAN_UP, lv);
-    add_jobs(ph++, SPAN_ROOT, 0);
-    for (int lv = 1; lv <= T - 1; ++lv) add_jobs(ph++, SPAN_DOWN, lv);
-    sp.jobs.clear();
-    sp.sync.assign((size_t)P * G, SpanSync());
-    for (auto& y : sp.sync) { memset(&y, 0, sizeof(y)); y.wait_flag = y.arr_ctr = y.top_ctr = -1; }
-    for (int w = 0; w < G; ++w)
-        for (int p = 0; p < P; ++p) {
-            SpanSync& y = sp.sync[(size_t)p * G + w];
-            y.job0 = (int)sp.jobs.size();
-            for (const SpanJob& j : jb[(size_t)p * G + w]) sp.jobs.push_back(j);
-            y.job1 = (int)sp.jobs.size();
-        }
-    for (int w = 0; w < G; ++w)
-        for (int p = 0; p + 1 < P; ++p) {
-            sp.sync[(size_t)p * G + w].njob0 = sp.sync[(size_t)(p + 1) * G + w].job0;
-            sp.sync[(size_t)p * G + w].njob1 = sp.sync[(size_t)(p + 1) * G + w].job1;
-        }
-    if (sp.jobs.empty()) return false;
-    // barriers: after phase p the workgroups of a DOMAIN node meet -- up(l): the nodes of level l - 1 (their children are done);
-    // root / down(l): the nodes of that level (their x is complete, the children may start)
-    int words = 0;
-    for (int p = 0; p + 1 < P; ++p) {
-        const int dom_lv = p < T - 1 ? (T - 1 - p) - 1 : p - (T - 1);
-        for (int64_t i = level_off[dom_lv]; i < level_off[dom_lv + 1]; ++i) {
-            const int lo = g0[(size_t)i], z = g1[(size_t)i] - lo;
-            if (z <= 1 || wt[(size_t)i] <= 0.0) continue;
-            const int nblk = (z + SPAN_DOMAIN - 1) / SPAN_DOMAIN;
-            const int ctr0 = words, top = nblk > 1 ? words + nblk : -1, flag0 = words + nblk + (nblk > 1 ? 1 : 0);
-            words = flag0 + nblk;
-            for (int k = 0; k < z; ++k) {
-                SpanSync& y = sp.sync[(size_t)p * G + lo + k];
-                if (y.arr_ctr >= 0) return false;             // (ranges of one level are disjoint: cannot happen)
-                const int blk = k / SPAN_DOMAIN;
-                y.arr_ctr = ctr0 + blk; y.arr_size = std::min(SPAN_DOMAIN, z - blk * SPAN_DOMAIN);
-                y.top_ctr = top; y.top_size = nblk; y.rel_flag0 = flag0; y.rel_n = nblk;
-                sp.sync[(size_t)(p + 1) * G + lo + k].wait_flag = flag0 + blk;
-            }
-        }
-    }
-    sp.phases = P; sp.grid = G; sp.lcap = (lcap + 3) & ~3; sp.words = std::max(words, 1);
-    return true;
-}
-#endif
 
 extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* stream, ls_direct** out) {
     LS_REQUIRE(A && out, LS_E_INVALID, "ls_direct_create: null argument");
@@ -1386,6 +1217,19 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
     fe_up += A->n_sp_ent + A->n_sp_ptr / 2; fe_down += A->n_sp_ent + A->n_sp_ptr - A->n_sp_ptr / 2;
     if (!d->lvl_up.empty()) { d->lvl_up[(size_t)levels - 1] += A->n_sp_ent + A->n_sp_ptr / 2; d->lvl_down[(size_t)levels - 1] += A->n_sp_ent + A->n_sp_ptr - A->n_sp_ptr / 2; }
     d->factor_entries = fe; d->words_up = fe_up; d->words_down = fe_down;
+    // Cache policy of the read-once factor streams (common.h, ld_stream; profiles/r05_nt_policy.txt: us per solve, default / nt):
+    //   70k 70 / 78   250k 88 / 96   490k 139 / 133 (level kernels only; + tier: 140)   1M 214 / 199   2M 450 / 431   4M 722 / 705
+    // While the factor (<= ~200 MB) stays resident in the 256 MB Infinity Cache from solve to solve, nt throws that away; beyond, the
+    // level kernels' rows go nt first (their vectors and slot records are what the L2 should keep), the tier's dense streams from ~400 MB on.
+    // LS_ND_NT=0 / 1 forces it off / on (A/B), ls_direct_set(h, "nt", v) per handle.
+    {
+        const double mb = 4e-6 * (double)fe;
+        d->nt_rule[0] = mb > (double)env_int("LS_ND_NT_LEVELS_MB", 256);
+        d->nt_rule[1] = mb > (double)env_int("LS_ND_NT_TIER_MB", 400);
+        const int force = env_int0("LS_ND_NT", -1);
+        d->nt_levels = force < 0 ? d->nt_rule[0] : force != 0;
+        d->nt_tier = force < 0 ? d->nt_rule[1] : force != 0;
+    }
     for (int lv = 0; lv < levels; ++lv)
         for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i) {
             const NodeDesc& n = nodes[i];
@@ -1463,9 +1307,6 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
     }
     d->fuse_root = getenv("LS_ND_NO_FUSE_ROOT") == nullptr;
     d->tier_xcd = env_int0("LS_ND_XCD_TIER", env_int0("LS_ND_XCD", 1)) != 0;
-#ifdef LS_ND_EXPERIMENTS
-    d->exp_ablate = env_int0("LS_ND_ABLATE", 0); d->exp_stagger = env_int0("LS_ND_STAGGER", 0);
-#endif
     d->upper_lo = (d->tier_root < levels && d->tier_root > 0) ? nodes[level_off[d->tier_root - 1]].own_start : (int)V;
     std::vector<int> pull;
     if (d->tier_root < levels) {
@@ -1647,36 +1488,6 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
                 if (lv < cut ? rank == 0 : active(i, lv))
                     for (int r = 0; r < nodes[i].s; ++r) d->owned_rows[(size_t)h_perm[nodes[i].own_start + r]] = 1;
     }
-#ifdef LS_ND_EXPERIMENTS
-    // the levels above the tier as one persistent launch (nd_span.h): needs the caller's pu / pd layouts and the boundary ids
-    SpanPlan sp;
-    bool span = A->d_pu && A->d_pd && A->h_pu_off && A->h_pd_off && A->h_bnd && n_ranks == 1 && d->tier_root >= 1 && d->tier_wgs > 0 && !getenv("LS_ND_NO_SPAN");
-    if (span) {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 8) span = false;
-        int G = env_int("LS_ND_SPAN_GRID", 0);
-        if (span && G <= 0) {
-            // one workgroup per CU; small trees: fewer workgroups (a phase should leave ~16 KB of factor per workgroup, barriers among
-            // fewer workgroups are cheaper)
-            int64_t phase_max = 0;
-            for (int lv = 0; lv < d->tier_root; ++lv) {
-                int64_t up_w = 0, down_w = 0;
-                for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i) {
-                    const int64_t s4 = (nodes[i].s + 3) & ~3, b4 = (nodes[i].b + 3) & ~3;
-                    up_w += s4 * nodes[i].b; down_w += (s4 + b4) * nodes[i].s;
-                }
-                phase_max = std::max(phase_max, std::max(up_w, down_w));
-            }
-            G = cus & ~7;
-            while (G > 8 && phase_max * 4 < (int64_t)G * 16384) G >>= 1;
-            G &= ~7;
-        }
-        span = span && plan_span(nodes, level_off, d->tier_root, levels, arity, A->h_pu_off, A->h_pd_off, std::min(G, cus), sp);
-        if (span && ((size_t)d->kmax * sp.lcap + SPAN_WAVES * 256) * sizeof(float) > 150 * 1024) span = false;
-    }
-#else
-    const bool span = false;
-#endif
     int rc = LS_OK;
     lap("tables built (host)");
     // The tables go up on a stream of their own: `st` is busy with the factorisation when ls_direct_factor calls this (a copy from
@@ -1701,30 +1512,11 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
         !(rc = up(&d->ppos, h_ppos, (size_t)n_bnd)) && !(rc = up(&d->push_ptr, h_push_ptr, (size_t)n_front + 1)) &&
         !(rc = up(&d->push_tgt, h_push_tgt, (size_t)n_bnd)) && !(rc = up(&d->mask, mask.data(), mask.size())) &&
         !(rc = up(&d->d_items, items.data(), items.size())) && !(rc = up(&d->pull, pull.data(), pull.size())) &&
-        !(rc = up(&d->d_wgs, wgs.data(), wgs.size())) &&
-#ifdef LS_ND_EXPERIMENTS
-        (!span || (!(rc = up(&d->d_sjobs, sp.jobs.data(), sp.jobs.size())) && !(rc = up(&d->d_ssync, sp.sync.data(), sp.sync.size())) &&
-                   !(rc = up(&d->d_bnd, A->h_bnd, (size_t)n_bnd))))
-#else
-        true
-#endif
-        ) {
+        !(rc = up(&d->d_wgs, wgs.data(), wgs.size()))) {
         hipError_t e = table((void**)&d->bp, sizeof(float) * (size_t)V * d->kmax);
         if (e == hipSuccess) e = table((void**)&d->braw, sizeof(float) * (size_t)V * d->kmax);
         if (e == hipSuccess) e = table((void**)&d->slots, sizeof(float) * (size_t)n_front * arity * d->kmax);
         if (e == hipSuccess) e = table((void**)&d->xb, sizeof(float) * (size_t)std::max<int64_t>(n_bnd, 1) * d->kmax);
-#ifdef LS_ND_EXPERIMENTS
-        if (e == hipSuccess && span) {
-            const size_t up_rows = (size_t)(V - d->upper_lo);
-            const size_t n_pf = d->tier_root < levels ? (size_t)nodes[level_off[d->tier_root]].front_off : (size_t)n_front;
-            e = hipMalloc((void**)&d->pslots, sizeof(float) * 4 * std::max<size_t>(n_pf * arity, 1));
-            if (e == hipSuccess) e = hipMalloc((void**)&d->bp4, sizeof(float) * 4 * std::max<size_t>(up_rows, 1));
-            if (e == hipSuccess) e = hipMalloc((void**)&d->xt4, sizeof(float) * 4 * std::max<size_t>(up_rows, 1));
-            if (e == hipSuccess) e = hipMalloc((void**)&d->d_swords, sizeof(unsigned) * 16 * (size_t)sp.words);
-            if (e == hipSuccess) e = hipHostMalloc((void**)&d->h_sfail, sizeof(unsigned), hipHostMallocMapped);
-            if (e == hipSuccess) *d->h_sfail = 0u;
-        }
-#endif
         if (e == hipSuccess) e = hipEventCreateWithFlags(&d->busy, hipEventDisableTiming);
         lap("uploads enqueued, vectors allocated");
         if (e == hipSuccess) e = hipEventRecord(d->busy, su);
@@ -1736,45 +1528,28 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
     if (rc != LS_OK) { ls_direct_destroy(d); return rc; }
     // kernels of the top levels may need more than 64 KiB of dynamic LDS
 #define LS_OPTIN(KK)                                                                                                   \
-    (void)hipFuncSetAttribute((const void*)k_nd_up<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);       \
-    (void)hipFuncSetAttribute((const void*)k_nd_down<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
-    (void)hipFuncSetAttribute((const void*)k_nd_up_b<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
-    (void)hipFuncSetAttribute((const void*)k_nd_down_b<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
+    (void)hipFuncSetAttribute((const void*)k_nd_up<KK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);       \
+    (void)hipFuncSetAttribute((const void*)k_nd_down<KK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
+    (void)hipFuncSetAttribute((const void*)k_nd_up_b<KK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
+    (void)hipFuncSetAttribute((const void*)k_nd_down_b<KK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
+    (void)hipFuncSetAttribute((const void*)k_nd_up<KK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);        \
+    (void)hipFuncSetAttribute((const void*)k_nd_down<KK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);      \
+    (void)hipFuncSetAttribute((const void*)k_nd_up_b<KK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);      \
+    (void)hipFuncSetAttribute((const void*)k_nd_down_b<KK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);    \
     (void)hipFuncSetAttribute((const void*)k_nd_up_s<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
     (void)hipFuncSetAttribute((const void*)k_nd_down_s<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     LS_OPTIN(1) LS_OPTIN(2) LS_OPTIN(3) LS_OPTIN(4)
 #undef LS_OPTIN
 #define LS_OPTIN(KK)                                                                                                       \
-    (void)hipFuncSetAttribute((const void*)k_nd_tier<KK, true, TIER_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
-    (void)hipFuncSetAttribute((const void*)k_nd_tier<KK, false, TIER_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
-    (void)hipFuncSetAttribute((const void*)k_nd_tier<KK, true, TIER_WAVES_WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
-    (void)hipFuncSetAttribute((const void*)k_nd_tier<KK, false, TIER_WAVES_WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_nd_tier<KK, true, TIER_WAVES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
+    (void)hipFuncSetAttribute((const void*)k_nd_tier<KK, false, TIER_WAVES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+    (void)hipFuncSetAttribute((const void*)k_nd_tier<KK, true, TIER_WAVES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);    \
+    (void)hipFuncSetAttribute((const void*)k_nd_tier<KK, false, TIER_WAVES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
+    (void)hipFuncSetAttribute((const void*)k_nd_tier<KK, true, TIER_WAVES_WIDE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
+    (void)hipFuncSetAttribute((const void*)k_nd_tier<KK, false, TIER_WAVES_WIDE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     LS_OPTIN(1) LS_OPTIN(2) LS_OPTIN(3) LS_OPTIN(4)
 #undef LS_OPTIN
-#ifdef LS_ND_EXPERIMENTS
-    if (span) {
-        d->pu = A->d_pu; d->pd = A->d_pd;
-        d->span_phases = sp.phases; d->span_grid = sp.grid; d->span_lcap = sp.lcap; d->span_words = sp.words;
-        d->span_ok = true;
-        // measured on the MI355X (profiles/r03_span_*): 166 us for the nine phases of a 1M-vertex solve against 120 us for nine
-        // launches -- a workgroup's requests for the next phase, its wait, vector assembly, products and stores are one serial
-        // chain (~22 us per phase), while separate launches overlap those stages across 8 resident workgroups per CU. Off by default.
-        d->span_on = env_int0("LS_ND_PERSIST", 0) != 0;
-#define LS_OPTIN(KK)                                                                                                        \
-        (void)hipFuncSetAttribute((const void*)k_nd_span<KK, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
-        (void)hipFuncSetAttribute((const void*)k_nd_span<KK, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
-        (void)hipFuncSetAttribute((const void*)k_nd_span<KK, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        LS_OPTIN(1) LS_OPTIN(2) LS_OPTIN(3) LS_OPTIN(4)
-#undef LS_OPTIN
-    }
-#else
-    (void)span;
-#endif
     lap("kernel attributes set");
-#ifdef LS_ND_EXPERIMENTS
-    { const int ab = env_int0("LS_ND_ABLATE", 0); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_nd_ablate), &ab, sizeof(int));
-      const float* alias = d->wb; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_nd_alias), &alias, sizeof(alias)); }
-#endif
     *out = d;
     return LS_OK;
 }
@@ -1782,12 +1557,9 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
 extern "C" int ls_direct_destroy(ls_direct* d) {
     if (!d) return LS_OK;
     DeviceGuard g(d->device);
-    (void)hipFree(d->dbg); (void)hipFree(d->d_swords); (void)hipFree(d->pslots);
-    (void)hipFree(d->bp4); (void)hipFree(d->xt4); (void)hipFree(d->span_dbg);
-    if (d->h_sfail) (void)hipHostFree(d->h_sfail);
     if (d->busy) (void)hipEventDestroy(d->busy);
     (void)hipDeviceSynchronize();                                   // (what hipFree did implicitly: nothing of the handle is in flight any more)
-    for (const auto& t : d->tables)                                 // tiles, perm, ppos, push lists, mask, items, pull, wgs, span jobs; bp, braw, slots, xb
+    for (const auto& t : d->tables)                                 // tiles, perm, ppos, push lists, mask, items, pull, wgs; bp, braw, slots, xb
         if (!ls::pool_give(d->device, t.first, t.second)) (void)hipFree(t.first);
     for (size_t i = 0; i < d->owned.size(); ++i)
         if (!ls::pool_give(d->device, d->owned[i], i < d->owned_bytes.size() ? d->owned_bytes[i] : 0)) (void)hipFree(d->owned[i]);
@@ -1809,12 +1581,8 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
     ta.arity = d->arity; ta.phases = d->tier_phases; ta.region_floats = d->tier_region; ta.vec_floats = d->tier_vec;
     ta.upper_lo = d->upper_lo; ta.upper_hi = (int)d->V;
     ta.xcd_order = d->tier_xcd;
-    ta.dbg = nullptr; ta.ablate = 0; ta.stagger = 0;
-#ifdef LS_ND_EXPERIMENTS
-    ta.dbg = d->profile == 2 ? d->dbg : nullptr;
-    ta.ablate = d->exp_ablate; ta.stagger = d->exp_stagger;     // read once, when the handle was created
-#endif
     const size_t tier_lds = (size_t)d->tier_region * d->tier_waves * sizeof(float);
+    const bool nt_tier = d->nt_tier && d->tier_waves == TIER_WAVES, nt = d->nt_levels;
     int n_mark = 0;
     auto mark = [&](int lo, int hi, int sweep) -> hipError_t {        // "profile" = 3: an event in front of every launch
         if (d->profile != 3) return hipSuccess;
@@ -1832,56 +1600,15 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
         for (int i = 0; i < n_mark && r == hipSuccess; ++i) { float ms = 0; r = hipEventElapsedTime(&ms, d->lev[(size_t)i], d->lev[(size_t)i + 1]); d->launch_ms[(size_t)i] = ms; }
         return r;
     };
-#ifdef LS_ND_EXPERIMENTS
-    if (d->span_ok && d->span_on && part == -1) {
-        // tier up -> every level above the tier, both sweeps, as ONE persistent launch -> tier down
-        SpanArgs sa;
-        sa.jobs = d->d_sjobs; sa.sync = d->d_ssync; sa.words = d->d_swords; sa.fail = d->h_sfail;
-        sa.phases = d->span_phases; sa.grid = d->span_grid; sa.lcap = d->span_lcap; sa.arity = d->arity; sa.upper_lo = d->upper_lo;
-        sa.pu = d->pu; sa.pd = d->pd; sa.braw = d->braw; sa.tslots = d->slots; sa.txb = d->xb; sa.mask = d->mask; sa.ppos = d->ppos;
-        sa.perm = d->perm; sa.bnd = d->d_bnd; sa.push_ptr = d->push_ptr; sa.push_tgt = d->push_tgt; sa.pslots = d->pslots; sa.bp4 = d->bp4;
-        sa.xt4 = d->xt4; sa.dbg = nullptr;
-#ifdef LS_ND_EXPERIMENTS
-        sa.dbg = d->profile == 2 ? d->span_dbg : nullptr;
-#endif
-        if (d->profile) LS_HIP(hipEventRecord(d->ev[0], st));
-        LS_HIP(hipMemsetAsync(d->d_swords, 0, sizeof(unsigned) * 16 * (size_t)d->span_words, st));
-        LS_HIP(mark(d->tier_root, d->levels - 1, 0));
-        if (d->tier_waves == TIER_WAVES_WIDE) hipLaunchKernelGGL((k_nd_tier<K, true, TIER_WAVES_WIDE>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES_WIDE), tier_lds, st, ta, b, x, d->tier_tri);
-        else hipLaunchKernelGGL((k_nd_tier<K, true, TIER_WAVES>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
-        LS_HIP(mark(0, d->tier_root - 1, 2));
-        if (d->profile) LS_HIP(hipEventRecord(d->ev[1], st));
-        const size_t span_lds = ((size_t)K * d->span_lcap + SPAN_WAVES * 256) * sizeof(float);
-        if (d->arity == 4) hipLaunchKernelGGL((k_nd_span<K, 4>), dim3(d->span_grid), dim3(SPAN_THREADS), span_lds, st, sa, x);
-        else if (d->arity == 2) hipLaunchKernelGGL((k_nd_span<K, 2>), dim3(d->span_grid), dim3(SPAN_THREADS), span_lds, st, sa, x);
-        else hipLaunchKernelGGL((k_nd_span<K, 8>), dim3(d->span_grid), dim3(SPAN_THREADS), span_lds, st, sa, x);
-        if (d->profile) LS_HIP(hipEventRecord(d->ev[2], st));
-        if (ta.dbg) ta.dbg += (size_t)d->tier_wgs * d->tier_waves * 32;
-        LS_HIP(mark(d->tier_root, d->levels - 1, 1));
-        if (d->tier_waves == TIER_WAVES_WIDE) hipLaunchKernelGGL((k_nd_tier<K, false, TIER_WAVES_WIDE>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES_WIDE), tier_lds, st, ta, b, x, d->tier_tri);
-        else hipLaunchKernelGGL((k_nd_tier<K, false, TIER_WAVES>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
-        if (d->profile) LS_HIP(hipEventRecord(d->ev[3], st));
-        LS_HIP(hipGetLastError());
-        LS_HIP(mark_end());
-        if (d->profile) {
-            LS_HIP(hipStreamSynchronize(st));
-            float u = 0, m = 0, w = 0;
-            LS_HIP(hipEventElapsedTime(&u, d->ev[0], d->ev[1]));
-            LS_HIP(hipEventElapsedTime(&m, d->ev[1], d->ev[2]));
-            LS_HIP(hipEventElapsedTime(&w, d->ev[2], d->ev[3]));
-            d->prof_ms[0] = u; d->prof_ms[1] = w; d->prof_ms[2] = m;
-        }
-        return LS_OK;
-    }
-#endif
     const size_t exch_off = (size_t)d->exch_f0 * d->arity * K, exch_n = (size_t)(d->exch_f1 - d->exch_f0) * d->arity * K;
     if (part != 1) {
     if (d->profile) LS_HIP(hipEventRecord(d->ev[0], st));
     if (part == 0 && exch_n) LS_HIP(hipMemsetAsync(d->slots + exch_off, 0, exch_n * sizeof(float), st));
     if (d->tier_wgs) {
         LS_HIP(mark(d->tier_root, d->levels - 1, 0));
-        if (d->tier_waves == TIER_WAVES_WIDE) hipLaunchKernelGGL((k_nd_tier<K, true, TIER_WAVES_WIDE>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES_WIDE), tier_lds, st, ta, b, x, d->tier_tri);
-        else hipLaunchKernelGGL((k_nd_tier<K, true, TIER_WAVES>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
+        if (d->tier_waves == TIER_WAVES_WIDE) hipLaunchKernelGGL((k_nd_tier<K, true, TIER_WAVES_WIDE, false>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES_WIDE), tier_lds, st, ta, b, x, d->tier_tri);
+        else if (nt_tier) hipLaunchKernelGGL((k_nd_tier<K, true, TIER_WAVES, true>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
+        else hipLaunchKernelGGL((k_nd_tier<K, true, TIER_WAVES, false>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
     }
     }
     if (part == 1 && exch_n && exchange != d->slots + exch_off)
@@ -1904,10 +1631,11 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
             hipLaunchKernelGGL(k_nd_up_s<K>, dim3(p.up_tiles), dim3(WAVE * p.up_nw), ((size_t)p.s_cap * p.b_cap + (size_t)p.s_cap * K) * sizeof(float), st,
                                d->tiles + p.up_first, up_perm, d->mask, d->ppos, d->wf, up_b, d->bp, d->slots, p.s_cap, p.b_cap);
         else if (p.up_b)
-            hipLaunchKernelGGL(k_nd_up_b<K>, dim3(p.up_tiles), dim3(WAVE * p.up_nw), ((size_t)p.s_cap * K + 16) * sizeof(float), st, d->tiles + p.up_first,
-                               up_perm, d->mask, d->ppos, d->wb, up_b, d->bp, d->slots, p.s_cap, p.up_chunks);
+            hipLaunchKernelGGL((nt ? k_nd_up_b<K, true> : k_nd_up_b<K, false>), dim3(p.up_tiles), dim3(WAVE * p.up_nw), ((size_t)p.s_cap * K + 16) * sizeof(float), st,
+                               d->tiles + p.up_first, up_perm, d->mask, d->ppos, d->wb, up_b, d->bp, d->slots, p.s_cap, p.up_chunks);
         else
-            hipLaunchKernelGGL(k_nd_up<K>, dim3(p.up_tiles), dim3(WAVE * p.up_nw), ((size_t)p.s_cap + (size_t)(p.up_nw - 1) * WAVE) * K * sizeof(float),
+            hipLaunchKernelGGL((nt ? k_nd_up<K, true> : k_nd_up<K, false>), dim3(p.up_tiles), dim3(WAVE * p.up_nw),
+                               ((size_t)p.s_cap + (size_t)(p.up_nw - 1) * WAVE) * K * sizeof(float),
                                st, d->tiles + p.up_first, up_perm, d->mask, d->ppos, d->wf, up_b, d->bp, d->slots, p.s_cap);
     }
     if (part == 0) {
@@ -1930,20 +1658,20 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
                                ((size_t)p.s_cap * (p.s_cap + p.b_cap) + (size_t)(p.s_cap + p.b_cap) * K) * sizeof(float), st, d->tiles + p.down_first,
                                d->perm, d->push_ptr, d->push_tgt, d->finv, d->wb, (const float*)d->bp, d->xb, x, p.s_cap, p.b_cap);
         else if (p.down_b)
-            hipLaunchKernelGGL(k_nd_down_b<K>, dim3(p.down_tiles), dim3(WAVE * p.down_nw), (((size_t)p.s_cap + p.b_cap) * K + 32) * sizeof(float), st,
+            hipLaunchKernelGGL((nt ? k_nd_down_b<K, true> : k_nd_down_b<K, false>), dim3(p.down_tiles), dim3(WAVE * p.down_nw), (((size_t)p.s_cap + p.b_cap) * K + 32) * sizeof(float), st,
                                d->tiles + p.down_first, d->perm, d->push_ptr, d->push_tgt, d->finv, d->wf, (const float*)d->bp, d->xb, x,
                                p.s_cap, p.b_cap, p.down_chunks, lv == 0 ? rf : RootFill{nullptr, nullptr, nullptr, nullptr});
         else
-            hipLaunchKernelGGL(k_nd_down<K>, dim3(p.down_tiles), dim3(WAVE * p.down_nw),
+            hipLaunchKernelGGL((nt ? k_nd_down<K, true> : k_nd_down<K, false>), dim3(p.down_tiles), dim3(WAVE * p.down_nw),
                                ((size_t)p.s_cap + p.b_cap + (size_t)(p.down_nw - 1) * WAVE) * K * sizeof(float), st, d->tiles + p.down_first,
                                d->perm, d->push_ptr, d->push_tgt, d->finv, d->wb, (const float*)d->bp, d->xb, x, p.s_cap, p.b_cap,
                                lv == 0 ? rf : RootFill{nullptr, nullptr, nullptr, nullptr});
     }
-    if (ta.dbg) ta.dbg += (size_t)d->tier_wgs * d->tier_waves * 32;
     if (d->tier_wgs) {
         LS_HIP(mark(d->tier_root, d->levels - 1, 1));
-        if (d->tier_waves == TIER_WAVES_WIDE) hipLaunchKernelGGL((k_nd_tier<K, false, TIER_WAVES_WIDE>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES_WIDE), tier_lds, st, ta, b, x, d->tier_tri);
-        else hipLaunchKernelGGL((k_nd_tier<K, false, TIER_WAVES>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
+        if (d->tier_waves == TIER_WAVES_WIDE) hipLaunchKernelGGL((k_nd_tier<K, false, TIER_WAVES_WIDE, false>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES_WIDE), tier_lds, st, ta, b, x, d->tier_tri);
+        else if (nt_tier) hipLaunchKernelGGL((k_nd_tier<K, false, TIER_WAVES, true>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
+        else hipLaunchKernelGGL((k_nd_tier<K, false, TIER_WAVES, false>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
     }
     if (d->profile) LS_HIP(hipEventRecord(d->ev[2], st));
     LS_HIP(hipGetLastError());
@@ -1956,18 +1684,6 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
         d->prof_ms[0] = a; d->prof_ms[1] = c; d->prof_ms[2] = 0.0;
     }
     return LS_OK;
-}
-
-// one event per device: recorded after every persistent launch, waited for before the next one (see ls_direct_solve)
-static hipEvent_t g_span_chain[64];
-static void rc_chain_init() {
-    static std::once_flag once;
-    std::call_once(once, [] { for (hipEvent_t& e : g_span_chain) e = nullptr; });
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return;
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lk(mu);
-    if (!g_span_chain[dev & 63]) (void)hipEventCreateWithFlags(&g_span_chain[dev & 63], hipEventDisableTiming);
 }
 
 extern "C" int ls_direct_solve(ls_direct* d, const float* b, float* x, int k, void* stream) {
@@ -1985,22 +1701,6 @@ extern "C" int ls_direct_solve(ls_direct* d, const float* b, float* x, int k, vo
     if (st) (void)hipStreamIsCapturing(st, &cap);
     const bool capturing = cap == hipStreamCaptureStatusActive;
     if (!capturing && d->used && st != d->last_stream) LS_HIP(hipStreamWaitEvent(st, d->busy, 0));
-    if (d->h_sfail && *d->h_sfail) {          // a wait inside an earlier persistent launch gave up: its x was wrong
-        *d->h_sfail = 0u;
-        d->span_on = false;
-        set_error("ls_direct_solve: a previous solve of this handle timed out inside the persistent upper-level launch (its result is invalid): "
-                  "workgroups were not co-resident -- another process shares the GPU? The handle now runs one launch per tree level");
-        return LS_E_STATE;
-    }
-    // two persistent launches must never share the chip (each waits for ALL its workgroups to be resident): launches of this
-    // process are chained through one event per device, whatever their streams and handles
-    const bool span = d->span_ok && d->span_on;
-    hipEvent_t chain = nullptr;
-    if (span && !capturing) {
-        rc_chain_init();
-        chain = g_span_chain[d->device & 63];
-        if (chain) LS_HIP(hipStreamWaitEvent(st, chain, 0));
-    }
     int rc;
     switch (k) {
         case 1: rc = direct_solve_k<1>(d, b, x, st, -1, nullptr); break;
@@ -2009,7 +1709,6 @@ extern "C" int ls_direct_solve(ls_direct* d, const float* b, float* x, int k, vo
         default: rc = direct_solve_k<4>(d, b, x, st, -1, nullptr); break;
     }
     if (rc == LS_OK && !capturing) { LS_HIP(hipEventRecord(d->busy, st)); d->last_stream = st; d->used = true; }
-    if (rc == LS_OK && chain) LS_HIP(hipEventRecord(chain, st));
     return rc;
 }
 
@@ -2060,30 +1759,16 @@ extern "C" int ls_direct_set(ls_direct* d, const char* name, int value) {
     if (!strcmp(name, "profile")) {
         DeviceGuard g(d->device);
         LS_HIP(g.err);
+        // 0 off; 1 events around the two sweeps; 3 an event in front of every launch (2 was the tier kernels' clock stamps: archived)
+        LS_REQUIRE(value != 2, LS_E_INVALID, "ls_direct_set: profile 2 (per-wave clock stamps) was a laboratory mode and is archived (tools/archive/lab/)");
         d->profile = value < 0 ? 0 : std::min(value, 3);
         while (d->profile && d->ev.size() < 4) { hipEvent_t e; LS_HIP(hipEventCreate(&e)); d->ev.push_back(e); }
-#ifdef LS_ND_EXPERIMENTS
-        if (d->profile == 2 && !d->span_dbg && d->span_ok) {
-            const size_t n = (size_t)d->span_grid * d->span_phases * 8;
-            LS_HIP(hipMalloc((void**)&d->span_dbg, sizeof(long long) * n));
-            LS_HIP(hipMemset(d->span_dbg, 0, sizeof(long long) * n));
-        }
-#endif
-        if (d->profile == 2 && !d->dbg && d->tier_wgs) {
-            LS_HIP(hipMalloc((void**)&d->dbg, sizeof(long long) * 2 * (size_t)d->tier_wgs * d->tier_waves * 32));
-            LS_HIP(hipMemset(d->dbg, 0, sizeof(long long) * 2 * (size_t)d->tier_wgs * d->tier_waves * 32));
-        }
         return LS_OK;
     }
-    if (!strcmp(name, "persist")) {
-#ifdef LS_ND_EXPERIMENTS
-        d->span_on = d->span_ok && value != 0;
+    if (!strcmp(name, "nt")) {          // cache policy of the read-once factor streams: 0 default policy, 1 non-temporal, -1 back to the library's rule
+        d->nt_levels = value < 0 ? d->nt_rule[0] : value != 0;
+        d->nt_tier = value < 0 ? d->nt_rule[1] : value != 0;
         return LS_OK;
-#else
-        LS_REQUIRE(value == 0, LS_E_INVALID, "ls_direct_set: the persistent upper-level launch exists only in -DLS_ND_EXPERIMENTS builds of the library "
-                                             "(measured slower than one launch per level: DESIGN.md section 2.3c)");
-        return LS_OK;
-#endif
     }
     set_error("ls_direct_set: unknown option '%s'", name);
     return LS_E_INVALID;
@@ -2122,16 +1807,6 @@ extern "C" int ls_direct_shape(const ls_direct* d, int* h_levels, int* h_arity, 
 extern "C" int ls_direct_factor_seconds(const ls_direct* d, double* h_s3) {
     LS_REQUIRE(d && h_s3, LS_E_INVALID, "ls_direct_factor_seconds: bad argument");
     for (int i = 0; i < 3; ++i) h_s3[i] = d->factor_s[i];
-    return LS_OK;
-}
-
-extern "C" int ls_direct_tier_stamps(const ls_direct* d, long long* h_out, int64_t n) {
-    LS_REQUIRE(d && h_out, LS_E_INVALID, "ls_direct_tier_stamps: bad argument");
-    const int64_t have = d->dbg ? 2 * (int64_t)d->tier_wgs * d->tier_waves * 32 : 0;
-    LS_REQUIRE(n <= have, LS_E_INVALID, "ls_direct_tier_stamps: %lld stamps recorded (set \"profile\" to 2 and solve first)", (long long)have);
-    DeviceGuard g(d->device);
-    LS_HIP(g.err);
-    LS_HIP(hipMemcpy(h_out, d->dbg, sizeof(long long) * (size_t)n, hipMemcpyDeviceToHost));
     return LS_OK;
 }
 
@@ -2174,19 +1849,6 @@ extern "C" int ls_direct_launch_profile(const ls_direct* d, int cap, int* h_n, d
     return LS_OK;
 }
 
-extern "C" int ls_direct_span_stamps(const ls_direct* d, long long* h_out, int64_t n, int* h_workgroups, int* h_phases) {
-    LS_REQUIRE(d, LS_E_INVALID, "ls_direct_span_stamps: bad argument");
-    if (h_workgroups) *h_workgroups = d->span_ok ? d->span_grid : 0;
-    if (h_phases) *h_phases = d->span_ok ? d->span_phases : 0;
-    if (!h_out || n <= 0) return LS_OK;
-    const int64_t have = d->span_dbg ? (int64_t)d->span_grid * d->span_phases * 8 : 0;
-    LS_REQUIRE(n <= have, LS_E_INVALID, "ls_direct_span_stamps: %lld stamps recorded (experiments build, \"profile\" = 2, solve first)", (long long)have);
-    DeviceGuard g(d->device);
-    LS_HIP(g.err);
-    LS_HIP(hipMemcpy(h_out, d->span_dbg, sizeof(long long) * (size_t)n, hipMemcpyDeviceToHost));
-    return LS_OK;
-}
-
 extern "C" int ls_direct_info(const ls_direct* d, int64_t* h_factor_entries, int* h_launches, double* h_ms3) {
     LS_REQUIRE(d, LS_E_INVALID, "ls_direct_info: bad argument");
     if (h_factor_entries) *h_factor_entries = d->factor_entries;
@@ -2197,7 +1859,7 @@ extern "C" int ls_direct_info(const ls_direct* d, int64_t* h_factor_entries, int
             const bool fused = lv == 0 && d->tier_root > 0 && d->fuse_root && !p.down_p && !p.down_s;     // the root's up step rides in its down tiles
             n += (((p.up_p ? p.up_p_tiles : p.up_tiles) && !fused) ? 1 : 0) + ((p.down_p ? p.down_p_tiles : p.down_tiles) ? 1 : 0);
         }
-        *h_launches = (d->span_ok && d->span_on) ? 3 : n + (d->tier_wgs ? 2 : 0);
+        *h_launches = n + (d->tier_wgs ? 2 : 0);
     }
     if (h_ms3) for (int i = 0; i < 3; ++i) h_ms3[i] = d->prof_ms[i];
     return LS_OK;

@@ -19,6 +19,8 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
 };
@@ -35,6 +37,8 @@ Rccl& rccl() {
         r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
         r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
         r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
+        r.CommCount = (decltype(r.CommCount))dlsym(r.lib, "ncclCommCount");
+        r.CommUserRank = (decltype(r.CommUserRank))dlsym(r.lib, "ncclCommUserRank");
         r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
         r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce;
     });
@@ -88,6 +92,19 @@ extern "C" int ls_dist_destroy(ls_dist* c) {
     ls::DeviceGuard g(c->device);
     if (c->comm) (void)rccl().CommDestroy(c->comm);
     delete c;
+    return LS_OK;
+}
+
+extern "C" int ls_dist_info(const ls_dist* c, int* h_rank, int* h_world) {
+    LS_REQUIRE(c && c->comm, LS_E_INVALID, "ls_dist_info: bad argument");
+    Rccl& r = rccl();
+    LS_REQUIRE(r.CommCount && r.CommUserRank, LS_E_STATE, "ls_dist_info: this librccl.so has no ncclCommCount / ncclCommUserRank");
+    int rank = -1, world = -1;
+    ncclResult_t e = r.CommUserRank(c->comm, &rank);
+    if (e == ncclSuccess) e = r.CommCount(c->comm, &world);
+    if (e != ncclSuccess) return rccl_fail(e, "ls_dist_info");
+    if (h_rank) *h_rank = rank;
+    if (h_world) *h_world = world;
     return LS_OK;
 }
 

@@ -21,6 +21,9 @@
 #include <sys/resource.h>
 #include <vector>
 
+#ifdef LS_ND_EXPERIMENTS
+#include "experiments/round_study.h"
+#endif
 namespace ls {
 
 struct SpEnt { float val; int idx; };      // same layout as csrc/nd_tier.h
@@ -238,7 +241,6 @@ struct FactorNode {              // device copy of what the assembly / conversio
     int s, b, own_start, parent;
     long long bnd_off, f_off, x_off, w_off;      // offsets into bnd / fronts (fp64) / Finv storage (fp64) / W storage (fp64)
     long long o_finv, o_w, o_tri;                // fp32 output offsets (plain: finv, wf/wb; quad: d4, u4; sparse leaf: tri)
-    long long o_pu, o_pd;                        // plain nodes: offsets in the persistent upper-level launch's layouts (nd_span.h), -1: none
     int layout, pad;                             // 0 plain, 1 quad, 2 sparse leaf
 };
 
@@ -343,32 +345,34 @@ __global__ void k_extend_add(const int* __restrict__ kids, int n_kids, const Fac
     }
 }
 
+#ifdef LS_ND_EXPERIMENTS
+#define LS_EXP_ROUND(v, nd) exp_round((v), (nd).layout, (nd).pad)
+#else
+#define LS_EXP_ROUND(v, nd) (v)
+#endif
 // fp64 results -> the fp32 arrays of the solve kernels
 __global__ void k_convert(const int* __restrict__ ids, const FactorNode* __restrict__ nodes, const double* __restrict__ xs,
                           const double* __restrict__ ws, float* __restrict__ finv, float* __restrict__ wf, float* __restrict__ wb,
-                          float* __restrict__ u4, float* __restrict__ d4, float* __restrict__ tri, float* __restrict__ pu,
-                          float* __restrict__ pd) {
+                          float* __restrict__ u4, float* __restrict__ d4, float* __restrict__ tri) {
     const FactorNode nd = nodes[ids[blockIdx.y]];
     const int s = nd.s, b = nd.b;
     const double* X = xs + nd.x_off;
     const double* W = ws + nd.w_off;                         // (b, s) row-major
-    const int s4 = (s + 3) & ~3, b4 = (b + 3) & ~3;
-    const bool span = nd.layout == 0 && nd.o_pu >= 0 && pu && pd;
+    const int s4 = (s + 3) & ~3;
     const int64_t total = (int64_t)s * s + (int64_t)b * s;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         if (e < (int64_t)s * s) {
             const int j = (int)(e / s), t = (int)(e % s);
-            const float v = (float)(0.5 * (X[(size_t)j * s + t] + X[(size_t)t * s + j]));
-            if (nd.layout == 0) { finv[nd.o_finv + (size_t)t * s + j] = v; if (span) pd[nd.o_pd + (size_t)j * (s4 + b4) + t] = v; }
+            const float v = LS_EXP_ROUND((float)(0.5 * (X[(size_t)j * s + t] + X[(size_t)t * s + j])), nd);
+            if (nd.layout == 0) finv[nd.o_finv + (size_t)t * s + j] = v;
             else if (nd.layout == 1) d4[nd.o_finv + ((size_t)(t >> 2) * s + j) * 4 + (t & 3)] = v;
             else if (t <= j) tri[nd.o_tri + (size_t)j * (j + 1) / 2 + t] = v;
         } else if (nd.layout != 2) {
             const int64_t f = e - (int64_t)s * s;
             const int i = (int)(f / s), j = (int)(f % s);
-            const float v = (float)W[(size_t)i * s + j];
+            const float v = LS_EXP_ROUND((float)W[(size_t)i * s + j], nd);
             if (nd.layout == 0) {
                 wb[nd.o_w + (size_t)i * s + j] = v; wf[nd.o_w + (size_t)j * b + i] = v;
-                if (span) { pu[nd.o_pu + (size_t)i * s4 + j] = v; pd[nd.o_pd + (size_t)j * (s4 + b4) + s4 + i] = v; }
             }
             else {
                 u4[nd.o_w + ((size_t)(j >> 2) * b + i) * 4 + (j & 3)] = v;
@@ -591,15 +595,7 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     std::vector<FactorNode> fn((size_t)n_nodes + 1);
     memset(fn.data(), 0, fn.size() * sizeof(FactorNode));
     std::vector<int64_t> hn((size_t)(n_nodes + 1) * LS_DIRECT_NODE_COLS, 0);
-    int64_t f_tot = 0, x_tot = 0, w_tot = 0, o_finv = 0, o_w = 0, o_d4 = 0, o_u4 = 0, o_tri = 0, o_pu = 0, o_pd = 0;
-    // the levels above the tier also get the layouts of the persistent upper-level launch (nd_span.h); unsharded handles only
-    // (experiments builds only, and only when asked for: the layouts double the upper levels' factor memory)
-#ifdef LS_ND_EXPERIMENTS
-    const bool want_span = tier_levels > 0 && tier_root >= 1 && shard_count <= 1 && !getenv("LS_ND_NO_SPAN");
-#else
-    const bool want_span = false;
-#endif
-    std::vector<int64_t> pu_off((size_t)n_nodes + 1, -1), pd_off((size_t)n_nodes + 1, -1);
+    int64_t f_tot = 0, x_tot = 0, w_tot = 0, o_finv = 0, o_w = 0, o_d4 = 0, o_u4 = 0, o_tri = 0;
     for (int i = 1; i <= n_nodes; ++i) {
         FactorNode& n = fn[i];
         const int s = P.s[i], b = P.b[i], lv = P.level_of[i];
@@ -609,7 +605,7 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
         n.w_off = w_tot; w_tot += (int64_t)s * b;
         const bool sparse = leaves_ok && lv == levels - 1 && s >= 1;
         const bool quad = !sparse && lv >= tier_root;
-        n.layout = sparse ? 2 : quad ? 1 : 0;
+        n.layout = sparse ? 2 : quad ? 1 : 0; n.pad = lv;
         int64_t* r = hn.data() + (size_t)i * LS_DIRECT_NODE_COLS;
         r[0] = s; r[1] = b; r[2] = P.own_start[i]; r[3] = P.bnd_off[i]; r[4] = P.front_off[i]; r[7] = P.parent[i];
         r[8] = -1; r[9] = -1; r[10] = -1; r[11] = quad;
@@ -617,13 +613,8 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
         if (sparse) { n.o_tri = o_tri; r[8] = o_tri; o_tri += ((int64_t)s * (s + 1) / 2 + 3) & ~(int64_t)3; }
         else if (quad) { n.o_finv = o_d4; n.o_w = o_u4; r[5] = o_d4; r[6] = o_u4; o_d4 += (s4 + b4) * s; o_u4 += s4 * b; }
         else { n.o_finv = o_finv; n.o_w = o_w; r[5] = o_finv; r[6] = o_w; o_finv += (int64_t)s * s; o_w += (int64_t)s * b; }
-        n.o_pu = n.o_pd = -1;
-        if (want_span && !sparse && !quad) {
-            n.o_pu = pu_off[(size_t)i] = o_pu; n.o_pd = pd_off[(size_t)i] = o_pd;
-            o_pu += s4 * b; o_pd += (s4 + b4) * s;
-        }
     }
-    LS_REQUIRE(o_finv + 2 * o_w + o_d4 + o_u4 + 2 * o_tri + o_pu + o_pd < (int64_t)4000000000, LS_E_WORKSPACE, "ls_direct_factor: the factor is too large");
+    LS_REQUIRE(o_finv + 2 * o_w + o_d4 + o_u4 + 2 * o_tri < (int64_t)4000000000, LS_E_WORKSPACE, "ls_direct_factor: the factor is too large");
     lap("layouts");
     // ---- sparse leaves: where every leaf's two pointer lists (A_bs by boundary row / by own row) start; the lists themselves are
     // built on the device below
@@ -665,7 +656,7 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
         (keep ? owned_bytes : scratch_bytes).push_back(cap);
         return true;
     };
-    float *finv = nullptr, *wf = nullptr, *wb = nullptr, *u4 = nullptr, *d4 = nullptr, *tri = nullptr, *pu = nullptr, *pd = nullptr;
+    float *finv = nullptr, *wf = nullptr, *wb = nullptr, *u4 = nullptr, *d4 = nullptr, *tri = nullptr;
     int32_t* d_sp_ptr = nullptr; SpEnt* d_sp_ent = nullptr;
     double *fronts = nullptr, *xs = nullptr, *ws = nullptr, *work = nullptr;
     int *d_inv = nullptr, *d_non = nullptr, *d_bnd = nullptr, *d_ppos = nullptr, *d_rowidx = nullptr, *d_ids = nullptr;
@@ -679,7 +670,6 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
               dalloc((void**)&wb, sizeof(float) * o_w, true, false) && dalloc((void**)&u4, sizeof(float) * o_u4, true, true) &&
               dalloc((void**)&d4, sizeof(float) * o_d4, true, true) && dalloc((void**)&tri, sizeof(float) * o_tri, true, true) &&
               dalloc((void**)&d_sp_ptr, sizeof(int32_t) * n_sp_ptr, true, false) &&
-              (!want_span || (dalloc((void**)&pu, sizeof(float) * o_pu, true, true) && dalloc((void**)&pd, sizeof(float) * o_pd, true, true))) &&
               dalloc((void**)&fronts, sizeof(double) * f_tot, false, true) && dalloc((void**)&xs, sizeof(double) * x_tot, false, false) &&
               dalloc((void**)&ws, sizeof(double) * w_tot, false, false) && dalloc((void**)&work, sizeof(double) * work_tot, false, false) &&
               dalloc((void**)&d_inv, sizeof(int) * V, false, false) && dalloc((void**)&d_non, sizeof(int) * V, false, false) &&
@@ -796,6 +786,9 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     // 10.6 ms of kernels of a 1M-vertex factorisation). Events order it: after its level's products, before the stream's end.
     hipStream_t sc = side_stream(device, 1);
     std::vector<hipEvent_t> evs;
+#ifdef LS_ND_EXPERIMENTS
+    exp_round_configure();
+#endif
     for (const Cmd& c : ctx.cmds) {
         if (e != hipSuccess) break;
         hipStream_t sk = st;
@@ -820,7 +813,7 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
                 break;
             case 2: hipLaunchKernelGGL(k_extend_add, dim3(c.gx, nb), dim3(256), 0, st, (const int*)(d_ids + c.off + b0), nb, d_nodes, d_ppos, fronts); break;
             default:
-                hipLaunchKernelGGL(k_convert, dim3(c.gx, nb), dim3(256), 0, sk, (const int*)(d_ids + c.off + b0), d_nodes, xs, ws, finv, wf, wb, u4, d4, tri, pu, pd);
+                hipLaunchKernelGGL(k_convert, dim3(c.gx, nb), dim3(256), 0, sk, (const int*)(d_ids + c.off + b0), d_nodes, xs, ws, finv, wf, wb, u4, d4, tri);
             }
         }
         ++ctx.launches;
@@ -846,7 +839,6 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     A.d_finv = finv; A.d_wf = wf; A.d_wb = wb; A.d_u4 = u4; A.d_d4 = d4; A.d_tri = tri; A.d_sp_ptr = d_sp_ptr; A.d_sp_ent = d_sp_ent;
     A.n_sp_ptr = n_sp_ptr; A.n_sp_ent = 2 * n_ent;
     A.shard_rank = shard_rank; A.shard_count = shard_count;
-    if (want_span) { A.d_pu = pu; A.d_pd = pd; A.h_pu_off = pu_off.data(); A.h_pd_off = pd_off.data(); A.h_bnd = P.bnd.data(); }
     rc = ls_direct_create(&A, device, stream, out);
     int flag = 0;
     e = hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st);

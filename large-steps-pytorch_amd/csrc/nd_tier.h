@@ -85,24 +85,7 @@ struct TierArgs {
     float* xb;
     int arity, phases, region_floats, vec_floats;    // LDS per wave: [vec_floats | partial sums: rounds x 64 x 4]
     int xcd_order;                                   // 1: workgroup -> subtree map that keeps neighbouring subtrees on one XCD
-    // Timing experiments exist only in builds with -DLS_ND_EXPERIMENTS (tools/ubench/Makefile builds such a library next to
-    // the product); the product library contains neither the fields' uses nor a way to set them.
-    long long* dbg;                                  // experiments, profile = 2: shader-clock stamps, 32 per wave (see k_nd_tier)
-    int stagger;                                     // experiments: half of the workgroups start this many x ~4 us (at 2 GHz) late
-    int ablate;                                      // experiments (WRONG results): 1 no leaf mat-vec, 2 no sparse product,
-                                                     // 4 no dense phases, 8 no leaf phase, 16 no triangle loads
 };
-
-#ifdef LS_ND_EXPERIMENTS
-#define LS_ABLATE(a, bits) ((a).ablate & (bits))
-__device__ __forceinline__ void tier_stamp(const TierArgs& a, int slot) {
-    if (a.dbg && (threadIdx.x & 63) == 0)
-        a.dbg[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32 + slot] = (long long)__builtin_amdgcn_s_memtime();
-}
-#else
-#define LS_ABLATE(a, bits) 0
-__device__ __forceinline__ void tier_stamp(const TierArgs&, int) {}
-#endif
 
 // Item records and the workgroup header are fetched with VECTOR loads (lane i takes dword i) and unpacked with
 // v_readlane: a scalar load on the critical path costs ~3 us next to a streaming CU (the scalar cache path queues behind
@@ -199,11 +182,11 @@ __device__ __forceinline__ void leaf_idx(const TierArgs& a, const TierItem& n, i
     }
 }
 
-template <int K, bool UP>
+template <int K, bool UP, bool NT>
 __device__ __forceinline__ void leaf_dat(const TierArgs& a, const TierItem& n, const LeafIdx& ix, const float* __restrict__ b_in,
                                          int lane, LeafDat<K>& d) {
     const float4* __restrict__ p = reinterpret_cast<const float4*>(a.tri + n.finv_off);
-    const int n4 = LS_ABLATE(a, 16) ? 0 : (n.s * (n.s + 1) / 2 + 3) >> 2;
+    const int n4 = (n.s * (n.s + 1) / 2 + 3) >> 2;
 #pragma unroll
     for (int e = 0; e < TIER_TRI4; ++e) {
         const int i = lane + e * 64;
@@ -223,7 +206,7 @@ __device__ __forceinline__ void leaf_dat(const TierArgs& a, const TierItem& n, c
 #pragma unroll
     for (int t = 0; t < TIER_SPE; ++t) {
         const bool ok = ix.p0 + t < ix.p1;
-        const float2 r = ent[ok ? ix.p0 + t : 0];
+        const float2 r = ld_stream2<NT>(ent + (ok ? ix.p0 + t : 0));
         d.e[t].val = ok ? r.x : 0.0f;
         d.e[t].idx = ok ? __float_as_int(r.y) : 0;
     }
@@ -285,9 +268,6 @@ __device__ __forceinline__ float tri_element(const float* stage, int j, int tj) 
     constexpr int c = 16 * T + E;
     const float lo = stage[tj + c];
     if (c == 0) return lo;
-#if defined(LS_ND_EXPERIMENTS) && defined(LS_TIER_NOHI)
-    return lo;                                                  // timing experiment (WRONG results): half the LDS reads of the mat-vec
-#endif
     const float hi = stage[c * (c + 1) / 2 + j];
     return tri_select<c>(lo, hi);
 }
@@ -354,16 +334,14 @@ __device__ __forceinline__ void leaf_up_compute(const TierArgs& a, const TierIte
     }
     wave_lds_sync();
     float y[K];
-    if (LS_ABLATE(a, 1)) { for (int q = 0; q < K; ++q) y[q] = bj[q]; } else
     tri_matvec<K>(region, yv, s, lane, y);
-    tier_stamp(a, 29);
     wave_lds_sync();
     if (lane < s) {
 #pragma unroll
         for (int q = 0; q < K; ++q) { yv[lane * 4 + q] = y[q]; a.bprime[(size_t)(n.own_start + lane) * K + q] = y[q]; }
     }
     wave_lds_sync();
-    if (n.pfront_off >= 0 && !LS_ABLATE(a, 2)) {
+    if (n.pfront_off >= 0) {
         const bool upc = n.flags & NODE_UPC;
         if (lane < b) {
             float u[K];
@@ -408,7 +386,6 @@ __device__ __forceinline__ void leaf_down_compute(const TierArgs& a, const TierI
     }
     wave_lds_sync();
     float t[K];
-    if (LS_ABLATE(a, 2)) { for (int q = 0; q < K; ++q) t[q] = yj[q]; } else
     sparse_row<K>(a, ix, e, xbv, t);
     float* tv = region + tri_floats;
     {
@@ -418,7 +395,6 @@ __device__ __forceinline__ void leaf_down_compute(const TierArgs& a, const TierI
     }
     wave_lds_sync();
     float z[K];
-    if (LS_ABLATE(a, 1)) { for (int q = 0; q < K; ++q) z[q] = t[q]; } else
     tri_matvec<K>(region, tv, s, lane, z);
     if (lane < s) {
 #pragma unroll
@@ -427,239 +403,16 @@ __device__ __forceinline__ void leaf_down_compute(const TierArgs& a, const TierI
     wave_lds_sync();
 }
 
-#ifndef LS_TIER_DMA
-#define LS_TIER_DMA 0
-#endif
-#ifndef LS_TIER_DMA_AUX
-#define LS_TIER_DMA_AUX 0      // cache policy bits of the LDS-DMA requests (2 = nt: streamed once by one CU)
-#endif
-#if LS_TIER_DMA
-// ---- the leaf loop as a software pipeline around LDS-DMA (round 4: BUILT, BIT-IDENTICAL, MEASURED, NOT FASTER -> a build variant) -----
-// make EXTRA=-DLS_TIER_DMA=1. The judge's round-3 item: round 3's loop stages every triangle global -> 36 VGPRs -> ds_write -> LDS and
-// requests nothing of the NEXT leaf but its record and index lists. global_load_lds (the gfx950 LDS-DMA: 16 bytes per lane, the
-// destination is a wave-uniform LDS base + lane x 16, i.e. the packed triangle lands exactly as tri_stage writes it) needs no staging
-// registers and no ds_write pass; the freed registers hold the next leaf's small operands, requested a whole leaf ahead; the triangle
-// buffer is free as soon as leaf k's mat-vec has read it, so leaf k + 1's DMA is issued THERE and flies under what leaf k still has to
-// do (up: y -> LDS, sparse product, update store; down: leaf k + 1's own sparse product, which needs no triangle):
-//   record k + 3 -> index lists k + 2 -> small operands k + 1 -> [triangle k + 1 by DMA] -> leaf k
-// Ordering of the DMA is by hand (hipcc orders neither a ds_read behind a pending DMA -- it hoisted one above the wait in a probe --
-// nor a DMA behind pending ds_reads): RAW: s_waitcnt vmcnt(0) + a wave-level fence at the top of a leaf; WAR: s_waitcnt lgkmcnt(0)
-// between the mat-vec's last LDS read and the DMA. No ordinary load is USED between the DMA and that wait (hipcc would wait vmcnt(0)
-// for it and drain the DMA): the operands of leaf k + 1 are requested before leaf k's mat-vec and pinned right before the DMA.
-// Result (profiles/r04_tier_leaf_variants.txt; 1M / 4M vertices, same box, solutions identical bit for bit): 221-224 / 748-777 us per
-// solve with this loop, 219-221 / 723-739 with round 3's loop, default and nt cache policy alike; per-wave clock stamps: a leaf takes
-// 5.4 us per wave in either. WHY: the four leaf rounds of a sweep move ~125 MB (105 algorithmic + the partial lines of the 12-byte
-// perm -> b gathers) in 22 us = 5.5+ TB/s -- the leaf rounds already stream at the rate the chip sustains, 16 waves per CU are enough
-// to cover the round trip; what the tier loses against its 3.4 TB/s average is its start (three dependent round trips and the burst of
-// 4096 first triangles: the first leaf is done after 12 us, the next ones every 5.4) and its two dense levels, not the leaf loop.
-typedef __attribute__((address_space(3))) void tier_lds_void;
-typedef __attribute__((address_space(1))) const void tier_glb_cvoid;
-__device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70); }        // vmcnt(0)   (expcnt, lgkmcnt: no wait)
-__device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC07F); }      // lgkmcnt(0) (vmcnt, expcnt: no wait)
-template <typename T> __device__ __forceinline__ void pin(T& v) { asm volatile("" : "+v"(v)); }
-
-__device__ __forceinline__ void tri_dma(const TierArgs& a, const TierItem& n, int lane, float* region) {
-    const float4* __restrict__ p = reinterpret_cast<const float4*>(a.tri + n.finv_off);
-    const int n4 = LS_ABLATE(a, 16) ? 0 : (n.s * (n.s + 1) / 2 + 3) >> 2;
-#pragma unroll
-    for (int e = 0; e < TIER_TRI4; ++e) {
-        const int i = lane + e * 64;
-        if (i < n4) __builtin_amdgcn_global_load_lds((tier_glb_cvoid*)(p + i), (tier_lds_void*)(region + e * 256), 16, 0, LS_TIER_DMA_AUX);
-    }
-}
-
-template <int K>
-struct LeafSmall {         // the operands of a leaf that are not its triangle
-    float v[K];            // up: b of own row `lane`; down: y of own row `lane`
-    float xv[K];           // down: x_bnd of boundary row `lane`
-    SpEnt e[TIER_SPE];
-};
-template <int K, bool UP>
-__device__ __forceinline__ void leaf_small(const TierArgs& a, const TierItem& n, const LeafIdx& ix, const float* __restrict__ b_in, int lane, LeafSmall<K>& d) {
-#pragma unroll
-    for (int q = 0; q < K; ++q) {
-        if (UP) { d.v[q] = lane < n.s ? b_in[(size_t)ix.g * K + q] : 0.0f; d.xv[q] = 0.0f; }
-        else {
-            d.v[q] = lane < n.s ? a.bprime[(size_t)(n.own_start + lane) * K + q] : 0.0f;
-            d.xv[q] = lane < n.b ? a.xb[(size_t)(n.bnd_off + lane) * K + q] : 0.0f;
-        }
-    }
-    const float2* __restrict__ ent = reinterpret_cast<const float2*>(a.sp_ent);       // (always a valid address, see leaf_dat)
-#pragma unroll
-    for (int t = 0; t < TIER_SPE; ++t) {
-        const bool ok = ix.p0 + t < ix.p1;
-        const float2 r = ent[ok ? ix.p0 + t : 0];
-        d.e[t].val = ok ? r.x : 0.0f;
-        d.e[t].idx = ok ? __float_as_int(r.y) : 0;
-    }
-}
-template <int K, bool UP>
-__device__ __forceinline__ void pin_small(LeafSmall<K>& d) {
-#pragma unroll
-    for (int q = 0; q < K; ++q) { pin(d.v[q]); if (!UP) pin(d.xv[q]); }
-#pragma unroll
-    for (int t = 0; t < TIER_SPE; ++t) { pin(d.e[t].val); pin(d.e[t].idx); }
-}
-
-// down sweep, the part of a leaf that needs no triangle:  t = A_sb x_bnd  as [row][4] in LDS behind the triangle
-template <int K>
-__device__ __forceinline__ void leaf_down_sparse(const TierArgs& a, const TierItem& n, const LeafIdx& ix, const LeafSmall<K>& d, float* region, int tri_floats) {
-    const int lane = threadIdx.x & 63, s = n.s, b = n.b;
-    float* xbv = region + tri_floats + 64 * 4;
-    if (lane < b) {
-#pragma unroll
-        for (int q = 0; q < K; ++q) xbv[lane * 4 + q] = d.xv[q];
-    }
-    for (int i = lane + 64; i < b; i += 64) {
-#pragma unroll
-        for (int q = 0; q < K; ++q) xbv[i * 4 + q] = a.xb[(size_t)(n.bnd_off + i) * K + q];
-    }
-    wave_lds_sync();
-    float t[K];
-    if (LS_ABLATE(a, 2)) { for (int q = 0; q < K; ++q) t[q] = d.v[q]; } else
-    sparse_row<K>(a, ix, d.e, xbv, t);
-    float* tv = region + tri_floats;
-    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < s) { w.x = t[0]; if (K > 1) w.y = t[K > 1 ? 1 : 0]; if (K > 2) w.z = t[K > 2 ? 2 : 0]; if (K > 3) w.w = t[K > 3 ? 3 : 0]; }
-    reinterpret_cast<float4*>(tv)[lane] = w;
-    wave_lds_sync();
-}
-
-// The records of the leaves ahead stay PACKED in one vector register each (r1: leaf k + 1, r2: leaf k + 2) and are unpacked with
-// v_readlane where a field is needed (rec_at: the pin keeps the compiler from merging the sites): carrying three unpacked records in
-// scalar registers next to the kernel's ~20 pointers spilled ~100 of them to vector lanes -- 42 v_writelane + 40 v_readlane per leaf
-// in a loop that is bound by instruction issue.
-__device__ __forceinline__ TierItem rec_at(int r) { pin(r); return rec_unpack(r); }
-
-template <int K, bool UP, int W>
-__device__ __forceinline__ void leaf_phase(const TierArgs& a, int k0, int k1, const float* __restrict__ b_in, float* __restrict__ x_out,
-                                           float* region, int tri_floats) {
-    const int lane = threadIdx.x & 63;
-    if (k0 >= k1) return;
-    constexpr int S = W;
-    tier_stamp(a, 24);
-    float* yv = region + tri_floats;
-    // prologue: three dependent round trips (record -> index lists -> operands), as before; then the first triangle goes out
-    TierItem it = rec_unpack(rec_load(a.items, k0, lane));
-    LeafIdx ix;
-    leaf_idx<UP>(a, it, lane, ix);
-    int r1 = k0 + S < k1 ? rec_load(a.items, k0 + S, lane) : 0;
-    int r2 = k0 + 2 * S < k1 ? rec_load(a.items, k0 + 2 * S, lane) : 0;
-    LeafSmall<K> sd;
-    leaf_small<K, UP>(a, it, ix, b_in, lane, sd);
-    LeafIdx ix1 = ix;
-    if (k0 + S < k1) leaf_idx<UP>(a, rec_at(r1), lane, ix1);
-    pin_small<K, UP>(sd);                                  // (landed: nothing ordinary is waited for behind the DMA)
-    tri_dma(a, it, lane, region);
-    if (!UP) leaf_down_sparse<K>(a, it, ix, sd, region, tri_floats);
-    tier_stamp(a, 25);
-    for (int k = k0; k < k1; k += S) {
-        const bool more = k + S < k1, more2 = k + 2 * S < k1;
-        // the wait for leaf k's triangle comes first (everything this wave has in flight is needed now), the requests for the leaves
-        // ahead right behind it: operands of leaf k + 1 (its index lists arrived a leaf ago) ...
-        wait_vm0();
-        wave_lds_sync();
-        if (k == k0) tier_stamp(a, 26);
-        LeafSmall<K> sd1 = sd;
-        if (more) leaf_small<K, UP>(a, rec_at(r1), ix1, b_in, lane, sd1);
-        LeafIdx ix2 = ix1;
-        int r3 = 0;
-        // ... index lists of leaf k + 2 and the record of leaf k + 3: AFTER the mat-vec, where 32 LDS reads are in flight and registers
-        // are scarce (they are first used behind the next leaf's wait)
-        auto request_ahead = [&]() {
-            if (more2) leaf_idx<UP>(a, rec_at(r2), lane, ix2);
-            r3 = k + 3 * S < k1 ? rec_load(a.items, k + 3 * S, lane) : 0;
-        };
-        const int s = it.s, b = it.b;
-        if (UP) {
-            {
-                float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (lane < s) { w.x = sd.v[0]; if (K > 1) w.y = sd.v[K > 1 ? 1 : 0]; if (K > 2) w.z = sd.v[K > 2 ? 2 : 0]; if (K > 3) w.w = sd.v[K > 3 ? 3 : 0]; }
-                reinterpret_cast<float4*>(yv)[lane] = w;
-            }
-            wave_lds_sync();
-            float y[K];
-            if (LS_ABLATE(a, 1)) { for (int q = 0; q < K; ++q) y[q] = sd.v[q]; } else
-            tri_matvec<K>(region, yv, s, lane, y);
-            tier_stamp(a, 29);
-            if (lane < s) {
-#pragma unroll
-                for (int q = 0; q < K; ++q) a.bprime[(size_t)(it.own_start + lane) * K + q] = y[q];
-            }
-            request_ahead();
-            // the triangle has been read: the next one may land on it
-            wait_lgkm0();
-            wave_lds_sync();
-            if (more) { pin_small<K, UP>(sd1); tri_dma(a, rec_at(r1), lane, region); }
-            if (lane < s) {
-#pragma unroll
-                for (int q = 0; q < K; ++q) yv[lane * 4 + q] = y[q];
-            }
-            wave_lds_sync();
-            if (it.pfront_off >= 0 && !LS_ABLATE(a, 2)) {
-                const bool upc = it.flags & NODE_UPC;
-                float* out = upc ? a.xb : a.slots;
-                if (lane < b) {
-                    float u[K];
-                    sparse_row<K>(a, ix, sd.e, yv, u);
-                    const size_t dst = upc ? (size_t)(it.bnd_off + lane) * K : ((size_t)(it.pfront_off + ix.pp) * a.arity + it.cix) * K;
-#pragma unroll
-                    for (int q = 0; q < K; ++q) out[dst + q] = u[q];
-                }
-                for (int i = lane + 64; i < b; i += 64) {          // leaves with more than 64 boundary rows: no prefetch
-                    const int p0 = a.sp_ptr[it.spb_off + i], p1 = a.sp_ptr[it.spb_off + i + 1], pp = a.ppos[it.bnd_off + i];
-                    float u[K];
-#pragma unroll
-                    for (int q = 0; q < K; ++q) u[q] = 0.0f;
-                    for (int p = p0; p < p1; ++p) {
-                        const SpEnt z = a.sp_ent[p];
-#pragma unroll
-                        for (int q = 0; q < K; ++q) u[q] = fmaf(z.val, yv[z.idx * 4 + q], u[q]);
-                    }
-                    const size_t dst = upc ? (size_t)(it.bnd_off + i) * K : ((size_t)(it.pfront_off + pp) * a.arity + it.cix) * K;
-#pragma unroll
-                    for (int q = 0; q < K; ++q) out[dst + q] = u[q];
-                }
-            }
-            wave_lds_sync();
-        } else {
-            float z[K];
-            if (LS_ABLATE(a, 1)) { for (int q = 0; q < K; ++q) z[q] = 0.0f; } else
-            tri_matvec<K>(region, yv, s, lane, z);                 // yv holds t = A_sb x_bnd of this leaf (leaf_down_sparse, a leaf ago)
-            tier_stamp(a, 29);
-            if (lane < s) {
-#pragma unroll
-                for (int q = 0; q < K; ++q) x_out[(size_t)ix.g * K + q] = sd.v[q] - z[q];
-            }
-            request_ahead();
-            wait_lgkm0();
-            wave_lds_sync();
-            if (more) {
-                pin_small<K, UP>(sd1);
-                const TierItem t1 = rec_at(r1);
-                tri_dma(a, t1, lane, region);
-                leaf_down_sparse<K>(a, t1, ix1, sd1, region, tri_floats);        // flies under the DMA: needs operands and LDS vectors only
-            }
-        }
-        if (more) it = rec_at(r1);
-        ix = ix1; sd = sd1; ix1 = ix2;
-        r1 = r2; r2 = r3;
-        tier_stamp(a, 16 + min(7, (k - k0) / S));
-    }
-    // the last DMA of this wave was waited for at the top of its last leaf: nothing of it is pending when the phase's barrier comes
-}
-#else
 // The leaves of this wave in one phase: items k0, k0 + stride, ... < k1, one after the other. Only the small loads of the NEXT
 // leaf are requested ahead (its item record and the index lists that depend on it: 5 registers). A full software pipeline
 // (next leaf's triangle in flight during the multiply, 36 more registers) was measured slower: it spilled, and the leaf
 // phase is bound by its dependent steps, not by bytes in flight.
-template <int K, bool UP, int W>
+template <int K, bool UP, int W, bool NT>
 __device__ __forceinline__ void leaf_phase(const TierArgs& a, int k0, int k1, const float* __restrict__ b_in, float* __restrict__ x_out,
                                            float* region, int tri_floats) {
     const int lane = threadIdx.x & 63;
     if (k0 >= k1) return;
     constexpr int S = W;
-    tier_stamp(a, 24);
     TierItem it = rec_unpack(rec_load(a.items, k0, lane));
     int rec_n = k0 + S < k1 ? rec_load(a.items, k0 + S, lane) : 0;
     LeafIdx ix;
@@ -669,7 +422,7 @@ __device__ __forceinline__ void leaf_phase(const TierArgs& a, int k0, int k1, co
         SpEnt e[TIER_SPE];
         {
             LeafDat<K> d;
-            leaf_dat<K, UP>(a, it, ix, b_in, lane, d);
+            leaf_dat<K, UP, NT>(a, it, ix, b_in, lane, d);
             tri_stage<K>(d, it.s, lane, region);
 #pragma unroll
             for (int q = 0; q < K; ++q) { v[q] = d.v[q]; xv[q] = UP ? 0.0f : d.xv[q]; }
@@ -686,11 +439,8 @@ __device__ __forceinline__ void leaf_phase(const TierArgs& a, int k0, int k1, co
         if (UP) leaf_up_compute<K>(a, it, ix, v, e, region, tri_floats);
         else leaf_down_compute<K>(a, it, ix, v, xv, e, x_out, region, tri_floats);
         it = it_n; ix = ix_n;
-        tier_stamp(a, 16 + min(7, (k - k0) / S));
     }
 }
-
-#endif
 
 // ---- dense nodes inside the tier ---------------------------------------------------------------------------------------
 // Dense nodes of the tier keep their matrices QUAD-INTERLEAVED along the reduction: entry (row, t) of a stream sits at
@@ -704,9 +454,10 @@ __device__ __forceinline__ void leaf_phase(const TierArgs& a, int k0, int k1, co
 #endif
 constexpr int TIER_Q = LS_TIER_Q;   // quads per lane and batch; two batches in flight
 
+template <bool NT>
 __device__ __forceinline__ void tier_prefetch(const float4* __restrict__ col, size_t rows, int q0, int q1, float4 (&cur)[TIER_Q]) {
 #pragma unroll
-    for (int e = 0; e < TIER_Q; ++e) cur[e] = (q0 + e < q1) ? col[(size_t)(q0 + e) * rows] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = 0; e < TIER_Q; ++e) cur[e] = (q0 + e < q1) ? ld_stream4<NT>(col + (size_t)(q0 + e) * rows) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // 4 quads (16 reduction entries) against one vector register; n = quads that exist
@@ -729,15 +480,16 @@ __device__ __forceinline__ void tier_mv_batch(const float* sv4, int base, int q,
     if (TIER_Q >= 8 && q + 4 < q1) tier_mv16(sv4[(4 * q + 16 - base) * 4 + lane], c[TIER_Q >= 8 ? 4 : 0], c[TIER_Q >= 8 ? 5 : 0],
                                              c[TIER_Q >= 8 ? 6 : 0], c[TIER_Q >= 8 ? 7 : 0], q1 - q - 4, acc);
 }
+template <bool NT>
 __device__ __forceinline__ void tier_dot(const float4* __restrict__ col, size_t rows, int q0, int q1, const float* sv4, int base,
                                          float4 (&A)[TIER_Q], f32x4& acc) {
     float4 B[TIER_Q];
-    tier_prefetch(col, rows, q0 + TIER_Q, q1, B);
+    tier_prefetch<NT>(col, rows, q0 + TIER_Q, q1, B);
     for (int q = q0; q < q1; q += 2 * TIER_Q) {
         tier_mv_batch(sv4, base, q, q1, A, acc);
-        tier_prefetch(col, rows, q + 2 * TIER_Q, q1, A);
+        tier_prefetch<NT>(col, rows, q + 2 * TIER_Q, q1, A);
         if (q + TIER_Q < q1) tier_mv_batch(sv4, base, q + TIER_Q, q1, B, acc);
-        tier_prefetch(col, rows, q + 3 * TIER_Q, q1, B);
+        tier_prefetch<NT>(col, rows, q + 3 * TIER_Q, q1, B);
     }
 }
 
@@ -767,12 +519,12 @@ struct DensePre {
     int plo[4], plb[4];    // up, arity 4: pull indices of own row r0 + lane and of boundary row row0 + lane (static lists)
 };
 
-template <int K>
+template <int K, bool NT>
 __device__ __forceinline__ void node_up_pre(const TierArgs& a, const TierItem& it, DensePre<K>& P) {
     const int lane = threadIdx.x & 63, i = it.row0 + lane;
     const bool row = i < it.b;
     const float4* col = reinterpret_cast<const float4*>(a.u4 + it.w_off) + (row ? i : 0);
-    tier_prefetch(col, (size_t)it.b, it.r0 >> 2, row ? it.r1 >> 2 : it.r0 >> 2, P.cur);
+    tier_prefetch<NT>(col, (size_t)it.b, it.r0 >> 2, row ? it.r1 >> 2 : it.r0 >> 2, P.cur);
     // the item that finishes a (row chunk of a) node -- the only part, or part 0 of a split node -- adds what the children
     // hand to the boundary rows and knows where the result goes
     const bool fin = it.part == 0 && row && it.pfront_off >= 0;
@@ -785,7 +537,7 @@ __device__ __forceinline__ void node_up_pre(const TierArgs& a, const TierItem& i
 
 // up: b'_j for the item's reduction range (stored by the row0 == 0 items), partial upd_i = sum_j W[i][j] b'_j.
 // braw: the right-hand side of the tier's dense rows in the tree's numbering (gathered at kernel start, see k_nd_tier).
-template <int K>
+template <int K, bool NT>
 __device__ __forceinline__ void node_up(const TierArgs& a, const TierItem& it, DensePre<K>& P, const float* __restrict__ b_in, float* region, float* pbuf) {
     const int lane = threadIdx.x & 63, b = it.b;
     const int i = it.row0 + lane;
@@ -830,7 +582,7 @@ __device__ __forceinline__ void node_up(const TierArgs& a, const TierItem& it, D
     }
     wave_lds_sync();
     f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
-    tier_dot(col, (size_t)b, it.r0 >> 2, it.r1 >> 2, sv4, it.r0, P.cur, a4);   // every lane takes part (matrix instruction)
+    tier_dot<NT>(col, (size_t)b, it.r0 >> 2, it.r1 >> 2, sv4, it.r0, P.cur, a4);   // every lane takes part (matrix instruction)
     float acc[K];
 #pragma unroll
     for (int q = 0; q < K; ++q) acc[q] = a4[q];
@@ -896,11 +648,11 @@ __device__ __forceinline__ void node_down_finish(const TierArgs& a, const TierIt
     if (!(it.flags & NODE_LEAF)) push_down<K>(a.push_tgt, a.push_ptr[it.front_off + j], a.push_ptr[it.front_off + j + 1], a.xb, acc);
 }
 
-template <int K>
+template <int K, bool NT>
 __device__ __forceinline__ void node_down_pre(const TierArgs& a, const TierItem& it, DensePre<K>& P) {
     const int lane = threadIdx.x & 63, s = it.s, j = it.row0 + lane;
     const bool row = j < s;
-    tier_prefetch(reinterpret_cast<const float4*>(a.d4 + it.finv_off) + (row ? j : 0), (size_t)s, it.r0 >> 2, row ? it.r1 >> 2 : it.r0 >> 2, P.cur);
+    tier_prefetch<NT>(reinterpret_cast<const float4*>(a.d4 + it.finv_off) + (row ? j : 0), (size_t)s, it.r0 >> 2, row ? it.r1 >> 2 : it.r0 >> 2, P.cur);
     const int t = it.r0 + lane;
 #pragma unroll
     for (int q = 0; q < K; ++q) P.v[q] = (t < it.r1 && t < s) ? a.bprime[(size_t)(it.own_start + t) * K + q] : 0.0f;
@@ -913,7 +665,7 @@ __device__ __forceinline__ void node_down_pre(const TierArgs& a, const TierItem&
 }
 
 // down: partial x_j = sum_{t in [r0, r1)} [Finv | -W^T][j][t] * [b' | x_bnd][t]
-template <int K>
+template <int K, bool NT>
 __device__ __forceinline__ void node_down(const TierArgs& a, const TierItem& it, DensePre<K>& P, float* __restrict__ x_out, float* region, float* pbuf) {
     const int lane = threadIdx.x & 63, s = it.s;
     const int j = it.row0 + lane;
@@ -947,7 +699,7 @@ __device__ __forceinline__ void node_down(const TierArgs& a, const TierItem& it,
 #pragma unroll
     for (int c = 0; c < 4; ++c) P.plb[c] = (it.nparts == 1 && P.plo[0] + c < P.plo[1]) ? a.push_tgt[P.plo[0] + c] : -1;
     f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
-    tier_dot(col, (size_t)s, it.r0 >> 2, it.r1 >> 2, sv4, it.r0, P.cur, a4);
+    tier_dot<NT>(col, (size_t)s, it.r0 >> 2, it.r1 >> 2, sv4, it.r0, P.cur, a4);
     float acc[K];
 #pragma unroll
     for (int q = 0; q < K; ++q) acc[q] = a4[q];
@@ -960,7 +712,7 @@ __device__ __forceinline__ void node_down(const TierArgs& a, const TierItem& it,
 }
 
 // One workgroup per subtree. UP: phases run leaves -> tier root. DOWN: tier root -> leaves.
-template <int K, bool UP, int W>
+template <int K, bool UP, int W, bool NT>
 __global__ __launch_bounds__(64 * W, 16 / W) void k_nd_tier(TierArgs a, const float* __restrict__ b_in, float* __restrict__ x_out,
                                                               int tri_floats) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -979,12 +731,6 @@ __global__ __launch_bounds__(64 * W, 16 / W) void k_nd_tier(TierArgs a, const fl
     const int hdr = lane < 32 ? reinterpret_cast<const int*>(a.wgs + sub)[lane] : 0;
     const int obase = UP ? 0 : TIER_MAX_H + 1;
     const unsigned split = (unsigned)rl(hdr, UP ? 14 : 15), leafy = (unsigned)rl(hdr, UP ? 16 : 17);
-    tier_stamp(a, 0);
-#ifdef LS_ND_EXPERIMENTS
-    if (a.stagger > 0 && (blockIdx.x & 8)) {            // phase shift for every other group of 8 workgroups (one per XCD)
-        for (int t = 0; t < a.stagger; ++t) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     if (UP) {
         // right-hand side of the tier's inner-node rows, gathered once into the tree's numbering (braw): the dense items
         // read it from a static address instead of walking perm -> b behind a barrier
@@ -1031,8 +777,8 @@ __global__ __launch_bounds__(64 * W, 16 / W) void k_nd_tier(TierArgs a, const fl
             if (has_nx) rec_nx = rec_load(a.items, j0, lane);
         }
         if ((leafy >> ph) & 1u) {
-            if (!LS_ABLATE(a, 8)) leaf_phase<K, UP, W>(a, i0 + wave, LS_ABLATE(a, 32) ? min(i1, i0 + W) : LS_ABLATE(a, 64) ? min(i1, i0 + 2 * W) : i1, b_in, x_out, region, tri_floats);
-        } else if (!LS_ABLATE(a, 4)) {
+            leaf_phase<K, UP, W, NT>(a, i0 + wave, i1, b_in, x_out, region, tri_floats);
+        } else {
             int rec = (!pre_valid && i0 + wave < i1) ? rec_load(a.items, i0 + wave, lane) : 0;
             // the (last) split row chunk this wave will finish once its parts have met: record and static indices stay in
             // registers across that barrier, nothing is loaded behind it
@@ -1043,9 +789,9 @@ __global__ __launch_bounds__(64 * W, 16 / W) void k_nd_tier(TierArgs a, const fl
                 const TierItem it = first ? it_pre : rec_unpack(rec);
                 rec = rec_next;
                 float* pbuf = region + a.vec_floats + ((k - i0) / W) * 256;
-                if (!first) { if (UP) node_up_pre<K>(a, it, pre); else node_down_pre<K>(a, it, pre); }
-                if (UP) node_up<K>(a, it, pre, b_in, region, pbuf);
-                else node_down<K>(a, it, pre, x_out, region, pbuf);
+                if (!first) { if (UP) node_up_pre<K, NT>(a, it, pre); else node_down_pre<K, NT>(a, it, pre); }
+                if (UP) node_up<K, NT>(a, it, pre, b_in, region, pbuf);
+                else node_down<K, NT>(a, it, pre, x_out, region, pbuf);
                 if (it.nparts > 1 && it.part == 0) {
                     head_k = k; head_idx = pre.idx; head_p0 = pre.plo[0]; head_p1 = pre.plo[1];
                 }
@@ -1081,10 +827,10 @@ __global__ __launch_bounds__(64 * W, 16 / W) void k_nd_tier(TierArgs a, const fl
             }
         }
         // every field of `pre` is rewritten here on every path: nothing of it stays live across a leaf phase
-        pre_valid = has_nx && !LS_ABLATE(a, 4);
+        pre_valid = has_nx;
         it_pre = rec_unpack(rec_nx);
         if (pre_valid) {
-            if (UP) node_up_pre<K>(a, it_pre, pre); else node_down_pre<K>(a, it_pre, pre);
+            if (UP) node_up_pre<K, NT>(a, it_pre, pre); else node_down_pre<K, NT>(a, it_pre, pre);
         } else {
 #pragma unroll
             for (int e = 0; e < TIER_Q; ++e) pre.cur[e] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1094,9 +840,7 @@ __global__ __launch_bounds__(64 * W, 16 / W) void k_nd_tier(TierArgs a, const fl
 #pragma unroll
             for (int c = 0; c < 4; ++c) { pre.plo[c] = -1; pre.plb[c] = -1; }
         }
-        tier_stamp(a, 1 + 2 * ph);
         __syncthreads();      // workgroup-scope release/acquire of the slots / boundary vectors written above (same CU)
-        tier_stamp(a, 2 + 2 * ph);
     }
 }
 

@@ -24,7 +24,7 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
 template <int K, int VARIANT>
 __global__ __launch_bounds__(BLOCK) void k_spmv(CsrView A, const float* __restrict__ x, float* __restrict__ y, int64_t V,
                                                 int T, int G) {
-    __shared__ int2 s_cv[VARIANT == 0 ? LDS_CAP : 1];
+    __shared__ __attribute__((aligned(16))) int2 s_cv[VARIANT == 0 ? LDS_CAP : 1];
     const TileSched sch(T, G);
     for (int tile = sch.first; tile < sch.end; tile += sch.step) {
         const int64_t r0 = (int64_t)tile * TILE_ROWS, r1 = min(r0 + (int64_t)TILE_ROWS, V);

@@ -16,7 +16,7 @@
 
 namespace ls {
 
-constexpr int LDS_CAP = 4096;   // {col,val} pairs staged per tile (32 KiB); denser tiles fall back to direct reads
+constexpr int LDS_CAP = 2560;   // {col,val} pairs staged per tile (20 KiB: eight workgroups per CU; a 256-row tile of a valence-6 mesh has ~1800); denser tiles fall back to direct reads
 
 struct CsrView {
     const int* __restrict__ rowptr;
@@ -44,6 +44,12 @@ __device__ __forceinline__ void row_csr_direct(const CsrView& A, const float* __
 
 // Workgroup-cooperative: every thread of the block must call this (barriers inside).
 // r0/r1: tile row range; `active` = this thread owns row i = r0 + threadIdx.x < r1.
+// Round 5: (1) the tile's col / val ranges are copied with 16-byte loads (4 entries per lane and request; the ranges start at any
+// 4-byte offset, which global_load_dwordx4 accepts) instead of one 4-byte load per entry and array; (2) a row's gathers x[col] are all
+// requested before the first product -- the loop `LDS read -> gather -> fma` had run a row's ~7 entries as 7 dependent round trips.
+// The products stay in row order: the result is the same bit for bit.
+typedef int i4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f4u_spmv __attribute__((ext_vector_type(4), aligned(4)));
 template <int K>
 __device__ __forceinline__ void row_csr_lds(const CsrView& A, const float* __restrict__ x, int64_t r0, int64_t r1,
                                             int2* __restrict__ s_cv, float (&acc)[K]) {
@@ -54,12 +60,33 @@ __device__ __forceinline__ void row_csr_lds(const CsrView& A, const float* __res
     int s = 0, e = 0;
     if (active) { s = A.rowptr[i]; e = A.rowptr[i + 1]; }
     if (total <= LDS_CAP) {
-        for (int t = threadIdx.x; t < total; t += BLOCK)
-            s_cv[t] = make_int2(A.col[base + t], __float_as_int(A.val[base + t]));
+        for (int t = 4 * threadIdx.x; t < total; t += 4 * BLOCK) {
+            if (t + 4 <= total) {
+                const i4u c = *reinterpret_cast<const i4u*>(A.col + base + t);
+                const f4u_spmv v = *reinterpret_cast<const f4u_spmv*>(A.val + base + t);
+                int4* o = reinterpret_cast<int4*>(s_cv + t);           // (t is a multiple of 4: 32-byte aligned in LDS)
+                o[0] = make_int4(c[0], __float_as_int(v[0]), c[1], __float_as_int(v[1]));
+                o[1] = make_int4(c[2], __float_as_int(v[2]), c[3], __float_as_int(v[3]));
+            } else {
+                for (int u = t; u < total; ++u) s_cv[u] = make_int2(A.col[base + u], __float_as_int(A.val[base + u]));
+            }
+        }
         __syncthreads();
-        for (int j = s - base; j < e - base; ++j) {
-            const int2 cv = s_cv[j];
-            fma_row<K>(acc, __int_as_float(cv.y), x, cv.x);
+        const int2* __restrict__ p = s_cv + (s - base);
+        const int n = e - s;
+        constexpr int B = 8;                                            // gathers in flight per lane (valence + 1 <= 8 on a regular mesh)
+        for (int j0 = 0; j0 < n; j0 += B) {
+            int2 c[B];
+            Vec<K> xv[B];
+#pragma unroll
+            for (int t = 0; t < B; ++t) c[t] = j0 + t < n ? p[j0 + t] : make_int2(0, 0);
+#pragma unroll
+            for (int t = 0; t < B; ++t) if (j0 + t < n) xv[t] = reinterpret_cast<const Vec<K>*>(x)[c[t].x];
+#pragma unroll
+            for (int t = 0; t < B; ++t) if (j0 + t < n) {
+#pragma unroll
+                for (int q = 0; q < K; ++q) acc[q] = fmaf(__int_as_float(c[t].y), xv[t].v[q], acc[q]);
+            }
         }
         __syncthreads();   // the next tile overwrites s_cv
     } else {

@@ -81,8 +81,6 @@ _SIGNATURES = {
                                                c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "ls_normals_pair_backward_verts": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
-    "ls_direct_tier_stamps": (c_int, [c_void_p, c_void_p, c_i64]),
-    "ls_direct_span_stamps": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
     "ls_shard_plan_create": (c_int, [c_i64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
     "ls_shard_plan_destroy": (c_int, [c_void_p]),
     "ls_shard_plan_info": (c_int, [c_void_p] + [ctypes.POINTER(c_i64)] * 5 + [ctypes.POINTER(c_int)] * 2 + [ctypes.POINTER(c_i64)]),
@@ -99,6 +97,7 @@ _SIGNATURES = {
     "ls_dist_create": (c_int, [c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
     "ls_dist_destroy": (c_int, [c_void_p]),
     "ls_dist_allreduce_sum": (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
+    "ls_dist_info": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "ls_dist_direct_solve": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ls_direct_launch_profile": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ls_direct_factor": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -538,6 +538,51 @@ class ShardedDirect:
     def info(self):
         return self.local.info()
 
+    def communicator(self):
+        """(rank, world) as the library's RCCL communicator reports them (ncclCommUserRank / ncclCommCount), None without one"""
+        if not self._comm.value:
+            return None
+        rk, wd = ctypes.c_int(-1), ctypes.c_int(-1)
+        _native.check(_native.lib().ls_dist_info(self._comm, ctypes.byref(rk), ctypes.byref(wd)))
+        return rk.value, wd.value
+
+    def profile_parts(self, b, repeats=5):
+        """The three pieces of a sharded solve on THIS rank, from HIP events on the solve's stream (mean of `repeats` solves, us):
+        part 0 (own subtrees upwards), the all-reduce of the exchange region, part 1 (replicated levels + own subtrees downwards).
+        The collective's figure includes the wait for the slowest rank's part 0. Same launches as solve(), issued piece by piece."""
+        b = b.contiguous()
+        k, dev, lib, h = b.shape[1], self.device, _native.lib(), self.local._direct._h
+        x = torch.zeros_like(b)
+        if self.P == 1:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            tot = 0.0
+            for _ in range(repeats):
+                ev[0].record(); self.local._direct.solve(b, x); ev[1].record()
+                torch.cuda.synchronize(dev)
+                tot += ev[0].elapsed_time(ev[1]) * 1e3 / repeats
+            return dict(part0_us=tot, collective_us=0.0, part1_us=0.0)
+        ex = self._exchange.get(k)
+        if ex is None:
+            ex = self._exchange[k] = torch.zeros(max(1, self.exchange_floats_per_column * k), dtype=torch.float32, device=dev)
+        acc = [0.0, 0.0, 0.0]
+        for _ in range(repeats):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            with torch.cuda.device(dev):
+                ev[0].record()
+                _native.check(lib.ls_direct_solve_part(h, _native.ptr(b), _native.ptr(x), k, 0, _native.ptr(ex), _native.stream_of(dev)))
+                ev[1].record()
+                if self._comm.value:
+                    _native.check(lib.ls_dist_allreduce_sum(self._comm, _native.ptr(ex), ex.numel(), _native.stream_of(dev)))
+                else:
+                    _all_reduce_sum(ex, self.group)
+                ev[2].record()
+                _native.check(lib.ls_direct_solve_part(h, _native.ptr(b), _native.ptr(x), k, 1, _native.ptr(ex), _native.stream_of(dev)))
+                ev[3].record()
+            torch.cuda.synchronize(dev)
+            for i in range(3):
+                acc[i] += ev[i].elapsed_time(ev[i + 1]) * 1e3 / repeats
+        return dict(part0_us=acc[0], collective_us=acc[1], part1_us=acc[2])
+
     def solve(self, b, gather=False):
         _native.require_device(b, "b")
         if b.dim() != 2 or b.shape[0] != self.V or not 1 <= b.shape[1] <= 4 or b.dtype != torch.float32:
@@ -787,7 +832,17 @@ def bench_sharded(workload, device, steps, warmup, shard="auto"):
             dist.all_reduce(words)              # every rank reads its share of the bottom levels and all of the replicated top
             rows = torch.tensor([int(sd.owned.sum())], dtype=torch.int64, device=device)
             dist.all_reduce(rows, op=dist.ReduceOp.MAX)
-            return dict(V=v.shape[0], nnz=int(M._nnz()), ms_per_step=float(elapsed.item()) / steps * 1e3, err=float(err.item()), shard="vertex",
+            # after the timed region: every rank's three pieces of a solve by HIP events, its device and what its RCCL communicator says
+            parts = sd.profile_parts(u_full, repeats=max(1, min(steps, 5)))
+            comm = sd.communicator()
+            mine = dict(rank=rank, device=torch.cuda.get_device_name(device), device_index=device.index, own_rows=int(sd.owned.sum()),
+                        kernel_us=parts["part0_us"] + parts["part1_us"], communicator_rank_world=list(comm) if comm else None, **parts)
+            everyone = [None] * world
+            dist.all_gather_object(everyone, mine)
+            return dict(per_rank=everyone, devices=[e["device_index"] for e in everyone],
+                        communicator=(dict(kind="ls_dist (library's own RCCL communicator, all-reduce in place on the solve's stream)", ranks=comm[1]) if comm else
+                                      dict(kind=f"torch.distributed all_reduce ({dist.get_backend()})", ranks=world)),
+                        V=v.shape[0], nnz=int(M._nnz()), ms_per_step=float(elapsed.item()) / steps * 1e3, err=float(err.item()), shard="vertex",
                         iterations=0, converged=True, halo=int(sd.exchange_floats_per_column * k), method="nested-dissection", depth=sd.cut_level,
                         rows_per_rank=int(rows.item()), solve_bytes=int(4 * int(words.item()) + 4 * k * 4 * v.shape[0]),
                         solver=(f"HIP nested-dissection direct solver sharded by subtrees of its elimination tree: cut at tree level {sd.cut_level}, "

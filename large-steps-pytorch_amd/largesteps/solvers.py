@@ -10,6 +10,7 @@ Neither cholespy/CHOLMOD nor torch sparse ops are used; there is no CPU path.
 """
 import ctypes
 import os
+import types
 import warnings
 
 import numpy as np
@@ -342,7 +343,10 @@ def release_scratch(device=None):
     _native.check(_native.lib().ls_release_scratch(-1 if idx is None else idx))
 
 
-_DIRECT_INFO = dict(iterations=0, converged=True, method="nested-dissection")      # (what every direct solve reports: one shared object)
+# What every direct solve reports. A direct solve has no stopping rule: `converged` only says that no iteration was cut short -- the
+# accuracy statement of this path is the FORWARD error against an fp64 solution (<= 1e-4 relative; tests/test_gpu_parity.py,
+# bench.py `config.tolerance`), not a residual. Read-only: one object is shared by every solver of the process.
+_DIRECT_INFO = types.MappingProxyType(dict(iterations=0, converged=True, method="nested-dissection"))
 
 
 class NestedDissectionSolver(Solver):

@@ -246,11 +246,7 @@ class _Arrays(ctypes.Structure):
                 ("h_perm", ctypes.c_void_p), ("h_ppos", ctypes.c_void_p), ("n_bnd", ctypes.c_int64), ("h_push_ptr", ctypes.c_void_p),
                 ("h_push_tgt", ctypes.c_void_p), ("n_front", ctypes.c_int64), ("d_finv", ctypes.c_void_p), ("d_wf", ctypes.c_void_p),
                 ("d_wb", ctypes.c_void_p), ("d_u4", ctypes.c_void_p), ("d_d4", ctypes.c_void_p), ("d_tri", ctypes.c_void_p), ("d_sp_ptr", ctypes.c_void_p), ("d_sp_ent", ctypes.c_void_p),
-                ("n_sp_ptr", ctypes.c_int64), ("n_sp_ent", ctypes.c_int64), ("shard_rank", ctypes.c_int32), ("shard_count", ctypes.c_int32),
-                # the persistent upper-level launch's layouts (csrc/nd_span.h): not produced by this statement -> NULL, the
-                # handle runs the levels above the tier as one launch per level
-                ("d_pu", ctypes.c_void_p), ("d_pd", ctypes.c_void_p), ("h_pu_off", ctypes.c_void_p), ("h_pd_off", ctypes.c_void_p),
-                ("h_bnd", ctypes.c_void_p)]
+                ("n_sp_ptr", ctypes.c_int64), ("n_sp_ent", ctypes.c_int64), ("shard_rank", ctypes.c_int32), ("shard_count", ctypes.c_int32)]
 
 
 NODE_COLS = 12
@@ -272,7 +268,7 @@ class DirectHandle:
         dp = lambda t: ctypes.c_void_p(t.data_ptr())         # noqa: E731
         arr = _Arrays(plan.V, plan.levels, plan.arity, as_p(nodes), as_p(perm32), as_p(ppos32), ppos32.shape[0], as_p(ptr32),
                       as_p(tgt32), ptr32.shape[0] - 1, dp(fac.finv), dp(fac.wf), dp(fac.wb), dp(fac.u4), dp(fac.d4), dp(fac.tri), dp(fac.sp_ptr),
-                      dp(fac.sp_ent), fac.n_sp_ptr, fac.n_sp_ent, 0, 1, None, None, None, None, None)
+                      dp(fac.sp_ent), fac.n_sp_ptr, fac.n_sp_ent, 0, 1)
         self._h = ctypes.c_void_p(None)
         with torch.cuda.device(device):
             _native.check(_native.lib().ls_direct_create(ctypes.byref(arr), device.index, _native.stream_of(device),

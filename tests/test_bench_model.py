@@ -79,7 +79,7 @@ def test_roofline_group_resolves_in_the_committed_pmc_file():
         doc = json.load(fh)
     assert doc["workload"] == b.WORKLOAD
     per_prefix = {}
-    for p in b.direct_group_prefixes(False):
+    for p in b.direct_group_prefixes():
         hits = {k: v for k, v in doc["kernels"].items() if k.startswith(p)}
         assert hits, f"no kernel of {b.PMC_FILE} starts with {p!r}"
         per_prefix[p] = sum(v["dispatches"] for v in hits.values())
@@ -90,7 +90,52 @@ def test_roofline_group_resolves_in_the_committed_pmc_file():
     d = json.loads([ln for ln in open(lines[-1]).read().splitlines() if ln.startswith("{")][-1])
     n_down = d["config"]["kernel_us"]["down_launches"]
     assert tier > 0 and levels == (n_down - 1) * tier, (levels, tier, n_down)
-    traffic, n = b.pmc_traffic_group(b.direct_group_prefixes(False), b.WORKLOAD)
+    traffic, n = b.pmc_traffic_group(b.direct_group_prefixes(), b.WORKLOAD)
     assert n == levels + tier
     assert traffic >= 0.9 * d["roofline"]["bytes_per_launch"], (traffic, d["roofline"]["bytes_per_launch"])
     assert traffic <= 1.5 * d["roofline"]["bytes_per_launch"]
+
+
+def test_plain_multi_gpu_start_launches_the_ranks_itself(monkeypatch):
+    """`python bench.py --gpus 8` without RANK in the environment (the shape of the driver's N = 1 command) must not die with KeyError:
+    bench.py starts torch.distributed.run itself, with the driver's own arguments, and picks the loopback transport when the box has
+    fewer devices than ranks."""
+    import subprocess
+    import sys
+    import types
+    import torch
+    bench = load_bench()
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return types.SimpleNamespace(returncode=0)
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "5", "--warmup", "2"])
+    for n_dev, loop in ((1, True), (8, False)):
+        monkeypatch.setattr(torch.cuda, "device_count", lambda n=n_dev: n)
+        monkeypatch.delenv("LS_DIST_LOOPBACK", raising=False)
+        rc = bench.launch_ranks(types.SimpleNamespace(gpus=8))
+        assert rc == 0
+        cmd = seen["cmd"]
+        assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+        assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+        assert cmd[-6:] == ["--gpus", "8", "--steps", "5", "--warmup", "2"] and cmd[-7].endswith("bench.py")
+        assert (seen["env"].get("LS_DIST_LOOPBACK") == "1") == loop
+        assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_shard_model_is_the_committed_table():
+    """the N > 1 line carries DESIGN.md section 5's prediction for its N (so that a SCALE record tests the model): the rows are the
+    per-rank kernel times of profiles/r04_shard_rank_kernel_times.txt"""
+    bench = load_bench()
+    text = open(os.path.join(ROOT, "profiles", "r04_shard_rank_kernel_times.txt")).read()
+    for wl, rows in bench.SHARD_MODEL_US.items():
+        for n, (kernel_us, above) in rows.items():
+            mine = [float(ln.split(":")[2].split("us")[0]) for ln in text.splitlines() if ln.startswith(f"{wl}: rank") and f" of {n}:" in ln]
+            assert mine and min(mine) - 1.0 <= kernel_us <= max(mine) + 1.0, (wl, n, mine, kernel_us)
+            m = bench.shard_model(wl, n)
+            assert m["kernel_us_per_rank"] == kernel_us and m["predicted_ms_per_step"][0] <= m["predicted_ms_per_step"][1]
+    assert bench.shard_model("cfg2_bunny70k", 2) is None and bench.shard_model("cfg4_plane1m", 3) is None
+    one = bench.shard_model("cfg4_plane1m", 1)
+    assert one["collective_us_assumed"] == [0.0, 0.0]

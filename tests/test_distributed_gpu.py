@@ -221,12 +221,15 @@ def test_rccl_process_group_initialises():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 8])
-def test_bench_line_of_a_multi_process_run(world):
-    """`bench.py --gpus N` exactly as the driver launches it (torch.distributed.run, one process per rank, 127.0.0.1), in loopback on the
-    one GPU (LS_DIST_LOOPBACK=1: every rank on cuda:0, gloo transport): rank 0 must print ONE JSON line with the keys the driver parses,
-    for the subtree-sharded direct solver, with the sharded answer correct. (The first SCALE record can only be taken on an 8-GPU node;
-    this keeps the command from failing there for a reason a 1-GPU box could have shown.)"""
+@pytest.mark.parametrize("world,launch,workload", [(2, "torchrun", "cfg2_bunny70k"), (8, "torchrun", "cfg2_bunny70k"),
+                                                   (2, "plain", "cfg2_bunny70k"), (8, "plain", "cfg4_plane1m")])
+def test_bench_line_of_a_multi_process_run(world, launch, workload):
+    """`bench.py --gpus N` in both forms it may be started in -- as the driver launches N > 1 (torch.distributed.run, one process per rank,
+    127.0.0.1) and PLAINLY (`python bench.py --gpus N`, the shape of the driver's N = 1 command: bench.py starts the ranks itself) -- in
+    loopback on the one GPU (every rank on cuda:0, gloo transport): rank 0 must print ONE JSON line with the keys the driver parses, for
+    the subtree-sharded direct solver, with the sharded answer correct, the ranks that took part, every rank's kernel / collective times
+    and, for the headline workload, the model's prediction for that N. (The first SCALE record can only be taken on an 8-GPU node; this
+    keeps the command from failing there for a reason a 1-GPU box could have shown.)"""
     import json
     import socket
     import subprocess
@@ -235,11 +238,18 @@ def test_bench_line_of_a_multi_process_run(world):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ, LS_DIST_LOOPBACK="1", LS_POOL_GB="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
-           "--workload", "cfg2_bunny70k"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    env = dict(os.environ, LS_POOL_GB="0")
+    tail = [os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--workload", workload]
+    if launch == "torchrun":
+        env["LS_DIST_LOOPBACK"] = "1"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + tail
+    else:
+        env.pop("LS_DIST_LOOPBACK", None)           # bench.py sees one device for N ranks and picks the loopback transport itself
+        for name in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(name, None)
+        cmd = [sys.executable] + tail
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -251,7 +261,18 @@ def test_bench_line_of_a_multi_process_run(world):
     assert d["scaling"] == "strong" and d["higher_is_better"] is True and d["dtype"] == "f32" and d["vs_baseline"] is None
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
     c = d["config"]
-    assert "cfg2_bunny70k" in c["workload"] and f"over {world} ranks" in c["workload"] and c["method"] == "nested-dissection"
+    assert workload in c["workload"] and f"over {world} ranks" in c["workload"] and c["method"] == "nested-dissection"
     assert c["max_abs_err_vs_v"] <= 1e-4, c["max_abs_err_vs_v"]
+    rk = c["ranks"]
+    assert rk["world_size"] == world and rk["communicator"]["ranks"] == world and "loopback" in rk["transport"]
+    assert [p["rank"] for p in rk["per_rank"]] == list(range(world))
+    assert sum(p["own_rows"] for p in rk["per_rank"]) == int(c["workload"].split("V=")[1].split(",")[0])
+    for p in rk["per_rank"]:
+        assert p["part0_us"] > 0 and p["part1_us"] > 0 and p["collective_us"] > 0 and abs(p["kernel_us"] - p["part0_us"] - p["part1_us"]) < 1e-6
+    if workload == "cfg4_plane1m":
+        m = c["model"]
+        assert m["kernel_us_per_rank"] == 118.0 and m["predicted_ms_per_step"][0] < m["predicted_ms_per_step"][1]
+    else:
+        assert c["model"] is None
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 * world and abs(rf["frac"] - rf["achieved"] / rf["peak"]) <= 1e-9

@@ -1,9 +1,9 @@
 // nd_drive.cpp -- C++ driver of the direct solver through the C ABI only (no Python, starts in a second): factorises the
-// uniform-Laplacian system M = I + lambda L of an n x n plane (BASELINE.json configs[3] at n = 1000), solves it with the levels
-// above the tier as one launch per level ("persist" 0) and as one persistent launch ("persist" 1, csrc/nd_span.h), checks both
-// against the residual on the host and against each other, and times them with HIP events.
+// uniform-Laplacian system M = I + lambda L of an n x n plane (BASELINE.json configs[3] at n = 1000), solves it, checks the solution
+// against the known one and the residual on the host, prints an FNV hash of the solution (variant builds must agree bit for bit) and
+// times the solve with HIP events (whole solve; per sweep; ND_DRIVE_TABLE=1: every launch). ND_DRIVE_NT=0/1 forces the cache policy.
 //   build: hipcc -O2 -std=c++17 tools/nd_drive.cpp -Iinclude -L large-steps-pytorch_amd/lib -llargesteps_hip -Wl,-rpath,'$ORIGIN/../../large-steps-pytorch_amd/lib' -o tools/build/nd_drive
-//   run:   tools/build/nd_drive [n = 1000] [solves = 200] [k = 3] [tier levels = -1] [modes: 1 = both, 0 = launches only]
+//   run:   tools/build/nd_drive [n = 1000] [solves = 200] [k = 3] [tier levels = -1]
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -18,7 +18,7 @@
 
 int main(int argc, char** argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 1000, solves = argc > 2 ? atoi(argv[2]) : 200, k = argc > 3 ? atoi(argv[3]) : 3;
-    const int tier = argc > 4 ? atoi(argv[4]) : -1, max_mode = argc > 5 ? atoi(argv[5]) : 1;          // tier levels (-1: the library picks); 0: skip the persistent mode
+    const int tier = argc > 4 ? atoi(argv[4]) : -1, max_mode = 0;          // tier levels (-1: the library picks)
     const float lambda = 50.0f;
     const int64_t V = (int64_t)n * n;
     // uniform Laplacian of the plane's triangulation (cell (x, y): triangles (i, i+1, i+n+1), (i, i+n+1, i+n)): neighbours E, W, N, S, NE, SW
@@ -67,7 +67,7 @@ int main(int argc, char** argv) {
     double span_us = 0;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int mode = 0; mode <= max_mode; ++mode) {
-        LS(ls_direct_set(h, "persist", mode));
+        if (getenv("ND_DRIVE_NT")) LS(ls_direct_set(h, "nt", atoi(getenv("ND_DRIVE_NT"))));
         LS(ls_direct_info(h, nullptr, &launches, nullptr));
         CK(hipMemsetAsync(d_x, 0xff, V * k * 4, st));
         for (int r = 0; r < 3; ++r) LS(ls_direct_solve(h, d_b, d_x, k, st));
@@ -118,48 +118,9 @@ int main(int argc, char** argv) {
             for (size_t i = 0; i < x.size() * 4; ++i) { hsh ^= pb[i]; hsh *= 1099511628211ull; }
             printf("solution hash %016llx\n", hsh);
         }
-        printf("persist %d: %2d launches  %8.2f us per solve   max |x - x*| %.2e   ||b - M x|| / ||b|| %.2e   events: first part %.1f us, last part %.1f us, middle %.1f us\n",
+        printf("solve (mode %d): %2d launches  %8.2f us per solve   max |x - x*| %.2e   ||b - M x|| / ||b|| %.2e   events: first part %.1f us, last part %.1f us, middle %.1f us\n",
                mode, launches, ms / solves * 1e3, err, sqrt(res / bn), acc[0] * 1e3, acc[1] * 1e3, acc[2] * 1e3);
     }
-    if (max_mode >= 1) {   // experiments library (-DLS_ND_EXPERIMENTS): where the persistent launch spends its time, from per-workgroup clock stamps
-        int G = 0, P = 0;
-        LS(ls_direct_span_stamps(h, nullptr, 0, &G, &P));
-        LS(ls_direct_set(h, "profile", 2));
-        LS(ls_direct_solve(h, d_b, d_x, k, st));
-        LS(ls_direct_solve(h, d_b, d_x, k, st));
-        std::vector<long long> sm((size_t)G * P * 8, 0);
-        if (G && P && ls_direct_span_stamps(h, sm.data(), (int64_t)sm.size(), nullptr, nullptr) == 0) {
-            // the counters of different XCDs are not synchronised: only differences inside one workgroup mean anything.
-            // Calibration: a workgroup's first to last stamp is (nearly) the launch's duration from HIP events.
-            double tick_sum = 0;
-            for (int w = 0; w < G; ++w) tick_sum += (double)(sm[((size_t)w * P + P - 1) * 8 + 4] - sm[((size_t)w * P) * 8]);
-            const double us = span_us > 0 && tick_sum > 0 ? span_us / (tick_sum / G) : 1.0 / 2100.0;
-            printf("persistent launch, %d workgroups x %d phases, %.0f clock ticks per us; us, mean over the workgroups:\n", G, P, 1.0 / us);
-            printf("  phase  length |    wait  vector products epilogue   drain  arrive request\n");
-            for (int ph = 0; ph < P; ++ph) {
-                double d[7] = {0, 0, 0, 0, 0, 0, 0}, len = 0;
-                for (int w = 0; w < G; ++w) {
-                    const long long* t = &sm[((size_t)w * P + ph) * 8];
-                    long long prev = t[0];
-                    for (int q = 1; q < 8; ++q) { if (t[q]) { d[q - 1] += (double)(t[q] - prev); prev = t[q]; } }
-                    len += (double)((ph + 1 < P ? t[8] : t[4]) - t[0]);
-                }
-                printf("  %5d %7.2f | %7.2f %7.2f %8.2f %8.2f %7.2f %7.2f %7.2f\n", ph, len / G * us, d[0] / G * us, d[1] / G * us, d[2] / G * us, d[3] / G * us,
-                       d[4] / G * us, d[5] / G * us, d[6] / G * us);
-            }
-        }
-        LS(ls_direct_set(h, "profile", 0));
-    }
-    double diff = 0;
-    if (max_mode < 1) { LS(ls_direct_destroy(h)); return 0; }
-    for (size_t i = 0; i < x0.size(); ++i) diff = std::max(diff, (double)fabsf(x0[i] - x1[i]));
-    printf("max |x(persist 1) - x(persist 0)| = %.3e\n", diff);
-    // a second run of the persistent path must be bitwise identical to the first
-    LS(ls_direct_solve(h, d_b, d_x, k, st));
-    CK(hipStreamSynchronize(st));
-    std::vector<float> x2((size_t)V * k);
-    CK(hipMemcpy(x2.data(), d_x, V * k * 4, hipMemcpyDeviceToHost));
-    printf("persistent path bitwise reproducible: %s\n", memcmp(x1.data(), x2.data(), x1.size() * 4) == 0 ? "yes" : "NO");
     LS(ls_direct_destroy(h));
-    return diff < 1e-3 ? 0 : 2;
+    return 0;
 }
