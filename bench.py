@@ -122,6 +122,70 @@ def pmc_traffic_group(prefixes, workload):
     return sum(r["traffic_bytes"] * r.get("dispatches", 1) for r in hits) / n, n
 
 
+ASSEMBLY_KERNELS = ("ls::k_count<", "ls::k_scan_reduce", "ls::k_scan_bsums", "ls::k_scan_final", "ls::k_scatter<", "ls::k_row_merge<",
+                    "ls::k_tile_scan", "ls::k_rowptr", "ls::k_emit")
+
+
+def pmc_traffic_per_call(prefixes, workload):
+    """HBM-side bytes of ONE call that launches each of the named kernels once (compute_matrix): the sum of their per-dispatch means in
+    the committed PMC file, or None when a kernel of the list is missing there."""
+    d = _pmc_doc(workload)
+    if not d:
+        return None
+    total = 0.0
+    for p in prefixes:
+        hits = [rec["traffic_bytes"] for name, rec in d["kernels"].items() if name.startswith(p)]
+        if not hits:
+            return None
+        total += sum(hits) / len(hits)
+    return total
+
+
+def assembly_entry(tv, tf, cfg, V, F, nnz, workload, repeats=5):
+    """`compute_matrix` as its own roofline entry (the first kernel group north_star names): SURVEY 8(d)'s algorithmic bytes -- the faces read
+    once, the CSR arrays and the row pointers written once; the int64 COO index list the reference's matrix handle carries is listed beside
+    it -- over the time of whole calls between two HIP events (host sync for nnz and torch's allocations included)."""
+    from largesteps.geometry import compute_matrix
+    lam = cfg["lambda_"] if cfg["lambda_"] is not None else 0.0
+    for _ in range(2):
+        compute_matrix(tv, tf, lam, alpha=cfg["alpha"], cotan=cfg["cotan"])
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(repeats):
+        compute_matrix(tv, tf, lam, alpha=cfg["alpha"], cotan=cfg["cotan"])
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / repeats
+    csr_bytes = tf.element_size() * 3 * F + 8 * nnz + 4 * (V + 1) + (12 * V if cfg["cotan"] else 0)
+    coo_bytes = 16 * nnz
+    traffic = pmc_traffic_per_call(ASSEMBLY_KERNELS, workload)
+    return dict(kernel="compute_matrix: k_count (corner ranks, one atomic per vertex pair and workgroup) -> scan -> k_scatter -> k_row_merge (rows sorted in "
+                       "registers) -> k_tile_scan / k_rowptr -> [nnz to the host] -> k_emit", us_per_call=us,
+                bytes=csr_bytes, bytes_with_coo_index_list=csr_bytes + coo_bytes, achieved=csr_bytes / (us * 1e-6) / 1e9, unit="GB/s",
+                frac=csr_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, frac_with_coo_index_list=(csr_bytes + coo_bytes) / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                traffic=traffic, traffic_source=f"profiles/{PMC_FILE}, sum of the per-dispatch means of the call's kernels" if traffic is not None else None)
+
+
+def spmv_entry(M, tv, V, nnz, workload, repeats=20):
+    """`to_differential` (ls_spmv, csrc/spmv.hip) as its own roofline entry: SURVEY 8(d)'s 8 nnz + 4 (V + 1) + 2 x 4 k V bytes over the mean of
+    `repeats` back-to-back calls between two HIP events (matrix and vectors then sit in the Infinity Cache: the warm figure; the one call per
+    (re)mesh of the reference's loop meets colder data -- profiles/r05_spmv.txt lists both)."""
+    from largesteps.parameterize import to_differential
+    k = tv.shape[1]
+    for _ in range(3):
+        to_differential(M, tv)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(repeats):
+        to_differential(M, tv)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / repeats
+    bts = 8 * nnz + 4 * (V + 1) + 2 * 4 * k * V
+    return dict(kernel="k_spmv<3, 0> (LDS-staged CSR tile, a row's gathers batched)", us_per_call=us, bytes=bts, achieved=bts / (us * 1e-6) / 1e9, unit="GB/s",
+                frac=bts / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, traffic=pmc_traffic("ls::k_spmv<3, 0>", workload))
+
+
 def cpu_baseline(v, f, cfg, u_np, seconds_cap=120.0):
     """Oracle direct solver timed on the host: factor once (reported, not counted), then re-solves."""
     from oracle import laplacian as ol, solve as osv
@@ -406,6 +470,7 @@ def report_direct(args, solver, M, u, x, tv, v, f, cfg, ms, t_assemble):
     grp_gbs = grp_bytes / (grp_ms * 1e-3) / 1e9
     traffic, traffic_n = pmc_traffic_group(grp_prefixes, args.workload)
     tm = solver.timings
+    assembly = assembly_entry(tv, torch.from_numpy(f).to(tv.device), cfg, V, f.shape[0], nnz, args.workload)
     # the constructor once more, after everything above (not timed, not used): the solver above was the FIRST one this process built and
     # paid the process' one-off costs (kernel code objects loaded on first launch, host thread pool, fresh heap); a remesh loop pays this
     # cycle (scripts/main.py:137-169: the old matrix and its solver are gone when the new one is built): the measured solver is closed first,
@@ -461,6 +526,7 @@ def report_direct(args, solver, M, u, x, tv, v, f, cfg, ms, t_assemble):
                     # duration between two HIP events on the solve's stream ("profile" 3 pass; events between the launches
                     # add ~1 us each, so the rows sum to a little more than ms_per_step), bytes / time
                     launches=table, vector_bytes_per_sweep=vec_bytes, solver_vector_bytes_per_sweep=hand_over_bytes,
+                    assemble=assembly, to_differential=spmv_entry(M, tv, V, nnz, args.workload),
                     device=torch.cuda.get_device_name(0)),
         roofline=dict(bound="hbm", kernel=grp_name,
                       achieved=grp_gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=grp_gbs / HBM_PEAK_GBS,

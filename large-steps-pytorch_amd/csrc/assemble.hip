@@ -23,21 +23,25 @@ namespace ls {
 // workspace layout (shared by ls_assemble_pattern and ls_assemble_fill; depends on V and F only)
 // ------------------------------------------------------------------------------------------------
 struct AsmLayout {
-    size_t cnt, slot_ptr, fill, ucnt, diag, flags, bsum, slot_col, slot_val, total;
-    int64_t nslots;
+    size_t cnt, slot_ptr, row_off, diag, flags, bsum, tile_cnt, tile_off, corner_off, slot_col, slot_val, comp, total;
+    int64_t nslots, tiles;
     AsmLayout(int64_t V, int64_t F) {
         auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
         nslots = 6 * F;
+        tiles = (V + TILE_ROWS - 1) / TILE_ROWS;
         size_t o = 0;
-        cnt = o;       o = al(o + 4 * (size_t)(V + 1));
+        cnt = o;       o = al(o + 4 * (size_t)(V + 2));        // (k_count reserves for vertex pairs with 64-bit atomics: one entry of slack)
         slot_ptr = o;  o = al(o + 4 * (size_t)(V + 1));
-        fill = o;      o = al(o + 4 * (size_t)(V + 1));
-        ucnt = o;      o = al(o + 4 * (size_t)(V + 1));
+        row_off = o;   o = al(o + 4 * (size_t)(V + 1));        // offset of a row's first entry inside its tile's compact block
         diag = o;      o = al(o + 4 * (size_t)(V + 1));
         flags = o;     o = al(o + 64);
         bsum = o;      o = al(o + 4 * (size_t)((V + 1) / 2048 + 4));
-        slot_col = o;  o = al(o + 4 * (size_t)nslots);
-        slot_val = o;  o = al(o + 4 * (size_t)nslots);
+        tile_cnt = o;  o = al(o + 4 * (size_t)(tiles + 1));    // entries of a 256-row tile
+        tile_off = o;  o = al(o + 4 * (size_t)(tiles + 1));    // ... and their exclusive scan: where the tile's rows start in the CSR arrays
+        corner_off = o; o = al(o + 4 * (size_t)(3 * F) + 64);  // where a face corner's two slots sit inside its vertex' row (k_count)
+        slot_col = o;  o = al(o + 4 * (size_t)nslots + 64);    // (+ 64: a row's last 16-byte quad may reach two slots past the array)
+        slot_val = o;  o = al(o + 4 * (size_t)nslots + 64);
+        comp = o;      o = al(o + 8 * (size_t)(nslots + V));   // final rows, tile by tile: tile t at entry slot_ptr[256 t] + 256 t ({col, value bits})
         total = o;
     }
 };
@@ -131,18 +135,69 @@ int exclusive_scan(const int* in, int64_t n, int* out, int* bsum, hipStream_t st
 }
 
 // ------------------------------------------------------------------------------------------------
-// 1. count half-edges per row, validate indices
+// 1. count half-edges per row, validate indices, and give every face corner its place inside its vertex' row.
+//    Round 5: one global atomic per DISTINCT vertex of a workgroup's 1024 faces instead of one per corner. The corners are first ranked
+//    per vertex in an LDS hash table (ds_cmpst / ds_add: open addressing, 4096 entries for at most 3072 distinct vertices), then every
+//    occupied entry reserves its vertex' slots with ONE returning atomic on the row counter, and a corner's offset = that base + 2 x its
+//    rank goes to corner_off. The scatter needs no atomics at all. (Round 1-4: 6 M atomics in k_count + 6 M returning ones in k_scatter,
+//    76 + 189 us of a 0.5 ms assembly at 1M vertices; meshes are stored coherently enough that a vertex' faces meet in few workgroups.)
+//    Which slots a corner gets depends on the order of the atomics; the final matrix does not (k_row_merge sorts every row).
 // ------------------------------------------------------------------------------------------------
+constexpr int CNT_FPT = 4;                       // faces per thread
+constexpr int CNT_HT = 4096;                     // hash table entries (power of two, > 3 * CNT_FPT * BLOCK)
 template <typename IdxT>
 __global__ __launch_bounds__(BLOCK) void k_count(const IdxT* __restrict__ faces, int64_t F, int64_t V,
-                                                 int* __restrict__ cnt, int* __restrict__ flags) {
-    for (int64_t f = (int64_t)blockIdx.x * BLOCK + threadIdx.x; f < F; f += (int64_t)gridDim.x * BLOCK) {
-        const int64_t i0 = (int64_t)faces[3 * f + 0], i1 = (int64_t)faces[3 * f + 1], i2 = (int64_t)faces[3 * f + 2];
-        if (i0 < 0 || i1 < 0 || i2 < 0 || i0 >= V || i1 >= V || i2 >= V) { flags[0] = 1; continue; }
-        // each of the 3 edges puts one slot into the rows of both of its end points
-        atomicAdd(&cnt[i0], 2);
-        atomicAdd(&cnt[i1], 2);
-        atomicAdd(&cnt[i2], 2);
+                                                 int* __restrict__ cnt, int* __restrict__ corner_off, int* __restrict__ flags) {
+    // an entry serves the vertex PAIR (2 p, 2 p + 1): neighbouring ids meet in the same faces, and one 64-bit atomic reserves for both
+    // (the returning atomics are what this kernel waits for: ~30 ns each at the L2 however few bytes they carry)
+    __shared__ int h_key[CNT_HT];
+    __shared__ int h_cnt[2 * CNT_HT];            // corners of the pair's even / odd vertex in this workgroup, then the bases of their reservations
+    for (int t = threadIdx.x; t < CNT_HT; t += BLOCK) { h_key[t] = -1; h_cnt[2 * t] = 0; h_cnt[2 * t + 1] = 0; }
+    __syncthreads();
+    const int64_t f0 = (int64_t)blockIdx.x * (BLOCK * CNT_FPT);
+    int slot[3 * CNT_FPT], rank[3 * CNT_FPT];
+#pragma unroll
+    for (int j = 0; j < CNT_FPT; ++j) {
+        const int64_t f = f0 + (int64_t)j * BLOCK + threadIdx.x;
+        int64_t v[3] = {-1, -1, -1};
+        if (f < F) {
+            v[0] = (int64_t)faces[3 * f + 0]; v[1] = (int64_t)faces[3 * f + 1]; v[2] = (int64_t)faces[3 * f + 2];
+            if (v[0] < 0 || v[1] < 0 || v[2] < 0 || v[0] >= V || v[1] >= V || v[2] >= V) { flags[0] = 1; v[0] = v[1] = v[2] = -1; }
+        }
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            int h = -1, r = 0;
+            if (v[e] >= 0) {
+                const int key = (int)(v[e] >> 1);
+                h = (int)(((unsigned)key * 2654435761u) >> 20) & (CNT_HT - 1);
+                for (;;) {
+                    const int old = atomicCAS(&h_key[h], -1, key);
+                    if (old == -1 || old == key) break;
+                    h = (h + 1) & (CNT_HT - 1);
+                }
+                h = 2 * h + (int)(v[e] & 1);
+                r = atomicAdd(&h_cnt[h], 1);
+            }
+            slot[3 * j + e] = h; rank[3 * j + e] = r;
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < CNT_HT; t += BLOCK) {
+        const int key = h_key[t];
+        if (key >= 0) {                                                    // each corner puts two half-edges into its vertex' row
+            const unsigned long long add = (unsigned long long)(unsigned)(2 * h_cnt[2 * t]) | ((unsigned long long)(unsigned)(2 * h_cnt[2 * t + 1]) << 32);
+            const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(cnt) + key, add);    // (cnt is 256-byte aligned, V + 1 entries)
+            h_cnt[2 * t] = (int)(unsigned)old; h_cnt[2 * t + 1] = (int)(unsigned)(old >> 32);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < CNT_FPT; ++j) {
+        const int64_t f = f0 + (int64_t)j * BLOCK + threadIdx.x;
+        if (f < F) {
+#pragma unroll
+            for (int e = 0; e < 3; ++e) corner_off[3 * f + e] = slot[3 * j + e] >= 0 ? h_cnt[slot[3 * j + e]] + 2 * rank[3 * j + e] : -1;
+        }
     }
 }
 
@@ -176,7 +231,7 @@ __device__ __forceinline__ void face_cot(const float* __restrict__ verts, int64_
 template <typename IdxT, bool COT>
 __global__ __launch_bounds__(BLOCK) void k_scatter(const IdxT* __restrict__ faces, int64_t F, int64_t V,
                                                    const float* __restrict__ verts, const int* __restrict__ slot_ptr,
-                                                   int* __restrict__ fill, int* __restrict__ slot_col,
+                                                   const int* __restrict__ corner_off, int* __restrict__ slot_col,
                                                    float* __restrict__ slot_val) {
     for (int64_t f = (int64_t)blockIdx.x * BLOCK + threadIdx.x; f < F; f += (int64_t)gridDim.x * BLOCK) {
         const int64_t i0 = (int64_t)faces[3 * f + 0], i1 = (int64_t)faces[3 * f + 1], i2 = (int64_t)faces[3 * f + 2];
@@ -184,14 +239,14 @@ __global__ __launch_bounds__(BLOCK) void k_scatter(const IdxT* __restrict__ face
         float wa = 1.0f, wb = 1.0f, wc = 1.0f;
         if (COT) face_cot(verts, i0, i1, i2, wa, wb, wc);
         // geometry.py:43-50: cota -> (f1,f2), cotb -> (f2,f0), cotc -> (f0,f1), then symmetrised: every vertex of the face
-        // receives the two half-edges towards the other two. One cursor atomic per vertex reserves both slots; rows hold
+        // receives the two half-edges towards the other two, at the offset k_count gave the corner inside the vertex' row; rows hold
         // an even number of slots, so the pair is 8-byte aligned and goes out as one int2 / float2 store.
         const int64_t row[3] = {i0, i1, i2};
         const int c0[3] = {(int)i2, (int)i2, (int)i1}, c1[3] = {(int)i1, (int)i0, (int)i0};
         const float w0[3] = {wb, wa, wa}, w1[3] = {wc, wc, wb};
         int slot[3];
 #pragma unroll
-        for (int e = 0; e < 3; ++e) slot[e] = slot_ptr[row[e]] + atomicAdd(&fill[row[e]], 2);
+        for (int e = 0; e < 3; ++e) slot[e] = slot_ptr[row[e]] + corner_off[3 * f + e];
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
             *reinterpret_cast<int2*>(slot_col + slot[e]) = make_int2(c0[e], c1[e]);
@@ -201,8 +256,12 @@ __global__ __launch_bounds__(BLOCK) void k_scatter(const IdxT* __restrict__ face
 }
 
 // ------------------------------------------------------------------------------------------------
-// 3. per row: sort slots by (col, weight), merge duplicates, produce the off-diagonal M entries in
-//    place (front of the row's slot range) and the diagonal value. One thread per row.
+// 3. per row: sort slots by (col, weight), merge duplicates -> the row's final entries (diagonal included, in column order), written
+//    tile by tile into a compact array; 4. a streaming copy of the tiles to their place in the CSR / COO arrays.
+//    Round 5 (was: insertion sort in LDS, sorted slots written back, a 1M-element scan, an emit kernel that walked the slot rows again --
+//    every half-edge crossed the memory system four times, 870 MB for 220 MB of output at 1M vertices): a row of up to 16 slots is
+//    sorted IN REGISTERS by a 60-comparator network, merged there, and only its final entries leave the kernel; the scan is over the
+//    3907 tile totals, not the rows; the emit is a coalesced copy.
 // ------------------------------------------------------------------------------------------------
 // One row: c / w point at its n slots (global memory or an LDS copy). Returns the number of distinct off-diagonal
 // columns (compacted to the front of the slots) and the diagonal value.
@@ -255,87 +314,178 @@ __device__ __forceinline__ int merge_row(int* c, float* w, int n, int i, float a
     return nu;
 }
 
-// A tile of TILE_ROWS rows owns one contiguous slot range: it is copied to LDS with coalesced loads, every thread
-// sorts / merges its row there, and the range is written back coalesced. (Sorting in place in global memory, one
-// thread per row with rows 48 bytes apart, moved 3.8 GB for a 1M-vertex mesh -- 35x the slot data.) Tiles whose
-// range exceeds the LDS copy (a vertex of huge valence) sort in global memory.
-constexpr int MERGE_CAP = 7168;   // slots per tile held in LDS (256 rows x 28): 56 KiB
 
+// 16 (col, weight) pairs in registers, ascending by (col, weight): the 60-comparator, 10-layer network (verified over all 2^16 0/1 inputs
+// by tools/check_sort16.py). The uniform Laplacian carries no weights.
 template <bool COT>
-__global__ __launch_bounds__(BLOCK) void k_row_merge(int64_t V, const int* __restrict__ slot_ptr, int* __restrict__ slot_col,
-                                                     float* __restrict__ slot_val, float a, float b,
-                                                     int* __restrict__ ucnt, float* __restrict__ diag) {
-    __shared__ int s_c[MERGE_CAP];
-    __shared__ float s_w[MERGE_CAP];
-    const int64_t t0 = (int64_t)blockIdx.x * TILE_ROWS;
-    const int64_t t1 = min(V, t0 + TILE_ROWS);
-    const int64_t i = t0 + threadIdx.x;
-    const int base = slot_ptr[t0], n_tile = slot_ptr[t1] - base;
-    const bool in_lds = n_tile <= MERGE_CAP;          // uniform per workgroup
-    if (in_lds) {
-        for (int e = threadIdx.x; e < n_tile; e += BLOCK) { s_c[e] = slot_col[base + e]; s_w[e] = slot_val[base + e]; }
-        __syncthreads();
+__device__ __forceinline__ void sort16(int (&c)[16], float (&w)[16]) {
+#define LS_CE(i, j)                                                                                                   \
+    {                                                                                                                 \
+        const bool sw = c[i] > c[j] || (COT && c[i] == c[j] && w[i] > w[j]);                                          \
+        const int ci = sw ? c[j] : c[i], cj = sw ? c[i] : c[j];                                                       \
+        c[i] = ci; c[j] = cj;                                                                                         \
+        if (COT) { const float wi = sw ? w[j] : w[i], wj = sw ? w[i] : w[j]; w[i] = wi; w[j] = wj; }                  \
     }
-    if (i < t1) {
-        const int s0 = slot_ptr[i], n = slot_ptr[i + 1] - s0;
-        float d;
-        const int nu = in_lds ? merge_row<COT>(s_c + (s0 - base), s_w + (s0 - base), n, (int)i, a, b, d)
-                              : merge_row<COT>(slot_col + s0, slot_val + s0, n, (int)i, a, b, d);
-        diag[i] = d;
-        ucnt[i] = nu + 1;
+    LS_CE(0, 13) LS_CE(1, 12) LS_CE(2, 15) LS_CE(3, 14) LS_CE(4, 8) LS_CE(5, 6) LS_CE(7, 11) LS_CE(9, 10)
+    LS_CE(0, 5) LS_CE(1, 7) LS_CE(2, 9) LS_CE(3, 4) LS_CE(6, 13) LS_CE(8, 14) LS_CE(10, 15) LS_CE(11, 12)
+    LS_CE(0, 1) LS_CE(2, 3) LS_CE(4, 5) LS_CE(6, 8) LS_CE(7, 9) LS_CE(10, 11) LS_CE(12, 13) LS_CE(14, 15)
+    LS_CE(0, 2) LS_CE(1, 3) LS_CE(4, 10) LS_CE(5, 11) LS_CE(6, 7) LS_CE(8, 9) LS_CE(12, 14) LS_CE(13, 15)
+    LS_CE(1, 2) LS_CE(3, 12) LS_CE(4, 6) LS_CE(5, 7) LS_CE(8, 10) LS_CE(9, 11) LS_CE(13, 14)
+    LS_CE(1, 4) LS_CE(2, 6) LS_CE(5, 8) LS_CE(7, 10) LS_CE(9, 13) LS_CE(11, 14)
+    LS_CE(2, 4) LS_CE(3, 6) LS_CE(9, 12) LS_CE(11, 13)
+    LS_CE(3, 5) LS_CE(6, 8) LS_CE(7, 9) LS_CE(10, 12)
+    LS_CE(3, 4) LS_CE(5, 6) LS_CE(7, 8) LS_CE(9, 10) LS_CE(11, 12)
+    LS_CE(6, 7) LS_CE(8, 9)
+#undef LS_CE
+}
+
+// One pass over a sorted register row (the summation order of merge_row: groups in column order, weights ascending inside a group).
+// emit(col, value) is called once per distinct off-diagonal column, in column order. Returns what merge_row returns.
+template <bool COT, typename Emit>
+__device__ __forceinline__ void walk16(const int (&c)[16], const float (&w)[16], int n, int i, float a, float b, int& n_off, int& n_lt,
+                                       float& d_out, Emit emit) {
+    int ndistinct = 0;
+    bool self = false;
+    float wsum = 0.0f, selfacc = 0.0f, acc = 0.0f;
+    n_off = 0; n_lt = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (k < n) {
+            if (COT) { wsum = wsum + w[k]; acc = acc + b * (-w[k]); }
+            const bool tail = k == 15 || k + 1 >= n || c[k < 15 ? k + 1 : 15] != c[k];
+            if (tail) {
+                ++ndistinct;
+                if (c[k] == i) { self = true; selfacc = acc; }
+                else { emit(c[k], COT ? acc : b * -1.0f, n_off); ++n_off; n_lt += c[k] < i ? 1 : 0; }
+                acc = 0.0f;
+            }
+        }
     }
-    if (in_lds) {
-        __syncthreads();
-        for (int e = threadIdx.x; e < n_tile; e += BLOCK) { slot_col[base + e] = s_c[e]; slot_val[base + e] = s_w[e]; }
+    if (COT) {
+        float t = b * wsum;
+        if (self) t = t + selfacc;
+        d_out = a + t;
+    } else {
+        const float lii = (float)(ndistinct - (self ? 1 : 0));        // geometry.py:86-94 (see merge_row)
+        d_out = a + b * lii;
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// 4. emit CSR (+ COO int64 indices, + 1/diag). Rows of a tile are staged in LDS in their final
-//    order so that the global stores of col/val/coo are fully coalesced.
-// ------------------------------------------------------------------------------------------------
-constexpr int EMIT_CAP = 6144;   // entries staged per tile (256 rows x 24); larger tiles store directly
+constexpr int OUT_CAP = 3328;   // final entries of a tile staged in LDS (256 rows x 13): 26 KiB; larger tiles store directly
+typedef int i4u_asm __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f4u_asm __attribute__((ext_vector_type(4), aligned(4)));
 
-__global__ __launch_bounds__(BLOCK) void k_emit(int64_t V, const int* __restrict__ slot_ptr, const int* __restrict__ slot_col,
-                                                const float* __restrict__ slot_val, const float* __restrict__ diag,
-                                                const int* __restrict__ rowptr, int* __restrict__ col, float* __restrict__ val,
-                                                int64_t* __restrict__ coo_row, int64_t* __restrict__ coo_col,
-                                                float* __restrict__ dinv) {
-    __shared__ int s_col[EMIT_CAP];
-    __shared__ float s_val[EMIT_CAP];
-    __shared__ unsigned short s_row[EMIT_CAP];
-    const int64_t r0 = (int64_t)blockIdx.x * TILE_ROWS;
-    const int64_t r1 = min(r0 + (int64_t)TILE_ROWS, V);
-    const int base = rowptr[r0], total = rowptr[r1] - base;
-    const bool staged = total <= EMIT_CAP;
-    const int64_t i = r0 + threadIdx.x;
-    if (i < r1) {
-        const int n = rowptr[i + 1] - rowptr[i] - 1;   // off-diagonal entries
-        const int* c = slot_col + slot_ptr[i];
-        const float* w = slot_val + slot_ptr[i];
-        const float d = diag[i];
-        if (dinv) dinv[i] = 1.0f / d;
-        int o = rowptr[i] - base;
-        auto put = [&](int ck, float wk) {
-            if (staged) { s_col[o] = ck; s_val[o] = wk; s_row[o] = (unsigned short)threadIdx.x; }
-            else {
-                col[base + o] = ck; val[base + o] = wk;
-                if (coo_row) { coo_row[base + o] = i; coo_col[base + o] = ck; }
-            }
-            ++o;
-        };
-        int k = 0;
-        while (k < n && c[k] < (int)i) { put(c[k], w[k]); ++k; }   // the self column was merged into d
-        put((int)i, d);
-        while (k < n) { put(c[k], w[k]); ++k; }
+template <bool COT>
+__global__ __launch_bounds__(BLOCK) void k_row_merge(int64_t V, const int* __restrict__ slot_ptr, int* __restrict__ slot_col,
+                                                     float* __restrict__ slot_val, float a, float b, int2* __restrict__ comp,
+                                                     int* __restrict__ row_off, int* __restrict__ tile_cnt, float* __restrict__ diag) {
+    __shared__ __attribute__((aligned(16))) int2 s_out[OUT_CAP];
+    __shared__ int s_scan[BLOCK / WAVE + 1];
+    const int64_t t0 = (int64_t)blockIdx.x * TILE_ROWS;
+    const int64_t t1 = min(V, t0 + TILE_ROWS);
+    const int64_t i = t0 + threadIdx.x;
+    const bool active = i < t1;
+    const int s0 = active ? slot_ptr[i] : 0, n = active ? slot_ptr[i + 1] - s0 : 0;
+    const bool big = n > 16;                      // valence > 8: the row is sorted and merged in place in global memory (merge_row)
+    int c[16];
+    float w[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                 // the row's slots: up to four 16-byte requests per array (slot ranges are 8-byte aligned)
+        i4u_asm cq = {0, 0, 0, 0};
+        f4u_asm wq = {0.f, 0.f, 0.f, 0.f};
+        if (!big && 4 * q < n) {
+            cq = *reinterpret_cast<const i4u_asm*>(slot_col + s0 + 4 * q);
+            if (COT) wq = *reinterpret_cast<const f4u_asm*>(slot_val + s0 + 4 * q);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { c[4 * q + e] = (!big && 4 * q + e < n) ? cq[e] : 0x7fffffff; w[4 * q + e] = (COT && !big && 4 * q + e < n) ? wq[e] : 0.0f; }
+    }
+    int n_off = 0, n_lt = 0;
+    float d = a;
+    if (big) {
+        n_off = merge_row<COT>(slot_col + s0, slot_val + s0, n, (int)i, a, b, d);
+        for (int k = 0; k < n_off; ++k) n_lt += slot_col[s0 + k] < (int)i ? 1 : 0;
+    } else if (active) {
+        sort16<COT>(c, w);
+        walk16<COT>(c, w, n, (int)i, a, b, n_off, n_lt, d, [](int, float, int) {});
+    }
+    int total;
+    const int o = block_exclusive_scan(active ? n_off + 1 : 0, &total, s_scan);
+    if (active) { row_off[i] = o; diag[i] = d; }
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total;
+    const size_t cbase = (size_t)slot_ptr[t0] + (size_t)t0;
+    const bool staged = total <= OUT_CAP;         // uniform per workgroup
+    int2* dst = staged ? s_out + o : comp + cbase + o;
+    if (active) {
+        dst[n_lt] = make_int2((int)i, __float_as_int(d));                  // the diagonal sits behind the n_lt smaller columns
+        if (big) {
+            for (int k = 0; k < n_off; ++k) dst[k + (k >= n_lt ? 1 : 0)] = make_int2(slot_col[s0 + k], __float_as_int(slot_val[s0 + k]));
+        } else {
+            int n2, l2;
+            float d2;
+            walk16<COT>(c, w, n, (int)i, a, b, n2, l2, d2, [&](int ck, float v, int p) { dst[p + (ck > (int)i ? 1 : 0)] = make_int2(ck, __float_as_int(v)); });
+        }
     }
     if (!staged) return;
     __syncthreads();
+    for (int t = threadIdx.x; t < total; t += BLOCK) comp[cbase + t] = s_out[t];
+}
+
+// where the tiles' rows start: exclusive scan of the tile totals (one workgroup), then rowptr[i] = tile_off[tile] + row_off[i]
+__global__ __launch_bounds__(1024) void k_tile_scan(const int* __restrict__ tile_cnt, int tiles, int* __restrict__ tile_off) {   // <<<1, 1024>>>
+    __shared__ int s_wave[17];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int per = (tiles + 1023) / 1024, lo = min(tiles, (int)threadIdx.x * per), hi = min(tiles, lo + per);
+    int sum = 0;
+    for (int t = lo; t < hi; ++t) sum += tile_cnt[t];
+    const int inc = wave_inclusive_scan(sum);
+    if (lane == 63) s_wave[w] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) { int run = 0; for (int k = 0; k < 16; ++k) { const int v = s_wave[k]; s_wave[k] = run; run += v; } s_wave[16] = run; }
+    __syncthreads();
+    int run = s_wave[w] + inc - sum;
+    for (int t = lo; t < hi; ++t) { tile_off[t] = run; run += tile_cnt[t]; }
+    if (threadIdx.x == 0) tile_off[tiles] = s_wave[16];
+}
+__global__ __launch_bounds__(BLOCK) void k_rowptr(int64_t V, const int* __restrict__ tile_off, const int* __restrict__ row_off, int* __restrict__ rowptr,
+                                                  int* __restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * TILE_ROWS + threadIdx.x;
+    if (i < V) rowptr[i] = tile_off[blockIdx.x] + row_off[i];
+    if (i == V - 1) { rowptr[V] = tile_off[gridDim.x]; flags[1] = tile_off[gridDim.x]; }      // (flags[0]: index check, flags[1]: nnz -- one copy back)
+}
+
+// ------------------------------------------------------------------------------------------------
+// 4. emit CSR (+ COO int64 indices, + 1/diag): a tile's compact block is copied to its place with fully coalesced loads and stores;
+//    the COO row of an entry is found by a binary search over the tile's 256 row offsets in LDS
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_emit(int64_t V, const int* __restrict__ slot_ptr, const int2* __restrict__ comp,
+                                                const int* __restrict__ row_off, const float* __restrict__ diag,
+                                                const int* __restrict__ rowptr, int* __restrict__ col, float* __restrict__ val,
+                                                int64_t* __restrict__ coo_row, int64_t* __restrict__ coo_col,
+                                                float* __restrict__ dinv) {
+    __shared__ int s_ro[TILE_ROWS + 1];
+    const int64_t r0 = (int64_t)blockIdx.x * TILE_ROWS;
+    const int64_t r1 = min(r0 + (int64_t)TILE_ROWS, V);
+    const int rows = (int)(r1 - r0);
+    const int base = rowptr[r0], total = rowptr[r1] - base;
+    const size_t cbase = (size_t)slot_ptr[r0] + (size_t)r0;
+    const int64_t i = r0 + threadIdx.x;
+    if (i < r1) {
+        s_ro[threadIdx.x] = row_off[i];
+        if (dinv) dinv[i] = 1.0f / diag[i];
+    }
+    if (threadIdx.x == 0) s_ro[rows] = total;
+    __syncthreads();
     for (int t = threadIdx.x; t < total; t += BLOCK) {
-        const int ck = s_col[t];
-        col[base + t] = ck;
-        val[base + t] = s_val[t];
-        if (coo_row) { coo_row[base + t] = r0 + s_row[t]; coo_col[base + t] = ck; }
+        const int2 e = comp[cbase + t];
+        col[base + t] = e.x;
+        val[base + t] = __int_as_float(e.y);
+        if (coo_row) {
+            int lo = 0, hi = rows;                // largest r with s_ro[r] <= t
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_ro[mid] <= t) lo = mid; else hi = mid; }
+            coo_row[base + t] = r0 + lo;
+            coo_col[base + t] = e.x;
+        }
     }
 }
 
@@ -394,46 +544,49 @@ extern "C" int ls_assemble_pattern(const void* faces, int idx_bytes, int64_t F, 
     char* ws = (char*)workspace;
     int* cnt = (int*)(ws + L.cnt);
     int* slot_ptr = (int*)(ws + L.slot_ptr);
-    int* fill = (int*)(ws + L.fill);
-    int* ucnt = (int*)(ws + L.ucnt);
+    int* corner_off = (int*)(ws + L.corner_off);
+    int* row_off = (int*)(ws + L.row_off);
+    int* tile_cnt = (int*)(ws + L.tile_cnt);
+    int* tile_off = (int*)(ws + L.tile_off);
+    int2* comp = (int2*)(ws + L.comp);
     float* diag = (float*)(ws + L.diag);
     int* flags = (int*)(ws + L.flags);
     int* bsum = (int*)(ws + L.bsum);
     int* slot_col = (int*)(ws + L.slot_col);
     float* slot_val = (float*)(ws + L.slot_val);
 
-    // cnt, slot_ptr, fill, ucnt, diag, flags are contiguous: one memset
+    // cnt, slot_ptr, row_off, diag, flags are contiguous: one memset
     LS_HIP(hipMemsetAsync(ws, 0, L.bsum, st));
     if (V == 0) { LS_HIP(hipMemsetAsync(rowptr, 0, 4, st)); *h_nnz = 0; LS_HIP(hipStreamSynchronize(st)); return LS_OK; }
     const int fgrid = F ? (int)std::min<int64_t>(div_up(F, BLOCK), 8192) : 1;
     if (F) {
-        if (idx_bytes == 4) hipLaunchKernelGGL(k_count<int32_t>, dim3(fgrid), dim3(BLOCK), 0, st, (const int32_t*)faces, F, V, cnt, flags);
-        else hipLaunchKernelGGL(k_count<int64_t>, dim3(fgrid), dim3(BLOCK), 0, st, (const int64_t*)faces, F, V, cnt, flags);
+        const int cgrid = div_up(F, BLOCK * CNT_FPT);
+        if (idx_bytes == 4) hipLaunchKernelGGL(k_count<int32_t>, dim3(cgrid), dim3(BLOCK), 0, st, (const int32_t*)faces, F, V, cnt, corner_off, flags);
+        else hipLaunchKernelGGL(k_count<int64_t>, dim3(cgrid), dim3(BLOCK), 0, st, (const int64_t*)faces, F, V, cnt, corner_off, flags);
     }
     int rc = exclusive_scan(cnt, V, slot_ptr, bsum, st);
     if (rc) return rc;
     if (F) {
         const bool cot = kind == LS_LAPLACIAN_COT;
         if (idx_bytes == 4) {
-            if (cot) hipLaunchKernelGGL((k_scatter<int32_t, true>), dim3(fgrid), dim3(BLOCK), 0, st, (const int32_t*)faces, F, V, verts, slot_ptr, fill, slot_col, slot_val);
-            else hipLaunchKernelGGL((k_scatter<int32_t, false>), dim3(fgrid), dim3(BLOCK), 0, st, (const int32_t*)faces, F, V, verts, slot_ptr, fill, slot_col, slot_val);
+            if (cot) hipLaunchKernelGGL((k_scatter<int32_t, true>), dim3(fgrid), dim3(BLOCK), 0, st, (const int32_t*)faces, F, V, verts, slot_ptr, (const int*)corner_off, slot_col, slot_val);
+            else hipLaunchKernelGGL((k_scatter<int32_t, false>), dim3(fgrid), dim3(BLOCK), 0, st, (const int32_t*)faces, F, V, verts, slot_ptr, (const int*)corner_off, slot_col, slot_val);
         } else {
-            if (cot) hipLaunchKernelGGL((k_scatter<int64_t, true>), dim3(fgrid), dim3(BLOCK), 0, st, (const int64_t*)faces, F, V, verts, slot_ptr, fill, slot_col, slot_val);
-            else hipLaunchKernelGGL((k_scatter<int64_t, false>), dim3(fgrid), dim3(BLOCK), 0, st, (const int64_t*)faces, F, V, verts, slot_ptr, fill, slot_col, slot_val);
+            if (cot) hipLaunchKernelGGL((k_scatter<int64_t, true>), dim3(fgrid), dim3(BLOCK), 0, st, (const int64_t*)faces, F, V, verts, slot_ptr, (const int*)corner_off, slot_col, slot_val);
+            else hipLaunchKernelGGL((k_scatter<int64_t, false>), dim3(fgrid), dim3(BLOCK), 0, st, (const int64_t*)faces, F, V, verts, slot_ptr, (const int*)corner_off, slot_col, slot_val);
         }
     }
     const int vgrid = div_up(V, TILE_ROWS);
-    if (kind == LS_LAPLACIAN_COT) hipLaunchKernelGGL(k_row_merge<true>, dim3(vgrid), dim3(BLOCK), 0, st, V, slot_ptr, slot_col, slot_val, a, b, ucnt, diag);
-    else hipLaunchKernelGGL(k_row_merge<false>, dim3(vgrid), dim3(BLOCK), 0, st, V, slot_ptr, slot_col, slot_val, a, b, ucnt, diag);
-    rc = exclusive_scan(ucnt, V, rowptr, bsum, st);
-    if (rc) return rc;
+    if (kind == LS_LAPLACIAN_COT) hipLaunchKernelGGL(k_row_merge<true>, dim3(vgrid), dim3(BLOCK), 0, st, V, slot_ptr, slot_col, slot_val, a, b, comp, row_off, tile_cnt, diag);
+    else hipLaunchKernelGGL(k_row_merge<false>, dim3(vgrid), dim3(BLOCK), 0, st, V, slot_ptr, slot_col, slot_val, a, b, comp, row_off, tile_cnt, diag);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, (const int*)tile_cnt, vgrid, tile_off);
+    hipLaunchKernelGGL(k_rowptr, dim3(vgrid), dim3(BLOCK), 0, st, V, (const int*)tile_off, (const int*)row_off, rowptr, flags);
     LS_HIP(hipGetLastError());
     int h[2] = {0, 0};
-    LS_HIP(hipMemcpyAsync(&h[0], rowptr + V, 4, hipMemcpyDeviceToHost, st));
-    LS_HIP(hipMemcpyAsync(&h[1], flags, 4, hipMemcpyDeviceToHost, st));
+    LS_HIP(hipMemcpyAsync(h, flags, 8, hipMemcpyDeviceToHost, st));
     LS_HIP(hipStreamSynchronize(st));
-    LS_REQUIRE(h[1] == 0, LS_E_INDEX, "a face index is outside [0, %lld)", (long long)V);
-    *h_nnz = h[0];
+    LS_REQUIRE(h[0] == 0, LS_E_INDEX, "a face index is outside [0, %lld)", (long long)V);
+    *h_nnz = h[1];
     return LS_OK;
 }
 
@@ -449,7 +602,7 @@ extern "C" int ls_assemble_fill(const void* workspace, size_t workspace_bytes, i
     LS_HIP(g.err);
     const char* ws = (const char*)workspace;
     hipLaunchKernelGGL(k_emit, dim3(div_up(V, TILE_ROWS)), dim3(BLOCK), 0, (hipStream_t)stream, V,
-                       (const int*)(ws + L.slot_ptr), (const int*)(ws + L.slot_col), (const float*)(ws + L.slot_val),
+                       (const int*)(ws + L.slot_ptr), (const int2*)(ws + L.comp), (const int*)(ws + L.row_off),
                        (const float*)(ws + L.diag), rowptr, col, val, coo_idx, coo_idx ? coo_idx + nnz : nullptr, dinv);
     LS_HIP(hipGetLastError());
     return LS_OK;

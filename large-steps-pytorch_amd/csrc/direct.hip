@@ -908,7 +908,7 @@ static int pick_nw(int len, bool up_sweep = false) {
     return nw;
 }
 
-int ls_direct_adopt(ls_direct* d, void* const* owned, const size_t* owned_bytes, int n_owned, const double* seconds3);
+int ls_direct_adopt(ls_direct* d, void* const* owned, const size_t* owned_bytes, int n_owned, const double* seconds3, const double* quality4);
 
 // ---- pool of large device buffers --------------------------------------------------------------------------------------------------
 // A remesh loop (scripts/main.py:137-169) destroys a solver and constructs one of nearly the same size again and again. The runtime gives
@@ -918,13 +918,15 @@ int ls_direct_adopt(ls_direct* d, void* const* owned, const size_t* owned_bytes,
 // pool instead of hipFree, and allocations of >= 64 MB take the best fit (at most 1.5x + 64 MB larger). What the pool may hold is
 // bounded PER DEVICE: LS_POOL_GB (default 24, 0 = no pool) and never more than a quarter of the device's memory (torch's caching
 // allocator cannot see or reclaim what sits here); oldest out first. An allocation of the library that fails empties the pool of its
-// device and is tried once more (pool_alloc below), ls_release_scratch() empties it on request, and the Python layer calls that when
-// torch itself runs out of memory (largesteps.solvers.release_scratch).
+// device and is tried once more (pool_alloc below), ls_release_scratch() empties it on request, and the Python layer calls that and
+// repeats the call once when torch itself runs out of memory inside compute_matrix / a solve / the normals (largesteps._native.retry_on_oom).
 namespace ls {
 // Two non-blocking streams per device for work that must not queue behind the caller's stream: which = 0 the handle's tables go up
 // while that stream factorises; which = 1 the fp32 conversion of a finished tree level runs beside the chain of small launches of
 // the level above (two streams: the uploads must not queue behind conversions that wait for the factorisation either).
-// Created on first use, kept for the life of the process. Ordering against the caller's stream is always by events.
+// Created on first use, kept for the life of the process. Ordering against the caller's stream is always by events. The two streams are
+// shared by every construction on the device: two host threads that construct on one device at the same moment queue their uploads and
+// conversions behind each other's (results stay correct -- ordering is by events -- but the two constructors are coupled in time).
 hipStream_t side_stream(int device, int which) {
     static std::mutex mu;
     static hipStream_t streams[64][2] = {{nullptr, nullptr}};

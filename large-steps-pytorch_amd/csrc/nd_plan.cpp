@@ -1,5 +1,7 @@
 // nd_plan.cpp -- see nd_plan.h. Integer / geometric work only, parallel over vertices or tree nodes with a few host threads.
 #include "nd_plan.h"
+#include <pthread.h>
+#include <new>
 
 #include <algorithm>
 #include <atomic>
@@ -116,6 +118,15 @@ std::mutex g_shared_m;
 Pool* g_shared = nullptr;
 long g_shared_pid = 0;
 bool g_shared_busy = false;
+// fork(): the child has none of the pool's threads, and g_shared_m may have been held by a thread that does not exist there. The child
+// handler gives it a fresh mutex (placement new over the old object: its state is never looked at again) and forgets the parent's pool
+// (leaked on purpose: destroying it would join threads the child does not have). The library must not be dlclose'd while the workers
+// sleep in its code -- nothing in the package unloads it.
+void shared_pool_after_fork_in_child() {
+    new (&g_shared_m) std::mutex();
+    g_shared = nullptr; g_shared_busy = false; g_shared_pid = 0;
+}
+struct ForkHandler { ForkHandler() { (void)pthread_atfork(nullptr, nullptr, shared_pool_after_fork_in_child); } } g_fork_handler;
 struct PoolLease {
     Pool* pool = nullptr;
     bool shared = false;

@@ -206,6 +206,24 @@ def require_device(t, what):
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)      # the handle without building a torch.cuda.Stream object (~5 us per call)
 
 
+def retry_on_oom(fn):
+    """Decorator of the package's allocating entry points (compute_matrix, the solvers' solve, the normals): the direct solver keeps up
+    to LS_POOL_GB of freed device buffers in a pool that torch's caching allocator cannot see (ls_release_scratch in the header). When
+    torch runs out of memory inside such a call the pool is emptied, torch's cache too, and the call is repeated ONCE; a second failure
+    is the caller's."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        try:
+            return fn(*args, **kwargs)
+        except torch.cuda.OutOfMemoryError:
+            check(lib().ls_release_scratch(-1))
+            torch.cuda.empty_cache()
+            return fn(*args, **kwargs)
+    return wrapped
+
+
 def stream_of(device):
     if _raw_stream is not None and device.index is not None:
         return ctypes.c_void_p(_raw_stream(device.index))

@@ -530,10 +530,13 @@ class ShardedDirect:
         self._comm = ctypes.c_void_p(None)
 
     def __del__(self):
-        import sys
-        if sys is None or sys.is_finalizing():        # interpreter shutdown: ncclCommDestroy may block on peers that are already gone
-            return
-        self.close()
+        try:                                           # (at interpreter shutdown even `import sys` can raise: then there is nothing to do)
+            import sys
+            if sys is None or sys.is_finalizing():    # ncclCommDestroy may block on peers that are already gone
+                return
+            self.close()
+        except Exception:
+            pass
 
     def info(self):
         return self.local.info()

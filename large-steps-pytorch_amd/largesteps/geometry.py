@@ -64,6 +64,7 @@ def _wrap(V, rowptr, col, val, idx, a_min=None, uniform=None, positions=None):
     return M
 
 
+@_native.retry_on_oom
 def laplacian_uniform(verts, faces):
     """
     Compute the uniform laplacian  L = D - A  (reference: geometry.py:65-94).
@@ -86,6 +87,7 @@ def laplacian_uniform(verts, faces):
     return _wrap(V, rowptr, col, val, idx)
 
 
+@_native.retry_on_oom
 def laplacian_cot(verts, faces):
     """
     Compute the cotangent laplacian (reference: geometry.py:3-63; weights cot a + cot b, no 1/2 factor).
@@ -96,6 +98,7 @@ def laplacian_cot(verts, faces):
     return _wrap(*_assemble(verts, faces, LS_LAPLACIAN_COT, 0.0, 1.0))
 
 
+@_native.retry_on_oom
 def compute_matrix(verts, faces, lambda_, alpha=None, cotan=False):
     """
     Build the parameterization matrix (reference: geometry.py:96-133).

@@ -277,6 +277,7 @@ class _VertexNormals(Function):
         return (gv if ctx.needs_input_grad[0] else None), None, (gfn if ctx.needs_input_grad[2] else None), None, None
 
 
+@_native.retry_on_oom
 def compute_face_normals(verts, faces):
     """
     Compute per-face normals (scripts/geometry.py:91-110). Returns a (3, F) tensor.
@@ -297,6 +298,7 @@ def compute_face_normals(verts, faces):
     return fn
 
 
+@_native.retry_on_oom
 def compute_vertex_normals(verts, faces, face_normals):
     """
     Compute per-vertex normals from face normals (scripts/geometry.py:115-147). Returns a (V, 3) tensor.

@@ -198,6 +198,7 @@ class PCGSolver(Solver):
             _native.check(rc)
         return x
 
+    @_native.retry_on_oom
     def solve(self, b, backward=False):
         _native.require_device(b, "b")
         csr = self._csr
@@ -387,6 +388,7 @@ class NestedDissectionSolver(Solver):
         self.timings = self._direct.timings
         self.plan_quality = self._direct.plan_quality
 
+    @_native.retry_on_oom
     def solve(self, b, backward=False):
         _native.require_device(b, "b")
         if b.device != self._csr.device:
@@ -471,6 +473,7 @@ class CholeskySolver(Solver):
             self._impl = IterativeCholeskySolver(M, rtol=rtol, max_iter=max_iter, chebyshev=chebyshev, patch_columns=patch_columns)
         self.method = "iterative" if isinstance(self._impl, IterativeCholeskySolver) else "nested-dissection"
 
+    @_native.retry_on_oom
     def solve(self, b, backward=False):
         return self._impl.solve(b, backward=backward)
 
@@ -498,6 +501,7 @@ class ConjugateGradientSolver(PCGSolver):
     def __init__(self, M, atol=1e-5, max_iter=10000, chebyshev=True):
         super().__init__(M, rtol=0.0, atol=atol, max_iter=max_iter, warm_start=True, chebyshev=chebyshev)
 
+    @_native.retry_on_oom
     def solve(self, b, backward=False):
         if len(b.shape) != 2:
             raise ValueError(f"Invalid array shape {b.shape} for ConjugateGradientSolver.solve: expected shape (a, b)")

@@ -1,6 +1,7 @@
 """compute_matrix timing at the 1M-vertex config (uniform and cotangent): python tools/time_assembly.py"""
 import os, sys, time
-sys.path[:0] = [os.getcwd(), os.path.join(os.getcwd(), "large-steps-pytorch_amd")]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "large-steps-pytorch_amd")]
 import torch
 from largesteps import synthetic
 from largesteps.geometry import compute_matrix

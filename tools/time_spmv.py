@@ -2,7 +2,8 @@
 Infinity Cache), and "cold" -- 600 MB of other data streamed through the caches before every timed call, which is what the one call per
 (re)mesh of the reference's loop meets (parameterize.py:19-30 after compute_matrix).   python tools/time_spmv.py [workload...]"""
 import os, sys
-sys.path[:0] = [os.getcwd(), os.path.join(os.getcwd(), "large-steps-pytorch_amd")]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "large-steps-pytorch_amd")]
 import torch
 from largesteps import synthetic, _native
 from largesteps.geometry import compute_matrix
