@@ -230,6 +230,10 @@ def run_single(args):
     v, f, cfg = synthetic.config_mesh(args.workload)
     lam = cfg["lambda_"] if cfg["lambda_"] is not None else 0.0
     tv, tf = torch.from_numpy(v).to(dev), torch.from_numpy(f).to(dev)
+    if args.reorder:          # the same mesh renumbered in the solver's dissection order (largesteps.meshops.reorder): NOT the headline
+        from largesteps.meshops import reorder
+        tv, tf, _ = reorder(tv, tf)
+        v, f = tv.cpu().numpy(), tf.cpu().numpy()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     M = compute_matrix(tv, tf, lam, alpha=cfg["alpha"], cotan=cfg["cotan"])
@@ -501,7 +505,7 @@ def report_direct(args, solver, M, u, x, tv, v, f, cfg, ms, t_assemble):
         metric="from_differential_solves_per_sec", value=1e3 / ms, unit="solves/s", n_gpus=1, steps=args.steps,
         warmup=args.warmup, ms_per_step=ms, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32",
         data="synthetic",
-        config=dict(workload=describe(args.workload, cfg, V, nnz) + ", factor once (not timed), re-solve timed",
+        config=dict(workload=describe(args.workload, cfg, V, nnz) + (", vertices renumbered by largesteps.meshops.reorder" if args.reorder else "") + ", factor once (not timed), re-solve timed",
                     solver=(f"HIP nested-dissection multifrontal direct solver behind ls_direct_factor: {inf['levels']} tree levels, "
                             f"symbolic analysis (bisection rounds on the device, tree and index lists on host threads), fp64 factorisation with hand-written kernels (once), fp32 factor "
                             f"{inf['factor_entries'] / 1e6:.1f} M words per solve; re-solve = {inf['launches']} launches (one per upper "
@@ -657,6 +661,8 @@ def main():
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--check-every", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reorder", action="store_true", help="N = 1: renumber the mesh in the solver's dissection order first (largesteps.meshops.reorder); "
+                                                            "reported beside the headline, which stays on the mesh as generated")
     ap.add_argument("--no-extra-baselines", action="store_true", help="skip the B2 / B3 legs (reference CG on the host / in stock torch ops)")
     ap.add_argument("--pcg", action="store_true", help="time the Jacobi-PCG instead of the default (Chebyshev) solver")
     ap.add_argument("--iterative", action="store_true",
