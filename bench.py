@@ -230,10 +230,6 @@ def run_single(args):
     v, f, cfg = synthetic.config_mesh(args.workload)
     lam = cfg["lambda_"] if cfg["lambda_"] is not None else 0.0
     tv, tf = torch.from_numpy(v).to(dev), torch.from_numpy(f).to(dev)
-    if args.reorder:          # the same mesh renumbered in the solver's dissection order (largesteps.meshops.reorder): NOT the headline
-        from largesteps.meshops import reorder
-        tv, tf, _ = reorder(tv, tf)
-        v, f = tv.cpu().numpy(), tf.cpu().numpy()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     M = compute_matrix(tv, tf, lam, alpha=cfg["alpha"], cotan=cfg["cotan"])
@@ -505,7 +501,7 @@ def report_direct(args, solver, M, u, x, tv, v, f, cfg, ms, t_assemble):
         metric="from_differential_solves_per_sec", value=1e3 / ms, unit="solves/s", n_gpus=1, steps=args.steps,
         warmup=args.warmup, ms_per_step=ms, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32",
         data="synthetic",
-        config=dict(workload=describe(args.workload, cfg, V, nnz) + (", vertices renumbered by largesteps.meshops.reorder" if args.reorder else "") + ", factor once (not timed), re-solve timed",
+        config=dict(workload=describe(args.workload, cfg, V, nnz) + ", factor once (not timed), re-solve timed",
                     solver=(f"HIP nested-dissection multifrontal direct solver behind ls_direct_factor: {inf['levels']} tree levels, "
                             f"symbolic analysis (bisection rounds on the device, tree and index lists on host threads), fp64 factorisation with hand-written kernels (once), fp32 factor "
                             f"{inf['factor_entries'] / 1e6:.1f} M words per solve; re-solve = {inf['launches']} launches (one per upper "
@@ -632,10 +628,11 @@ def launch_ranks(args):
 
 
 # kernels of ONE rank per solve and the part of them above the cut level, measured on one MI355X with the plan that rank gets
-# (tools/shard_rank_time.py -> profiles/r04_shard_rank_kernel_times.txt); the whole-job prediction adds one latency-bound all-reduce
+# (tools/shard_rank_time.py -> profiles/r05_run1_shard_rank_kernel_times.txt); the whole-job prediction adds one latency-bound all-reduce
+SHARD_MODEL_FILE = "r05_run1_shard_rank_kernel_times.txt"
 SHARD_MODEL_US = {
-    "cfg4_plane1m": {1: (213.9, 0.0), 2: (153.0, 13.5), 4: (121.3, 11.6), 8: (118.0, 39.2)},
-    "cfg5_plane4m": {1: (736.8, 0.0), 2: (416.0, 23.9), 4: (300.0, 22.8), 8: (283.1, 74.8)},
+    "cfg4_plane1m": {1: (203.3, 0.0), 2: (148.2, 12.6), 4: (125.7, 12.4), 8: (122.6, 45.2)},
+    "cfg5_plane4m": {1: (722.1, 0.0), 2: (409.0, 25.7), 4: (292.9, 21.2), 8: (260.7, 72.1)},
 }
 SHARD_MODEL_COLLECTIVE_US = (15.0, 30.0)
 
@@ -648,7 +645,7 @@ def shard_model(workload, world):
     lo, hi = (0.0, 0.0) if world == 1 else SHARD_MODEL_COLLECTIVE_US
     return dict(kernel_us_per_rank=row[0], of_which_above_the_cut_us=row[1], collective_us_assumed=[lo, hi],
                 predicted_ms_per_step=[(row[0] + lo) * 1e-3, (row[0] + hi) * 1e-3],
-                source="profiles/r04_shard_rank_kernel_times.txt (one rank's kernels on one MI355X) + one RCCL all-reduce of the exchange region")
+                source=f"profiles/{SHARD_MODEL_FILE} (one rank's kernels on one MI355X) + one RCCL all-reduce of the exchange region")
 
 
 def main():
@@ -661,8 +658,6 @@ def main():
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--check-every", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--reorder", action="store_true", help="N = 1: renumber the mesh in the solver's dissection order first (largesteps.meshops.reorder); "
-                                                            "reported beside the headline, which stays on the mesh as generated")
     ap.add_argument("--no-extra-baselines", action="store_true", help="skip the B2 / B3 legs (reference CG on the host / in stock torch ops)")
     ap.add_argument("--pcg", action="store_true", help="time the Jacobi-PCG instead of the default (Chebyshev) solver")
     ap.add_argument("--iterative", action="store_true",

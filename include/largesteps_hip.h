@@ -193,7 +193,7 @@ int ls_solver_poll(ls_solver* s, int k, int n_enqueued, ls_solve_info* h_info, v
 int ls_gather_rows(const float* src, const int32_t* idx, int64_t n, int k, float* dst, int device, void* stream);
 
 /* ---- factor-once / re-solve direct solver (nested dissection, multifrontal; symbolic analysis: csrc/nd_plan.cpp,
- *      numeric factorisation: csrc/nd_factor.hip, re-solve: csrc/direct.hip + csrc/nd_tier.h + csrc/nd_span.h) ---------
+ *      numeric factorisation: csrc/nd_factor.hip, re-solve: csrc/direct.hip + csrc/nd_tier.h) ---------
  * The elimination tree is a complete `arity`-ary tree (2, 4 or 8) of `levels` levels; node ids are 1-based and
  * level-major (level l: arity^l nodes, node (l, q) has the children (l+1, arity*q + c)). The vertices are renumbered
  * deepest level first (h_perm[new] = old); node i owns the new ids [own_start, own_start + s) and has b boundary
@@ -325,7 +325,7 @@ typedef struct ls_direct_arrays {
 int ls_direct_create(const ls_direct_arrays* arrays, int device, void* stream, ls_direct** out);
 /* The tree ls_direct_factor picks for a V x V system: on entry *leaf_size / *arity <= 0 mean "pick" (explicit values are kept), on return
  * both hold what the factorisation will use. Host only (no device is touched): the rule is a table of measured crossovers
- * (profiles/r03_leaf_size_sweep.txt), documented in DESIGN.md section 2.3. */
+ * (profiles/r03_leaf_size_sweep.txt), documented in DESIGN.md section 2.3 (table: docs/history_rounds_1_4.md). */
 int ls_direct_pick_tree(int64_t V, int* leaf_size, int* arity);
 /* Matrix in, solver out: symbolic analysis (bisection rounds on the device, csrc/nd_bisect.hip; tree, fronts and index lists on
  * host threads), numeric multifrontal factorisation in fp64 on the device with hand-written kernels (csrc/nd_factor.hip: products

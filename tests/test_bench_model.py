@@ -85,7 +85,7 @@ def test_roofline_group_resolves_in_the_committed_pmc_file():
         per_prefix[p] = sum(v["dispatches"] for v in hits.values())
     levels, tier = per_prefix["ls::k_nd_down"], per_prefix["ls::k_nd_tier<3, false"]
     # the up-sweep tier kernel must not be caught by the down-sweep prefix
-    assert not any(k.startswith("ls::k_nd_tier<3, false") and "true" in k for k in doc["kernels"])
+    assert all(k.split(",")[1].strip() == "false" for k in doc["kernels"] if k.startswith("ls::k_nd_tier<3, false"))
     lines = sorted(glob.glob(os.path.join(ROOT, "profiles", b.PMC_FILE[:3] + "_*bench_direct*.json")))
     d = json.loads([ln for ln in open(lines[-1]).read().splitlines() if ln.startswith("{")][-1])
     n_down = d["config"]["kernel_us"]["down_launches"]
@@ -127,9 +127,9 @@ def test_plain_multi_gpu_start_launches_the_ranks_itself(monkeypatch):
 
 def test_shard_model_is_the_committed_table():
     """the N > 1 line carries DESIGN.md section 5's prediction for its N (so that a SCALE record tests the model): the rows are the
-    per-rank kernel times of profiles/r04_shard_rank_kernel_times.txt"""
+    per-rank kernel times of the committed profiles/r05_run1_shard_rank_kernel_times.txt"""
     bench = load_bench()
-    text = open(os.path.join(ROOT, "profiles", "r04_shard_rank_kernel_times.txt")).read()
+    text = open(os.path.join(ROOT, "profiles", bench.SHARD_MODEL_FILE)).read()
     for wl, rows in bench.SHARD_MODEL_US.items():
         for n, (kernel_us, above) in rows.items():
             mine = [float(ln.split(":")[2].split("us")[0]) for ln in text.splitlines() if ln.startswith(f"{wl}: rank") and f" of {n}:" in ln]
