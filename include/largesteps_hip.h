@@ -274,6 +274,11 @@ int ls_nd_plan_create_device(const int32_t* d_rowptr, const int32_t* d_col, cons
 #define LS_ND_ORDER_MINSEP 1
 int ls_nd_plan_create_ordered(int64_t V, const int32_t* h_rowptr, const int32_t* h_col, const float* h_positions, int leaf_size,
                               int arity, int smooth, int ordering, ls_nd_plan** out);
+/* ls_nd_plan_create_device with the ordering rule as an argument: LS_ND_ORDER_MINSEP runs the trial cuts ON THE DEVICE (six sorted lists, a
+ * side bit and a cut bit per vertex and direction; the graph distances are breadth-first sweeps on the host) and is bit-identical to
+ * ls_nd_plan_create_ordered(..., LS_ND_ORDER_MINSEP) on the same input; LS_ND_ORDER_AUTO is what ls_direct_factor runs. SYNC. */
+int ls_nd_plan_create_device_ordered(const int32_t* d_rowptr, const int32_t* d_col, const float* d_positions, int64_t V, int64_t nnz,
+                                     int leaf_size, int arity, int smooth, int ordering, int device, void* stream, ls_nd_plan** out);
 int ls_nd_plan_quality(const ls_nd_plan* p, int* h_ordering, double* h_words_per_vertex, double* h_spread, double* h_words_other);
 int ls_nd_plan_destroy(ls_nd_plan* p);
 int ls_nd_plan_info(const ls_nd_plan* p, int* levels, int* arity, int* n_nodes, int64_t* n_bnd, int64_t* n_front, double* seconds);

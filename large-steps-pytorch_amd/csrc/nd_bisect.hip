@@ -34,18 +34,24 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 constexpr int BI = 8;                       // list positions per thread in the regroup kernels
 constexpr int BCH = BLOCK * BI;             // list positions per workgroup
 
+constexpr int NAX = 6;                      // most candidate directions per domain (trial cuts: three position axes + three graph distances)
 struct Round {
-    int n_dom;
+    int n_dom, NA;                          // NA = 3 lists (longest-axis rule, or trial cuts without positions) or 6 (trial cuts with positions)
     const int* seg;                         // [n_dom + 1] segment starts of this round (seg[n_dom] = live vertices)
     int* seg_next;                          // [2 n_dom + 1]
-    const int* L[3];                        // the three lists, grouped by domain, sorted by their axis inside a domain
-    int* Ln[3];
-    const double* pos;                      // V x 3
+    const int* L[NAX];                      // the lists, grouped by domain, sorted by their axis inside a domain
+    int* Ln[NAX];
+    const double* pos;                      // V x 3: axes 0-2
+    const double* pos2;                     // V x 3: axes 3-5 (NA == 6)
     long long* state;                       // (heap id << 2) | side << 1 | fixed
     unsigned char* endp;
     int* ax; int* half; int* ecnt; int* use1; int* base0; int* base1;
-    unsigned long long* bsum;               // [3][nb] packed block sums / offsets
+    unsigned long long* bsum;               // [NA][nb] packed block sums / offsets
     int nb;
+    // trial cuts (ND_ORDER_MINSEP): bit k of sidebits[u] = side of vertex u under direction k; bit k of cutbits[u] = u is an end point of
+    // a cut edge under direction k; ecnt6[(d * NA + k) * 2 + side] = end points per (domain, direction, side)
+    unsigned* sidebits; unsigned char* cutbits; int* ecnt6;
+    __device__ __forceinline__ double coord(int u, int k) const { return (k < 3 ? pos : pos2)[3 * (size_t)u + (k < 3 ? k : k - 3)]; }
 };
 
 __global__ __launch_bounds__(BLOCK) void k_f32_to_f64(const float* __restrict__ in, int64_t n, double* __restrict__ out) {
@@ -115,6 +121,71 @@ __global__ __launch_bounds__(BLOCK) void k_cut(Round r, const int* __restrict__ 
     for (int p = rowptr[u]; p < p1 && !cut; ++p) cut = (r.state[col[p]] ^ mine) == 2;
     r.endp[u] = cut;
     if (cut) atomicAdd(&r.ecnt[2 * (int)((mine >> 2) - r.n_dom) + (int)((mine >> 1) & 1)], 1);
+}
+
+// ---- trial cuts (ND_ORDER_MINSEP; the host statement: nd_plan.cpp, "every candidate axis of every domain is TRIED") ---------------------
+// Every domain tries all NA directions -- a median split of its segment of that direction's list, the end points of the edges the split
+// cuts counted per side -- and takes the direction whose smaller end-point set is smallest (ties: the lower direction; a direction that
+// is constant over the domain would order by vertex id: never). With the lists sorted once, a trial is a bit per vertex and direction.
+__global__ __launch_bounds__(BLOCK) void k_trial_init(Round r) {
+    const int d = blockIdx.x * BLOCK + threadIdx.x;
+    if (d >= r.n_dom) return;
+    r.half[d] = (r.seg[d + 1] - r.seg[d]) / 2;
+    for (int t = 0; t < 2 * r.NA; ++t) r.ecnt6[(size_t)d * 2 * r.NA + t] = 0;
+}
+__global__ __launch_bounds__(BLOCK) void k_trial_side(Round r) {          // grid (vertices, NA): list position -> side bit
+    const int k = blockIdx.y, i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= r.seg[r.n_dom]) return;
+    const int u = r.L[k][i];
+    const int d = (int)((r.state[u] >> 2) - r.n_dom);
+    if ((i - r.seg[d]) >= r.half[d]) atomicOr(&r.sidebits[u], 1u << k);
+}
+__global__ __launch_bounds__(BLOCK) void k_trial_cut(Round r, const int* __restrict__ rowptr, const int* __restrict__ col) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= r.seg[r.n_dom]) return;
+    const int u = r.L[0][i];
+    const long long node = r.state[u] >> 2;
+    const unsigned mine = r.sidebits[u];
+    unsigned diff = 0;
+    const int p1 = rowptr[u + 1];
+    for (int p = rowptr[u]; p < p1; ++p) {
+        const int w = col[p];
+        const long long sw = r.state[w];
+        if ((sw >> 2) == node && !(sw & 1)) diff |= r.sidebits[w] ^ mine;          // same domain, live
+    }
+    diff &= (1u << r.NA) - 1u;
+    r.cutbits[u] = (unsigned char)diff;
+    const int d = (int)(node - r.n_dom);
+    for (int k = 0; k < r.NA; ++k)
+        if ((diff >> k) & 1u) atomicAdd(&r.ecnt6[((size_t)d * r.NA + k) * 2 + ((mine >> k) & 1u)], 1);
+}
+__global__ __launch_bounds__(BLOCK) void k_trial_pick(Round r) {
+    const int d = blockIdx.x * BLOCK + threadIdx.x;
+    if (d >= r.n_dom) return;
+    const int a = r.seg[d], e = r.seg[d + 1], cnt = e - a;
+    int best = 0, best_sep = 0;
+    for (int k = 0; k < r.NA; ++k) {
+        int sep = 0;
+        if (cnt > 0) {
+            const double lo = r.coord(r.L[k][a], k), hi = r.coord(r.L[k][e - 1], k);
+            if (!(hi > lo) && cnt > 1) sep = INT32_MAX;
+            else { const int e0 = r.ecnt6[((size_t)d * r.NA + k) * 2], e1 = r.ecnt6[((size_t)d * r.NA + k) * 2 + 1]; sep = e0 < e1 ? e0 : e1; }
+        }
+        if (k == 0 || sep < best_sep) { best = k; best_sep = sep; }
+    }
+    r.ax[d] = best;
+    r.ecnt[2 * d] = r.ecnt6[((size_t)d * r.NA + best) * 2];
+    r.ecnt[2 * d + 1] = r.ecnt6[((size_t)d * r.NA + best) * 2 + 1];
+}
+__global__ __launch_bounds__(BLOCK) void k_trial_apply(Round r) {          // the picked direction's side and end-point flag become the round's
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= r.seg[r.n_dom]) return;
+    const int u = r.L[0][i];
+    const long long node = r.state[u] >> 2;
+    const int k = r.ax[(int)(node - r.n_dom)];
+    const long long s = (r.sidebits[u] >> k) & 1u;
+    r.state[u] = (node << 2) | (s << 1);
+    r.endp[u] = (r.cutbits[u] >> k) & 1u;
 }
 
 // one workgroup: which side gives the separator, the sizes of the child segments and their scans:
@@ -264,7 +335,10 @@ struct NdBisectDevice {
     int32_t* h_col_pending;                 // not nullptr: the host copy of the column indices is still to be made -- WHILE the rounds run
 };
 
-std::string nd_bisect_device(void* ctx, int64_t V, int D, int smooth, const double* embedded, int64_t* node) {
+// ordering = ND_ORDER_LONGEST: the longest axis of the caller's positions (averaged `smooth` times), or of `embedded` as it is.
+// ordering = ND_ORDER_MINSEP:  trial cuts over the position axes AND the three graph distances of `embedded` (both averaged `smooth`
+//                              times), or over the embedding alone when there are no positions.
+std::string nd_bisect_device(void* ctx, int64_t V, int D, int smooth, const double* embedded, int64_t* node, int ordering) {
     const NdBisectDevice& A = *(const NdBisectDevice*)ctx;
     hipStream_t st = A.st;
     if (D > 24) return "nd_bisect_device: more than 24 bisection rounds";
@@ -275,19 +349,24 @@ std::string nd_bisect_device(void* ctx, int64_t V, int D, int smooth, const doub
             return "nd_bisect_device: copy of the pattern failed";
         return "";
     }
+    const bool minsep = ordering == ND_ORDER_MINSEP, has_pos = A.d_pos != nullptr;
+    if (!has_pos && !embedded) return "nd_bisect_device: neither positions nor an embedding";
+    const int NA = (minsep && has_pos && embedded) ? 6 : 3;
     const int max_dom = 1 << (D - 1), nb = div_up(V, BCH);
     const size_t nbr = (size_t)div_up(V, rs_chunk(V));
     // one allocation: positions (two copies), 3 x 2 lists, state, node, end-point flags, per-domain tables, scan scratch, sort scratch
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_pos = take(sizeof(double) * 3 * V), o_pos2 = take(sizeof(double) * 3 * V);
-    size_t o_L[6];
-    for (int k = 0; k < 6; ++k) o_L[k] = take(sizeof(int) * V);
+    const size_t o_pos3 = NA == 6 ? take(sizeof(double) * 3 * V) : 0;
+    size_t o_L[2 * NAX];
+    for (int k = 0; k < 2 * NA; ++k) o_L[k] = take(sizeof(int) * V);
     const size_t o_state = take(sizeof(long long) * V), o_node = take(sizeof(long long) * V), o_endp = take(V);
     const size_t o_seg0 = take(sizeof(int) * (2 * (size_t)max_dom + 2)), o_seg1 = take(sizeof(int) * (2 * (size_t)max_dom + 2));
     const size_t o_ax = take(sizeof(int) * max_dom), o_half = take(sizeof(int) * max_dom), o_ecnt = take(sizeof(int) * 2 * (size_t)max_dom),
                  o_use1 = take(sizeof(int) * max_dom), o_b0 = take(sizeof(int) * max_dom), o_b1 = take(sizeof(int) * max_dom);
-    const size_t o_bsum = take(sizeof(unsigned long long) * 3 * (size_t)nb);
+    const size_t o_bsum = take(sizeof(unsigned long long) * NA * (size_t)nb);
+    const size_t o_sideb = minsep ? take(sizeof(unsigned) * V) : 0, o_cutb = minsep ? take(V) : 0, o_ecnt6 = minsep ? take(sizeof(int) * 2 * NAX * (size_t)max_dom) : 0;
     const size_t o_keys = take(sizeof(unsigned) * 2 * (size_t)V);            // carried key words of the coordinate sorts
     const size_t o_hist = take(sizeof(int) * (256 * nbr + 16)), o_offs = take(sizeof(int) * (256 * nbr + 16)),
                  o_sb = take(sizeof(int) * ((size_t)scan_blocks(256 * (int64_t)nbr) + 64));
@@ -302,27 +381,38 @@ std::string nd_bisect_device(void* ctx, int64_t V, int D, int smooth, const doub
     } guard{base, cap, dev, st};
     double* pos = (double*)(base + o_pos);
     double* pos2 = (double*)(base + o_pos2);
-    int* L[6];
-    for (int k = 0; k < 6; ++k) L[k] = (int*)(base + o_L[k]);
+    int* L[2 * NAX];
+    for (int k = 0; k < 2 * NA; ++k) L[k] = (int*)(base + o_L[k]);
     long long* state = (long long*)(base + o_state);
     long long* d_node = (long long*)(base + o_node);
     int* seg[2] = {(int*)(base + o_seg0), (int*)(base + o_seg1)};
     // ---- positions ------------------------------------------------------------------------------------------------------------------
-    if (embedded) {
-        if (hipMemcpyAsync(pos, embedded, sizeof(double) * 3 * V, hipMemcpyHostToDevice, st) != hipSuccess) return "nd_bisect_device: copy failed";
-    } else {
-        hipLaunchKernelGGL(k_f32_to_f64, dim3(div_up(3 * V, BLOCK)), dim3(BLOCK), 0, st, A.d_pos, 3 * V, pos);
-        for (int it = 0; it < smooth; ++it) {
-            hipLaunchKernelGGL(k_smooth, dim3(div_up(V, BLOCK)), dim3(BLOCK), 0, st, A.d_rowptr, A.d_col, V, (const double*)pos, pos2);
-            std::swap(pos, pos2);
+    // axes 0-2: the caller's positions, averaged; without positions the embedding (averaged under the trial-cut rule only: the plain
+    // embedding is what the longest-axis rounds are pinned to). Axes 3-5 (NA == 6): the embedding, averaged.
+    double* posB = NA == 6 ? (double*)(base + o_pos3) : nullptr;
+    auto smooth_passes = [&](double*& p, double*& scratch, int passes) {
+        for (int it = 0; it < passes; ++it) {
+            hipLaunchKernelGGL(k_smooth, dim3(div_up(V, BLOCK)), dim3(BLOCK), 0, st, A.d_rowptr, A.d_col, V, (const double*)p, scratch);
+            std::swap(p, scratch);
         }
+    };
+    if (has_pos && !(embedded && !minsep)) {
+        hipLaunchKernelGGL(k_f32_to_f64, dim3(div_up(3 * V, BLOCK)), dim3(BLOCK), 0, st, A.d_pos, 3 * V, pos);
+        smooth_passes(pos, pos2, smooth);
+        if (NA == 6) {
+            if (hipMemcpyAsync(posB, embedded, sizeof(double) * 3 * V, hipMemcpyHostToDevice, st) != hipSuccess) return "nd_bisect_device: copy failed";
+            smooth_passes(posB, pos2, smooth);            // (pos2 is scratch from here on)
+        }
+    } else {
+        if (hipMemcpyAsync(pos, embedded, sizeof(double) * 3 * V, hipMemcpyHostToDevice, st) != hipSuccess) return "nd_bisect_device: copy failed";
+        if (minsep) smooth_passes(pos, pos2, smooth);
     }
     // ---- the three coordinate orders: stable LSD radix sort of the ids by the 8 key bytes -> (coordinate, id) order -----------------
-    const int* Lc[3];
-    int* Lo[3];
-    for (int k = 0; k < 3; ++k) {
+    const int* Lc[NAX];
+    int* Lo[NAX];
+    for (int k = 0; k < NA; ++k) {
         const int* res = nullptr;
-        const int rc = radix_argsort_words(KeyF64{pos, k}, V, 2, L[2 * k], L[2 * k + 1], (unsigned*)(base + o_keys), (unsigned*)(base + o_keys) + V, (int*)(base + o_hist),
+        const int rc = radix_argsort_words(KeyF64{k < 3 ? pos : posB, k < 3 ? k : k - 3}, V, 2, L[2 * k], L[2 * k + 1], (unsigned*)(base + o_keys), (unsigned*)(base + o_keys) + V, (int*)(base + o_hist),
                                            (int*)(base + o_offs), (int*)(base + o_sb), st, &res);
         if (rc) return "nd_bisect_device: sort failed";
         Lc[k] = res;
@@ -332,24 +422,35 @@ std::string nd_bisect_device(void* ctx, int64_t V, int D, int smooth, const doub
     // ---- D rounds ---------------------------------------------------------------------------------------------------------------------
     for (int r = 0; r < D; ++r) {
         Round R;
-        R.n_dom = 1 << r;
+        R.n_dom = 1 << r; R.NA = NA;
         R.seg = seg[r & 1]; R.seg_next = seg[(r + 1) & 1];
-        for (int k = 0; k < 3; ++k) { R.L[k] = Lc[k]; R.Ln[k] = Lo[k]; }
-        R.pos = pos; R.state = state; R.endp = (unsigned char*)(base + o_endp);
+        for (int k = 0; k < NAX; ++k) { R.L[k] = k < NA ? Lc[k] : nullptr; R.Ln[k] = k < NA ? Lo[k] : nullptr; }
+        R.pos = pos; R.pos2 = posB; R.state = state; R.endp = (unsigned char*)(base + o_endp);
+        R.sidebits = minsep ? (unsigned*)(base + o_sideb) : nullptr; R.cutbits = minsep ? (unsigned char*)(base + o_cutb) : nullptr;
+        R.ecnt6 = minsep ? (int*)(base + o_ecnt6) : nullptr;
         R.ax = (int*)(base + o_ax); R.half = (int*)(base + o_half); R.ecnt = (int*)(base + o_ecnt); R.use1 = (int*)(base + o_use1);
         R.base0 = (int*)(base + o_b0); R.base1 = (int*)(base + o_b1);
         R.bsum = (unsigned long long*)(base + o_bsum); R.nb = nb;
         const int gv = div_up(V, BLOCK);
-        hipLaunchKernelGGL(k_axis, dim3(div_up(R.n_dom, BLOCK)), dim3(BLOCK), 0, st, R);
-        hipLaunchKernelGGL(k_side, dim3(gv, 3), dim3(BLOCK), 0, st, R);
-        hipLaunchKernelGGL(k_cut, dim3(gv), dim3(BLOCK), 0, st, R, A.d_rowptr, A.d_col);
+        if (minsep) {
+            if (hipMemsetAsync(R.sidebits, 0, sizeof(unsigned) * V, st) != hipSuccess) return "nd_bisect_device: memset failed";
+            hipLaunchKernelGGL(k_trial_init, dim3(div_up(R.n_dom, BLOCK)), dim3(BLOCK), 0, st, R);
+            hipLaunchKernelGGL(k_trial_side, dim3(gv, NA), dim3(BLOCK), 0, st, R);
+            hipLaunchKernelGGL(k_trial_cut, dim3(gv), dim3(BLOCK), 0, st, R, A.d_rowptr, A.d_col);
+            hipLaunchKernelGGL(k_trial_pick, dim3(div_up(R.n_dom, BLOCK)), dim3(BLOCK), 0, st, R);
+            hipLaunchKernelGGL(k_trial_apply, dim3(gv), dim3(BLOCK), 0, st, R);
+        } else {
+            hipLaunchKernelGGL(k_axis, dim3(div_up(R.n_dom, BLOCK)), dim3(BLOCK), 0, st, R);
+            hipLaunchKernelGGL(k_side, dim3(gv, 3), dim3(BLOCK), 0, st, R);
+            hipLaunchKernelGGL(k_cut, dim3(gv), dim3(BLOCK), 0, st, R, A.d_rowptr, A.d_col);
+        }
         hipLaunchKernelGGL(k_plan, dim3(1), dim3(PLAN_T), 0, st, R);
-        hipLaunchKernelGGL(k_regroup_reduce, dim3(nb, 3), dim3(BLOCK), 0, st, R);
-        hipLaunchKernelGGL(k_regroup_offsets, dim3(3), dim3(PLAN_T), 0, st, R);
-        // lists 1 and 2 first (their threads read the old states), then list 0, whose threads write the new ones
-        hipLaunchKernelGGL(k_regroup_scatter, dim3(nb, 2), dim3(BLOCK), 0, st, R, 1);
+        hipLaunchKernelGGL(k_regroup_reduce, dim3(nb, NA), dim3(BLOCK), 0, st, R);
+        hipLaunchKernelGGL(k_regroup_offsets, dim3(NA), dim3(PLAN_T), 0, st, R);
+        // lists 1 .. NA - 1 first (their threads read the old states), then list 0, whose threads write the new ones
+        hipLaunchKernelGGL(k_regroup_scatter, dim3(nb, NA - 1), dim3(BLOCK), 0, st, R, 1);
         hipLaunchKernelGGL(k_regroup_scatter, dim3(nb, 1), dim3(BLOCK), 0, st, R, 0);
-        for (int k = 0; k < 3; ++k) { const int* t = Lc[k]; Lc[k] = Lo[k]; Lo[k] = (int*)t; }
+        for (int k = 0; k < NA; ++k) { const int* t = Lc[k]; Lc[k] = Lo[k]; Lo[k] = (int*)t; }
     }
     hipLaunchKernelGGL(k_nodes, dim3(div_up(V, BLOCK)), dim3(BLOCK), 0, st, V, (const long long*)state, d_node);
     if (A.h_col_pending) {
@@ -378,9 +479,18 @@ std::string ls::nd_plan_build_device(const int32_t* d_rowptr, const int32_t* d_c
     hipStream_t st = (hipStream_t)stream;
     // the host's copy of the pattern: the row pointers now (the analysis looks at them first), the column indices during the device
     // rounds -- unless there are no positions: the graph embedding walks the pattern on the host before anything else
-    const bool host_rounds = ordering == ND_ORDER_MINSEP;             // every domain tries six directions: host threads (nd_plan.cpp)
+    static const bool host_trials = getenv("LS_ND_HOST_TRIALS") != nullptr;      // the trial cuts on host threads, as in round 4 (A/B, tests)
+    // (Round 5 measured making the trial cuts the automatic choice between 12k and 300k vertices, where they find 5-10 % thinner separators
+    // on rough closed surfaces: cfg3 0.1024 -> 0.0899 ms per solve, cfg2 0.0571 -> 0.0547 -- for +12 ms of constructor at 250k on a mesh in
+    // generation order and +23 ms on a mesh fresh from remove_duplicates, whose lexicographic vertex order makes the host's breadth-first
+    // sweeps three times slower; the eager optimisation step at these sizes is host-bound and does not get faster at all. Not the
+    // default: LS_ND_ORDER=1 asks for it -- a long captured run on one mesh -- and costs 0.026-0.038 s instead of round 4's 0.10.
+    // profiles/r05_trial_cuts_on_device.txt)
+    const bool host_rounds = ordering == ND_ORDER_MINSEP && host_trials;
+    // (the trial cuts need the graph distances, i.e. the pattern on the host, before the rounds start; so does a matrix without positions)
+    const bool col_first = !d_positions || ordering == ND_ORDER_MINSEP;
     if (hipMemcpyAsync(h_rowptr, d_rowptr, sizeof(int32_t) * (V + 1), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        ((!d_positions || host_rounds) && hipMemcpyAsync(h_col, d_col, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost, st) != hipSuccess) ||
+        (col_first && hipMemcpyAsync(h_col, d_col, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost, st) != hipSuccess) ||
         hipStreamSynchronize(st) != hipSuccess)
         return "the copy of the matrix pattern to the host failed";
     if (h_rowptr[0] != 0 || h_rowptr[V] != nnz) return "rowptr does not match nnz";
@@ -397,20 +507,24 @@ std::string ls::nd_plan_build_device(const int32_t* d_rowptr, const int32_t* d_c
         if (!fetch_positions()) return "the copy of the positions to the host failed";
         return nd_plan_build(V, h_rowptr, h_col, d_positions ? h_pos.data() : nullptr, leaf_size, arity, smooth, out, nullptr, nullptr, ND_ORDER_MINSEP, defer_push_lists);
     }
-    NdBisectDevice ctx{d_rowptr, d_col, d_positions, nnz, st, d_positions ? h_col : nullptr};
+    NdBisectDevice ctx{d_rowptr, d_col, d_positions, nnz, st, col_first ? nullptr : h_col};
     const float given = 0.0f;                  // "positions were given": nd_plan_build only tests the pointer, the values are read on the device
-    std::string err = nd_plan_build(V, h_rowptr, h_col, d_positions ? &given : nullptr, leaf_size, arity, smooth, out, nd_bisect_device, &ctx, ND_ORDER_LONGEST,
-                                    defer_push_lists);
+    std::string err = nd_plan_build(V, h_rowptr, h_col, d_positions ? &given : nullptr, leaf_size, arity, smooth, out, nd_bisect_device, &ctx,
+                                    ordering == ND_ORDER_MINSEP ? ND_ORDER_MINSEP : ND_ORDER_LONGEST, defer_push_lists);
     if (timing) fprintf(stderr, "[nd_plan] returned (pool joined, temporaries released) %.3f s after its start; %.1f factor numbers per vertex, spread %.2f\n",
                         now_s() - t0, out.words_per_vertex, out.spread);
     if (!err.empty() || ordering != ND_ORDER_AUTO || out.spread <= nd_plan_suspect()) return err;
     // Separators thicker than a surface's should be: the cutting planes cross several layers of a surface that is folded or rolled up
-    // in space (or several components that lie inside each other). The rounds are run again on the host with graph distances among the
-    // candidate directions; the cheaper plan is kept. Costs a few tenths of a second at 1M vertices -- against a factor that is
-    // 1.5-30 x larger, or no factor at all (fronts beyond the solver's limit).
-    if (!fetch_positions()) return "";
+    // in space (or several components that lie inside each other). The rounds are run again with graph distances among the candidate
+    // directions (on the device; the breadth-first sweeps that give the distances run on the host); the cheaper plan is kept.
     NdPlan B;
-    err = nd_plan_build(V, h_rowptr, h_col, d_positions ? h_pos.data() : nullptr, leaf_size, arity, smooth, B, nullptr, nullptr, ND_ORDER_MINSEP, defer_push_lists);
+    if (host_trials) {
+        if (!fetch_positions()) return "";
+        err = nd_plan_build(V, h_rowptr, h_col, d_positions ? h_pos.data() : nullptr, leaf_size, arity, smooth, B, nullptr, nullptr, ND_ORDER_MINSEP, defer_push_lists);
+    } else {
+        NdBisectDevice ctx2{d_rowptr, d_col, d_positions, nnz, st, nullptr};         // (h_col is complete: the first set of rounds has returned)
+        err = nd_plan_build(V, h_rowptr, h_col, d_positions ? &given : nullptr, leaf_size, arity, smooth, B, nd_bisect_device, &ctx2, ND_ORDER_MINSEP, defer_push_lists);
+    }
     if (timing) fprintf(stderr, "[nd_plan] suspect dissection: tried graph distances as well: %.1f factor numbers per vertex, spread %.2f (%s), %.3f s after the start\n",
                         B.words_per_vertex, B.spread, err.empty() ? (B.words_per_vertex < out.words_per_vertex ? "taken" : "not taken") : err.c_str(), now_s() - t0);
     if (!err.empty()) return "";
@@ -432,6 +546,22 @@ extern "C" int ls_nd_plan_create_device(const int32_t* d_rowptr, const int32_t* 
     uvec<int32_t> rowptr((size_t)V + 1), col((size_t)nnz);
     ls_nd_plan* h = new ls_nd_plan();
     const std::string err = nd_plan_build_device(d_rowptr, d_col, d_positions, V, nnz, rowptr.data(), col.data(), leaf_size, arity, smooth, st, h->p);
+    if (!err.empty()) { delete h; set_error("%s", err.c_str()); return LS_E_INVALID; }
+    *out = h;
+    return LS_OK;
+}
+
+extern "C" int ls_nd_plan_create_device_ordered(const int32_t* d_rowptr, const int32_t* d_col, const float* d_positions, int64_t V, int64_t nnz,
+                                                int leaf_size, int arity, int smooth, int ordering, int device, void* stream, ls_nd_plan** out) {
+    using namespace ls;
+    LS_REQUIRE(out && d_rowptr && d_col && V > 0 && nnz > 0 && nnz < INT32_MAX, LS_E_INVALID, "ls_nd_plan_create_device_ordered: bad argument");
+    LS_REQUIRE(ordering >= ND_ORDER_AUTO && ordering <= ND_ORDER_MINSEP, LS_E_INVALID, "ls_nd_plan_create_device_ordered: ordering must be -1, 0 or 1");
+    *out = nullptr;
+    DeviceGuard g(device);
+    LS_HIP(g.err);
+    uvec<int32_t> rowptr((size_t)V + 1), col((size_t)nnz);
+    ls_nd_plan* h = new ls_nd_plan();
+    const std::string err = nd_plan_build_device(d_rowptr, d_col, d_positions, V, nnz, rowptr.data(), col.data(), leaf_size, arity, smooth, (hipStream_t)stream, h->p, ordering);
     if (!err.empty()) { delete h; set_error("%s", err.c_str()); return LS_E_INVALID; }
     *out = h;
     return LS_OK;

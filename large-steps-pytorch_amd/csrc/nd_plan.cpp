@@ -255,18 +255,18 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
     uvec<int64_t> node((size_t)V);                    // binary heap id of the domain a vertex lives in / became a separator of
     if (!bisect) std::fill(node.begin(), node.end(), (int64_t)1);
     if (bisect) {
-        // positions and the D rounds run elsewhere (csrc/nd_bisect.hip: on the device); only the graph embedding of a matrix that
-        // comes without positions is formed here
+        // positions and the D rounds run elsewhere (csrc/nd_bisect.hip: on the device); only the graph embedding -- of a matrix that
+        // comes without positions, or as the trial cuts' second set of directions -- is formed here
         std::vector<double> emb;
-        bool all_rows = true;
-        if (pos_in) {
-            std::atomic<bool> empty_row(false);
+        const bool minsep = ordering == ND_ORDER_MINSEP;
+        std::atomic<bool> empty_row(false);
+        if (pos_in || minsep)
             parallel_for(V, 65536, [&](int64_t lo, int64_t hi) { for (int64_t v = lo; v < hi; ++v) if (rowptr[v + 1] <= rowptr[v]) { empty_row = true; break; } });
-            all_rows = !empty_row;
-        }
-        else graph_embedding(V, rowptr, col, emb);
+        const bool all_rows = !empty_row;
+        if (!pos_in || minsep) graph_embedding(V, rowptr, col, emb);
         lap("positions");
-        const std::string err = bisect(bisect_ctx, V, D, (pos_in && all_rows) ? smooth : 0, pos_in ? nullptr : emb.data(), node.data());
+        const int passes = minsep ? (all_rows ? smooth : 0) : ((pos_in && all_rows) ? smooth : 0);
+        const std::string err = bisect(bisect_ctx, V, D, passes, (!pos_in || minsep) ? emb.data() : nullptr, node.data(), minsep ? ND_ORDER_MINSEP : ND_ORDER_LONGEST);
         if (!err.empty()) return err;
     } else {
         // ---- coordinates: NA candidate axes per vertex. Axes 0-2: the caller's positions (averaged `smooth` times over the matrix
@@ -697,7 +697,7 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
         nd_plan_push_lists(P);
         lap("push lists");
     }
-    P.ordering = (bisect || ordering != ND_ORDER_MINSEP) ? ND_ORDER_LONGEST : ND_ORDER_MINSEP;
+    P.ordering = ordering == ND_ORDER_MINSEP ? ND_ORDER_MINSEP : ND_ORDER_LONGEST;
     nd_plan_quality(P);
     lap("quality");
     P.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();

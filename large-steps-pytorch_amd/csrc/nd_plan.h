@@ -58,20 +58,24 @@ struct NdPlan {
 // (csrc/nd_bisect.hip runs them on the device): it fills node[v] = binary heap id of the domain vertex v ended in (a separator
 // vertex: the domain it separates; everything else: its leaf, an id >= 2^D). embedded: nullptr = take the caller's positions and
 // average them `smooth` times over the matrix neighbours; otherwise V x 3 doubles formed here from graph distances (smooth = 0).
+// With ordering == ND_ORDER_MINSEP the callee gets BOTH where there are positions (its own copy of them and `embedded`), averages both
+// `smooth` times and runs the trial cuts over the six directions (without positions: over the averaged embedding's three).
 // The host's own rounds (bisect == nullptr) are what the host-only entry points and the CPU tests run, and what the device
 // rounds are checked against (tests/test_nested_gpu.py): both must produce the same node[] bit for bit.
 // How a domain's cutting direction is chosen (the `ordering` argument below):
 //   ND_ORDER_LONGEST  median cut along the longest axis of the domain's bounding box in the embedding it is given (the caller's
 //                     positions, or graph distances when there are none): what the device rounds run, a few milliseconds
 //   ND_ORDER_MINSEP   every domain TRIES six directions -- the three position axes and three graph distances (level sets of a
-//                     graph distance do not care how the surface lies in space) -- and takes the thinnest separator. Host rounds.
+//                     graph distance do not care how the surface lies in space) -- and takes the thinnest separator. On the device
+//                     too since round 5 (six sorted lists, a side bit and a cut bit per vertex and direction; the graph distances
+//                     themselves are breadth-first sweeps on the host); LS_ND_HOST_TRIALS=1 keeps the host rounds (A/B, tests).
 //   ND_ORDER_AUTO     LONGEST first; when its separators are thicker than a surface's should be (NdPlan::spread above
 //                     nd_plan_suspect(), 1.3), MINSEP as well, and the cheaper plan of the two.
 // CHOLMOD's ordering behind the reference's constructor (largesteps/solvers.py:34) is graph based and has no such dependence on
 // the embedding; ND_ORDER_AUTO is what ls_direct_factor runs.
 enum { ND_ORDER_AUTO = -1, ND_ORDER_LONGEST = 0, ND_ORDER_MINSEP = 1 };
 double nd_plan_suspect();                                    // the threshold on NdPlan::spread (environment LS_ND_SUSPECT)
-typedef std::string (*NdBisectFn)(void* ctx, int64_t V, int D, int smooth, const double* embedded, int64_t* node);
+typedef std::string (*NdBisectFn)(void* ctx, int64_t V, int D, int smooth, const double* embedded, int64_t* node, int ordering);
 int nd_plan_rounds(int64_t V, int leaf_size, int arity);
 std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, const float* pos, int leaf_size, int arity,
                           int smooth, NdPlan& out, NdBisectFn bisect = nullptr, void* bisect_ctx = nullptr, int ordering = ND_ORDER_LONGEST,

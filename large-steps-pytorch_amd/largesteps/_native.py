@@ -114,6 +114,7 @@ _SIGNATURES = {
     "ls_nd_plan_create": (c_int, [c_i64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
     "ls_nd_plan_create_device": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_int, c_int, c_int, c_int, c_void_p, ctypes.POINTER(c_void_p)]),
     "ls_nd_plan_create_ordered": (c_int, [c_i64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "ls_nd_plan_create_device_ordered": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_int, c_int, c_int, c_int, c_int, c_void_p, ctypes.POINTER(c_void_p)]),
     "ls_nd_plan_quality": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_double), ctypes.POINTER(c_double), ctypes.POINTER(c_double)]),
     "ls_direct_plan_quality": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_double), ctypes.POINTER(c_double), ctypes.POINTER(c_double)]),
     "ls_nd_plan_destroy": (c_int, [c_void_p]),

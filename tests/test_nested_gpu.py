@@ -49,7 +49,7 @@ def _arrays(lib, h, V):
     return out
 
 
-def _both(rowptr, col, pos, leaf, arity, smooth=4):
+def _both(rowptr, col, pos, leaf, arity, smooth=4, ordering=0):
     from largesteps import _native
     lib = _native.lib()
     dev = torch.device("cuda:0")
@@ -57,7 +57,10 @@ def _both(rowptr, col, pos, leaf, arity, smooth=4):
     as_p = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)   # noqa: E731
     pos32 = None if pos is None else np.ascontiguousarray(pos, dtype=np.float32)
     h = ctypes.c_void_p()
-    _native.check(lib.ls_nd_plan_create(V, as_p(rowptr), as_p(col), as_p(pos32), leaf, arity, smooth, ctypes.byref(h)))
+    if ordering:
+        _native.check(lib.ls_nd_plan_create_ordered(V, as_p(rowptr), as_p(col), as_p(pos32), leaf, arity, smooth, ordering, ctypes.byref(h)))
+    else:
+        _native.check(lib.ls_nd_plan_create(V, as_p(rowptr), as_p(col), as_p(pos32), leaf, arity, smooth, ctypes.byref(h)))
     try:
         host = _arrays(lib, h, V)
     finally:
@@ -65,8 +68,12 @@ def _both(rowptr, col, pos, leaf, arity, smooth=4):
     d_rp, d_col = torch.from_numpy(rowptr).to(dev), torch.from_numpy(col).to(dev)
     d_pos = None if pos32 is None else torch.from_numpy(pos32).to(dev)
     h = ctypes.c_void_p()
-    _native.check(lib.ls_nd_plan_create_device(_native.ptr(d_rp), _native.ptr(d_col), _native.ptr(d_pos), V, col.shape[0], leaf, arity, smooth,
-                                               0, _native.stream_of(dev), ctypes.byref(h)))
+    if ordering:
+        _native.check(lib.ls_nd_plan_create_device_ordered(_native.ptr(d_rp), _native.ptr(d_col), _native.ptr(d_pos), V, col.shape[0], leaf, arity, smooth,
+                                                           ordering, 0, _native.stream_of(dev), ctypes.byref(h)))
+    else:
+        _native.check(lib.ls_nd_plan_create_device(_native.ptr(d_rp), _native.ptr(d_col), _native.ptr(d_pos), V, col.shape[0], leaf, arity, smooth,
+                                                   0, _native.stream_of(dev), ctypes.byref(h)))
     try:
         device = _arrays(lib, h, V)
     finally:
@@ -108,6 +115,40 @@ def test_device_plan_equals_host_plan(arity):
         rowptr, col = _pattern(v, f)
         host, device = _both(rowptr, col, v, 64, arity)
         _same(host, device, f"{name}, arity {arity}")
+
+
+@pytest.mark.parametrize("arity", [2, 4, 8])
+def test_device_trial_cuts_equal_host_trial_cuts(arity):
+    """ND_ORDER_MINSEP (every domain tries the three position axes and three graph distances and takes the thinnest separator) on the
+    device -- six sorted lists, a side bit and a cut bit per vertex and direction -- against the host rounds of round 4: every array of the
+    finished plan, on smooth, rough and open meshes with ties, on a surface rolled up in space, without positions (three directions) and
+    with empty rows (no averaging)."""
+    from largesteps import synthetic
+    for name, v, f in _meshes():
+        rowptr, col = _pattern(v, f)
+        host, device = _both(rowptr, col, v, 64, arity, ordering=1)
+        _same(host, device, f"trial cuts: {name}, arity {arity}")
+    v, f = synthetic.scroll(120, 3)
+    rowptr, col = _pattern(v, f)
+    host, device = _both(rowptr, col, v, 64, arity, ordering=1)
+    _same(host, device, f"trial cuts: scroll, arity {arity}")
+    v, f = synthetic.icosphere(4)
+    rowptr, col = _pattern(v, f)
+    host, device = _both(rowptr, col, None, 32, arity, ordering=1)
+    _same(host, device, "trial cuts without positions")
+    rp2 = np.concatenate([rowptr, [rowptr[-1], rowptr[-1]]]).astype(np.int32)
+    v2 = np.concatenate([v, [[3.0, 0, 0], [0, 3.0, 0]]]).astype(np.float32)
+    host, device = _both(rp2, col, v2, 32, arity, ordering=1)
+    _same(host, device, "trial cuts with empty rows")
+
+
+def test_device_trial_cuts_after_every_round():
+    v, f = _grid(120, 90)
+    rowptr, col = _pattern(v, f)
+    V = v.shape[0]
+    for r in range(1, 9):
+        host, device = _both(rowptr, col, v, V >> r, 2, ordering=1)
+        _same(host, device, f"trial cuts after {r} rounds")
 
 
 def test_device_plan_without_positions_and_with_empty_rows():
