@@ -86,6 +86,21 @@ int main(int argc, char** argv) {
         for (int r = 0; r < solves; ++r) LS(ls_direct_solve(h, d_b, d_x, k, st));
         CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (getenv("ND_DRIVE_GRAPH")) {          // the same solve captured once and replayed: what the launches cost the HOST at small sizes
+            hipGraph_t g; hipGraphExec_t ge;
+            CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            LS(ls_direct_solve(h, d_b, d_x, k, st));
+            CK(hipStreamEndCapture(st, &g));
+            CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            for (int r = 0; r < 3; ++r) CK(hipGraphLaunch(ge, st));
+            CK(hipStreamSynchronize(st));
+            CK(hipEventRecord(e0, st));
+            for (int r = 0; r < solves; ++r) CK(hipGraphLaunch(ge, st));
+            CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+            float gms; CK(hipEventElapsedTime(&gms, e0, e1));
+            printf("replayed as a graph: %8.2f us per solve (launched one by one: %8.2f)\n", gms / solves * 1e3, ms / solves * 1e3);
+            CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+        }
         LS(ls_direct_set(h, "profile", 1));
         double pm[3] = {0, 0, 0}, acc[3] = {0, 0, 0};
         for (int r = 0; r < 10; ++r) { LS(ls_direct_solve(h, d_b, d_x, k, st)); LS(ls_direct_info(h, nullptr, nullptr, pm)); for (int t = 0; t < 3; ++t) acc[t] += pm[t] / 10; }
