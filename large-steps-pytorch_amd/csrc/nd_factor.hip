@@ -539,8 +539,8 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     NdPlan P;
     {
         // how the cutting directions are chosen: ND_ORDER_AUTO (nd_plan.h) unless the environment says otherwise (LS_ND_ORDER = 0: always
-        // the longest axis of the embedding, 1: always the thinnest of six trial separators on host threads -- 5-10 % fewer factor
-        // numbers on rough scans for a constructor of tenths of a second)
+        // the longest axis of the embedding, 1: always the thinnest of six trial separators -- on the device since round 5: 5-10 % fewer
+        // factor numbers on rough scans for 10-25 ms more constructor at 250k vertices)
         const char* oe = getenv("LS_ND_ORDER");
         const int ordering = oe ? std::max(-1, std::min(1, atoi(oe))) : ND_ORDER_AUTO;
         const std::string err = nd_plan_build_device(d_rowptr, d_col, d_positions, V, nnz, rowptr.data(), col.data(), leaf_size, arity, 4, st, P, ordering,

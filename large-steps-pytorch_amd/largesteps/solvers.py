@@ -10,6 +10,7 @@ Neither cholespy/CHOLMOD nor torch sparse ops are used; there is no CPU path.
 """
 import ctypes
 import os
+import threading
 import types
 import warnings
 
@@ -250,17 +251,37 @@ class IterativeCholeskySolver(PCGSolver):
 class _NativeDirect:
     """Owner of a native ls_direct handle built by ls_direct_factor (symbolic analysis + numeric factorisation behind the C ABI)."""
 
-    def __init__(self, csr, leaf_size, arity, tier_levels, sparse_leaves, shard=(0, 1)):
+    _ORDERINGS = {None: None, "auto": "-1", "longest-axis": "0", "trial-cuts": "1"}
+    _order_lock = threading.Lock()
+
+    def __init__(self, csr, leaf_size, arity, tier_levels, sparse_leaves, shard=(0, 1), ordering=None):
         self.device = csr.device
         self._h = ctypes.c_void_p(None)
         pos = csr.positions
         if pos is not None:
             pos = pos.detach().to(torch.float32).contiguous()
         dev = csr.device
-        with torch.cuda.device(dev):
-            _native.check(_native.lib().ls_direct_factor(_native.ptr(csr.rowptr), _native.ptr(csr.col), _native.ptr(csr.val), csr.V, csr.nnz,
-                                                         _native.ptr(pos), int(leaf_size or 0), int(arity or 0), int(tier_levels), int(bool(sparse_leaves)),
-                                                         int(shard[0]), int(shard[1]), dev.index, _native.stream_of(dev), ctypes.byref(self._h)))
+        if ordering not in self._ORDERINGS:
+            raise ValueError(f"ordering must be one of {sorted(k for k in self._ORDERINGS if k)} or None, got {ordering!r}")
+
+        def factor():
+            with torch.cuda.device(dev):
+                _native.check(_native.lib().ls_direct_factor(_native.ptr(csr.rowptr), _native.ptr(csr.col), _native.ptr(csr.val), csr.V, csr.nnz,
+                                                             _native.ptr(pos), int(leaf_size or 0), int(arity or 0), int(tier_levels), int(bool(sparse_leaves)),
+                                                             int(shard[0]), int(shard[1]), dev.index, _native.stream_of(dev), ctypes.byref(self._h)))
+        if ordering is None:
+            factor()
+        else:                      # the native call reads LS_ND_ORDER when it starts: set for the duration of this one construction
+            with self._order_lock:
+                old = os.environ.get("LS_ND_ORDER")
+                os.environ["LS_ND_ORDER"] = self._ORDERINGS[ordering]
+                try:
+                    factor()
+                finally:
+                    if old is None:
+                        os.environ.pop("LS_ND_ORDER", None)
+                    else:
+                        os.environ["LS_ND_ORDER"] = old
         s3 = (ctypes.c_double * 3)()
         _native.check(_native.lib().ls_direct_factor_seconds(self._h, ctypes.byref(s3)))
         self.timings = dict(plan_seconds=s3[0], table_seconds=s3[1], factor_seconds=s3[2])
@@ -366,12 +387,13 @@ class NestedDissectionSolver(Solver):
     The dissection uses the vertex positions the matrix was assembled from (`compute_matrix`); a symmetric matrix built
     elsewhere gets graph-distance pseudo-positions instead. A surface that is folded or rolled up in space (cloth, a scroll, shells
     inside each other) is recognised by its thick separators and dissected again with graph distances among the cutting directions
-    (`plan_quality['ordering'] == 'trial-cuts'`; LS_ND_ORDER=1 asks for that always: 5-10 % fewer factor numbers on rough scans
-    for a constructor of tenths of a second). Raises ValueError when the matrix is not symmetric or not
+    (`plan_quality['ordering'] == 'trial-cuts'`). ordering='trial-cuts' (or LS_ND_ORDER=1) asks for those trial cuts always: 5-10 % fewer
+    factor numbers on rough closed scans (the 250k cotangent config: 0.102 -> 0.090 ms per solve) for 10-25 ms more constructor --
+    worth it for a long captured run on one mesh; 'longest-axis' never tries them; None / 'auto' is the library's rule. Raises ValueError when the matrix is not symmetric or not
     positive definite, RuntimeError when the mesh does not dissect into fronts that fit the kernels.
     """
 
-    def __init__(self, M, leaf_size=None, arity=None, shard=(0, 1)):
+    def __init__(self, M, leaf_size=None, arity=None, shard=(0, 1), ordering=None):
         import time
         csr = _native.csr_of(M)
         self._csr = csr
@@ -382,7 +404,7 @@ class NestedDissectionSolver(Solver):
         t0 = time.perf_counter()
         tier = max(-1, min(6, int(os.environ.get("LS_ND_TIER_H", "-1"))))      # -1: the library picks (and never picks one that does not fit)
         sparse = not os.environ.get("LS_ND_DENSE_LEAVES")
-        self._direct = _NativeDirect(csr, leaf_size, arity, tier, sparse, shard=shard)
+        self._direct = _NativeDirect(csr, leaf_size, arity, tier, sparse, shard=shard, ordering=ordering)
         torch.cuda.synchronize(csr.device)
         self.build_seconds = time.perf_counter() - t0
         self.timings = self._direct.timings

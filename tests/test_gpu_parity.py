@@ -1262,3 +1262,25 @@ def test_many_constructions_in_one_process(dev):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_threads.py"), "60"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "failures: none" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
+
+
+def test_ordering_argument_of_the_direct_solver(dev):
+    """NestedDissectionSolver(M, ordering=...): 'trial-cuts' runs the six-direction trial cuts (on the device) whatever the automatic rule
+    would do, 'longest-axis' never does; the environment is left as it was; both solve the system."""
+    from largesteps.geometry import compute_matrix
+    from largesteps.solvers import NestedDissectionSolver
+    from largesteps import synthetic
+    v, f = synthetic.icosphere(40)
+    v = synthetic.perturb(v, radial=0.05, tangential=0.2, edge=0.03, seed=4)
+    M = compute_matrix(_t(v, dev), _t(f, dev), 30.0)
+    b = _t(np.random.default_rng(9).standard_normal(v.shape).astype(np.float32), dev)
+    before = os.environ.get("LS_ND_ORDER")
+    a = NestedDissectionSolver(M, ordering="longest-axis")
+    t = NestedDissectionSolver(M, ordering="trial-cuts")
+    assert os.environ.get("LS_ND_ORDER") == before
+    assert a.plan_quality["ordering"] == "longest-axis" and t.plan_quality["ordering"] == "trial-cuts"
+    assert t.plan_quality["words_per_vertex"] <= 1.02 * a.plan_quality["words_per_vertex"]
+    xa, xt = a.solve(b), t.solve(b)
+    assert float((xa - xt).abs().max()) <= 2e-5 * float(xa.abs().max())
+    with pytest.raises(ValueError, match="ordering must be"):
+        NestedDissectionSolver(M, ordering="best")
