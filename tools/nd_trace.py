@@ -2,12 +2,17 @@
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k_nd_" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+def tier_up(n):
+    # k_nd_tier<K, UP, W, NT>: the second template argument is the direction
+    return n.split("k_nd_tier<", 1)[1].split(",")[1].strip().startswith("true")
+
+
 def is_up(n):
-    return "k_nd_up" in n or ("k_nd_tier" in n and "true" in n)
+    return "k_nd_up" in n or ("k_nd_tier" in n and tier_up(n))
 
 
 def is_down(n):
-    return "k_nd_down" in n or ("k_nd_tier" in n and "false" in n)
+    return "k_nd_down" in n or ("k_nd_tier" in n and not tier_up(n))
 
 
 # a solve starts with the first up-sweep kernel after a down-sweep kernel
