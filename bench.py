@@ -122,8 +122,7 @@ def pmc_traffic_group(prefixes, workload):
     return sum(r["traffic_bytes"] * r.get("dispatches", 1) for r in hits) / n, n
 
 
-ASSEMBLY_KERNELS = ("ls::k_count<", "ls::k_scan_reduce", "ls::k_scan_bsums", "ls::k_scan_final", "ls::k_scatter<", "ls::k_row_merge<",
-                    "ls::k_tile_scan", "ls::k_rowptr", "ls::k_emit")
+ASSEMBLY_KERNELS = ("ls::k_count<", "ls::k_scan_chained", "ls::k_scatter<", "ls::k_row_merge<", "ls::k_tile_scan", "ls::k_rowptr", "ls::k_emit")
 
 
 def pmc_traffic_per_call(prefixes, workload):
@@ -159,7 +158,7 @@ def assembly_entry(tv, tf, cfg, V, F, nnz, workload, repeats=5):
     csr_bytes = tf.element_size() * 3 * F + 8 * nnz + 4 * (V + 1) + (12 * V if cfg["cotan"] else 0)
     coo_bytes = 16 * nnz
     traffic = pmc_traffic_per_call(ASSEMBLY_KERNELS, workload)
-    return dict(kernel="compute_matrix: k_count (corner ranks, one atomic per vertex pair and workgroup) -> scan -> k_scatter -> k_row_merge (rows sorted in "
+    return dict(kernel="compute_matrix: k_count (corner ranks, one atomic per vertex pair and workgroup) -> k_scan_chained (one launch) -> k_scatter -> k_row_merge (rows sorted in "
                        "registers) -> k_tile_scan / k_rowptr -> [nnz to the host] -> k_emit", us_per_call=us,
                 bytes=csr_bytes, bytes_with_coo_index_list=csr_bytes + coo_bytes, achieved=csr_bytes / (us * 1e-6) / 1e9, unit="GB/s",
                 frac=csr_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, frac_with_coo_index_list=(csr_bytes + coo_bytes) / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,

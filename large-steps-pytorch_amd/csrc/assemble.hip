@@ -23,19 +23,20 @@ namespace ls {
 // workspace layout (shared by ls_assemble_pattern and ls_assemble_fill; depends on V and F only)
 // ------------------------------------------------------------------------------------------------
 struct AsmLayout {
-    size_t cnt, slot_ptr, row_off, diag, flags, bsum, tile_cnt, tile_off, corner_off, slot_col, slot_val, comp, total;
+    size_t flags, chain_rows, cnt, slot_ptr, row_off, diag, tile_cnt, tile_off, corner_off, slot_col, slot_val, comp, total;
     int64_t nslots, tiles;
     AsmLayout(int64_t V, int64_t F) {
         auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
         nslots = 6 * F;
         tiles = (V + TILE_ROWS - 1) / TILE_ROWS;
         size_t o = 0;
+        // what has to be ZERO when the kernels start comes first: one memset over [0, slot_ptr)
+        flags = o;     o = al(o + 64);
+        chain_rows = o;  o = al(o + 8 * (size_t)((V + 1) / 4096 + 4));   // single-pass scan of the row counters: ticket + one word per 4096 rows
         cnt = o;       o = al(o + 4 * (size_t)(V + 2));        // (k_count reserves for vertex pairs with 64-bit atomics: one entry of slack)
         slot_ptr = o;  o = al(o + 4 * (size_t)(V + 1));
         row_off = o;   o = al(o + 4 * (size_t)(V + 1));        // offset of a row's first entry inside its tile's compact block
         diag = o;      o = al(o + 4 * (size_t)(V + 1));
-        flags = o;     o = al(o + 64);
-        bsum = o;      o = al(o + 4 * (size_t)((V + 1) / 2048 + 4));
         tile_cnt = o;  o = al(o + 4 * (size_t)(tiles + 1));    // entries of a 256-row tile
         tile_off = o;  o = al(o + 4 * (size_t)(tiles + 1));    // ... and their exclusive scan: where the tile's rows start in the CSR arrays
         corner_off = o; o = al(o + 4 * (size_t)(3 * F) + 64);  // where a face corner's two slots sit inside its vertex' row (k_count)
@@ -135,16 +136,140 @@ int exclusive_scan(const int* in, int64_t n, int* out, int* bsum, hipStream_t st
 }
 
 // ------------------------------------------------------------------------------------------------
+// single-pass exclusive scan (round 5): the workgroups hand their sums along a chain of status words ("decoupled look-back")
+// instead of meeting at two kernel boundaries. state[0] = ticket counter, state[1 + k] = status << 62 | value of chunk k -- status 1:
+// the chunk's own sum, 2: the sum of everything up to and including the chunk. ALL ZERO before the launch (the caller's memset).
+// A workgroup takes its chunk from the ticket counter, so a chunk's predecessors are running or done whatever order the hardware
+// starts workgroups in: the spin below always ends. Status and value share one 64-bit word: no fence between them.
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned long long CH_AGG = 1ull << 62, CH_INC = 2ull << 62;
+__device__ __forceinline__ unsigned long long chain_load(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void chain_store(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int chain_ticket(unsigned long long* state, int* s_tk) {      // all threads; *s_tk in LDS
+    if (threadIdx.x == 0) *s_tk = (int)atomicAdd(state, 1ull);
+    __syncthreads();
+    return *s_tk;
+}
+__device__ __forceinline__ void chain_publish(unsigned long long* state, int k, int agg) {   // one thread
+    chain_store(state + 1 + k, (k == 0 ? CH_INC : CH_AGG) | (unsigned long long)(unsigned)agg);
+}
+// all 64 lanes of ONE wave, after chain_publish(k, agg): the sum of the chunks before k. A lane looks at CH_PER consecutive chunks
+// (lane 0 the nearest), the window of 64 x CH_PER chunks moves back until one of them knows its inclusive sum. A hop of the chain is a
+// store becoming visible to another CU's load (~1 us), so the chain pays for FEW chunks only: the row counters of 1M vertices are 245
+// chunks = one window. (The same chain inside k_row_merge -- 3907 tiles handing their entry counts along, to drop k_tile_scan and
+// k_rowptr -- made that kernel 67 us with a window of 64 and 88 us with 256 instead of 23: measured and taken out.)
+constexpr int CH_PER = 4;
+__device__ __forceinline__ int chain_lookback(unsigned long long* state, int k, int agg) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    int prefix = 0;
+    for (int j0 = k - 1 - lane * CH_PER;; j0 -= WAVE * CH_PER) {
+        unsigned long long w[CH_PER];
+#pragma unroll
+        for (int e = 0; e < CH_PER; ++e) w[e] = j0 - e >= 0 ? chain_load(state + 1 + j0 - e) : CH_INC;      // before chunk 0: an inclusive sum of 0
+        bool pending;
+        do {
+            pending = false;
+#pragma unroll
+            for (int e = 0; e < CH_PER; ++e) {
+                if ((w[e] >> 62) == 0) { w[e] = chain_load(state + 1 + j0 - e); pending |= (w[e] >> 62) == 0; }
+            }
+        } while (pending);
+        int v = 0;
+        bool has = false;                                           // this lane holds a chunk that knows its inclusive sum
+#pragma unroll
+        for (int e = 0; e < CH_PER; ++e) {
+            if (!has) { v += (int)(unsigned)w[e]; has = (w[e] >> 62) == 2; }
+        }
+        const unsigned long long inc = __ballot(has);
+        const int first = inc ? __ffsll((long long)inc) - 1 : WAVE;   // the nearest lane with one
+        v = lane <= first ? v : 0;
+#pragma unroll
+        for (int o = WAVE / 2; o; o >>= 1) v += __shfl_xor(v, o, WAVE);
+        prefix += v;
+        if (inc) break;
+    }
+    if (lane == 0 && k > 0) chain_store(state + 1 + k, CH_INC | (unsigned long long)(unsigned)(prefix + agg));
+    return prefix;
+}
+
+constexpr int CH_ITEMS = 16;
+constexpr int CH_CHUNK = BLOCK * CH_ITEMS;       // 4096 elements per workgroup
+typedef int i4a_scan __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(BLOCK) void k_scan_chained(const int* __restrict__ in, int64_t n, int* __restrict__ out /* n + 1 */,
+                                                        unsigned long long* __restrict__ state) {
+    __shared__ int smem[BLOCK / WAVE + 1];
+    __shared__ int s_tk, s_pref;
+    const int k = chain_ticket(state, &s_tk);
+    const int64_t base = (int64_t)k * CH_CHUNK + (int64_t)threadIdx.x * CH_ITEMS;
+    const bool quad = base + CH_ITEMS <= n && ((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0;
+    int v[CH_ITEMS];
+    if (quad) {
+#pragma unroll
+        for (int q = 0; q < CH_ITEMS / 4; ++q) {
+            const i4a_scan t = *reinterpret_cast<const i4a_scan*>(in + base + 4 * q);
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < CH_ITEMS; ++i) v[i] = (base + i < n) ? in[base + i] : 0;
+    }
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < CH_ITEMS; ++i) s += v[i];
+    int total;
+    int run = block_exclusive_scan(s, &total, smem);
+    if (threadIdx.x < WAVE) {
+        if (threadIdx.x == 0) chain_publish(state, k, total);
+        const int p = chain_lookback(state, k, total);
+        if (threadIdx.x == 0) s_pref = p;
+    }
+    __syncthreads();
+    run += s_pref;
+    if (quad) {
+#pragma unroll
+        for (int q = 0; q < CH_ITEMS / 4; ++q) {
+            i4a_scan t;
+            t.x = run; run += v[4 * q]; t.y = run; run += v[4 * q + 1]; t.z = run; run += v[4 * q + 2]; t.w = run; run += v[4 * q + 3];
+            *reinterpret_cast<i4a_scan*>(out + base + 4 * q) = t;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < CH_ITEMS; ++i) {
+            if (base + i < n) out[base + i] = run;
+            run += v[i];
+        }
+    }
+    if (threadIdx.x == 0 && (int64_t)(k + 1) * CH_CHUNK >= n) out[n] = s_pref + total;
+}
+
+// out[0..n] = exclusive scan of in[0..n) in ONE launch; `state`: 8 * (ceil(n / 4096) + 1) bytes, ZERO on entry
+int exclusive_scan_chained(const int* in, int64_t n, int* out, unsigned long long* state, hipStream_t st) {
+    if (n <= 0) { LS_HIP(hipMemsetAsync(out, 0, sizeof(int), st)); return LS_OK; }
+    hipLaunchKernelGGL(k_scan_chained, dim3((unsigned)div_up(n, CH_CHUNK)), dim3(BLOCK), 0, st, in, n, out, state);
+    LS_HIP(hipGetLastError());
+    return LS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // 1. count half-edges per row, validate indices, and give every face corner its place inside its vertex' row.
-//    Round 5: one global atomic per DISTINCT vertex of a workgroup's 1024 faces instead of one per corner. The corners are first ranked
-//    per vertex in an LDS hash table (ds_cmpst / ds_add: open addressing, 4096 entries for at most 3072 distinct vertices), then every
-//    occupied entry reserves its vertex' slots with ONE returning atomic on the row counter, and a corner's offset = that base + 2 x its
+//    Round 5: one global atomic per DISTINCT vertex pair of a workgroup's faces instead of one per corner. The corners are first ranked
+//    per vertex in an LDS hash table (ds_cmpst / ds_add: open addressing; a corner that finds no entry within CNT_PROBES steps -- a
+//    soup whose faces share no vertices -- reserves with its own atomic, the round-4 way), then every occupied entry reserves its vertex' slots with ONE returning atomic on the row counter, and a corner's offset = that base + 2 x its
 //    rank goes to corner_off. The scatter needs no atomics at all. (Round 1-4: 6 M atomics in k_count + 6 M returning ones in k_scatter,
 //    76 + 189 us of a 0.5 ms assembly at 1M vertices; meshes are stored coherently enough that a vertex' faces meet in few workgroups.)
 //    Which slots a corner gets depends on the order of the atomics; the final matrix does not (k_row_merge sorts every row).
 // ------------------------------------------------------------------------------------------------
-constexpr int CNT_FPT = 4;                       // faces per thread
-constexpr int CNT_HT = 4096;                     // hash table entries (power of two, > 3 * CNT_FPT * BLOCK)
+// Workgroup size of the ranking, measured at 1M vertices (profiles/r05_assembler_count_variants.txt): the kernel's phases (face stream,
+// LDS hashing, returning atomics) only overlap ACROSS workgroups, so many small ones win -- 1024 faces and a 4096-entry table (3 per
+// CU, all 2048 resident at once and in step) 64 us, 512 faces / 2048 entries 59, 512 / 512 35, 256 faces / 512 entries 31.
+constexpr int CNT_FPT = 1;                       // faces per thread
+constexpr int CNT_HT = 512;                      // hash table entries (power of two); sized for meshes, see CNT_PROBES
+constexpr int CNT_PROBES = 8;                    // entries a corner tries before it reserves directly
+static_assert((CNT_HT & (CNT_HT - 1)) == 0 && CNT_HT <= 4096 && CNT_HT >= 64, "hash table of k_count");
 template <typename IdxT>
 __global__ __launch_bounds__(BLOCK) void k_count(const IdxT* __restrict__ faces, int64_t F, int64_t V,
                                                  int* __restrict__ cnt, int* __restrict__ corner_off, int* __restrict__ flags) {
@@ -170,13 +295,23 @@ __global__ __launch_bounds__(BLOCK) void k_count(const IdxT* __restrict__ faces,
             if (v[e] >= 0) {
                 const int key = (int)(v[e] >> 1);
                 h = (int)(((unsigned)key * 2654435761u) >> 20) & (CNT_HT - 1);
-                for (;;) {
+                bool found = false;
+#pragma unroll 1
+                for (int probe = 0; probe < CNT_PROBES; ++probe) {
                     const int old = atomicCAS(&h_key[h], -1, key);
-                    if (old == -1 || old == key) break;
+                    if (old == -1 || old == key) { found = true; break; }
                     h = (h + 1) & (CNT_HT - 1);
                 }
-                h = 2 * h + (int)(v[e] & 1);
-                r = atomicAdd(&h_cnt[h], 1);
+                if (found) {
+                    h = 2 * h + (int)(v[e] & 1);
+                    r = atomicAdd(&h_cnt[h], 1);
+                } else {
+                    // the table is sized for meshes (a workgroup's faces share most of their vertices), not for the worst case: a corner
+                    // that finds no entry reserves its two slots directly
+                    const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(cnt) + key, (v[e] & 1) ? (2ull << 32) : 2ull);
+                    h = -2;
+                    r = (int)(unsigned)((v[e] & 1) ? (old >> 32) : old);
+                }
             }
             slot[3 * j + e] = h; rank[3 * j + e] = r;
         }
@@ -186,7 +321,7 @@ __global__ __launch_bounds__(BLOCK) void k_count(const IdxT* __restrict__ faces,
         const int key = h_key[t];
         if (key >= 0) {                                                    // each corner puts two half-edges into its vertex' row
             const unsigned long long add = (unsigned long long)(unsigned)(2 * h_cnt[2 * t]) | ((unsigned long long)(unsigned)(2 * h_cnt[2 * t + 1]) << 32);
-            const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(cnt) + key, add);    // (cnt is 256-byte aligned, V + 1 entries)
+            const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(cnt) + key, add);    // (cnt is 256-byte aligned, V + 2 entries)
             h_cnt[2 * t] = (int)(unsigned)old; h_cnt[2 * t + 1] = (int)(unsigned)(old >> 32);
         }
     }
@@ -196,7 +331,10 @@ __global__ __launch_bounds__(BLOCK) void k_count(const IdxT* __restrict__ faces,
         const int64_t f = f0 + (int64_t)j * BLOCK + threadIdx.x;
         if (f < F) {
 #pragma unroll
-            for (int e = 0; e < 3; ++e) corner_off[3 * f + e] = slot[3 * j + e] >= 0 ? h_cnt[slot[3 * j + e]] + 2 * rank[3 * j + e] : -1;
+            for (int e = 0; e < 3; ++e) {
+                const int sl = slot[3 * j + e];
+                corner_off[3 * f + e] = sl >= 0 ? h_cnt[sl] + 2 * rank[3 * j + e] : (sl == -2 ? rank[3 * j + e] : -1);
+            }
         }
     }
 }
@@ -250,7 +388,7 @@ __global__ __launch_bounds__(BLOCK) void k_scatter(const IdxT* __restrict__ face
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
             *reinterpret_cast<int2*>(slot_col + slot[e]) = make_int2(c0[e], c1[e]);
-            *reinterpret_cast<float2*>(slot_val + slot[e]) = make_float2(w0[e], w1[e]);
+            if (COT) *reinterpret_cast<float2*>(slot_val + slot[e]) = make_float2(w0[e], w1[e]);     // (the uniform Laplacian carries no weights)
         }
     }
 }
@@ -271,11 +409,11 @@ __device__ __forceinline__ int merge_row(int* c, float* w, int n, int i, float a
     // summation order, hence the fp32 result, does not depend on the atomics' arrival order
     for (int k = 1; k < n; ++k) {
         const int ck = c[k];
-        const float wk = w[k];
+        const float wk = COT ? w[k] : 0.0f;        // uniform: the value slots are not even written (k_scatter)
         int j = k - 1;
-        while (j >= 0 && (c[j] > ck || (c[j] == ck && w[j] > wk))) { c[j + 1] = c[j]; w[j + 1] = w[j]; --j; }
+        while (j >= 0 && (c[j] > ck || (COT && c[j] == ck && w[j] > wk))) { c[j + 1] = c[j]; if (COT) w[j + 1] = w[j]; --j; }
         c[j + 1] = ck;
-        w[j + 1] = wk;
+        if (COT) w[j + 1] = wk;
     }
     int nu = 0;          // distinct off-diagonal columns written so far
     int ndistinct = 0;   // distinct columns including a self loop (uniform degree bookkeeping)
@@ -478,7 +616,7 @@ __global__ __launch_bounds__(BLOCK) void k_emit(int64_t V, const int* __restrict
     __syncthreads();
     for (int t = threadIdx.x; t < total; t += BLOCK) {
         const int2 e = comp[cbase + t];
-        col[base + t] = e.x;
+        col[base + t] = e.x;                      // (non-temporal stores measured: 55 against 48 us)
         val[base + t] = __int_as_float(e.y);
         if (coo_row) {
             int lo = 0, hi = rows;                // largest r with s_ro[r] <= t
@@ -546,17 +684,17 @@ extern "C" int ls_assemble_pattern(const void* faces, int idx_bytes, int64_t F, 
     int* slot_ptr = (int*)(ws + L.slot_ptr);
     int* corner_off = (int*)(ws + L.corner_off);
     int* row_off = (int*)(ws + L.row_off);
+    unsigned long long* chain_rows = (unsigned long long*)(ws + L.chain_rows);
     int* tile_cnt = (int*)(ws + L.tile_cnt);
     int* tile_off = (int*)(ws + L.tile_off);
     int2* comp = (int2*)(ws + L.comp);
     float* diag = (float*)(ws + L.diag);
     int* flags = (int*)(ws + L.flags);
-    int* bsum = (int*)(ws + L.bsum);
     int* slot_col = (int*)(ws + L.slot_col);
     float* slot_val = (float*)(ws + L.slot_val);
 
-    // cnt, slot_ptr, row_off, diag, flags are contiguous: one memset
-    LS_HIP(hipMemsetAsync(ws, 0, L.bsum, st));
+    // flags, the scan's chain and cnt are contiguous: one memset
+    LS_HIP(hipMemsetAsync(ws, 0, L.slot_ptr, st));
     if (V == 0) { LS_HIP(hipMemsetAsync(rowptr, 0, 4, st)); *h_nnz = 0; LS_HIP(hipStreamSynchronize(st)); return LS_OK; }
     const int fgrid = F ? (int)std::min<int64_t>(div_up(F, BLOCK), 8192) : 1;
     if (F) {
@@ -564,7 +702,7 @@ extern "C" int ls_assemble_pattern(const void* faces, int idx_bytes, int64_t F, 
         if (idx_bytes == 4) hipLaunchKernelGGL(k_count<int32_t>, dim3(cgrid), dim3(BLOCK), 0, st, (const int32_t*)faces, F, V, cnt, corner_off, flags);
         else hipLaunchKernelGGL(k_count<int64_t>, dim3(cgrid), dim3(BLOCK), 0, st, (const int64_t*)faces, F, V, cnt, corner_off, flags);
     }
-    int rc = exclusive_scan(cnt, V, slot_ptr, bsum, st);
+    int rc = exclusive_scan_chained(cnt, V, slot_ptr, chain_rows, st);
     if (rc) return rc;
     if (F) {
         const bool cot = kind == LS_LAPLACIAN_COT;
