@@ -916,6 +916,32 @@ def test_adam_uniform(golden, dev):
     assert set(opt.state[p].keys()) == {"step", "g1", "g2"}
 
 
+@pytest.mark.parametrize("n", [1, 3, 4, 1023, 30002, 3 * 70001])
+@pytest.mark.parametrize("capturable", [False, True])
+def test_adam_uniform_16_byte_path_equals_the_4_byte_path(dev, n, capturable):
+    """The step streams 16 bytes per lane when parameter, gradient and moments are 16-byte aligned (csrc/adam.hip) and falls back to
+    4-byte accesses otherwise (a view that starts one float into its storage): same bits after three steps, tails included."""
+    from largesteps.optimize import AdamUniform
+    g = torch.Generator(device="cpu").manual_seed(n)
+    p0 = torch.randn(n, generator=g)
+    grads = [torch.randn(n, generator=g) for _ in range(3)]
+    out = []
+    for shift in (0, 1):
+        store = torch.zeros(n + shift, device=dev)
+        p = torch.nn.Parameter(store[shift:])
+        assert p.data_ptr() % 16 == (4 * shift) % 16
+        with torch.no_grad():
+            p.copy_(p0.to(dev))
+        opt = AdamUniform([p], lr=0.05, betas=(0.9, 0.999), capturable=capturable)
+        for gr in grads:
+            gs = torch.zeros(n + shift, device=dev)
+            gs[shift:] = gr.to(dev)
+            p.grad = gs[shift:]
+            opt.step()
+        out.append(p.detach().cpu().numpy().copy())
+    np.testing.assert_array_equal(out[0], out[1])
+
+
 def test_adam_uniform_capturable_matches_the_fixture(golden, dev):
     """capturable=True keeps the step count on the device (ls_adam_uniform_step_device): same trajectory as the reference's."""
     from largesteps.optimize import AdamUniform
