@@ -161,7 +161,7 @@ __global__ __launch_bounds__(G * G) void k_spd_inverse_reg(const InvDesc* __rest
     const InvDesc d = descs[blockIdx.x];
     const int n = d.n;
     if (n <= 0) return;
-    __shared__ double rowb[2][NB], colb[2][NB];
+    __shared__ double rowb[2][NB], colb[2][NB], ipb[2];
     const int bx = threadIdx.x % G, by = threadIdx.x / G;
     double a[RB][RB];
 #pragma unroll
@@ -180,17 +180,22 @@ __global__ __launch_bounds__(G * G) void k_spd_inverse_reg(const InvDesc* __rest
 #pragma unroll
         for (int r = 0; r < RB; ++r) colb[0][by * RB + r] = a[r][0];
     }
-    __syncthreads();
     bool bad = false;
+    // 1 / pivot is formed ONCE, by the thread that owns the pivot, and published with the row and the column (round 5: as every
+    // thread's own fp64 division -- ~35 instructions at a quarter of the fp32 rate, four waves per SIMD -- it was half of a step)
+    if (bx == 0 && by == 0) {
+        double p = a[0][0];
+        if (!(p > 0.0)) { bad = true; p = 1.0; }
+        ipb[0] = 1.0 / p;
+    }
+    __syncthreads();
     for (int kb = 0; kb * RB < n; ++kb) {
 #pragma unroll
         for (int kk = 0; kk < RB; ++kk) {
             const int k = kb * RB + kk;
             if (k < n) {                                      // uniform over the workgroup
                 const int cur = kk & 1, nxt = cur ^ 1;        // RB is even: the parity of k is the parity of kk
-                double p = colb[cur][k];
-                if (!(p > 0.0)) { bad = true; p = 1.0; }
-                const double ip = 1.0 / p;
+                const double ip = ipb[cur];
                 double rr[RB], ck[RB];
 #pragma unroll
                 for (int c = 0; c < RB; ++c) rr[c] = rowb[cur][bx * RB + c] * ip;
@@ -220,6 +225,11 @@ __global__ __launch_bounds__(G * G) void k_spd_inverse_reg(const InvDesc* __rest
                 if (bx == ob) {
 #pragma unroll
                     for (int r = 0; r < RB; ++r) colb[nxt][by * RB + r] = a[r][kn];
+                    if (by == ob && k + 1 < n) {               // the next pivot and its reciprocal
+                        double p = a[kn][kn];
+                        if (!(p > 0.0)) { bad = true; p = 1.0; }
+                        ipb[nxt] = 1.0 / p;
+                    }
                 }
                 __syncthreads();
             }
@@ -233,7 +243,7 @@ __global__ __launch_bounds__(G * G) void k_spd_inverse_reg(const InvDesc* __rest
             if (i < n && j < n) d.X[(size_t)i * d.ldx + j] = a[r][c];
         }
     }
-    if (threadIdx.x == 0 && bad) atomicExch(flag, 1);
+    if (bad) atomicExch(flag, 1);
 }
 
 // ---- assembly -------------------------------------------------------------------------------------------------------------------
