@@ -542,6 +542,85 @@ __global__ __launch_bounds__(BLOCK) void k_pair_bwd_verts(const float* __restric
     }
 }
 
+// ---- the pair, vertex-major (round 5) ----------------------------------------------------------------------------------------
+// The face-major passes above move one 3-vector per CORNER through memory (72 MB written + 72 MB read per direction at 2M faces) to
+// sum it per vertex without atomics. The forward sums can be formed where they are needed: a thread per VERTEX walks its corners in
+// rank order (order[] = the inverse of cpos: rank -> corner id 3 f + i), loads that face's three vertices (its neighbours: L2 hits)
+// and recomputes the face's contribution -- three times the face arithmetic, no corner buffer, one launch instead of two. The
+// statements per corner are those of k_vertex_normals_scatter_geo and the sum runs in the same rank order: the same bits.
+// 1M vertices: 32-33 us against 31.9 + 14.4 (profiles/r05_normals_vertex_major.txt). Bound by its occupancy (four dependent round
+// trips per thread, 96 VGPRs): 12-byte loads and 3 / 4 / 8 corners in flight change nothing. The BACKWARD built the same way (the
+// whole face gradient recomputed per corner, 120 VGPRs) takes 58 us against 35.5 + 14.4 and was not kept.
+
+// a 3-vector at a 4-byte aligned address as ONE 12-byte access (global_load_dwordx3): 24 gather instructions per thread instead of 72
+typedef float f3_nrm __attribute__((ext_vector_type(3), aligned(4)));
+typedef int i3_nrm __attribute__((ext_vector_type(3), aligned(4)));
+__device__ __forceinline__ void ld3(const float* __restrict__ base, size_t row, float (&v)[3]) {
+    const f3_nrm t = *reinterpret_cast<const f3_nrm*>(base + row * 3);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z;
+}
+__device__ __forceinline__ void ld_ids(const int32_t* __restrict__ faces, int64_t f, int (&id)[3]) {
+    const i3_nrm t = *reinterpret_cast<const i3_nrm*>(faces + f * 3);
+    id[0] = t.x; id[1] = t.y; id[2] = t.z;
+}
+__device__ __forceinline__ void ld_ids(const int64_t* __restrict__ faces, int64_t f, int (&id)[3]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) id[c] = (int)faces[f * 3 + c];
+}
+
+__device__ __forceinline__ float sel3(int i, float a, float b, float c) { return i == 0 ? a : (i == 1 ? b : c); }
+
+// theta of corner i (known at run time only) of a face: corner_of's arithmetic on operands picked by selects (no indexed registers)
+__device__ __forceinline__ float corner_theta_rt(const float (&p)[3][3], int i, const InvNorms& nr) {
+    const float ina = sel3(i, nr.inv[0], nr.inv[2], nr.inv[1]), inb = sel3(i, nr.inv[1], nr.inv[0], nr.inv[2]);   // corner_of: na, nb
+    const float iab = ina * inb;
+    float d = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const float pa = sel3(i, p[0][q], p[1][q], p[2][q]), pb = sel3(i, p[1][q], p[2][q], p[0][q]), pc = sel3(i, p[2][q], p[0][q], p[1][q]);
+        const float ea = pb - pa, eb = pc - pa;
+        d += ea * eb;
+    }
+    const float sdot = d * iab;
+    return acosf(fminf(fmaxf(sdot, -1.0f), 1.0f));
+}
+
+template <typename IDX, int VG>
+__global__ __launch_bounds__(BLOCK) void k_vertex_normals_gather_geo(const float* __restrict__ verts, const IDX* __restrict__ faces, int64_t V,
+                                                                     const float* __restrict__ norms, const int* __restrict__ vptr,
+                                                                     const int* __restrict__ order, float* __restrict__ raw,
+                                                                     float* __restrict__ out) {
+    const InvNorms nr = inv_norms(norms);
+    const int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (v >= V) return;
+    const int e0 = vptr[v], e1 = vptr[v + 1];
+    float x = 0.0f, y = 0.0f, z = 0.0f;
+    for (int eb = e0; eb < e1; eb += VG) {
+        int cid[VG], id[VG][3];
+        float p[VG][3][3];
+#pragma unroll
+        for (int t = 0; t < VG; ++t) cid[t] = order[min(eb + t, e1 - 1)];
+#pragma unroll
+        for (int t = 0; t < VG; ++t) ld_ids(faces, (int64_t)(cid[t] / 3), id[t]);
+#pragma unroll
+        for (int t = 0; t < VG; ++t) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) ld3(verts, (size_t)id[t][c], p[t][c]);
+        }
+#pragma unroll
+        for (int t = 0; t < VG; ++t) {
+            if (eb + t < e1) {
+                const FaceGeo g = face_geo(p[t]);
+                const float th = corner_theta_rt(p[t], cid[t] - 3 * (cid[t] / 3), nr);
+                x += g.n[0] * th; y += g.n[1] * th; z += g.n[2] * th;
+            }
+        }
+    }
+    raw[v * 3] = x; raw[v * 3 + 1] = y; raw[v * 3 + 2] = z;
+    const float len = sqrtf(x * x + y * y + z * z);
+    out[v * 3] = x / len; out[v * 3 + 1] = y / len; out[v * 3 + 2] = z / len;
+}
+
 static int reduce_grid(int64_t F) { return (int)std::min<int64_t>(NRM_MAXG, std::max<int64_t>(1, div_up(F, BLOCK))); }
 // slots per row of the partial-sum array: the looping reductions use NRM_MAXG, the per-block ones one per block of faces
 static int64_t part_slots(int64_t F) { return std::max<int64_t>(NRM_MAXG, div_up(std::max<int64_t>(F, 1), BLOCK)); }
@@ -760,6 +839,21 @@ extern "C" int ls_normals_pair_backward_verts(const float* verts, const void* fa
                                              g_raw, gN, g_fn, cpos, w.corner));
     hipLaunchKernelGGL(k_gather_corners, dim3(div_up(V, BLOCK)), dim3(BLOCK), 0, st, vptr, (const float*)w.corner, V, grad_verts,
                        (float*)nullptr);
+    LS_HIP(hipGetLastError());
+    return LS_OK;
+}
+
+// ---- the pair's forward, vertex-major: no corner buffer, no workspace (order = the inverse permutation of cpos) ---------------------
+extern "C" int ls_vertex_normals_gathered(const float* verts, const void* faces, int idx_bytes, int64_t F, int64_t V, const int32_t* vptr,
+                                          const int32_t* order, const float* norms, float* out, float* raw, int device, void* stream) {
+    int rc = check_mesh_args(verts, faces, idx_bytes, F, V, "ls_vertex_normals_gathered");
+    if (rc) return rc;
+    LS_REQUIRE(out && raw && norms && vptr && (order || F == 0), LS_E_INVALID, "ls_vertex_normals_gathered: null argument");
+    DeviceGuard g(device);
+    LS_HIP(g.err);
+    hipStream_t st = (hipStream_t)stream;
+    LS_IDX(idx_bytes, hipLaunchKernelGGL((k_vertex_normals_gather_geo<IDX, 6>), dim3(div_up(V, BLOCK)), dim3(BLOCK), 0, st, verts, (const IDX*)faces, V,
+                                         norms, vptr, order, raw, out));
     LS_HIP(hipGetLastError());
     return LS_OK;
 }

@@ -81,6 +81,7 @@ _SIGNATURES = {
                                                c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "ls_normals_pair_backward_verts": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "ls_vertex_normals_gathered": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ls_shard_plan_create": (c_int, [c_i64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
     "ls_shard_plan_destroy": (c_int, [c_void_p]),
     "ls_shard_plan_info": (c_int, [c_void_p] + [ctypes.POINTER(c_i64)] * 5 + [ctypes.POINTER(c_int)] * 2 + [ctypes.POINTER(c_i64)]),

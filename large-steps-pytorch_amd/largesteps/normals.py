@@ -52,7 +52,10 @@ def _plan(f, V):
         _plans.clear()
     # the kernels read the connectivity six times per step: 4-byte indices (validated above) halve that traffic
     narrow = f.to(torch.int32) if (f.dtype == torch.int64 and V < 2 ** 31) else f
-    plan = (vptr, vcorner, narrow)
+    # rank -> corner, the inverse of vcorner: what the vertex-major passes of the pair walk (one-off integer plumbing, like `narrow`)
+    order = torch.empty_like(vcorner)
+    order[vcorner.long()] = torch.arange(3 * F, dtype=torch.int32, device=f.device)
+    plan = (vptr, vcorner, narrow, order)
     try:
         _plans[key] = (weakref.ref(f), f._version, tuple(f.shape), f.dtype, f.data_ptr(), V, plan)
     except TypeError:           # an object that cannot be weakly referenced: do not cache
@@ -73,8 +76,8 @@ def _prep(verts, faces):
     if v.dtype != torch.float32 or not v.is_contiguous():
         v = v.to(torch.float32).contiguous()
     f = faces if faces.is_contiguous() else faces.contiguous()
-    vptr, vcorner, narrow = _plan(f, v.shape[0])
-    return v, narrow, vptr, vcorner
+    vptr, vcorner, narrow, order = _plan(f, v.shape[0])
+    return v, narrow, vptr, vcorner, order
 
 
 _ws_bytes = {}
@@ -152,7 +155,7 @@ _handoff = threading.local()   # .tag: the tag of the face-normal node this thre
 class _FaceNormals(Function):
     @staticmethod
     def forward(ctx, verts, faces):
-        v, f, vptr, vcorner = _prep(verts, faces)
+        v, f, vptr, vcorner, _ = _prep(verts, faces)
         F, V, dev = f.shape[0], v.shape[0], v.device
         fn = torch.empty((3, F), dtype=torch.float32, device=dev)
         norms = torch.empty(3, dtype=torch.float32, device=dev)
@@ -202,7 +205,7 @@ class _VertexNormals(Function):
     @staticmethod
     def forward(ctx, verts, faces, face_normals, tag, can_defer=False):
         ctx.can_defer = bool(can_defer)
-        v, f, vptr, vcorner = _prep(verts, faces)
+        v, f, vptr, vcorner, order = _prep(verts, faces)
         F, V, dev = f.shape[0], v.shape[0], v.device
         _native.require_device(face_normals, "face_normals")
         if tuple(face_normals.shape) != (3, F):
@@ -214,9 +217,11 @@ class _VertexNormals(Function):
         ctx.tag = tag
         if tag is not None:                                     # the pair: norms are there, n_f is recomputed
             with _on(dev):
-                _native.check(lib.ls_vertex_normals_from_norms(_native.ptr(v), _native.ptr(f), f.element_size(), F, V, _native.ptr(vptr),
-                                                               _native.ptr(vcorner), _native.ptr(tag.norms), _native.ptr(out), _native.ptr(raw),
-                                                               _native.ptr(ws), ws.numel(), dev.index, _native.stream_of(dev)))
+                # vertex-major: each vertex recomputes the contributions of its corners in rank order -- the bits of
+                # ls_vertex_normals_from_norms without its corner buffer (tests/test_gpu_parity.py compares the two)
+                _native.check(lib.ls_vertex_normals_gathered(_native.ptr(v), _native.ptr(f), f.element_size(), F, V, _native.ptr(vptr),
+                                                             _native.ptr(order), _native.ptr(tag.norms), _native.ptr(out), _native.ptr(raw),
+                                                             dev.index, _native.stream_of(dev)))
             ctx.save_for_backward(v, f, raw, vptr, vcorner)
             return out
         fn = face_normals.detach().to(torch.float32).contiguous()

@@ -153,6 +153,48 @@ def test_hip_pair_paths_vs_reference(ref, dev, name, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("idx", [np.int64, np.int32])
+@pytest.mark.parametrize("name", MESHES + ["cfg2_bunny70k", "spike"])
+def test_vertex_major_forward_equals_the_corner_buffer_forward(ref, dev, name, idx):
+    """ls_vertex_normals_gathered (a thread per vertex recomputes the contributions of its corners in rank order; what the pair's forward
+    runs) against ls_vertex_normals_from_norms (corner buffer written per face, summed per vertex), both through the C ABI on the same
+    norms: the same bits in `raw` and `out`, NaN rows of unreferenced vertices included; a vertex of valence 40 walks its corners in
+    several trips."""
+    import ctypes
+    from largesteps import _native, normals, synthetic
+    if name == "spike":                                   # a fan of 40 triangles around vertex 0 + an unreferenced vertex
+        k = 40
+        ang = np.linspace(0, 2 * np.pi, k, endpoint=False)
+        v = np.concatenate([[[0, 0, 0.3]], np.stack([np.cos(ang), np.sin(ang), 0.05 * np.cos(3 * ang)], 1), [[5, 5, 5]]]).astype(np.float32)
+        f = np.stack([np.zeros(k, np.int64), 1 + np.arange(k), 1 + (np.arange(k) + 1) % k], 1)
+    elif name.startswith("cfg"):
+        v, f, _ = synthetic.config_mesh(name)
+    else:
+        v, f = ref[f"{name}/verts"], ref[f"{name}/faces"]
+    tv, tf = _t(v.astype(np.float32), dev), _t(f.astype(idx), dev)
+    vv, ff, vptr, vcorner, order = normals._prep(tv, tf)
+    assert torch.equal(order[vcorner.long()].cpu(), torch.arange(3 * f.shape[0], dtype=torch.int32))
+    F, V = ff.shape[0], vv.shape[0]
+    lib = _native.lib()
+    ws = normals._workspace(F, V, dev)
+    fn = torch.empty((3, F), device=dev)
+    norms = torch.empty(3, device=dev)
+    _native.check(lib.ls_face_normals_with_norms(_native.ptr(vv), _native.ptr(ff), ff.element_size(), F, V, _native.ptr(fn), _native.ptr(norms),
+                                                 _native.ptr(ws), ws.numel(), dev.index, _native.stream_of(dev)))
+    out_a, raw_a, out_b, raw_b = (torch.empty_like(vv) for _ in range(4))
+    _native.check(lib.ls_vertex_normals_from_norms(_native.ptr(vv), _native.ptr(ff), ff.element_size(), F, V, _native.ptr(vptr), _native.ptr(vcorner),
+                                                   _native.ptr(norms), _native.ptr(out_a), _native.ptr(raw_a), _native.ptr(ws), ws.numel(),
+                                                   dev.index, _native.stream_of(dev)))
+    _native.check(lib.ls_vertex_normals_gathered(_native.ptr(vv), _native.ptr(ff), ff.element_size(), F, V, _native.ptr(vptr), _native.ptr(order),
+                                                 _native.ptr(norms), _native.ptr(out_b), _native.ptr(raw_b), dev.index, _native.stream_of(dev)))
+    torch.cuda.synchronize()
+    for a, b in ((raw_a, raw_b), (out_a, out_b)):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    assert lib.ls_vertex_normals_gathered(_native.ptr(vv), _native.ptr(ff), ff.element_size(), F, V, _native.ptr(vptr), None, _native.ptr(norms),
+                                          _native.ptr(out_b), _native.ptr(raw_b), dev.index, _native.stream_of(dev)) == _native.LS_E_INVALID
+
+
+@pytest.mark.gpu
 def test_hip_large_mesh_vs_oracle_and_errors(dev):
     from largesteps import synthetic
     from largesteps.normals import compute_face_normals, compute_vertex_normals
