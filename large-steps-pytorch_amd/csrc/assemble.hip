@@ -2,8 +2,9 @@
 //
 // Replaces largesteps/geometry.py:3-133 of the reference, which builds the same matrix through
 // torch.unique(dim=1) + sparse add + coalesce() (several device-wide radix sorts and host syncs).
-// Here:   count half-edges per vertex (atomics) -> scan -> scatter half-edges into per-row slots
-//         -> per-row sort + merge (rows are ~12 slots long) -> scan -> LDS-staged coalesced emit.
+// Here:   rank the face corners per vertex in LDS and reserve their slots (one returning atomic per vertex pair and workgroup)
+//         -> one-launch scan of the row counters -> atomic-free scatter of the half-edges into per-row slots
+//         -> per-row sort (in registers) + merge -> scan of the tile totals -> LDS-staged coalesced emit.
 // Semantics reproduced exactly:
 //   * uniform: every undirected edge once per direction (dedup), diag = #distinct neighbours,
 //     off-diag = fl(b*(-1)), diag = fl(a + fl(b*deg)); unreferenced vertices keep only the a*I entry.
