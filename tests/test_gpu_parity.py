@@ -140,6 +140,38 @@ def test_assembly_random_soup(dev, seed):
     np.testing.assert_allclose(Mc.values().cpu().numpy(), val, rtol=0, atol=2e-5 * scale)
 
 
+@pytest.mark.parametrize("kind", ["scattered", "one_pair", "shuffled_plane"])
+def test_assembly_when_the_corner_table_overflows(dev, kind):
+    """k_count ranks the corners of a workgroup's 256 faces in a 512-entry LDS table sized for meshes; a corner that finds no entry
+    within 8 probes reserves its slots with its own atomic (csrc/assemble.hip). Faces that share no vertices (768 distinct vertex pairs
+    per workgroup), faces that all meet in ONE vertex pair, and a plane whose faces are shuffled so that no workgroup sees a vertex
+    twice: pattern and uniform values exact, cotangent values within the accumulation-order tolerance."""
+    from largesteps.geometry import compute_matrix
+    rng = np.random.default_rng(7)
+    if kind == "scattered":
+        V, F = 200000, 20000
+        f = rng.permutation(V)[: 3 * F].reshape(F, 3).astype(np.int64)           # every vertex in at most one face
+        v = rng.standard_normal((V, 3)).astype(np.float32)
+    elif kind == "one_pair":
+        V, F = 5000, 3000
+        f = np.stack([np.full(F, 10), np.full(F, 11), 12 + rng.integers(0, V - 12, F)], 1).astype(np.int64)   # valence 3000
+        v = rng.standard_normal((V, 3)).astype(np.float32)
+    else:
+        from largesteps import synthetic
+        v, f = synthetic.plane(150)[:2]
+        f = f[rng.permutation(f.shape[0])].astype(np.int64)
+    for idx in (np.int64, np.int32):
+        M = compute_matrix(_t(v, dev), _t(f.astype(idx), dev), 7.5)
+        r, c, val = ol.compute_matrix(v, f, 7.5)
+        assert np.array_equal(M.indices().cpu().numpy(), np.stack([r, c]))
+        assert np.array_equal(M.values().cpu().numpy(), val)
+    Mc = compute_matrix(_t(v, dev), _t(f, dev), 7.5, alpha=0.6, cotan=True)
+    r, c, val = ol.compute_matrix(v, f, 7.5, alpha=0.6, cotan=True)
+    assert np.array_equal(Mc.indices().cpu().numpy(), np.stack([r, c]))
+    scale = max(np.abs(val).max(), 0.6 * np.abs(ol.face_cotangents(v, f)).max())
+    np.testing.assert_allclose(Mc.values().cpu().numpy(), val, rtol=0, atol=2e-5 * scale)
+
+
 def test_assembly_errors(golden, dev):
     from largesteps.geometry import compute_matrix
     e = golden.errors()
