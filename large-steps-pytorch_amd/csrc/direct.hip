@@ -1118,7 +1118,7 @@ static size_t plan_tier(const std::vector<NodeD>& nd, const std::vector<int64_t>
 
 // Host only, called by ls_direct_factor BEFORE it lays the factor out: would a tier of `tier_levels` levels (sparse or dense leaves)
 // fit the tier kernels' LDS budget on this tree? (s, b, own_start: per node id, 1-based, level-major.)
-bool direct_tier_fits(int levels, int arity, const int* s, const int* b, const int* own_start, int tier_levels, bool sparse_leaves) {
+bool direct_tier_fits(int levels, int arity, const int* s, const int* b, const int* own_start, int tier_levels, bool sparse_leaves, int waves) {
     if (tier_levels <= 0) return true;
     if (tier_levels > levels || tier_levels > TIER_MAX_H) return false;
     std::vector<int64_t> level_off((size_t)levels + 1);
@@ -1138,8 +1138,20 @@ bool direct_tier_fits(int levels, int arity, const int* s, const int* b, const i
     std::vector<TierItem> items;
     std::vector<TierWG> wgs;
     int vec = 0, tri = 0;
-    const size_t region = plan_tier(nd, level_off, levels, arity, root, 0, level_off[root + 1] - level_off[root], items, wgs, vec, tri);
-    return region && region * sizeof(float) * TIER_WAVES <= 150 * 1024;
+    const size_t region = plan_tier(nd, level_off, levels, arity, root, 0, level_off[root + 1] - level_off[root], items, wgs, vec, tri, waves);
+    return region && ((region + 3) & ~(size_t)3) * sizeof(float) * waves <= (waves == TIER_WAVES_FULL ? 160 : 150) * 1024;
+}
+
+// One workgroup of SIXTEEN waves per CU walking a subtree one level taller (round 5): at 1M vertices the 256 subtrees below level 4
+// instead of the 1024 below level 5 -- two launches less, the level's nodes cut into parts over the sixteen waves. Measured through
+// the C ABI on planes (profiles/r05_tier16.txt): 1M 201.5 -> 197.2 us, 1.44M 376 -> 359, 2M 428 -> 415, 4M 719-729 -> 714; between
+// 300k and 722k vertices even to worse (722k: 157-162 -> 164), below 300k the arity-8 trees stay ahead. So: arity 4, at least 8 levels,
+// from 900k vertices, one GPU (a rank of a sharded solve keeps its own rule). LS_ND_TIER_WAVES = 4 / 8 / 16 overrides.
+bool direct_tier_full16(int64_t V, int arity, int levels, int tier_levels, int shard_count) {
+    const int env = env_int0("LS_ND_TIER_WAVES", 0);
+    if (env == TIER_WAVES_FULL) return tier_levels >= 2;
+    if (env == TIER_WAVES || env == TIER_WAVES_WIDE) return false;
+    return shard_count <= 1 && arity == 4 && levels >= 8 && V >= 900000 && tier_levels == levels - 4 && tier_levels <= TIER_MAX_H;
 }
 
 
@@ -1295,13 +1307,22 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
             }
             // few subtrees (<= 768 workgroups: three per CU or less): 8 waves per workgroup, two workgroups per CU, if that fits the LDS
             // (a tier of the leaf level alone -- dense leaves of 2-4 row chunks -- does not gain: 40k vertices 44.3 against 42.7 us)
-            if (H >= 2 && (int)wgs.size() <= 768 && env_int0("LS_ND_TIER_WAVES", TIER_WAVES_WIDE) == TIER_WAVES_WIDE) {
+            if (H >= 2 && (int)wgs.size() <= 768 && env_int0("LS_ND_TIER_WAVES", TIER_WAVES_WIDE) == TIER_WAVES_WIDE && !direct_tier_full16(V, arity, levels, H, n_ranks)) {
                 std::vector<TierItem> items8;
                 std::vector<TierWG> wgs8;
                 int vec8 = 0, tri8 = 0;
                 const size_t region8 = plan_tier(nd, level_off, levels, arity, root, sub_lo * span, sub_hi * span, items8, wgs8, vec8, tri8, TIER_WAVES_WIDE);
                 if (region8 && ((region8 + 3) & ~(size_t)3) * sizeof(float) * TIER_WAVES_WIDE <= 80 * 1024) {
                     items.swap(items8); wgs.swap(wgs8); d->tier_vec = vec8; d->tier_tri = tri8; region = region8; d->tier_waves = TIER_WAVES_WIDE;
+                }
+            }
+            if (direct_tier_full16(V, arity, levels, H, n_ranks)) {
+                std::vector<TierItem> items16;
+                std::vector<TierWG> wgs16;
+                int vec16 = 0, tri16 = 0;
+                const size_t region16 = plan_tier(nd, level_off, levels, arity, root, sub_lo * span, sub_hi * span, items16, wgs16, vec16, tri16, TIER_WAVES_FULL);
+                if (region16 && ((region16 + 3) & ~(size_t)3) * sizeof(float) * TIER_WAVES_FULL <= 160 * 1024) {
+                    items.swap(items16); wgs.swap(wgs16); d->tier_vec = vec16; d->tier_tri = tri16; region = region16; d->tier_waves = TIER_WAVES_FULL;
                 }
             }
             d->tier_root = root; d->tier_phases = H; d->tier_wgs = (int)wgs.size(); d->tier_region = (int)((region + 3) & ~(size_t)3);
@@ -1548,7 +1569,11 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
     (void)hipFuncSetAttribute((const void*)k_nd_tier<KK, true, TIER_WAVES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);    \
     (void)hipFuncSetAttribute((const void*)k_nd_tier<KK, false, TIER_WAVES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
     (void)hipFuncSetAttribute((const void*)k_nd_tier<KK, true, TIER_WAVES_WIDE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
-    (void)hipFuncSetAttribute((const void*)k_nd_tier<KK, false, TIER_WAVES_WIDE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_nd_tier<KK, false, TIER_WAVES_WIDE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+    (void)hipFuncSetAttribute((const void*)k_nd_tier<KK, true, TIER_WAVES_FULL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
+    (void)hipFuncSetAttribute((const void*)k_nd_tier<KK, false, TIER_WAVES_FULL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+    (void)hipFuncSetAttribute((const void*)k_nd_tier<KK, true, TIER_WAVES_FULL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);    \
+    (void)hipFuncSetAttribute((const void*)k_nd_tier<KK, false, TIER_WAVES_FULL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     LS_OPTIN(1) LS_OPTIN(2) LS_OPTIN(3) LS_OPTIN(4)
 #undef LS_OPTIN
     lap("kernel attributes set");
@@ -1584,7 +1609,7 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
     ta.upper_lo = d->upper_lo; ta.upper_hi = (int)d->V;
     ta.xcd_order = d->tier_xcd;
     const size_t tier_lds = (size_t)d->tier_region * d->tier_waves * sizeof(float);
-    const bool nt_tier = d->nt_tier && d->tier_waves == TIER_WAVES, nt = d->nt_levels;
+    const bool nt_tier = d->nt_tier && d->tier_waves != TIER_WAVES_WIDE, nt = d->nt_levels;
     int n_mark = 0;
     auto mark = [&](int lo, int hi, int sweep) -> hipError_t {        // "profile" = 3: an event in front of every launch
         if (d->profile != 3) return hipSuccess;
@@ -1608,7 +1633,9 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
     if (part == 0 && exch_n) LS_HIP(hipMemsetAsync(d->slots + exch_off, 0, exch_n * sizeof(float), st));
     if (d->tier_wgs) {
         LS_HIP(mark(d->tier_root, d->levels - 1, 0));
-        if (d->tier_waves == TIER_WAVES_WIDE) hipLaunchKernelGGL((k_nd_tier<K, true, TIER_WAVES_WIDE, false>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES_WIDE), tier_lds, st, ta, b, x, d->tier_tri);
+        if (d->tier_waves == TIER_WAVES_FULL && nt_tier) hipLaunchKernelGGL((k_nd_tier<K, true, TIER_WAVES_FULL, true>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES_FULL), tier_lds, st, ta, b, x, d->tier_tri);
+        else if (d->tier_waves == TIER_WAVES_FULL) hipLaunchKernelGGL((k_nd_tier<K, true, TIER_WAVES_FULL, false>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES_FULL), tier_lds, st, ta, b, x, d->tier_tri);
+        else if (d->tier_waves == TIER_WAVES_WIDE) hipLaunchKernelGGL((k_nd_tier<K, true, TIER_WAVES_WIDE, false>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES_WIDE), tier_lds, st, ta, b, x, d->tier_tri);
         else if (nt_tier) hipLaunchKernelGGL((k_nd_tier<K, true, TIER_WAVES, true>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
         else hipLaunchKernelGGL((k_nd_tier<K, true, TIER_WAVES, false>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
     }
@@ -1671,7 +1698,9 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
     }
     if (d->tier_wgs) {
         LS_HIP(mark(d->tier_root, d->levels - 1, 1));
-        if (d->tier_waves == TIER_WAVES_WIDE) hipLaunchKernelGGL((k_nd_tier<K, false, TIER_WAVES_WIDE, false>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES_WIDE), tier_lds, st, ta, b, x, d->tier_tri);
+        if (d->tier_waves == TIER_WAVES_FULL && nt_tier) hipLaunchKernelGGL((k_nd_tier<K, false, TIER_WAVES_FULL, true>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES_FULL), tier_lds, st, ta, b, x, d->tier_tri);
+        else if (d->tier_waves == TIER_WAVES_FULL) hipLaunchKernelGGL((k_nd_tier<K, false, TIER_WAVES_FULL, false>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES_FULL), tier_lds, st, ta, b, x, d->tier_tri);
+        else if (d->tier_waves == TIER_WAVES_WIDE) hipLaunchKernelGGL((k_nd_tier<K, false, TIER_WAVES_WIDE, false>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES_WIDE), tier_lds, st, ta, b, x, d->tier_tri);
         else if (nt_tier) hipLaunchKernelGGL((k_nd_tier<K, false, TIER_WAVES, true>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
         else hipLaunchKernelGGL((k_nd_tier<K, false, TIER_WAVES, false>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES), tier_lds, st, ta, b, x, d->tier_tri);
     }

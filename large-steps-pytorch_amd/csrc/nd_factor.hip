@@ -491,7 +491,8 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* stream, ls_direct** out);
 int ls_direct_adopt(ls_direct* d, void* const* owned, const size_t* owned_bytes, int n_owned, const double* seconds3, const double* quality4);
 namespace ls { hipStream_t side_stream(int device, int which); }
-bool direct_tier_fits(int levels, int arity, const int* s, const int* b, const int* own_start, int tier_levels, bool sparse_leaves);
+bool direct_tier_fits(int levels, int arity, const int* s, const int* b, const int* own_start, int tier_levels, bool sparse_leaves, int waves);
+bool direct_tier_full16(int64_t V, int arity, int levels, int tier_levels, int shard_count);
 
 // ---- the tree the library picks for a system of V unknowns (leaf_size <= 0 / arity <= 0 on entry = "pick"; explicit values stay) ----------
 extern "C" int ls_direct_pick_tree(int64_t V, int* leaf_size_io, int* arity_io) {
@@ -598,8 +599,14 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     for (int64_t i = P.level_off[levels - 1]; i < P.level_off[levels] && leaves_ok; ++i) leaves_ok = P.s[i] <= 64;
     // a tier the library picked itself never fails for lack of LDS: one level less until its subtrees fit a workgroup
     // (an explicit tier_levels that does not fit is reported by ls_direct_create: LS_E_WORKSPACE)
-    if (tier_auto)
-        while (tier_levels > 0 && !direct_tier_fits(levels, arity, P.s.data(), P.b.data(), P.own_start.data(), tier_levels, leaves_ok)) --tier_levels;
+    if (tier_auto) {
+        // large systems: a subtree one level taller per workgroup of sixteen waves, if its leaves and vectors fit the 160 KB of LDS
+        const int taller = levels - 4;
+        if (direct_tier_full16(V, arity, levels, taller, shard_count) && direct_tier_fits(levels, arity, P.s.data(), P.b.data(), P.own_start.data(), taller, leaves_ok, 16))
+            tier_levels = taller;
+        else
+            while (tier_levels > 0 && !direct_tier_fits(levels, arity, P.s.data(), P.b.data(), P.own_start.data(), tier_levels, leaves_ok, 4)) --tier_levels;
+    }
     if (tier_levels == 0) leaves_ok = false;
     const int tier_root = levels - tier_levels;
     std::vector<FactorNode> fn((size_t)n_nodes + 1);

@@ -58,11 +58,13 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(d_b, b.data(), V * k * 4, hipMemcpyHostToDevice));
     hipStream_t st; CK(hipStreamCreate(&st));
     ls_direct* h = nullptr;
-    LS(ls_direct_factor(d_rowptr, d_col, d_val, V, nnz, d_pos, 64, 4, tier, 1, 0, 1, 0, st, &h));
+    int leaf = getenv("ND_DRIVE_LEAF") ? atoi(getenv("ND_DRIVE_LEAF")) : 64, ar = getenv("ND_DRIVE_ARITY") ? atoi(getenv("ND_DRIVE_ARITY")) : 4;
+    if (getenv("ND_DRIVE_PICK")) { leaf = ar = 0; LS(ls_direct_pick_tree(V, &leaf, &ar)); }       // the tree the library picks for this size
+    LS(ls_direct_factor(d_rowptr, d_col, d_val, V, nnz, d_pos, leaf, ar, tier, 1, 0, 1, 0, st, &h));
     int levels, arity, tl, tw, launches; int64_t wu, wd, nb;
     LS(ls_direct_shape(h, &levels, &arity, &tl, &tw, &wu, &wd, &nb));
-    printf("plane %d x %d: V %lld nnz %lld, %d levels, tier of %d (%d workgroups), factor %.1f MB up + %.1f MB down\n", n, n, (long long)V, (long long)nnz,
-           levels, tl, tw, wu * 4e-6, wd * 4e-6);
+    printf("plane %d x %d: V %lld nnz %lld, arity %d, %d levels, tier of %d (%d workgroups), factor %.1f MB up + %.1f MB down\n", n, n, (long long)V, (long long)nnz,
+           arity, levels, tl, tw, wu * 4e-6, wd * 4e-6);
     std::vector<float> x0((size_t)V * k), x1((size_t)V * k);
     double span_us = 0;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
