@@ -271,7 +271,7 @@ def test_bench_line_of_a_multi_process_run(world, launch, workload):
         assert p["part0_us"] > 0 and p["part1_us"] > 0 and p["collective_us"] > 0 and abs(p["kernel_us"] - p["part0_us"] - p["part1_us"]) < 1e-6
     if workload == "cfg4_plane1m":
         m = c["model"]
-        assert m["kernel_us_per_rank"] == 122.6 and m["predicted_ms_per_step"][0] < m["predicted_ms_per_step"][1]
+        assert m["kernel_us_per_rank"] == 122.2 and m["predicted_ms_per_step"][0] < m["predicted_ms_per_step"][1]
     else:
         assert c["model"] is None
     rf = d["roofline"]
