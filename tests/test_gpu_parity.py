@@ -812,6 +812,40 @@ def test_cfg5_four_million_vs_oracle(dev):
     assert np.abs(xp - x64).max() <= 1e-4 * np.abs(x64).max()
 
 
+def test_sixteen_wave_tier_for_every_number_of_columns(dev, monkeypatch):
+    """From 900k vertices the tier kernel walks a subtree one level taller on one 16-wave workgroup per CU (direct.hip:
+    direct_tier_full16; 9 launches instead of 11). A 950 x 950 plane (902 500 vertices) through it with k = 1, 2, 3, 4 and 6 columns
+    (the last: two column blocks): the round trip from_differential(to_differential(v)) within the forward tolerance, a column does
+    not depend on its neighbours (the same bits at every k), and the 4-wave tier of rounds 2-4 (LS_ND_TIER_WAVES=4) agrees."""
+    from largesteps.geometry import compute_matrix
+    from largesteps.parameterize import to_differential
+    from largesteps.solvers import NestedDissectionSolver
+    from largesteps import synthetic
+    v, f = synthetic.plane(950)[:2]
+    tv, tf = _t(v, dev), _t(f, dev)
+    M = compute_matrix(tv, tf, 30.0)
+    s16 = NestedDissectionSolver(M)
+    inf = s16.info()
+    assert inf["launches"] == 9 and inf["tier_levels"] == 4, inf
+    g = torch.Generator(device=dev).manual_seed(3)
+    base = torch.cat([tv, torch.rand(v.shape[0], 3, device=dev, generator=g)], 1)          # 6 columns: positions + noise
+    cols = {}
+    for k in (1, 2, 3, 4, 6):
+        x_true = base[:, :k].contiguous()
+        x = s16.solve(to_differential(M, x_true))
+        assert float((x - x_true).abs().max()) <= 1e-4 * float(x_true.abs().max())
+        for c in range(k):
+            if c in cols:
+                assert torch.equal(cols[c], x[:, c]), f"column {c} changed with k = {k}"
+            else:
+                cols[c] = x[:, c].clone()
+    monkeypatch.setenv("LS_ND_TIER_WAVES", "4")
+    s4 = NestedDissectionSolver(M)
+    assert s4.info()["launches"] == 11 and s4.info()["tier_levels"] == 3
+    x4 = s4.solve(to_differential(M, tv))
+    assert float((x4 - torch.stack([cols[0], cols[1], cols[2]], 1)).abs().max()) <= 2e-5
+
+
 def test_one_million_vertices_properties(dev, chol_path):
     """Config 4 at full size (1000 x 1000 plane, lambda = 50): size independent properties only."""
     from largesteps.geometry import compute_matrix
