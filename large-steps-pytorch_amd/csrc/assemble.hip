@@ -178,6 +178,7 @@ __device__ __forceinline__ int chain_lookback(unsigned long long* state, int k, 
             for (int e = 0; e < CH_PER; ++e) {
                 if ((w[e] >> 62) == 0) { w[e] = chain_load(state + 1 + j0 - e); pending |= (w[e] >> 62) == 0; }
             }
+            if (pending) __builtin_amdgcn_s_sleep(2);               // a predecessor is still summing: do not hammer its status word
         } while (pending);
         int v = 0;
         bool has = false;                                           // this lane holds a chunk that knows its inclusive sum
