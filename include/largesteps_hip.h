@@ -344,7 +344,7 @@ int ls_direct_pick_tree(int64_t V, int* leaf_size, int* arity);
  *   300k (three levels of dense nodes up to 36k, four levels with dense leaves of 70-205 rows up to 105k, five levels with 64-vertex
  *   sparse leaves beyond), arity 4 with 64-vertex sparse leaves -- the large-mesh setting -- above 300k;
  * tier_levels deepest levels go into the tier layouts (-1 = chosen by the library: tree levels - 5, at least 2 and at most 4; from
- *   900k unknowns on an arity-4 tree of at least 8 levels, one GPU: tree levels - 4, walked by one 16-wave workgroup per CU; the leaf
+ *   800k unknowns on an arity-4 tree of at least 8 levels, one GPU: tree levels - 4, walked by one 16-wave workgroup per CU; the leaf
  *   level alone for many dense leaves of 65-224 rows in a tree of at most 4 levels; none for leaves of more than 256 rows or a single
  *   node; 0 = none); sparse_leaves != 0 stores leaves of at most 64 rows as packed triangle + sparse block;
  * shard_rank / shard_count: subtree sharding (0 / 1: none; every rank factorises the whole matrix, the re-solve is sharded, see

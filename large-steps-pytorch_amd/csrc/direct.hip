@@ -1145,13 +1145,14 @@ bool direct_tier_fits(int levels, int arity, const int* s, const int* b, const i
 // One workgroup of SIXTEEN waves per CU walking a subtree one level taller (round 5): at 1M vertices the 256 subtrees below level 4
 // instead of the 1024 below level 5 -- two launches less, the level's nodes cut into parts over the sixteen waves. Measured through
 // the C ABI on planes (profiles/r05_tier16.txt): 1M 201.5 -> 197.2 us, 1.44M 376 -> 359, 2M 428 -> 415, 4M 719-729 -> 714; between
-// 300k and 722k vertices even to worse (722k: 157-162 -> 164), below 300k the arity-8 trees stay ahead. So: arity 4, at least 8 levels,
-// from 900k vertices, one GPU (a rank of a sharded solve keeps its own rule). LS_ND_TIER_WAVES = 4 / 8 / 16 overrides.
+// 300k and 722k vertices even to worse (640k: 150.8 = 150.8; 722k: 157-162 -> 164), 810k 177.4 -> 171.5, below 300k the arity-8 trees stay
+// ahead. So: arity 4, at least 8 levels,
+// from 800k vertices, one GPU (a rank of a sharded solve keeps its own rule). LS_ND_TIER_WAVES = 4 / 8 / 16 overrides.
 bool direct_tier_full16(int64_t V, int arity, int levels, int tier_levels, int shard_count) {
     const int env = env_int0("LS_ND_TIER_WAVES", 0);
     if (env == TIER_WAVES_FULL) return tier_levels >= 2;
     if (env == TIER_WAVES || env == TIER_WAVES_WIDE) return false;
-    return shard_count <= 1 && arity == 4 && levels >= 8 && V >= 900000 && tier_levels == levels - 4 && tier_levels <= TIER_MAX_H;
+    return shard_count <= 1 && arity == 4 && levels >= 8 && V >= 800000 && tier_levels == levels - 4 && tier_levels <= TIER_MAX_H;
 }
 
 

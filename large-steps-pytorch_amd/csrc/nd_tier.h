@@ -32,7 +32,7 @@ constexpr int TIER_MAX_H = 6;            // tree levels one workgroup may walk
 constexpr int TIER_WAVES = 4;            // waves per tier workgroup: 4 (four workgroups per CU), or TIER_WAVES_WIDE for trees with few subtrees
 constexpr int TIER_WAVES_WIDE = 8;       // (<= 768 workgroups -- the arity-8 trees of 105k-300k vertices have 512: with 4 waves each that is half a
                                          //  CU's waves; 8 waves per workgroup, two workgroups per CU: -5 %)
-constexpr int TIER_WAVES_FULL = 16;      // one workgroup per CU on a subtree one level taller (direct_tier_full16, direct.hip: from 900k vertices)
+constexpr int TIER_WAVES_FULL = 16;      // one workgroup per CU on a subtree one level taller (direct_tier_full16, direct.hip: from 800k vertices)
 constexpr int TIER_TRI4 = 9;             // 16-byte loads per lane that hold a leaf triangle (s <= 64: 2080 floats = 520 float4)
 constexpr int TIER_SPE = 4;              // sparse entries per row prefetched to registers (longer rows: loop)
 

@@ -813,7 +813,7 @@ def test_cfg5_four_million_vs_oracle(dev):
 
 
 def test_sixteen_wave_tier_for_every_number_of_columns(dev, monkeypatch):
-    """From 900k vertices the tier kernel walks a subtree one level taller on one 16-wave workgroup per CU (direct.hip:
+    """From 800k vertices the tier kernel walks a subtree one level taller on one 16-wave workgroup per CU (direct.hip:
     direct_tier_full16; 9 launches instead of 11). A 950 x 950 plane (902 500 vertices) through it with k = 1, 2, 3, 4 and 6 columns
     (the last: two column blocks): the round trip from_differential(to_differential(v)) within the forward tolerance, a column does
     not depend on its neighbours (the same bits at every k), and the 4-wave tier of rounds 2-4 (LS_ND_TIER_WAVES=4) agrees."""
