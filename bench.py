@@ -211,7 +211,8 @@ def describe(workload, cfg, V, nnz):
     """one-line description of a synthetic config (largesteps.synthetic.CONFIGS)"""
     mesh = {"cfg4_plane1m": "1000x1000 plane", "cfg5_plane4m": "2000x2000 plane", "scroll250k": "500x500 sheet rolled up 3 turns",
             "scroll10_250k": "500x500 sheet rolled up 10 turns", "folded250k": "500x500 sheet folded once, layers 1e-3 apart",
-            "shells250k": "two concentric geodesic spheres 1e-3 apart"}.get(workload, "noisy geodesic sphere (stand-in mesh)")
+            "shells250k": "two concentric geodesic spheres 1e-3 apart", "scroll1m": "1000x1000 sheet rolled up 3 turns",
+            "folded1m": "1000x1000 sheet folded once, layers 1e-3 apart"}.get(workload, "noisy geodesic sphere (stand-in mesh)")
     if cfg["alpha"] is not None:
         mat = f"M=(1-{cfg['alpha']:g})I+{cfg['alpha']:g}*L_{'cot' if cfg['cotan'] else 'uniform'}"
     else:

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define LS_VERSION 100 /* 0.1.0 */
+#define LS_VERSION 110 /* 0.1.1: ls_direct_factor_ex / ls_direct_options (round 6), ls_direct_arrays.tier_waves */
 
 #define LS_OK 0
 #define LS_E_INVALID (-1)      /* bad argument (null pointer, negative size, unsupported k, ...) */
@@ -326,6 +326,7 @@ typedef struct ls_direct_arrays {
     const void* d_sp_ent;          /* {float value; int32 index} pairs */
     int64_t n_sp_ptr, n_sp_ent;    /* lengths of the two sparse-leaf arrays (accounting only) */
     int32_t shard_rank, shard_count;   /* subtree sharding over `shard_count` processes (0 or 1: none), see ls_direct_solve_part */
+    int32_t tier_waves;                /* waves per tier workgroup: 0 = the library's rule (see ls_direct_options), 4 / 8 / 16 */
 } ls_direct_arrays;
 int ls_direct_create(const ls_direct_arrays* arrays, int device, void* stream, ls_direct** out);
 /* The tree ls_direct_factor picks for a V x V system: on entry *leaf_size / *arity <= 0 mean "pick" (explicit values are kept), on return
@@ -358,6 +359,27 @@ int ls_direct_pick_tree(int64_t V, int* leaf_size, int* arity);
 int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, const float* d_val, int64_t V, int64_t nnz,
                      const float* d_positions, int leaf_size, int arity, int tier_levels, int sparse_leaves, int shard_rank,
                      int shard_count, int device, void* stream, ls_direct** out);
+/* The same constructor with every choice as an argument (round 6; `ordering` used to reach the library through the process
+ * environment only). Fill the struct with ls_direct_options_default, change what you need:
+ *   leaf_size, arity, tier_levels, sparse_leaves, shard_rank, shard_count: as ls_direct_factor's arguments (defaults 0, 0, -1, 1, 0, 1);
+ *   ordering    how the bisection picks its cutting directions: LS_ND_ORDER_AUTO (the library's rule: trial cuts where the separators
+ *               are thicker than a surface's should be), LS_ND_ORDER_LONGEST, LS_ND_ORDER_MINSEP (trial cuts always: 5-10 % fewer factor
+ *               numbers on rough closed scans for 10-25 ms more constructor). An explicit value wins; AUTO lets the environment
+ *               variable LS_ND_ORDER override the rule (A/B runs);
+ *   tier_waves  waves per workgroup of the tier kernels: 0 = the library's rule (16 on one workgroup per CU and a subtree one level
+ *               taller from 800k unknowns, 8 for <= 768 subtrees, 4 otherwise), or 4 / 8 / 16. An explicit value wins; 0 lets
+ *               LS_ND_TIER_WAVES override.
+ * struct_bytes = sizeof(ls_direct_options) of the CALLER's header: fields a newer library knows beyond it take their defaults.
+ * opt == NULL: all defaults (= ls_direct_factor(..., 0, 0, -1, 1, 0, 1, ...)). */
+typedef struct ls_direct_options {
+    int32_t struct_bytes;
+    int32_t leaf_size, arity, tier_levels, sparse_leaves, shard_rank, shard_count;
+    int32_t ordering;
+    int32_t tier_waves;
+} ls_direct_options;
+int ls_direct_options_default(ls_direct_options* opt);
+int ls_direct_factor_ex(const int32_t* d_rowptr, const int32_t* d_col, const float* d_val, int64_t V, int64_t nnz,
+                        const float* d_positions, const ls_direct_options* opt, int device, void* stream, ls_direct** out);
 /* The direct solver keeps its device buffers (>= 256 KB: the constructor's fp64 fronts and work arrays -- 3-4 GB at 1M vertices, 14 GB
  * at 4M --, the analysis' scratch, a destroyed handle's factor arrays, index tables and vectors) in a per-process pool instead of freeing them: a remesh loop
  * (scripts/main.py:137-169) destroys a solver and constructs one of nearly the same size again and again, and the runtime gives freed
@@ -376,6 +398,13 @@ int ls_direct_level_words(const ls_direct* d, int cap, int64_t* h_up, int64_t* h
 /* own rows (vertices) and boundary entries of each tree level (level 0 = root): what the vectors a level's launch moves are made
  * of -- per sweep b / b' / x rows of its vertices and the boundary vectors of its nodes. Host only. */
 int ls_direct_level_rows(const ls_direct* d, int cap, int64_t* h_rows, int64_t* h_bnd);
+/* bytes of STATIC index data each tree level's launch reads per sweep, besides the factor words (ls_direct_level_words) and the vectors
+ * (ls_direct_level_rows): tile / item records, children masks, parent positions, the tier's pull lists (arity indices per front position
+ * of an inner node), push-list pointers and targets. perm (4 bytes per own row and sweep) is counted with the vectors. Host only. */
+int ls_direct_level_index_bytes(const ls_direct* d, int cap, int64_t* h_up, int64_t* h_down);
+/* how evenly the tier's subtrees (one workgroup each) are loaded: h_words4 = {max, mean} factor words of a subtree in the up sweep,
+ * {max, mean} in the down sweep. With one workgroup per CU the heaviest subtree is the launch's time. Zeros without a tier. Host only. */
+int ls_direct_tier_balance(const ls_direct* d, double* h_words4);
 /* After a solve with "profile" = 3 (an event in front of every launch; the solve synchronises): number of launches and, for
  * the first `cap` of them, duration in ms, factor words read, tree levels [lo, hi] covered, sweep (0 up, 1 down, 2 both).
  * Any pointer may be NULL. */
@@ -491,7 +520,10 @@ int ls_vertex_normals_backward(const float* verts, const void* faces, int idx_by
  * two backward calls); workspace as above.
  * ls_vertex_normals_gathered = ls_vertex_normals_from_norms bit for bit, vertex-major: a thread per vertex walks its corners in
  * rank order and recomputes their contributions (no corner buffer, no workspace, one launch instead of two: 32 against 46 us at
- * 1M vertices). order[3 F] is the inverse permutation of cpos (order[cpos[c]] = c: rank -> corner id 3 f + i). */
+ * 1M vertices). order[3 F] is the inverse permutation of cpos (order[cpos[c]] = c: rank -> corner id 3 f + i).
+ * PRECONDITION of ls_vertex_normals_gathered (NOT checked on the device, unlike ls_corner_ranks / ls_assemble_*, which validate and
+ * return LS_E_INDEX): vptr / order must be what ls_corner_ranks returned FOR THESE faces, i.e. every face index lies in [0, V) and
+ * every order entry in [0, 3 F) -- the kernel indexes verts through them without a range check. */
 int ls_face_normals_with_norms(const float* verts, const void* faces, int idx_bytes, int64_t F, int64_t V, float* fn, float* norms,
                                void* workspace, size_t ws_bytes, int device, void* stream);
 int ls_vertex_normals_from_norms(const float* verts, const void* faces, int idx_bytes, int64_t F, int64_t V, const int32_t* vptr,

@@ -894,6 +894,8 @@ struct ls_direct {
     std::vector<double> launch_ms;
     std::vector<int64_t> lvl_up, lvl_down;            // 4-byte words of factor data per tree level and sweep
     std::vector<int64_t> lvl_rows, lvl_bnd;           // own rows / boundary entries per tree level (the vectors' share of a launch's bytes)
+    std::vector<int64_t> lvl_idx_up, lvl_idx_down;    // bytes of STATIC index data a level's launch reads per sweep besides perm: tile / item records, mask, ppos, pull, push lists
+    double tier_balance[4] = {0, 0, 0, 0};            // factor words of the tier's subtrees (one workgroup each): max and mean, up sweep / down sweep
     double prof_ms[3] = {0, 0, 0};     // up sweep, down sweep, 0 (last profiled solve)
 };
 
@@ -1086,7 +1088,7 @@ static size_t plan_tier(const std::vector<NodeD>& nd, const std::vector<int64_t>
                     it.spb_off = n.spb_off; it.sps_off = n.sps_off; it.nparts = 1;
                     if (n.flags & NODE_SPARSE) {
                         items.push_back(it);
-                        leaf_need = std::max(leaf_need, tri_cap + 256 + 4 * n.b);
+                        leaf_need = std::max(leaf_need, std::max(tri_cap, (4 * n.b + 3) & ~3) + 256);     // x_bnd (down) is staged in the triangle area
                         continue;
                     }
                     if (n.s == 0 && n.b == 0) continue;
@@ -1148,8 +1150,8 @@ bool direct_tier_fits(int levels, int arity, const int* s, const int* b, const i
 // 300k and 722k vertices even to worse (640k: 150.8 = 150.8; 722k: 157-162 -> 164), 810k 177.4 -> 171.5, below 300k the arity-8 trees stay
 // ahead. So: arity 4, at least 8 levels,
 // from 800k vertices, one GPU (a rank of a sharded solve keeps its own rule). LS_ND_TIER_WAVES = 4 / 8 / 16 overrides.
-bool direct_tier_full16(int64_t V, int arity, int levels, int tier_levels, int shard_count) {
-    const int env = env_int0("LS_ND_TIER_WAVES", 0);
+bool direct_tier_full16(int64_t V, int arity, int levels, int tier_levels, int shard_count, int tier_waves) {
+    const int env = tier_waves > 0 ? tier_waves : env_int0("LS_ND_TIER_WAVES", 0);       // an explicit argument wins over the environment
     if (env == TIER_WAVES_FULL) return tier_levels >= 2;
     if (env == TIER_WAVES || env == TIER_WAVES_WIDE) return false;
     return shard_count <= 1 && arity == 4 && levels >= 8 && V >= 800000 && tier_levels == levels - 4 && tier_levels <= TIER_MAX_H;
@@ -1300,30 +1302,33 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
             if (cut > root) { delete d; set_error("ls_direct_create: %d ranks need a cut below the tier's root level (tree too small)", n_ranks); return LS_E_INVALID; }
             int64_t span = 1;
             for (int t = cut; t < root; ++t) span *= arity;
-            size_t region = H <= TIER_MAX_H ? plan_tier(nd, level_off, levels, arity, root, sub_lo * span, sub_hi * span, items, wgs, d->tier_vec, d->tier_tri) : 0;
-            if (!region || region * sizeof(float) * TIER_WAVES > 150 * 1024) {
-                delete d;
-                set_error("ls_direct_create: a tier of %d levels does not fit the kernel (LDS per wave: %zu floats)", H, region);
-                return LS_E_WORKSPACE;
-            }
-            // few subtrees (<= 768 workgroups: three per CU or less): 8 waves per workgroup, two workgroups per CU, if that fits the LDS
-            // (a tier of the leaf level alone -- dense leaves of 2-4 row chunks -- does not gain: 40k vertices 44.3 against 42.7 us)
-            if (H >= 2 && (int)wgs.size() <= 768 && env_int0("LS_ND_TIER_WAVES", TIER_WAVES_WIDE) == TIER_WAVES_WIDE && !direct_tier_full16(V, arity, levels, H, n_ranks)) {
-                std::vector<TierItem> items8;
-                std::vector<TierWG> wgs8;
-                int vec8 = 0, tri8 = 0;
-                const size_t region8 = plan_tier(nd, level_off, levels, arity, root, sub_lo * span, sub_hi * span, items8, wgs8, vec8, tri8, TIER_WAVES_WIDE);
-                if (region8 && ((region8 + 3) & ~(size_t)3) * sizeof(float) * TIER_WAVES_WIDE <= 80 * 1024) {
-                    items.swap(items8); wgs.swap(wgs8); d->tier_vec = vec8; d->tier_tri = tri8; region = region8; d->tier_waves = TIER_WAVES_WIDE;
+            // the kernel that will run is the one whose budget is checked: sixteen waves first where the rule asks for them (a subtree one
+            // level taller may fit 160 KB as 16 regions and not 150 KB as 4), the 4- / 8-wave plans otherwise
+            size_t region = 0;
+            if (H <= TIER_MAX_H && direct_tier_full16(V, arity, levels, H, n_ranks, A->tier_waves)) {
+                int vec16 = 0, tri16 = 0;
+                const size_t region16 = plan_tier(nd, level_off, levels, arity, root, sub_lo * span, sub_hi * span, items, wgs, vec16, tri16, TIER_WAVES_FULL);
+                if (region16 && ((region16 + 3) & ~(size_t)3) * sizeof(float) * TIER_WAVES_FULL <= 160 * 1024) {
+                    d->tier_vec = vec16; d->tier_tri = tri16; region = region16; d->tier_waves = TIER_WAVES_FULL;
                 }
             }
-            if (direct_tier_full16(V, arity, levels, H, n_ranks)) {
-                std::vector<TierItem> items16;
-                std::vector<TierWG> wgs16;
-                int vec16 = 0, tri16 = 0;
-                const size_t region16 = plan_tier(nd, level_off, levels, arity, root, sub_lo * span, sub_hi * span, items16, wgs16, vec16, tri16, TIER_WAVES_FULL);
-                if (region16 && ((region16 + 3) & ~(size_t)3) * sizeof(float) * TIER_WAVES_FULL <= 160 * 1024) {
-                    items.swap(items16); wgs.swap(wgs16); d->tier_vec = vec16; d->tier_tri = tri16; region = region16; d->tier_waves = TIER_WAVES_FULL;
+            if (!region) {
+                region = H <= TIER_MAX_H ? plan_tier(nd, level_off, levels, arity, root, sub_lo * span, sub_hi * span, items, wgs, d->tier_vec, d->tier_tri) : 0;
+                if (!region || region * sizeof(float) * TIER_WAVES > 150 * 1024) {
+                    delete d;
+                    set_error("ls_direct_create: a tier of %d levels does not fit the kernel (LDS per wave: %zu floats)", H, region);
+                    return LS_E_WORKSPACE;
+                }
+                // few subtrees (<= 768 workgroups: three per CU or less): 8 waves per workgroup, two workgroups per CU, if that fits the LDS
+                // (a tier of the leaf level alone -- dense leaves of 2-4 row chunks -- does not gain: 40k vertices 44.3 against 42.7 us)
+                if (H >= 2 && (int)wgs.size() <= 768 && (A->tier_waves > 0 ? A->tier_waves : env_int0("LS_ND_TIER_WAVES", TIER_WAVES_WIDE)) == TIER_WAVES_WIDE) {
+                    std::vector<TierItem> items8;
+                    std::vector<TierWG> wgs8;
+                    int vec8 = 0, tri8 = 0;
+                    const size_t region8 = plan_tier(nd, level_off, levels, arity, root, sub_lo * span, sub_hi * span, items8, wgs8, vec8, tri8, TIER_WAVES_WIDE);
+                    if (region8 && ((region8 + 3) & ~(size_t)3) * sizeof(float) * TIER_WAVES_WIDE <= 80 * 1024) {
+                        items.swap(items8); wgs.swap(wgs8); d->tier_vec = vec8; d->tier_tri = tri8; region = region8; d->tier_waves = TIER_WAVES_WIDE;
+                    }
                 }
             }
             d->tier_root = root; d->tier_phases = H; d->tier_wgs = (int)wgs.size(); d->tier_region = (int)((region + 3) & ~(size_t)3);
@@ -1495,6 +1500,63 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
         xcd_order(p.down_first, down_nodes, false);
         p.down_tiles = (int)tiles.size() - p.down_first;
         lds_max = std::max(lds_max, ((size_t)p.s_cap + p.b_cap + 16 * WAVE) * d->kmax * sizeof(float));
+    }
+    // ---- accounting (host only): the static index bytes of every level's launches, and how evenly the tier's subtrees are loaded -------
+    {
+        d->lvl_idx_up.assign((size_t)levels, 0); d->lvl_idx_down.assign((size_t)levels, 0);
+        std::vector<int64_t> fpos((size_t)levels, 0), bsum((size_t)levels + 1, 0);
+        for (int lv = 0; lv < levels; ++lv)
+            for (int64_t i = level_off[lv]; i < level_off[lv + 1]; ++i)
+                if (active(i, lv)) { fpos[(size_t)lv] += nodes[i].s + nodes[i].b; bsum[(size_t)lv] += nodes[i].b; }
+        for (int lv = 0; lv < d->tier_root; ++lv) {
+            const LevelPlan& p = d->plan[lv];
+            // up: tile records, the children mask of every front position, the parent positions of the boundary rows (+ perm when no
+            // tier launch gathered b into the tree's numbering); down: tile records, row pointers of the push lists, the children's targets
+            d->lvl_idx_up[(size_t)lv] = (p.up_p ? (int64_t)p.up_p_tiles * (int64_t)sizeof(PackedTile) : (int64_t)p.up_tiles * (int64_t)sizeof(Tile)) + fpos[(size_t)lv] + 4 * bsum[(size_t)lv];
+            d->lvl_idx_down[(size_t)lv] = (p.down_p ? (int64_t)p.down_p_tiles * (int64_t)sizeof(PackedTile) : (int64_t)p.down_tiles * (int64_t)sizeof(Tile)) + 4 * fpos[(size_t)lv] +
+                                          4 * bsum[(size_t)lv + 1];
+        }
+        if (d->tier_root < levels) {
+            const int H = levels - d->tier_root;
+            // item records by the level they belong to: phase ph of the up sweep is level levels - 1 - ph, of the down sweep tier_root + ph
+            for (const TierWG& g : wgs)
+                for (int ph = 0; ph < H; ++ph) {
+                    d->lvl_idx_up[(size_t)(levels - 1 - ph)] += (int64_t)(g.up_off[ph + 1] - g.up_off[ph]) * (int64_t)sizeof(TierItem);
+                    d->lvl_idx_down[(size_t)(d->tier_root + ph)] += (int64_t)(g.down_off[ph + 1] - g.down_off[ph]) * (int64_t)sizeof(TierItem);
+                }
+            d->lvl_idx_up[(size_t)d->tier_root] += (int64_t)wgs.size() * (int64_t)sizeof(TierWG);
+            d->lvl_idx_down[(size_t)d->tier_root] += (int64_t)wgs.size() * (int64_t)sizeof(TierWG);
+            for (int lv = d->tier_root; lv < levels; ++lv) {
+                const bool inner = lv + 1 < levels;
+                // up: an inner node pulls its children's updates through `arity` indices per front position; the tier's root level and the
+                // leaves read the parent positions of their boundary rows. down: push-list pointers per front position + the children's targets
+                if (inner) d->lvl_idx_up[(size_t)lv] += 4 * (int64_t)arity * fpos[(size_t)lv];
+                if (lv == d->tier_root || !inner) d->lvl_idx_up[(size_t)lv] += 4 * bsum[(size_t)lv];
+                if (inner) d->lvl_idx_down[(size_t)lv] += 4 * fpos[(size_t)lv] + 4 * bsum[(size_t)lv + 1];
+            }
+            // factor words per subtree = per workgroup: with one workgroup per CU the slowest subtree is the launch's time
+            int64_t span0 = 1;
+            for (int t = cut; t < d->tier_root; ++t) span0 *= arity;
+            const int64_t q0 = sub_lo * span0;
+            double mx[2] = {0, 0}, sum[2] = {0, 0};
+            for (size_t w = 0; w < wgs.size(); ++w) {
+                double wu = 0, wd = 0;
+                int64_t span = 1;
+                for (int lv = d->tier_root; lv < levels; ++lv) {
+                    const int64_t first = level_off[lv] + (q0 + (int64_t)w) * span;
+                    for (int64_t i = first; i < first + span; ++i) {
+                        const NodeD& n = nd[i];
+                        const double s4 = (n.s + 3) & ~3, b4 = (n.b + 3) & ~3, tri_w = ((int64_t)n.s * (n.s + 1) / 2 + 3) & ~(int64_t)3;
+                        if (n.flags & NODE_SPARSE) { wu += tri_w + 3.0 * n.b; wd += tri_w + 3.0 * n.b; }      // (+ ~3 words per boundary row of sparse block and pointers)
+                        else { wu += s4 * n.b; wd += (s4 + b4) * n.s; }
+                    }
+                    span *= arity;
+                }
+                mx[0] = std::max(mx[0], wu); mx[1] = std::max(mx[1], wd); sum[0] += wu; sum[1] += wd;
+            }
+            const double nw = (double)std::max<size_t>(wgs.size(), 1);
+            d->tier_balance[0] = mx[0]; d->tier_balance[1] = sum[0] / nw; d->tier_balance[2] = mx[1]; d->tier_balance[3] = sum[1] / nw;
+        }
     }
     if (lds_max > 150 * 1024) {
         delete d;
@@ -1857,6 +1919,21 @@ extern "C" int ls_direct_level_rows(const ls_direct* d, int cap, int64_t* h_rows
         if (h_rows) h_rows[lv] = lv < (int)d->lvl_rows.size() ? d->lvl_rows[(size_t)lv] : 0;
         if (h_bnd) h_bnd[lv] = lv < (int)d->lvl_bnd.size() ? d->lvl_bnd[(size_t)lv] : 0;
     }
+    return LS_OK;
+}
+
+extern "C" int ls_direct_level_index_bytes(const ls_direct* d, int cap, int64_t* h_up, int64_t* h_down) {
+    LS_REQUIRE(d && cap >= 0, LS_E_INVALID, "ls_direct_level_index_bytes: bad argument");
+    for (int lv = 0; lv < cap && lv < d->levels; ++lv) {
+        if (h_up) h_up[lv] = lv < (int)d->lvl_idx_up.size() ? d->lvl_idx_up[(size_t)lv] : 0;
+        if (h_down) h_down[lv] = lv < (int)d->lvl_idx_down.size() ? d->lvl_idx_down[(size_t)lv] : 0;
+    }
+    return LS_OK;
+}
+
+extern "C" int ls_direct_tier_balance(const ls_direct* d, double* h_words4) {
+    LS_REQUIRE(d && h_words4, LS_E_INVALID, "ls_direct_tier_balance: bad argument");
+    for (int i = 0; i < 4; ++i) h_words4[i] = d->tier_balance[i];
     return LS_OK;
 }
 

@@ -479,7 +479,7 @@ std::string ls::nd_plan_build_device(const int32_t* d_rowptr, const int32_t* d_c
     hipStream_t st = (hipStream_t)stream;
     // the host's copy of the pattern: the row pointers now (the analysis looks at them first), the column indices during the device
     // rounds -- unless there are no positions: the graph embedding walks the pattern on the host before anything else
-    static const bool host_trials = getenv("LS_ND_HOST_TRIALS") != nullptr;      // the trial cuts on host threads, as in round 4 (A/B, tests)
+    const bool host_trials = getenv("LS_ND_HOST_TRIALS") != nullptr;      // the trial cuts on host threads, as in round 4 (A/B, tests)
     // (Round 5 measured making the trial cuts the automatic choice between 12k and 300k vertices, where they find 5-10 % thinner separators
     // on rough closed surfaces: cfg3 0.1024 -> 0.0899 ms per solve, cfg2 0.0571 -> 0.0547 -- for +12 ms of constructor at 250k on a mesh in
     // generation order and +23 ms on a mesh fresh from remove_duplicates, whose lexicographic vertex order makes the host's breadth-first

@@ -492,7 +492,7 @@ extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* str
 int ls_direct_adopt(ls_direct* d, void* const* owned, const size_t* owned_bytes, int n_owned, const double* seconds3, const double* quality4);
 namespace ls { hipStream_t side_stream(int device, int which); }
 bool direct_tier_fits(int levels, int arity, const int* s, const int* b, const int* own_start, int tier_levels, bool sparse_leaves, int waves);
-bool direct_tier_full16(int64_t V, int arity, int levels, int tier_levels, int shard_count);
+bool direct_tier_full16(int64_t V, int arity, int levels, int tier_levels, int shard_count, int tier_waves);
 
 // ---- the tree the library picks for a system of V unknowns (leaf_size <= 0 / arity <= 0 on entry = "pick"; explicit values stay) ----------
 extern "C" int ls_direct_pick_tree(int64_t V, int* leaf_size_io, int* arity_io) {
@@ -531,9 +531,45 @@ extern "C" int ls_direct_pick_tree(int64_t V, int* leaf_size_io, int* arity_io) 
     return LS_OK;
 }
 
+static int direct_factor_impl(const int32_t* d_rowptr, const int32_t* d_col, const float* d_val, int64_t V, int64_t nnz,
+                              const float* d_positions, int leaf_size, int arity, int tier_levels, int sparse_leaves, int shard_rank,
+                              int shard_count, int ordering_arg, int tier_waves, int device, void* stream, ls_direct** out);
+
 extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, const float* d_val, int64_t V, int64_t nnz,
                                 const float* d_positions, int leaf_size, int arity, int tier_levels, int sparse_leaves, int shard_rank,
                                 int shard_count, int device, void* stream, ls_direct** out) {
+    return direct_factor_impl(d_rowptr, d_col, d_val, V, nnz, d_positions, leaf_size, arity, tier_levels, sparse_leaves, shard_rank, shard_count,
+                              LS_ND_ORDER_AUTO, 0, device, stream, out);
+}
+
+// the same constructor with every choice as an ARGUMENT (round 6: `ordering` used to travel through the process environment)
+extern "C" int ls_direct_factor_ex(const int32_t* d_rowptr, const int32_t* d_col, const float* d_val, int64_t V, int64_t nnz,
+                                   const float* d_positions, const ls_direct_options* opt, int device, void* stream, ls_direct** out) {
+    ls_direct_options o;
+    ls_direct_options_default(&o);
+    if (opt) {
+        LS_REQUIRE(opt->struct_bytes >= 8 && opt->struct_bytes <= 4096, LS_E_INVALID, "ls_direct_factor_ex: options.struct_bytes is not set (ls_direct_options_default)");
+        memcpy(&o, opt, std::min((size_t)opt->struct_bytes, sizeof(o)));      // fields the caller's header did not know keep their defaults
+        o.struct_bytes = (int32_t)sizeof(o);
+    }
+    LS_REQUIRE(o.ordering >= LS_ND_ORDER_AUTO && o.ordering <= LS_ND_ORDER_MINSEP, LS_E_INVALID, "ls_direct_factor_ex: ordering must be LS_ND_ORDER_AUTO / _LONGEST / _MINSEP");
+    LS_REQUIRE(o.tier_waves == 0 || o.tier_waves == 4 || o.tier_waves == 8 || o.tier_waves == 16, LS_E_INVALID, "ls_direct_factor_ex: tier_waves must be 0 (library's rule), 4, 8 or 16");
+    return direct_factor_impl(d_rowptr, d_col, d_val, V, nnz, d_positions, o.leaf_size, o.arity, o.tier_levels, o.sparse_leaves, o.shard_rank,
+                              o.shard_count, o.ordering, o.tier_waves, device, stream, out);
+}
+
+extern "C" int ls_direct_options_default(ls_direct_options* o) {
+    LS_REQUIRE(o, LS_E_INVALID, "ls_direct_options_default: null argument");
+    memset(o, 0, sizeof(*o));
+    o->struct_bytes = (int32_t)sizeof(*o);
+    o->leaf_size = 0; o->arity = 0; o->tier_levels = -1; o->sparse_leaves = 1; o->shard_rank = 0; o->shard_count = 1;
+    o->ordering = LS_ND_ORDER_AUTO; o->tier_waves = 0;
+    return LS_OK;
+}
+
+static int direct_factor_impl(const int32_t* d_rowptr, const int32_t* d_col, const float* d_val, int64_t V, int64_t nnz,
+                              const float* d_positions, int leaf_size, int arity, int tier_levels, int sparse_leaves, int shard_rank,
+                              int shard_count, int ordering_arg, int tier_waves, int device, void* stream, ls_direct** out) {
     LS_REQUIRE(out && d_rowptr && d_col && d_val && V > 0 && nnz > 0 && nnz < INT32_MAX, LS_E_INVALID, "ls_direct_factor: bad argument");
     *out = nullptr;
     { const int rc_pick = ls_direct_pick_tree(V, &leaf_size, &arity); if (rc_pick) return rc_pick; }      // leaf_size / arity <= 0: picked from V
@@ -552,8 +588,9 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
         // how the cutting directions are chosen: ND_ORDER_AUTO (nd_plan.h) unless the environment says otherwise (LS_ND_ORDER = 0: always
         // the longest axis of the embedding, 1: always the thinnest of six trial separators -- on the device since round 5: 5-10 % fewer
         // factor numbers on rough scans for 10-25 ms more constructor at 250k vertices)
+        // an explicit argument (ls_direct_factor_ex) wins; "auto" lets the environment override the library's rule
         const char* oe = getenv("LS_ND_ORDER");
-        const int ordering = oe ? std::max(-1, std::min(1, atoi(oe))) : ND_ORDER_AUTO;
+        const int ordering = ordering_arg != ND_ORDER_AUTO ? ordering_arg : oe ? std::max(-1, std::min(1, atoi(oe))) : ND_ORDER_AUTO;
         const std::string err = nd_plan_build_device(d_rowptr, d_col, d_positions, V, nnz, rowptr.data(), col.data(), leaf_size, arity, 4, st, P, ordering,
                                                      /* defer_push_lists = */ true);
         LS_REQUIRE(err.empty(), LS_E_INVALID, "%s", err.c_str());
@@ -602,7 +639,7 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     if (tier_auto) {
         // large systems: a subtree one level taller per workgroup of sixteen waves, if its leaves and vectors fit the 160 KB of LDS
         const int taller = levels - 4;
-        if (direct_tier_full16(V, arity, levels, taller, shard_count) && direct_tier_fits(levels, arity, P.s.data(), P.b.data(), P.own_start.data(), taller, leaves_ok, 16))
+        if (direct_tier_full16(V, arity, levels, taller, shard_count, tier_waves) && direct_tier_fits(levels, arity, P.s.data(), P.b.data(), P.own_start.data(), taller, leaves_ok, 16))
             tier_levels = taller;
         else
             while (tier_levels > 0 && !direct_tier_fits(levels, arity, P.s.data(), P.b.data(), P.own_start.data(), tier_levels, leaves_ok, 4)) --tier_levels;
@@ -855,7 +892,7 @@ extern "C" int ls_direct_factor(const int32_t* d_rowptr, const int32_t* d_col, c
     A.h_push_ptr = P.push_ptr.data(); A.h_push_tgt = P.push_tgt.data(); A.n_front = P.n_front;
     A.d_finv = finv; A.d_wf = wf; A.d_wb = wb; A.d_u4 = u4; A.d_d4 = d4; A.d_tri = tri; A.d_sp_ptr = d_sp_ptr; A.d_sp_ent = d_sp_ent;
     A.n_sp_ptr = n_sp_ptr; A.n_sp_ent = 2 * n_ent;
-    A.shard_rank = shard_rank; A.shard_count = shard_count;
+    A.shard_rank = shard_rank; A.shard_count = shard_count; A.tier_waves = tier_waves;
     rc = ls_direct_create(&A, device, stream, out);
     int flag = 0;
     e = hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st);

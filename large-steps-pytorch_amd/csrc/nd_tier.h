@@ -186,6 +186,24 @@ __device__ __forceinline__ void leaf_idx(const TierArgs& a, const TierItem& n, i
 template <int K, bool UP, bool NT>
 __device__ __forceinline__ void leaf_dat(const TierArgs& a, const TierItem& n, const LeafIdx& ix, const float* __restrict__ b_in,
                                          int lane, LeafDat<K>& d) {
+    // down sweep: x_bnd and the sparse entries are needed FIRST (the sparse product runs while the triangle is still in flight, see
+    // leaf_phase), so they are requested first -- loads return in order
+    if (!UP) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) d.xv[q] = lane < n.b ? a.xb[(size_t)(n.bnd_off + lane) * K + q] : 0.0f;
+    }
+    // always a load from a valid address (a conditional load of a struct becomes a flat load through a scratch copy, and
+    // flat loads would tie the LDS counter to these global loads): entry 0 of the array exists, unused values are zeroed
+    const float2* __restrict__ ent = reinterpret_cast<const float2*>(a.sp_ent);
+    if (!UP) {
+#pragma unroll
+        for (int t = 0; t < TIER_SPE; ++t) {
+            const bool ok = ix.p0 + t < ix.p1;
+            const float2 r = ld_stream2<NT>(ent + (ok ? ix.p0 + t : 0));
+            d.e[t].val = ok ? r.x : 0.0f;
+            d.e[t].idx = ok ? __float_as_int(r.y) : 0;
+        }
+    }
     const float4* __restrict__ p = reinterpret_cast<const float4*>(a.tri + n.finv_off);
     const int n4 = (n.s * (n.s + 1) / 2 + 3) >> 2;
 #pragma unroll
@@ -196,20 +214,16 @@ __device__ __forceinline__ void leaf_dat(const TierArgs& a, const TierItem& n, c
 #pragma unroll
     for (int q = 0; q < K; ++q) {
         if (UP) d.v[q] = lane < n.s ? b_in[(size_t)ix.g * K + q] : 0.0f;
-        else {
-            d.v[q] = lane < n.s ? a.bprime[(size_t)(n.own_start + lane) * K + q] : 0.0f;
-            d.xv[q] = lane < n.b ? a.xb[(size_t)(n.bnd_off + lane) * K + q] : 0.0f;
-        }
+        else d.v[q] = lane < n.s ? a.bprime[(size_t)(n.own_start + lane) * K + q] : 0.0f;
     }
-    // always a load from a valid address (a conditional load of a struct becomes a flat load through a scratch copy, and
-    // flat loads would tie the LDS counter to these global loads): entry 0 of the array exists, unused values are zeroed
-    const float2* __restrict__ ent = reinterpret_cast<const float2*>(a.sp_ent);
+    if (UP) {
 #pragma unroll
-    for (int t = 0; t < TIER_SPE; ++t) {
-        const bool ok = ix.p0 + t < ix.p1;
-        const float2 r = ld_stream2<NT>(ent + (ok ? ix.p0 + t : 0));
-        d.e[t].val = ok ? r.x : 0.0f;
-        d.e[t].idx = ok ? __float_as_int(r.y) : 0;
+        for (int t = 0; t < TIER_SPE; ++t) {
+            const bool ok = ix.p0 + t < ix.p1;
+            const float2 r = ld_stream2<NT>(ent + (ok ? ix.p0 + t : 0));
+            d.e[t].val = ok ? r.x : 0.0f;
+            d.e[t].idx = ok ? __float_as_int(r.y) : 0;
+        }
     }
 }
 
@@ -322,7 +336,7 @@ __device__ __forceinline__ void sparse_row(const TierArgs& a, const LeafIdx& ix,
     }
 }
 
-// LDS of a leaf item: [triangle: tri_floats][y: 64 x 4][x_bnd: b x 4]
+// LDS of a leaf item: [triangle: tri_floats][y / t: 64 x 4]; the down sweep's x_bnd (b x 4) is staged in the triangle area before the triangle
 template <int K>
 __device__ __forceinline__ void leaf_up_compute(const TierArgs& a, const TierItem& n, const LeafIdx& ix, const float (&bj)[K],
                                                 const SpEnt (&e)[TIER_SPE], float* region, int tri_floats) {
@@ -371,12 +385,16 @@ __device__ __forceinline__ void leaf_up_compute(const TierArgs& a, const TierIte
     wave_lds_sync();
 }
 
+// Down sweep of a leaf in two steps around the staging of its triangle. x_bnd lives in the TRIANGLE area of the wave's LDS region: it
+// is dead once the sparse product t = A_sb x_bnd is in registers, and only then is the triangle written over it -- a leaf's LDS need
+// is triangle + one vector whatever its boundary (round 6: a closed 1M-vertex scan has leaves of up to 83 boundary rows; with x_bnd
+// BEHIND the triangle its 16-wave tier did not fit the 160 KB and the solve fell back to 11 launches on 3 workgroups per CU: 315 us).
+// The arithmetic and its order are unchanged (bit-identical results).
 template <int K>
-__device__ __forceinline__ void leaf_down_compute(const TierArgs& a, const TierItem& n, const LeafIdx& ix, const float (&yj)[K],
-                                                  const float (&xv)[K], const SpEnt (&e)[TIER_SPE], float* __restrict__ x_out,
-                                                  float* region, int tri_floats) {
-    const int lane = threadIdx.x & 63, s = n.s, b = n.b;
-    float* xbv = region + tri_floats + 64 * 4;
+__device__ __forceinline__ void leaf_down_head(const TierArgs& a, const TierItem& n, const LeafIdx& ix, const float (&xv)[K],
+                                               const SpEnt (&e)[TIER_SPE], float* region, float (&t)[K]) {
+    const int lane = threadIdx.x & 63, b = n.b;
+    float* xbv = region;                                   // (4 b floats; the planner guarantees 4 b <= the triangle area)
     if (lane < b) {
 #pragma unroll
         for (int q = 0; q < K; ++q) xbv[lane * 4 + q] = xv[q];
@@ -386,17 +404,24 @@ __device__ __forceinline__ void leaf_down_compute(const TierArgs& a, const TierI
         for (int q = 0; q < K; ++q) xbv[i * 4 + q] = a.xb[(size_t)(n.bnd_off + i) * K + q];
     }
     wave_lds_sync();
-    float t[K];
     sparse_row<K>(a, ix, e, xbv, t);
-    float* tv = region + tri_floats;
-    {
-        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lane < s) { w.x = t[0]; if (K > 1) w.y = t[K > 1 ? 1 : 0]; if (K > 2) w.z = t[K > 2 ? 2 : 0]; if (K > 3) w.w = t[K > 3 ? 3 : 0]; }
-        reinterpret_cast<float4*>(tv)[lane] = w;
-    }
-    wave_lds_sync();
+    wave_lds_sync();                                       // every lane has read x_bnd: the triangle may overwrite it
+}
+
+template <int K>
+__device__ __forceinline__ void leaf_down_vec(const TierItem& n, const float (&t)[K], float* region, int tri_floats) {
+    const int lane = threadIdx.x & 63;
+    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < n.s) { w.x = t[0]; if (K > 1) w.y = t[K > 1 ? 1 : 0]; if (K > 2) w.z = t[K > 2 ? 2 : 0]; if (K > 3) w.w = t[K > 3 ? 3 : 0]; }
+    reinterpret_cast<float4*>(region + tri_floats)[lane] = w;
+}
+
+template <int K>
+__device__ __forceinline__ void leaf_down_tail(const TierItem& n, const LeafIdx& ix, const float (&yj)[K], float* __restrict__ x_out,
+                                               float* region, int tri_floats) {
+    const int lane = threadIdx.x & 63, s = n.s;
     float z[K];
-    tri_matvec<K>(region, tv, s, lane, z);
+    tri_matvec<K>(region, region + tri_floats, s, lane, z);
     if (lane < s) {
 #pragma unroll
         for (int q = 0; q < K; ++q) x_out[(size_t)ix.g * K + q] = yj[q] - z[q];
@@ -419,17 +444,21 @@ __device__ __forceinline__ void leaf_phase(const TierArgs& a, int k0, int k1, co
     LeafIdx ix;
     leaf_idx<UP>(a, it, lane, ix);
     for (int k = k0; k < k1; k += S) {
-        float v[K], xv[K];
+        float v[K];
         SpEnt e[TIER_SPE];
+        float t[K];
         {
             LeafDat<K> d;
             leaf_dat<K, UP, NT>(a, it, ix, b_in, lane, d);
+            // down: the sparse product first (x_bnd staged in the triangle area), THEN the triangle over it
+            if (!UP) leaf_down_head<K>(a, it, ix, d.xv, d.e, region, t);
             tri_stage<K>(d, it.s, lane, region);
 #pragma unroll
-            for (int q = 0; q < K; ++q) { v[q] = d.v[q]; xv[q] = UP ? 0.0f : d.xv[q]; }
+            for (int q = 0; q < K; ++q) v[q] = d.v[q];
 #pragma unroll
-            for (int t = 0; t < TIER_SPE; ++t) e[t] = d.e[t];
+            for (int u = 0; u < TIER_SPE; ++u) e[u] = d.e[u];
         }
+        if (!UP) leaf_down_vec<K>(it, t, region, tri_floats);
         wave_lds_sync();
         // the next leaf's record has arrived by now: its index loads go out before this leaf is multiplied
         const bool more = k + S < k1;
@@ -438,7 +467,7 @@ __device__ __forceinline__ void leaf_phase(const TierArgs& a, int k0, int k1, co
         if (more) { it_n = rec_unpack(rec_n); leaf_idx<UP>(a, it_n, lane, ix_n); }
         rec_n = k + 2 * S < k1 ? rec_load(a.items, k + 2 * S, lane) : 0;
         if (UP) leaf_up_compute<K>(a, it, ix, v, e, region, tri_floats);
-        else leaf_down_compute<K>(a, it, ix, v, xv, e, x_out, region, tri_floats);
+        else leaf_down_tail<K>(it, ix, v, x_out, region, tri_floats);
         it = it_n; ix = ix_n;
     }
 }

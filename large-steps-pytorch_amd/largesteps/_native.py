@@ -32,6 +32,13 @@ class SolveInfo(ctypes.Structure):
                 ("rnorm", ctypes.c_double * 4), ("bnorm", ctypes.c_double * 4)]
 
 
+class DirectOptions(ctypes.Structure):
+    """ls_direct_options of include/largesteps_hip.h (filled by ls_direct_options_default)"""
+    _fields_ = [("struct_bytes", ctypes.c_int32), ("leaf_size", ctypes.c_int32), ("arity", ctypes.c_int32), ("tier_levels", ctypes.c_int32),
+                ("sparse_leaves", ctypes.c_int32), ("shard_rank", ctypes.c_int32), ("shard_count", ctypes.c_int32), ("ordering", ctypes.c_int32),
+                ("tier_waves", ctypes.c_int32)]
+
+
 _SIGNATURES = {
     "ls_version": (c_int, []),
     "ls_last_error": (ctypes.c_char_p, []),
@@ -92,6 +99,8 @@ _SIGNATURES = {
     "ls_patch_plan_info": (c_int, [c_void_p] + [ctypes.POINTER(c_int)] * 5 + [ctypes.POINTER(c_i64)] * 3 + [ctypes.POINTER(ctypes.c_double)]),
     "ls_patch_plan_arrays": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ls_direct_level_words": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "ls_direct_level_index_bytes": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "ls_direct_tier_balance": (c_int, [c_void_p, ctypes.POINTER(c_double * 4)]),
     "ls_direct_level_rows": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "ls_direct_exchange_region": (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_i64)]),
     "ls_dist_unique_id": (c_int, [c_void_p]),
@@ -103,6 +112,8 @@ _SIGNATURES = {
     "ls_direct_launch_profile": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ls_direct_factor": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                  c_void_p, ctypes.POINTER(c_void_p)]),
+    "ls_direct_factor_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_int, c_void_p, ctypes.POINTER(c_void_p)]),
+    "ls_direct_options_default": (c_int, [c_void_p]),
     "ls_direct_solve_part": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ls_direct_shard_info": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_i64),
                                      c_void_p]),
@@ -208,21 +219,34 @@ def require_device(t, what):
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)      # the handle without building a torch.cuda.Stream object (~5 us per call)
 
 
+_oom_state = threading.local()
+
+
 def retry_on_oom(fn):
     """Decorator of the package's allocating entry points (compute_matrix, the solvers' solve, the normals): the direct solver keeps up
     to LS_POOL_GB of freed device buffers in a pool that torch's caching allocator cannot see (ls_release_scratch in the header). When
     torch runs out of memory inside such a call the pool is emptied, torch's cache too, and the call is repeated ONCE; a second failure
-    is the caller's."""
+    is the caller's. Decorated calls nest (CholeskySolver.solve -> NestedDissectionSolver.solve): only the OUTERMOST one on a thread
+    retries, so one failure costs one repetition, and nothing is repeated while a stream capture is in progress (emptying the caches
+    would invalidate the capture: the error goes to the caller as it is)."""
     import functools
 
     @functools.wraps(fn)
     def wrapped(*args, **kwargs):
+        if getattr(_oom_state, "inside", False):
+            return fn(*args, **kwargs)
+        _oom_state.inside = True
         try:
-            return fn(*args, **kwargs)
-        except torch.cuda.OutOfMemoryError:
-            check(lib().ls_release_scratch(-1))
-            torch.cuda.empty_cache()
-            return fn(*args, **kwargs)
+            try:
+                return fn(*args, **kwargs)
+            except torch.cuda.OutOfMemoryError:
+                if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                    raise
+                check(lib().ls_release_scratch(-1))
+                torch.cuda.empty_cache()
+                return fn(*args, **kwargs)
+        finally:
+            _oom_state.inside = False
     return wrapped
 
 

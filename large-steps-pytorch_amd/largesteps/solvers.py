@@ -10,7 +10,6 @@ Neither cholespy/CHOLMOD nor torch sparse ops are used; there is no CPU path.
 """
 import ctypes
 import os
-import threading
 import types
 import warnings
 
@@ -251,10 +250,9 @@ class IterativeCholeskySolver(PCGSolver):
 class _NativeDirect:
     """Owner of a native ls_direct handle built by ls_direct_factor (symbolic analysis + numeric factorisation behind the C ABI)."""
 
-    _ORDERINGS = {None: None, "auto": "-1", "longest-axis": "0", "trial-cuts": "1"}
-    _order_lock = threading.Lock()
+    _ORDERINGS = {None: -1, "auto": -1, "longest-axis": 0, "trial-cuts": 1}      # LS_ND_ORDER_AUTO / _LONGEST / _MINSEP
 
-    def __init__(self, csr, leaf_size, arity, tier_levels, sparse_leaves, shard=(0, 1), ordering=None):
+    def __init__(self, csr, leaf_size, arity, tier_levels, sparse_leaves, shard=(0, 1), ordering=None, tier_waves=0):
         self.device = csr.device
         self._h = ctypes.c_void_p(None)
         pos = csr.positions
@@ -263,25 +261,18 @@ class _NativeDirect:
         dev = csr.device
         if ordering not in self._ORDERINGS:
             raise ValueError(f"ordering must be one of {sorted(k for k in self._ORDERINGS if k)} or None, got {ordering!r}")
-
-        def factor():
-            with torch.cuda.device(dev):
-                _native.check(_native.lib().ls_direct_factor(_native.ptr(csr.rowptr), _native.ptr(csr.col), _native.ptr(csr.val), csr.V, csr.nnz,
-                                                             _native.ptr(pos), int(leaf_size or 0), int(arity or 0), int(tier_levels), int(bool(sparse_leaves)),
-                                                             int(shard[0]), int(shard[1]), dev.index, _native.stream_of(dev), ctypes.byref(self._h)))
-        if ordering is None:
-            factor()
-        else:                      # the native call reads LS_ND_ORDER when it starts: set for the duration of this one construction
-            with self._order_lock:
-                old = os.environ.get("LS_ND_ORDER")
-                os.environ["LS_ND_ORDER"] = self._ORDERINGS[ordering]
-                try:
-                    factor()
-                finally:
-                    if old is None:
-                        os.environ.pop("LS_ND_ORDER", None)
-                    else:
-                        os.environ["LS_ND_ORDER"] = old
+        if tier_waves not in (0, 4, 8, 16):
+            raise ValueError(f"tier_waves must be 0 (the library's rule), 4, 8 or 16, got {tier_waves!r}")
+        # every choice travels as an argument of the C ABI (ls_direct_factor_ex); the process environment is not touched
+        lib = _native.lib()
+        opt = _native.DirectOptions()
+        _native.check(lib.ls_direct_options_default(ctypes.byref(opt)))
+        opt.leaf_size, opt.arity, opt.tier_levels, opt.sparse_leaves = int(leaf_size or 0), int(arity or 0), int(tier_levels), int(bool(sparse_leaves))
+        opt.shard_rank, opt.shard_count = int(shard[0]), int(shard[1])
+        opt.ordering, opt.tier_waves = self._ORDERINGS[ordering], int(tier_waves)
+        with torch.cuda.device(dev):
+            _native.check(lib.ls_direct_factor_ex(_native.ptr(csr.rowptr), _native.ptr(csr.col), _native.ptr(csr.val), csr.V, csr.nnz,
+                                                  _native.ptr(pos), ctypes.byref(opt), dev.index, _native.stream_of(dev), ctypes.byref(self._h)))
         s3 = (ctypes.c_double * 3)()
         _native.check(_native.lib().ls_direct_factor_seconds(self._h, ctypes.byref(s3)))
         self.timings = dict(plan_seconds=s3[0], table_seconds=s3[1], factor_seconds=s3[2])
@@ -345,6 +336,20 @@ class _NativeDirect:
         _native.check(_native.lib().ls_direct_level_rows(self._h, n, rows, bnd))
         return list(rows), list(bnd)
 
+    def level_index_bytes(self):
+        """bytes of static index data per tree level: (up sweep, down sweep), level 0 = root (ls_direct_level_index_bytes)"""
+        n = self.info()["levels"]
+        up, down = (ctypes.c_int64 * n)(), (ctypes.c_int64 * n)()
+        _native.check(_native.lib().ls_direct_level_index_bytes(self._h, n, up, down))
+        return list(up), list(down)
+
+    def tier_balance(self):
+        """factor words of the tier's subtrees: dict(up_max, up_mean, down_max, down_mean, max_over_mean) (ls_direct_tier_balance)"""
+        w = (ctypes.c_double * 4)()
+        _native.check(_native.lib().ls_direct_tier_balance(self._h, ctypes.byref(w)))
+        tot_max, tot_mean = w[0] + w[2], w[1] + w[3]
+        return dict(up_max=w[0], up_mean=w[1], down_max=w[2], down_mean=w[3], max_over_mean=(tot_max / tot_mean if tot_mean else None))
+
     def launch_profile(self):
         """Launches of the last solve run with set_option("profile", 3): dicts of ms, factor words, levels (lo, hi), sweep."""
         n = ctypes.c_int(0)
@@ -389,11 +394,12 @@ class NestedDissectionSolver(Solver):
     inside each other) is recognised by its thick separators and dissected again with graph distances among the cutting directions
     (`plan_quality['ordering'] == 'trial-cuts'`). ordering='trial-cuts' (or LS_ND_ORDER=1) asks for those trial cuts always: 5-10 % fewer
     factor numbers on rough closed scans (the 250k cotangent config: 0.102 -> 0.090 ms per solve) for 10-25 ms more constructor --
-    worth it for a long captured run on one mesh; 'longest-axis' never tries them; None / 'auto' is the library's rule. Raises ValueError when the matrix is not symmetric or not
+    worth it for a long captured run on one mesh; 'longest-axis' never tries them; None / 'auto' is the library's rule.
+    tier_waves=4 / 8 / 16 picks the tier kernel's workgroup shape (0: the library's rule; A/B runs and tests). Raises ValueError when the matrix is not symmetric or not
     positive definite, RuntimeError when the mesh does not dissect into fronts that fit the kernels.
     """
 
-    def __init__(self, M, leaf_size=None, arity=None, shard=(0, 1), ordering=None):
+    def __init__(self, M, leaf_size=None, arity=None, shard=(0, 1), ordering=None, tier_waves=0):
         import time
         csr = _native.csr_of(M)
         self._csr = csr
@@ -404,7 +410,7 @@ class NestedDissectionSolver(Solver):
         t0 = time.perf_counter()
         tier = max(-1, min(6, int(os.environ.get("LS_ND_TIER_H", "-1"))))      # -1: the library picks (and never picks one that does not fit)
         sparse = not os.environ.get("LS_ND_DENSE_LEAVES")
-        self._direct = _NativeDirect(csr, leaf_size, arity, tier, sparse, shard=shard, ordering=ordering)
+        self._direct = _NativeDirect(csr, leaf_size, arity, tier, sparse, shard=shard, ordering=ordering, tier_waves=tier_waves)
         torch.cuda.synchronize(csr.device)
         self.build_seconds = time.perf_counter() - t0
         self.timings = self._direct.timings
@@ -453,6 +459,12 @@ class NestedDissectionSolver(Solver):
     def launch_profile(self):
         return self._direct.launch_profile()
 
+    def level_index_bytes(self):
+        return self._direct.level_index_bytes()
+
+    def tier_balance(self):
+        return self._direct.tier_balance()
+
 
 class CholeskySolver(Solver):
     """
@@ -461,7 +473,7 @@ class CholeskySolver(Solver):
     on b only.
 
     * matrices built by `compute_matrix` (vertex positions known): `NestedDissectionSolver` -- factor once on the
-      device, then one HIP launch per upper tree level and sweep plus one per sweep for the deepest levels (11 at 1M vertices);
+      device, then one HIP launch per upper tree level and sweep plus one per sweep for the deepest levels (9 launches at 1M vertices);
     * anything else, or a mesh whose fronts exceed that solver's limits: `IterativeCholeskySolver` (Chebyshev-Jacobi /
       Jacobi-PCG run to a residual reduction `rtol`).
     `direct=False` (or LARGESTEPS_NO_DIRECT=1) forces the iterative path; `method` says which one is in use and every

@@ -144,6 +144,12 @@ CONFIGS = {
     "scroll10_250k": dict(kind="scroll", n=500, turns=10, lambda_=19.0, alpha=None, cotan=False),
     "folded250k": dict(kind="folded", n=500, lambda_=19.0, alpha=None, cotan=False),
     "shells250k": dict(kind="shells", n=112, lambda_=19.0, alpha=None, cotan=False),
+    # the headline size on surfaces that are not the plane (round 6): cfg3's recipe at 1M vertices (a closed, noisy scan: what the
+    # reference's figures/*/generate_data.py feed it), its uniform-Laplacian twin, a rolled and a folded 1000 x 1000 sheet
+    "cfg4b_sphere1m": dict(kind="icosphere", n=316, radial=0.05, tangential=0.25, lambda_=None, alpha=0.95, cotan=True),
+    "cfg4b_sphere1m_uniform": dict(kind="icosphere", n=316, radial=0.05, tangential=0.25, lambda_=50.0, alpha=None, cotan=False),
+    "scroll1m": dict(kind="scroll", n=1000, turns=3, lambda_=50.0, alpha=None, cotan=False),
+    "folded1m": dict(kind="folded", n=1000, lambda_=50.0, alpha=None, cotan=False),
 }
 
 

@@ -1376,3 +1376,119 @@ def test_ordering_argument_of_the_direct_solver(dev):
     assert float((xa - xt).abs().max()) <= 2e-5 * float(xa.abs().max())
     with pytest.raises(ValueError, match="ordering must be"):
         NestedDissectionSolver(M, ordering="best")
+
+
+# ---------------------------------------------------------------------------------------------------
+# round 6: the headline size on meshes that are not planes (the 16-wave / 4-level tier is the default path from 800k vertices)
+# ---------------------------------------------------------------------------------------------------
+def _irregular_system(name, dev):
+    from largesteps.geometry import compute_matrix
+    from largesteps import synthetic
+    v, f, c = synthetic.config_mesh(name)
+    tv, tf = _t(v, dev), _t(f, dev)
+    M = compute_matrix(tv, tf, c["lambda_"] if c["lambda_"] is not None else 0.0, alpha=c["alpha"], cotan=c["cotan"])
+    return v, tv, M
+
+
+@pytest.mark.parametrize("name", ["cfg4b_sphere1m", "cfg4b_sphere1m_uniform"])
+def test_one_million_vertex_sphere_vs_oracle(dev, name):
+    """cfg3's recipe at the headline size (noisy geodesic sphere n = 316, 998 562 vertices; cotangent alpha = 0.95 and its uniform
+    lambda = 50 twin): a closed surface whose separators are ~1.7x the plane's. 'Cholesky' must be the nested-dissection solver on the
+    DEFAULT path of this size (9 launches, a tier of 4 levels on one 16-wave workgroup per CU) and match the oracle's fp64 SOLUTION
+    for a smooth and a white right-hand side: stated tolerance 1e-4 * ||x*||_inf (solvers.py:34-39 on the inputs the reference's
+    figures feed it)."""
+    from largesteps.parameterize import from_differential, to_differential
+    from largesteps import parameterize
+    v, tv, M = _irregular_system(name, dev)
+    assert v.shape[0] == 998562
+    idx, val = M.indices().cpu().numpy(), M.values().cpu().numpy()
+    direct = osv.DirectSolver(idx[0], idx[1], val, v.shape[0])
+    u = to_differential(M, tv)
+    rhs = np.random.default_rng(17).standard_normal(v.shape).astype(np.float32)
+    for b_np in (u.cpu().numpy(), rhs):
+        x64 = direct.solve(b_np)
+        x = from_differential(M, _t(b_np, dev), "Cholesky").cpu().numpy()
+        assert np.abs(x - x64).max() <= 1e-4 * np.abs(x64).max()
+    chol = parameterize._cache[(id(M), "Cholesky")][0]
+    assert chol.method == "nested-dissection", chol.direct_error
+    inf = chol.info()
+    assert inf["launches"] == 9 and inf["tier_levels"] == 4 and inf["tier_workgroups"] == 256, inf
+
+
+@pytest.mark.parametrize("name", ["cfg4b_sphere1m", "scroll1m", "folded1m"])
+def test_sixteen_wave_tier_on_irregular_meshes_agrees_with_the_four_wave_tier(dev, name):
+    """Every mesh >= 800k vertices of rounds 1-5 was a plane. The same 16-wave / 4-level tier on a closed noisy sphere, a 3-turn scroll
+    and a folded sheet of 1M vertices (the last two dissect through trial cuts): the round trip from_differential(to_differential(v))
+    within the forward tolerance 1e-4, and the 4-wave / 3-level tier of rounds 2-4 (tier_waves=4: 11 launches) agrees to 2e-5 --
+    both are fp32 evaluations of the same factor in a different summation order."""
+    from largesteps.parameterize import to_differential
+    from largesteps.solvers import NestedDissectionSolver
+    v, tv, M = _irregular_system(name, dev)
+    u = to_differential(M, tv)
+    scale = float(tv.abs().max())
+    s16 = NestedDissectionSolver(M)
+    inf = s16.info()
+    assert inf["launches"] == 9 and inf["tier_levels"] == 4, inf
+    if name != "cfg4b_sphere1m":
+        assert s16.plan_quality["ordering"] == "trial-cuts", s16.plan_quality
+    x16 = s16.solve(u)
+    assert float((x16 - tv).abs().max()) <= 1e-4 * scale
+    assert torch.equal(x16, s16.solve(u)), "bitwise reproducible"
+    s16.close()
+    s4 = NestedDissectionSolver(M, tier_waves=4)
+    assert s4.info()["launches"] == 11 and s4.info()["tier_levels"] == 3, s4.info()
+    x4 = s4.solve(u)
+    assert float((x4 - tv).abs().max()) <= 1e-4 * scale
+    assert float((x4 - x16).abs().max()) <= 2e-5 * scale
+
+
+def test_direct_options_through_the_c_abi(dev):
+    """ls_direct_factor_ex (round 6): ordering and tier shape are ARGUMENTS of the C ABI -- a raw ctypes caller gets them without the
+    process environment, an explicit argument wins over LS_ND_ORDER / LS_ND_TIER_WAVES, and opt = NULL is ls_direct_factor's default."""
+    import ctypes
+    from largesteps import _native, synthetic
+    from largesteps.geometry import compute_matrix
+    v, f = synthetic.scroll(160, 3)
+    tv, tf = _t(v, dev), _t(f, dev)
+    M = compute_matrix(tv, tf, 19.0)
+    csr = _native.csr_of(M)
+    lib = _native.lib()
+
+    def factor(opt):
+        h = ctypes.c_void_p()
+        _native.check(lib.ls_direct_factor_ex(_native.ptr(csr.rowptr), _native.ptr(csr.col), _native.ptr(csr.val), csr.V, csr.nnz, _native.ptr(tv),
+                                              ctypes.byref(opt) if opt is not None else None, 0, _native.stream_of(dev), ctypes.byref(h)))
+        o, w = ctypes.c_int(0), ctypes.c_double(0)
+        _native.check(lib.ls_direct_plan_quality(h, ctypes.byref(o), ctypes.byref(w), None, None))
+        x = torch.empty_like(tv)
+        b = _native.spmv(csr, tv)
+        _native.check(lib.ls_direct_solve(h, b.data_ptr(), x.data_ptr(), 3, _native.raw_stream(dev)))
+        torch.cuda.synchronize()
+        lib.ls_direct_destroy(h)
+        assert float((x - tv).abs().max()) <= 1e-4
+        return o.value, w.value
+
+    opt = _native.DirectOptions()
+    _native.check(lib.ls_direct_options_default(ctypes.byref(opt)))
+    assert opt.struct_bytes == ctypes.sizeof(_native.DirectOptions) and opt.tier_levels == -1 and opt.sparse_leaves == 1 and opt.ordering == -1
+    auto = factor(None)
+    opt.ordering = 0
+    longest = factor(opt)
+    opt.ordering = 1
+    trial = factor(opt)
+    assert longest[0] == 0 and trial[0] == 1 and trial[1] < longest[1]           # a scroll: the trial cuts find much thinner separators
+    assert auto == trial                                                             # ... and the automatic rule picks them
+    os.environ["LS_ND_ORDER"] = "0"
+    try:
+        assert factor(opt) == trial                                                  # explicit argument wins over the environment
+        opt.ordering = -1
+        assert factor(opt) == longest                                                # AUTO: the environment overrides the rule
+    finally:
+        del os.environ["LS_ND_ORDER"]
+    opt.ordering = 7
+    with pytest.raises(ValueError, match="ordering"):
+        factor(opt)
+    opt.ordering = -1
+    opt.struct_bytes = 0
+    with pytest.raises(ValueError, match="struct_bytes"):
+        factor(opt)

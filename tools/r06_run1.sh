@@ -1,0 +1,9 @@
+set -x
+mkdir -p gpurun_out/r1
+python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "irregular or sphere_vs_oracle or direct_options or ordering_argument or sixteen_wave" > gpurun_out/r1/pytest_new.log 2>&1; echo "pytest rc $?" >> gpurun_out/r1/pytest_new.log
+python tools/irregular_1m.py 200 > gpurun_out/r1/irregular.txt 2>&1
+python tools/irregular_1m.py 200 --sizes > gpurun_out/r1/irregular_sizes.txt 2>&1
+python bench.py --no-extra-baselines > gpurun_out/r1/bench_plane.json 2> gpurun_out/r1/bench_plane.err
+python bench.py --no-extra-baselines --workload cfg4b_sphere1m > gpurun_out/r1/bench_sphere.json 2> gpurun_out/r1/bench_sphere.err
+tail -3 gpurun_out/r1/pytest_new.log
+cat gpurun_out/r1/irregular.txt
