@@ -897,6 +897,9 @@ struct ls_direct {
     std::vector<int64_t> lvl_idx_up, lvl_idx_down;    // bytes of STATIC index data a level's launch reads per sweep besides perm: tile / item records, mask, ppos, pull, push lists
     double tier_balance[4] = {0, 0, 0, 0};            // factor words of the tier's subtrees (one workgroup each): max and mean, up sweep / down sweep
     double prof_ms[3] = {0, 0, 0};     // up sweep, down sweep, 0 (last profiled solve)
+#ifdef LS_TIER_STAMPS
+    long long* stamps = nullptr;       // experiments build: 2 sweeps x tier_wgs x tier_waves x TIER_STAMP_SLOTS clock stamps of the last solve with "profile" = 2
+#endif
 };
 
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); const int v = e ? atoi(e) : 0; return v > 0 ? v : dflt; }
@@ -1654,6 +1657,9 @@ extern "C" int ls_direct_destroy(ls_direct* d) {
     for (size_t i = 0; i < d->owned.size(); ++i)
         if (!ls::pool_give(d->device, d->owned[i], i < d->owned_bytes.size() ? d->owned_bytes[i] : 0)) (void)hipFree(d->owned[i]);
     for (hipEvent_t e : d->ev) (void)hipEventDestroy(e);
+#ifdef LS_TIER_STAMPS
+    if (d->stamps) (void)hipFree(d->stamps);
+#endif
     for (hipEvent_t e : d->lev) (void)hipEventDestroy(e);
     delete d;
     return LS_OK;
@@ -1671,6 +1677,12 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
     ta.arity = d->arity; ta.phases = d->tier_phases; ta.region_floats = d->tier_region; ta.vec_floats = d->tier_vec;
     ta.upper_lo = d->upper_lo; ta.upper_hi = (int)d->V;
     ta.xcd_order = d->tier_xcd;
+#ifdef LS_TIER_STAMPS
+    const size_t stamp_n = (size_t)d->tier_wgs * d->tier_waves * TIER_STAMP_SLOTS;
+    if (d->profile == 2 && !d->stamps && stamp_n) LS_HIP(hipMalloc((void**)&d->stamps, 2 * stamp_n * sizeof(long long)));
+    if (d->profile == 2 && d->stamps) LS_HIP(hipMemsetAsync(d->stamps, 0, 2 * stamp_n * sizeof(long long), st));
+    ta.stamps = d->profile == 2 ? d->stamps : nullptr;
+#endif
     const size_t tier_lds = (size_t)d->tier_region * d->tier_waves * sizeof(float);
     const bool nt_tier = d->nt_tier && d->tier_waves != TIER_WAVES_WIDE, nt = d->nt_levels;
     int n_mark = 0;
@@ -1759,6 +1771,9 @@ static int direct_solve_k(ls_direct* d, const float* b, float* x, hipStream_t st
                                d->perm, d->push_ptr, d->push_tgt, d->finv, d->wb, (const float*)d->bp, d->xb, x, p.s_cap, p.b_cap,
                                lv == 0 ? rf : RootFill{nullptr, nullptr, nullptr, nullptr});
     }
+#ifdef LS_TIER_STAMPS
+    if (ta.stamps) ta.stamps += stamp_n;
+#endif
     if (d->tier_wgs) {
         LS_HIP(mark(d->tier_root, d->levels - 1, 1));
         if (d->tier_waves == TIER_WAVES_FULL && nt_tier) hipLaunchKernelGGL((k_nd_tier<K, false, TIER_WAVES_FULL, true>), dim3(d->tier_wgs), dim3(WAVE * TIER_WAVES_FULL), tier_lds, st, ta, b, x, d->tier_tri);
@@ -1854,7 +1869,9 @@ extern "C" int ls_direct_set(ls_direct* d, const char* name, int value) {
         DeviceGuard g(d->device);
         LS_HIP(g.err);
         // 0 off; 1 events around the two sweeps; 3 an event in front of every launch (2 was the tier kernels' clock stamps: archived)
-        LS_REQUIRE(value != 2, LS_E_INVALID, "ls_direct_set: profile 2 (per-wave clock stamps) was a laboratory mode and is archived (tools/archive/lab/)");
+#ifndef LS_TIER_STAMPS
+        LS_REQUIRE(value != 2, LS_E_INVALID, "ls_direct_set: profile 2 (per-wave clock stamps of the tier kernels) exists in the experiments build only (tools/build_variant.sh stamps -DLS_TIER_STAMPS)");
+#endif
         d->profile = value < 0 ? 0 : std::min(value, 3);
         while (d->profile && d->ev.size() < 4) { hipEvent_t e; LS_HIP(hipEventCreate(&e)); d->ev.push_back(e); }
         return LS_OK;
@@ -1921,6 +1938,19 @@ extern "C" int ls_direct_level_rows(const ls_direct* d, int cap, int64_t* h_rows
     }
     return LS_OK;
 }
+
+#ifdef LS_TIER_STAMPS
+// experiments build only (tools/build_variant.sh stamps "-DLS_TIER_STAMPS"; not declared in the header, not in the product library)
+extern "C" int ls_direct_tier_stamps(ls_direct* d, long long* h_out, int64_t n) {
+    LS_REQUIRE(d && h_out && d->stamps, LS_E_STATE, "ls_direct_tier_stamps: no stamps (solve with \"profile\" = 2 first)");
+    const int64_t have = 2 * (int64_t)d->tier_wgs * d->tier_waves * TIER_STAMP_SLOTS;
+    LS_REQUIRE(n >= have, LS_E_WORKSPACE, "ls_direct_tier_stamps: %lld entries needed", (long long)have);
+    DeviceGuard g(d->device);
+    LS_HIP(hipDeviceSynchronize());
+    LS_HIP(hipMemcpy(h_out, d->stamps, (size_t)have * sizeof(long long), hipMemcpyDeviceToHost));
+    return LS_OK;
+}
+#endif
 
 extern "C" int ls_direct_level_index_bytes(const ls_direct* d, int cap, int64_t* h_up, int64_t* h_down) {
     LS_REQUIRE(d && cap >= 0, LS_E_INVALID, "ls_direct_level_index_bytes: bad argument");

@@ -86,7 +86,22 @@ struct TierArgs {
     float* xb;
     int arity, phases, region_floats, vec_floats;    // LDS per wave: [vec_floats | partial sums: rounds x 64 x 4]
     int xcd_order;                                   // 1: workgroup -> subtree map that keeps neighbouring subtrees on one XCD
+#ifdef LS_TIER_STAMPS
+    long long* stamps;                               // experiments build only: per wave TIER_STAMP_SLOTS clock stamps (100 MHz), nullptr = off
+#endif
 };
+
+// Per-phase timeline of the tier kernels (build variant -DLS_TIER_STAMPS, tools/tier_stamps.py; never in the product library):
+// slot 0 wave start, 1 header + right-hand-side gather done, 2 + 2 ph phase ph's work done, 3 + 2 ph its barrier passed,
+// 16 + r the r-th leaf of the wave done (r < 8), 24 + ph items this wave ran in phase ph
+constexpr int TIER_STAMP_SLOTS = 32;
+#ifdef LS_TIER_STAMPS
+#define LS_STAMP(slot) do { if (a.stamps && lane == 0) stamp_base[(slot)] = (long long)wall_clock64(); } while (0)
+#define LS_STAMP_VAL(slot, v) do { if (a.stamps && lane == 0) stamp_base[(slot)] = (long long)(v); } while (0)
+#else
+#define LS_STAMP(slot) do { } while (0)
+#define LS_STAMP_VAL(slot, v) do { } while (0)
+#endif
 
 // Item records and the workgroup header are fetched with VECTOR loads (lane i takes dword i) and unpacked with
 // v_readlane: a scalar load on the critical path costs ~3 us next to a streaming CU (the scalar cache path queues behind
@@ -435,8 +450,10 @@ __device__ __forceinline__ void leaf_down_tail(const TierItem& n, const LeafIdx&
 // phase is bound by its dependent steps, not by bytes in flight.
 template <int K, bool UP, int W, bool NT>
 __device__ __forceinline__ void leaf_phase(const TierArgs& a, int k0, int k1, const float* __restrict__ b_in, float* __restrict__ x_out,
-                                           float* region, int tri_floats) {
+                                           float* region, int tri_floats, long long* stamp_base) {
     const int lane = threadIdx.x & 63;
+    int leaf_no = 0;
+    (void)leaf_no; (void)stamp_base;
     if (k0 >= k1) return;
     constexpr int S = W;
     TierItem it = rec_unpack(rec_load(a.items, k0, lane));
@@ -468,6 +485,8 @@ __device__ __forceinline__ void leaf_phase(const TierArgs& a, int k0, int k1, co
         rec_n = k + 2 * S < k1 ? rec_load(a.items, k + 2 * S, lane) : 0;
         if (UP) leaf_up_compute<K>(a, it, ix, v, e, region, tri_floats);
         else leaf_down_tail<K>(it, ix, v, x_out, region, tri_floats);
+        if (leaf_no < 8) LS_STAMP(16 + leaf_no);
+        ++leaf_no;
         it = it_n; ix = ix_n;
     }
 }
@@ -510,11 +529,11 @@ __device__ __forceinline__ void tier_mv_batch(const float* sv4, int base, int q,
     if (TIER_Q >= 8 && q + 4 < q1) tier_mv16(sv4[(4 * q + 16 - base) * 4 + lane], c[TIER_Q >= 8 ? 4 : 0], c[TIER_Q >= 8 ? 5 : 0],
                                              c[TIER_Q >= 8 ? 6 : 0], c[TIER_Q >= 8 ? 7 : 0], q1 - q - 4, acc);
 }
+// Round 6: B is requested by the CALLER too, at the item's entry -- most dense items of a 16-wave tier are 8 quads long, and with B
+// requested here, behind the assembly of the vector, its round trip was a dependent step of every dense phase.
 template <bool NT>
 __device__ __forceinline__ void tier_dot(const float4* __restrict__ col, size_t rows, int q0, int q1, const float* sv4, int base,
-                                         float4 (&A)[TIER_Q], f32x4& acc) {
-    float4 B[TIER_Q];
-    tier_prefetch<NT>(col, rows, q0 + TIER_Q, q1, B);
+                                         float4 (&A)[TIER_Q], float4 (&B)[TIER_Q], f32x4& acc) {
     for (int q = q0; q < q1; q += 2 * TIER_Q) {
         tier_mv_batch(sv4, base, q, q1, A, acc);
         tier_prefetch<NT>(col, rows, q + 2 * TIER_Q, q1, A);
@@ -547,7 +566,20 @@ struct DensePre {
     float v[K];            // down: b' of reduction entry r0 + lane (if it is an own row)
     int idx;               // up: parent position of this lane's boundary row; down: the caller's id of this lane's own row
     int plo[4], plb[4];    // up, arity 4: pull indices of own row r0 + lane and of boundary row row0 + lane (static lists)
+    int fw0, fw1;          // down, inner node: push-list range of the boundary row this lane hands down (fwd_slice), fw0 > fw1: none
 };
+
+// The boundary rows of an inner node hand their x down to the children; that is independent of the node's own arithmetic (x_bnd is
+// complete when the phase starts). Rounds 3-5: the node's first item did it for ALL boundary rows in a loop of two dependent round
+// trips per 64 rows before its own work (level 4 at 1M: 234 rows = four iterations in front of the phase's critical wave -- round 6's
+// stamps: that phase was the longest dense phase of the down sweep). Now EVERY item of the node takes a slice of the rows (<= 64 each
+// when the node has at least b / 64 items), its row pointers are requested before the barrier, value and targets at the item's entry,
+// and the stores go out after the item's product.
+__device__ __forceinline__ void fwd_slice(const TierItem& it, int& f0, int& f1) {
+    const int chunks = (max(it.s, 1) + 63) >> 6, total = chunks * it.nparts, ord = (it.row0 >> 6) * it.nparts + it.part;
+    f0 = (int)((long long)it.b * ord / total);
+    f1 = (int)((long long)it.b * (ord + 1) / total);
+}
 
 template <int K, bool NT>
 __device__ __forceinline__ void node_up_pre(const TierArgs& a, const TierItem& it, DensePre<K>& P) {
@@ -562,7 +594,11 @@ __device__ __forceinline__ void node_up_pre(const TierArgs& a, const TierItem& i
     const bool inner = !(it.flags & NODE_LEAF) && a.arity == 4;
     const int j = it.r0 + lane;
     pull_indices(a, (size_t)(it.front_off + j), inner && j < it.r1 && j < it.s, P.plo);
-    // (the boundary rows' hand-over is needed only after the product: its two round trips hide behind the matrix stream)
+    // the boundary rows' hand-over (needed by the item that finishes the row chunk): its static indices too -- round 6's stamps show
+    // dense phases of 8-quad items whose whole stream is in flight before the barrier; two dependent round trips behind it were
+    // the phase, not something the stream hid
+    // (k = 4 columns: the four index registers across the barrier would be the kernel's 129th-130th VGPR -- it keeps the two-trip form)
+    if (K <= 3) pull_indices(a, (size_t)(it.front_off + it.s + i), inner && fin, P.plb);
 }
 
 // up: b'_j for the item's reduction range (stored by the row0 == 0 items), partial upd_i = sum_j W[i][j] b'_j.
@@ -574,13 +610,15 @@ __device__ __forceinline__ void node_up(const TierArgs& a, const TierItem& it, D
     const bool row = i < b;
     float* sv4 = region;
     const float4* __restrict__ col = reinterpret_cast<const float4*>(a.u4 + it.w_off) + (row ? i : 0);
+    float4 B[TIER_Q];                               // second batch of the matrix stream: in flight while the vector is assembled
+    tier_prefetch<NT>(col, (size_t)b, (it.r0 >> 2) + TIER_Q, it.r1 >> 2, B);
     float pass[K];
 #pragma unroll
     for (int q = 0; q < K; ++q) pass[q] = 0.0f;
     const bool fin = it.part == 0 && row && it.pfront_off >= 0;        // this item adds the children's hand-over (and, unsplit, stores)
     const bool pre4 = a.arity == 4;
     if (fin && !(it.flags & NODE_LEAF)) {
-        pull_compact<K>(a, (size_t)(it.front_off + it.s + i), pass);
+        if (pre4 && K <= 3) pull_values<K>(a, P.plb, pass); else pull_compact<K>(a, (size_t)(it.front_off + it.s + i), pass);
     }
     for (int j = it.r0 + lane; j < it.r1; j += 64) {
         float v[K];
@@ -612,7 +650,7 @@ __device__ __forceinline__ void node_up(const TierArgs& a, const TierItem& it, D
     }
     wave_lds_sync();
     f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
-    tier_dot<NT>(col, (size_t)b, it.r0 >> 2, it.r1 >> 2, sv4, it.r0, P.cur, a4);   // every lane takes part (matrix instruction)
+    tier_dot<NT>(col, (size_t)b, it.r0 >> 2, it.r1 >> 2, sv4, it.r0, P.cur, B, a4);   // every lane takes part (matrix instruction)
     float acc[K];
 #pragma unroll
     for (int q = 0; q < K; ++q) acc[q] = a4[q];
@@ -629,22 +667,6 @@ __device__ __forceinline__ void node_up(const TierArgs& a, const TierItem& it, D
         for (int q = 0; q < K; ++q) pbuf[lane * 4 + q] = acc[q] + pass[q];
     }
     wave_lds_sync();
-}
-
-// the boundary rows of an inner node hand their x down to the children: independent of the node's own arithmetic (x_bnd is
-// complete when the phase starts), so the item that owns it (row chunk 0, part 0) issues it FIRST and it overlaps with the
-// matrix stream instead of adding three round trips behind it
-template <int K>
-__device__ __forceinline__ void node_down_forward(const TierArgs& a, const TierItem& it) {
-    const int lane = threadIdx.x & 63;
-    for (int i = lane; i < it.b; i += 64) {
-        const size_t f = (size_t)(it.front_off + it.s + i);
-        const int p0 = a.push_ptr[f], p1 = a.push_ptr[f + 1];
-        float v[K];
-#pragma unroll
-        for (int q = 0; q < K; ++q) v[q] = a.xb[(size_t)(it.bnd_off + i) * K + q];
-        push_down<K>(a.push_tgt, p0, p1, a.xb, v);
-    }
 }
 
 // x of the own rows: to the caller's numbering and into the children's boundary vectors. g, [p0, p1) and the first four
@@ -692,6 +714,11 @@ __device__ __forceinline__ void node_down_pre(const TierArgs& a, const TierItem&
     P.idx = fin ? a.perm[it.own_start + j] : 0;
     P.plo[0] = push ? a.push_ptr[it.front_off + j] : 0;
     P.plo[1] = push ? a.push_ptr[it.front_off + j + 1] : 0;
+    int f0, f1;
+    fwd_slice(it, f0, f1);
+    const bool fw = !(it.flags & NODE_LEAF) && f0 + lane < f1;
+    P.fw0 = fw ? a.push_ptr[it.front_off + s + f0 + lane] : 1;
+    P.fw1 = fw ? a.push_ptr[it.front_off + s + f0 + lane + 1] : 0;
 }
 
 // down: partial x_j = sum_{t in [r0, r1)} [Finv | -W^T][j][t] * [b' | x_bnd][t]
@@ -702,7 +729,18 @@ __device__ __forceinline__ void node_down(const TierArgs& a, const TierItem& it,
     const bool row = j < s;
     float* sv4 = region;
     const float4* __restrict__ col = reinterpret_cast<const float4*>(a.d4 + it.finv_off) + (row ? j : 0);
-    if (!(it.flags & NODE_LEAF) && it.row0 == 0 && it.part == 0) node_down_forward<K>(a, it);
+    float4 B[TIER_Q];                               // second batch of the matrix stream: in flight while the vector is assembled
+    tier_prefetch<NT>(col, (size_t)s, (it.r0 >> 2) + TIER_Q, it.r1 >> 2, B);
+    // this item's slice of the boundary rows to hand down: value and the first two targets requested now, stored after the product
+    int f0, f1;
+    fwd_slice(it, f0, f1);
+    const bool fw = P.fw0 <= P.fw1;
+    float fv[K];
+    int ftg[2];
+#pragma unroll
+    for (int q = 0; q < K; ++q) fv[q] = fw ? a.xb[(size_t)(it.bnd_off + f0 + lane) * K + q] : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) ftg[c] = (fw && P.fw0 + c < P.fw1) ? a.push_tgt[P.fw0 + c] : -1;
     const int s4 = (s + 3) & ~3;                  // reduction index space: [0, s4) own rows (padded), [s4, ..) boundary rows (padded)
     for (int t = it.r0 + lane; t < it.r1; t += 64) {
         float v[K];
@@ -729,7 +767,7 @@ __device__ __forceinline__ void node_down(const TierArgs& a, const TierItem& it,
 #pragma unroll
     for (int c = 0; c < 4; ++c) P.plb[c] = (it.nparts == 1 && P.plo[0] + c < P.plo[1]) ? a.push_tgt[P.plo[0] + c] : -1;
     f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
-    tier_dot<NT>(col, (size_t)s, it.r0 >> 2, it.r1 >> 2, sv4, it.r0, P.cur, a4);
+    tier_dot<NT>(col, (size_t)s, it.r0 >> 2, it.r1 >> 2, sv4, it.r0, P.cur, B, a4);
     float acc[K];
 #pragma unroll
     for (int q = 0; q < K; ++q) acc[q] = a4[q];
@@ -737,6 +775,25 @@ __device__ __forceinline__ void node_down(const TierArgs& a, const TierItem& it,
     else {
 #pragma unroll
         for (int q = 0; q < K; ++q) pbuf[lane * 4 + q] = acc[q];
+    }
+    // the hand-down of this item's slice of boundary rows (requested at entry)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        if (ftg[c] >= 0) {
+#pragma unroll
+            for (int q = 0; q < K; ++q) a.xb[(size_t)ftg[c] * K + q] = fv[q];
+        }
+    }
+    if (fw && P.fw1 - P.fw0 > 2) push_down<K>(a.push_tgt, P.fw0 + 2, P.fw1, a.xb, fv);
+    if (!(it.flags & NODE_LEAF)) {
+        for (int i = f0 + 64 + lane; i < f1; i += 64) {          // a slice of more than 64 rows (a node with fewer items than b / 64)
+            const size_t f = (size_t)(it.front_off + s + i);
+            const int p0 = a.push_ptr[f], p1 = a.push_ptr[f + 1];
+            float v[K];
+#pragma unroll
+            for (int q = 0; q < K; ++q) v[q] = a.xb[(size_t)(it.bnd_off + i) * K + q];
+            push_down<K>(a.push_tgt, p0, p1, a.xb, v);
+        }
     }
     wave_lds_sync();
 }
@@ -758,6 +815,12 @@ __global__ __launch_bounds__(64 * W, 16 / W) void k_nd_tier(TierArgs a, const fl
     // contiguous eighth of them: subtree = (b % 8) * (n / 8) + b / 8
     const int n_wg = (int)gridDim.x;
     const int sub = (a.xcd_order && (n_wg & 7) == 0) ? (int)(blockIdx.x & 7) * (n_wg >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+#ifdef LS_TIER_STAMPS
+    long long* stamp_base = a.stamps ? a.stamps + ((size_t)sub * W + wave) * TIER_STAMP_SLOTS : nullptr;
+#else
+    long long* stamp_base = nullptr;
+#endif
+    LS_STAMP(0);
     const int hdr = lane < 32 ? reinterpret_cast<const int*>(a.wgs + sub)[lane] : 0;
     const int obase = UP ? 0 : TIER_MAX_H + 1;
     const unsigned split = (unsigned)rl(hdr, UP ? 14 : 15), leafy = (unsigned)rl(hdr, UP ? 16 : 17);
@@ -786,12 +849,13 @@ __global__ __launch_bounds__(64 * W, 16 / W) void k_nd_tier(TierArgs a, const fl
             for (int q = 0; q < K; ++q) a.braw[(size_t)r * K + q] = b_in[g * K + q];
         }
     }
+    LS_STAMP(1);
     DensePre<K> pre;
 #pragma unroll
     for (int e = 0; e < TIER_Q; ++e) pre.cur[e] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int q = 0; q < K; ++q) pre.v[q] = 0.0f;
-    pre.idx = 0;
+    pre.idx = 0; pre.fw0 = 1; pre.fw1 = 0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) { pre.plo[c] = -1; pre.plb[c] = -1; }
     TierItem it_pre = rec_unpack(0);
@@ -807,7 +871,7 @@ __global__ __launch_bounds__(64 * W, 16 / W) void k_nd_tier(TierArgs a, const fl
             if (has_nx) rec_nx = rec_load(a.items, j0, lane);
         }
         if ((leafy >> ph) & 1u) {
-            leaf_phase<K, UP, W, NT>(a, i0 + wave, i1, b_in, x_out, region, tri_floats);
+            leaf_phase<K, UP, W, NT>(a, i0 + wave, i1, b_in, x_out, region, tri_floats, stamp_base);
         } else {
             int rec = (!pre_valid && i0 + wave < i1) ? rec_load(a.items, i0 + wave, lane) : 0;
             // the (last) split row chunk this wave will finish once its parts have met: record and static indices stay in
@@ -856,6 +920,7 @@ __global__ __launch_bounds__(64 * W, 16 / W) void k_nd_tier(TierArgs a, const fl
                 }
             }
         }
+        if (ph < 6) { LS_STAMP(2 + 2 * ph); LS_STAMP_VAL(24 + ph, (i1 - i0 - wave + W - 1) / W); }
         // every field of `pre` is rewritten here on every path: nothing of it stays live across a leaf phase
         pre_valid = has_nx;
         it_pre = rec_unpack(rec_nx);
@@ -866,11 +931,12 @@ __global__ __launch_bounds__(64 * W, 16 / W) void k_nd_tier(TierArgs a, const fl
             for (int e = 0; e < TIER_Q; ++e) pre.cur[e] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int q = 0; q < K; ++q) pre.v[q] = 0.0f;
-            pre.idx = 0;
+            pre.idx = 0; pre.fw0 = 1; pre.fw1 = 0;
 #pragma unroll
             for (int c = 0; c < 4; ++c) { pre.plo[c] = -1; pre.plb[c] = -1; }
         }
         __syncthreads();      // workgroup-scope release/acquire of the slots / boundary vectors written above (same CU)
+        if (ph < 6) LS_STAMP(3 + 2 * ph);
     }
 }
 

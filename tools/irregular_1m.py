@@ -50,6 +50,11 @@ if "--sizes" in sys.argv:
     for n in (900, 1000, 1200, 1414):
         v, f = synthetic.scroll(n, 3)
         run(f"scroll n={n}", v, f, dict(lambda_=50.0, alpha=None, cotan=False), [(16, None), (4, None)])
+elif "--quick" in sys.argv:
+    for rep in range(2):
+        for name in ("cfg4_plane1m", "cfg4b_sphere1m_uniform", "scroll1m"):
+            v, f, cfg = synthetic.config_mesh(name)
+            run(name, v, f, cfg, [(0, None)])
 else:
     for name in ("cfg4_plane1m", "cfg4b_sphere1m", "cfg4b_sphere1m_uniform", "scroll1m", "folded1m"):
         v, f, cfg = synthetic.config_mesh(name)
