@@ -181,8 +181,25 @@ def spmv_entry(M, tv, V, nnz, workload, repeats=20):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / repeats
     bts = 8 * nnz + 4 * (V + 1) + 2 * 4 * k * V
+    # ... and COLD: the reference's loop calls to_differential once per (re)mesh, on data no cache holds. 1 GB is overwritten in front of
+    # every timed call (4x the Infinity Cache), one call between two events, median of 5
+    flush = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device=tv.device)
+    cold = []
+    for _ in range(5):
+        flush.fill_(1.0)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        to_differential(M, tv)
+        c1.record()
+        torch.cuda.synchronize()
+        cold.append(c0.elapsed_time(c1) * 1e3)
+    del flush
+    us_cold = sorted(cold)[len(cold) // 2]
     return dict(kernel="k_spmv<3, 0> (LDS-staged CSR tile, a row's gathers batched)", us_per_call=us, bytes=bts, achieved=bts / (us * 1e-6) / 1e9, unit="GB/s",
-                frac=bts / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, traffic=pmc_traffic("ls::k_spmv<3, 0>", workload))
+                frac=bts / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                note="frac is the WARM figure (back-to-back calls, 84 MB of operands in the 256 MB Infinity Cache); frac_cold is one call after 1 GB of other traffic -- what "
+                     "the once-per-remesh call of the reference's loop meets",
+                us_per_call_cold=us_cold, frac_cold=bts / (us_cold * 1e-6) / 1e9 / HBM_PEAK_GBS, traffic=pmc_traffic("ls::k_spmv<3, 0>", workload))
 
 
 def cpu_baseline(v, f, cfg, u_np, seconds_cap=120.0):
@@ -442,8 +459,11 @@ def report_direct(args, solver, M, u, x, tv, v, f, cfg, ms, t_assemble):
     # the vectors' share of a launch: per sweep the b / b' / x rows of its levels' vertices and the boundary vectors of their nodes
     # (the per-sweep total below, 4k (2V + 3 n_bnd) + 4V, split by level: ls_direct_level_rows)
     lv_rows, lv_bnd = solver.level_rows()
+    idx_up, idx_down = solver.level_index_bytes()
     for row in table:
         lo, hi = row["levels"]
+        # static index data of the launch besides perm: tile / item records, masks, parent positions, pull lists, push lists
+        row["index_bytes"] = (sum(idx_up[max(lo, 0):hi + 1]) if row["sweep"] != "down" else 0) + (sum(idx_down[max(lo, 0):hi + 1]) if row["sweep"] != "up" else 0)
         nv, nb_ = sum(lv_rows[max(lo, 0):hi + 1]), sum(lv_bnd[max(lo, 0):hi + 1])
         both = 2 if row["sweep"] == "both" else 1
         # strict: the factor words + per sweep one read and one write of the level's k-column rows (b -> b', b' -> x) and its index word;
@@ -521,7 +541,12 @@ def report_direct(args, solver, M, u, x, tv, v, f, cfg, ms, t_assemble):
                                       "(SURVEY 8d's 1e-6 is the ITERATIONS' stopping rule: --iterative / --pcg)",
                     max_abs_err_vs_v=float((x - tv).abs().max()), assemble_ms=t_assemble * 1e3,
                     dissection=getattr(solver, "plan_quality", None),
+                    # factor words of the tier's subtrees, one workgroup (one CU) each: the heaviest one is the tier launches' time
+                    tier_balance=(solver.tier_balance() if hasattr(solver, "tier_balance") else None), tier_workgroups=inf["tier_workgroups"],
                     factor_seconds=getattr(solver, "build_seconds", None), factor_seconds_second_construction=repeat_seconds, factor_seconds_steady=steady_seconds,
+                    factor_seconds_note="first: the process' first construction (code objects loaded, thread pool started, fresh heap); second: right after the measured "
+                                        "solver was closed (its buffers in the pool); steady: the LAST of two further constructions -- single samples of a quantity that "
+                                        "varies 25-45 ms from pass to pass at 1M (host-side analysis), so steady may exceed second; spread over 6+ cycles: tools/bench_remesh.py",
                     factor_stages_seconds=dict(symbolic_analysis=tm["plan_seconds"], layouts_host=tm["table_seconds"], numeric_device_and_solve_tables=tm["factor_seconds"]),
                     solve_bytes=solve_bytes, solve_gbs=solve_bytes / (ms * 1e-3) / 1e9,
                     solve_frac_of_8tbs=solve_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -599,6 +624,9 @@ def run_distributed(args):
                                    "functional run, the timings mean nothing" if loopback else "RCCL over xGMI, one process per GPU",
                                    communicator=out.get("communicator"), devices=out.get("devices"), per_rank=out.get("per_rank")),
                         model=shard_model(args.workload, world) if out["shard"] == "vertex" else None,
+                        # the sharded x against one unsharded solve of the same system, the owners' cover, the communicator's world size
+                        # (largesteps/distributed.py bench_sharded); a failed check fails the run: rc 1, no throughput is reported as valid
+                        shard_check=out.get("shard_check"),
                         converged=out["converged"], max_abs_err_vs_v=out["err"], halo_vertices=out["halo"], method=out["method"],
                         halo_depth=out["depth"], rows_per_rank=out["rows_per_rank"],
                         solve_bytes=bts["solve"], solve_gbs=bts["solve"] / (ms * 1e-3) / 1e9),
@@ -609,8 +637,13 @@ def run_distributed(args):
             cpu_baseline=None,
         )
         print(json.dumps(res), flush=True)
+    bad = out.get("shard_check") is not None and not out["shard_check"]["ok"]
     dist.barrier()
     dist.destroy_process_group()
+    if bad:
+        if rank == 0:
+            print(f"bench.py: the sharded solve FAILED its self-check: {out['shard_check']}", file=sys.stderr, flush=True)
+        sys.exit(1)
 
 
 def launch_ranks(args):

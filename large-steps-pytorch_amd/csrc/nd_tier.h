@@ -876,7 +876,7 @@ __global__ __launch_bounds__(64 * W, 16 / W) void k_nd_tier(TierArgs a, const fl
             int rec = (!pre_valid && i0 + wave < i1) ? rec_load(a.items, i0 + wave, lane) : 0;
             // the (last) split row chunk this wave will finish once its parts have met: record and static indices stay in
             // registers across that barrier, nothing is loaded behind it
-            int head_k = -1, head_idx = 0, head_p0 = 0, head_p1 = 0;
+            int head_k = -1, head_idx = 0, head_p0 = 0, head_p1 = 0, head_flags = 0;
             for (int k = i0 + wave; k < i1; k += W) {
                 const int rec_next = k + W < i1 ? rec_load(a.items, k + W, lane) : 0;
                 const bool first = k == i0 + wave && pre_valid;
@@ -887,11 +887,16 @@ __global__ __launch_bounds__(64 * W, 16 / W) void k_nd_tier(TierArgs a, const fl
                 if (UP) node_up<K, NT>(a, it, pre, b_in, region, pbuf);
                 else node_down<K, NT>(a, it, pre, x_out, region, pbuf);
                 if (it.nparts > 1 && it.part == 0) {
-                    head_k = k; head_idx = pre.idx; head_p0 = pre.plo[0]; head_p1 = pre.plo[1];
+                    head_k = k; head_idx = pre.idx; head_p0 = pre.plo[0]; head_p1 = pre.plo[1]; head_flags = it.flags;
                 }
             }
             if ((split >> ph) & 1u) {
                 const int rec_head = head_k >= 0 ? rec_load(a.items, head_k, lane) : 0;      // arrives while the parts meet
+                // ... and so do the first four push targets of the row this lane will store (static list; round 6: one round trip less
+                // behind the combine barrier of the down sweep's split phases)
+                int head_tg[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) head_tg[c] = (!UP && head_k >= 0 && head_p0 + c < head_p1 && !(head_flags & NODE_LEAF)) ? a.push_tgt[head_p0 + c] : -1;
                 __syncthreads();
                 for (int k = i0 + wave; k < i1; k += W) {
                     const bool mine = k == head_k;
@@ -911,10 +916,7 @@ __global__ __launch_bounds__(64 * W, 16 / W) void k_nd_tier(TierArgs a, const fl
                         const int pp = mine ? head_idx : ((i < it.b && it.pfront_off >= 0 && !(it.flags & NODE_UPC)) ? a.ppos[it.bnd_off + i] : 0);
                         node_up_finish<K>(a, it, i, pp, acc);
                     } else if (mine) {
-                        int tg[4];
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) tg[c] = (head_p0 + c < head_p1 && !(it.flags & NODE_LEAF)) ? a.push_tgt[head_p0 + c] : -1;
-                        node_down_store<K>(a, it, head_idx, head_p0, head_p1, tg, x_out, acc);
+                        node_down_store<K>(a, it, head_idx, head_p0, head_p1, head_tg, x_out, acc);
                     }
                     else node_down_finish<K>(a, it, x_out, acc);
                 }

@@ -842,7 +842,26 @@ def bench_sharded(workload, device, steps, warmup, shard="auto"):
                         kernel_us=parts["part0_us"] + parts["part1_us"], communicator_rank_world=list(comm) if comm else None, **parts)
             everyone = [None] * world
             dist.all_gather_object(everyone, mine)
-            return dict(per_rank=everyone, devices=[e["device_index"] for e in everyone],
+            # Self-check AFTER the timed region, so that a first run on real multi-GPU hardware cannot report a wrong answer as a throughput:
+            # (1) every row of x has exactly one designated owner; (2) the sharded x, assembled from the owners' rows, against ONE unsharded
+            # ls_direct_solve of the same system (every rank holds the whole matrix): max-abs <= 2e-5 of max |x| -- two fp32 evaluations of
+            # the same factorisation in a different summation order; (3) the library's RCCL communicator reports the job's world size.
+            from .solvers import NestedDissectionSolver
+            cover = sd.owned.to(torch.int32).clone()
+            dist.all_reduce(cover)
+            x_all = torch.where(sd.owned.unsqueeze(1), x, torch.zeros_like(x))
+            dist.all_reduce(x_all)
+            single = NestedDissectionSolver(M)
+            x_one = single.solve(u_full)
+            single.close()
+            scale = float(x_one.abs().max())
+            diff = (x_all - x_one).abs().max().reshape(1).double()
+            dist.all_reduce(diff, op=dist.ReduceOp.MAX)
+            comm_ok = all(e["communicator_rank_world"] is None or e["communicator_rank_world"][1] == world for e in everyone)
+            check = dict(max_abs_diff_vs_unsharded=float(diff.item()), max_abs_x=scale, tolerance_rel=2e-5,
+                         every_row_has_one_owner=bool((cover == 1).all().item()), communicator_world_matches=bool(comm_ok))
+            check["ok"] = bool(check["max_abs_diff_vs_unsharded"] <= 2e-5 * scale and check["every_row_has_one_owner"] and comm_ok)
+            return dict(per_rank=everyone, devices=[e["device_index"] for e in everyone], shard_check=check,
                         communicator=(dict(kind="ls_dist (library's own RCCL communicator, all-reduce in place on the solve's stream)", ranks=comm[1]) if comm else
                                       dict(kind=f"torch.distributed all_reduce ({dist.get_backend()})", ranks=world)),
                         V=v.shape[0], nnz=int(M._nnz()), ms_per_step=float(elapsed.item()) / steps * 1e3, err=float(err.item()), shard="vertex",

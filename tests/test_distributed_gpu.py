@@ -269,6 +269,11 @@ def test_bench_line_of_a_multi_process_run(world, launch, workload):
     assert sum(p["own_rows"] for p in rk["per_rank"]) == int(c["workload"].split("V=")[1].split(",")[0])
     for p in rk["per_rank"]:
         assert p["part0_us"] > 0 and p["part1_us"] > 0 and p["collective_us"] > 0 and abs(p["kernel_us"] - p["part0_us"] - p["part1_us"]) < 1e-6
+    # the run checks itself (round 6): the sharded x against ONE unsharded solve, every row owned once, the communicator's world size;
+    # a failed check would have made the command exit with rc 1 above
+    chk = c["shard_check"]
+    assert chk["ok"] and chk["every_row_has_one_owner"] and chk["communicator_world_matches"]
+    assert chk["max_abs_diff_vs_unsharded"] <= chk["tolerance_rel"] * chk["max_abs_x"]
     if workload == "cfg4_plane1m":
         m = c["model"]
         assert m["kernel_us_per_rank"] == 122.2 and m["predicted_ms_per_step"][0] < m["predicted_ms_per_step"][1]
