@@ -460,6 +460,7 @@ def report_direct(args, solver, M, u, x, tv, v, f, cfg, ms, t_assemble):
     # (the per-sweep total below, 4k (2V + 3 n_bnd) + 4V, split by level: ls_direct_level_rows)
     lv_rows, lv_bnd = solver.level_rows()
     idx_up, idx_down = solver.level_index_bytes()
+    tier_bal = solver.tier_balance() if hasattr(solver, "tier_balance") else None        # (before the handle is closed below)
     for row in table:
         lo, hi = row["levels"]
         # static index data of the launch besides perm: tile / item records, masks, parent positions, pull lists, push lists
@@ -542,7 +543,7 @@ def report_direct(args, solver, M, u, x, tv, v, f, cfg, ms, t_assemble):
                     max_abs_err_vs_v=float((x - tv).abs().max()), assemble_ms=t_assemble * 1e3,
                     dissection=getattr(solver, "plan_quality", None),
                     # factor words of the tier's subtrees, one workgroup (one CU) each: the heaviest one is the tier launches' time
-                    tier_balance=(solver.tier_balance() if hasattr(solver, "tier_balance") else None), tier_workgroups=inf["tier_workgroups"],
+                    tier_balance=tier_bal, tier_workgroups=inf["tier_workgroups"],
                     factor_seconds=getattr(solver, "build_seconds", None), factor_seconds_second_construction=repeat_seconds, factor_seconds_steady=steady_seconds,
                     factor_seconds_note="first: the process' first construction (code objects loaded, thread pool started, fresh heap); second: right after the measured "
                                         "solver was closed (its buffers in the pool); steady: the LAST of two further constructions -- single samples of a quantity that "

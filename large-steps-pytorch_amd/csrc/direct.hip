@@ -20,6 +20,7 @@
 #include <vector>
 #include <chrono>
 #include <algorithm>
+#include <atomic>
 #include <string.h>
 #include <mutex>
 
@@ -1011,8 +1012,13 @@ bool pool_give(int device, void* p, size_t bytes) {
 
 // hipMalloc that gives the pool's memory back before it gives up: a remesh to a size outside the pool's fit window, or a torch /
 // renderer allocation next to a full pool, must not fail for memory the library is only keeping warm
+// LS_PLAN_TIMING: how many allocations missed the pool and what hipMalloc cost them (read and reset by ls_direct_factor's last lap)
+std::atomic<long long> g_malloc_calls{0}, g_malloc_us{0}, g_malloc_bytes{0};
 hipError_t pool_alloc(int device, void** p, size_t bytes) {
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(p, bytes);
+    g_malloc_calls += 1; g_malloc_bytes += (long long)bytes;
+    g_malloc_us += (long long)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     if (e != hipErrorOutOfMemory && e != hipErrorMemoryAllocation) return e;
     (void)hipGetLastError();
     (void)ls_release_scratch(device);

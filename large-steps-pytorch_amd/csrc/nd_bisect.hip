@@ -333,7 +333,205 @@ __global__ __launch_bounds__(BLOCK) void k_nodes(int64_t V, const long long* __r
 struct NdBisectDevice {
     const int32_t* d_rowptr; const int32_t* d_col; const float* d_pos; int64_t nnz; hipStream_t st;
     int32_t* h_col_pending;                 // not nullptr: the host copy of the column indices is still to be made -- WHILE the rounds run
+    double* d_emb = nullptr;                // graph embedding formed ON THE DEVICE (nd_embed_device): nd_bisect_device reads it instead of `embedded`
+    size_t d_emb_cap = 0;
+    ~NdBisectDevice() {
+        if (d_emb) { int dev = 0; (void)hipGetDevice(&dev); (void)hipStreamSynchronize(st); if (!pool_give(dev, d_emb, d_emb_cap)) (void)hipFree(d_emb); }
+    }
 };
+
+// ---- the graph embedding on the device (round 6) -------------------------------------------------------------------------------------
+// nd_plan.cpp's graph_embedding -- per connected component four breadth-first sweeps (seed -> p1 -> p2, p3 = far from both) -- took
+// 70-80 ms of host time on a 1M-vertex closed scan (single thread, ~1000 levels of a few thousand vertices each), half of that mesh's
+// constructor. A sweep is a chain of ~1000 dependent steps however many threads walk a level, so ONE workgroup runs many levels per
+// launch (__syncthreads() between them, the frontier in two global queues, no launch and no grid barrier per level): ~4 us per level.
+// Same numbers as the host's: distances are exact levels, "the last vertex reached" is the SMALLEST index of the last level, p3 the
+// smallest index among the maxima of min(d1, d2).
+namespace {
+// One launch per level, a few dozen workgroups each: a level of a 1M-vertex surface mesh is ~1000 vertices = ~15 000 scattered addresses
+// (row pointers, column indices, distances, claims) -- ONE workgroup walking it is bound by its CU's address rate (measured: 14 us per
+// level as a single persistent workgroup with __syncthreads() between levels, 53 ms for the four sweeps; unrolled variants with more
+// loads in flight 70-75 ms); spread over the chip a level costs about a dependent launch. cnt[l] = size of level l (zeroed per sweep),
+// queues alternate; the host looks at the counters every BFS_CHUNK levels.
+constexpr int BFS_CHUNK = 128, BFS_MAX_LEVELS = 60000, BFS_WG = 64;
+
+__global__ __launch_bounds__(BLOCK) void k_bfs_init(int64_t V, int* __restrict__ dist, int start, int* __restrict__ q0, int* __restrict__ cnt, int n_cnt) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < V) dist[i] = i == start ? 0 : -1;
+    if (i < n_cnt) cnt[i] = i == 0 ? 1 : 0;
+    if (i == 0) q0[0] = start;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_bfs_level(const int* __restrict__ rowptr, const int* __restrict__ col, int* dist, const int* __restrict__ qi,
+                                                     int* __restrict__ qo, int* cnt, int level) {
+    const int n = cnt[level];
+    const int lane = threadIdx.x & 63;
+    for (int i0 = blockIdx.x * BLOCK; i0 < n; i0 += gridDim.x * BLOCK) {
+        const int i = i0 + (int)threadIdx.x;
+        const int u = i < n ? qi[i] : -1;
+        const int p0 = u >= 0 ? rowptr[u] : 0, p1 = u >= 0 ? rowptr[u + 1] : 0;
+        int deg = p1 - p0;
+        for (int o = 32; o > 0; o >>= 1) deg = max(deg, __shfl_xor(deg, o));        // the wave walks its longest row together (aggregated claims)
+        for (int j = 0; j < deg; ++j) {
+            const int w = p0 + j < p1 ? col[p0 + j] : -1;
+            const bool win = w >= 0 && dist[w] < 0 && atomicCAS(&dist[w], -1, level + 1) == -1;
+            const unsigned long long m = __ballot(win);
+            if (m) {                                               // one counter update per wave
+                const int leader = __ffsll((long long)m) - 1;
+                int base = 0;
+                if (lane == leader) base = atomicAdd(&cnt[level + 1], __popcll(m));
+                base = __shfl(base, leader);
+                if (win) qo[base + __popcll(m & ((1ull << lane) - 1ull))] = w;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_bfs_last(const int* __restrict__ q, int n, int* out) {
+    int v = 0x7fffffff;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) v = min(v, q[i]);
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0) atomicMin(out, v);
+}
+
+// p3 = the smallest index among the maxima of min(d1, d2) over the component (d0 >= 0): packed (value << 32 | ~index) maximum
+__global__ __launch_bounds__(BLOCK) void k_far_from_both(int64_t V, const int* __restrict__ d0, const int* __restrict__ d1, const int* __restrict__ d2,
+                                                         unsigned long long* best) {
+    const int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    unsigned long long key = 0;
+    if (v < V && d0[v] >= 0) key = ((unsigned long long)(unsigned)min(d1[v], d2[v]) << 32) | (unsigned)(0x7fffffff - (int)v);
+    // wave maximum first: one atomic per wave
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = __shfl_xor(key, o); key = other > key ? other : key; }
+    if ((threadIdx.x & 63) == 0 && key) atomicMax(best, key);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_emb_write(int64_t V, const int* __restrict__ d0, const int* __restrict__ d1, const int* __restrict__ d2,
+                                                     const int* __restrict__ d3, double offset, double* __restrict__ emb, unsigned char* __restrict__ done) {
+    const int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (v < V && d0[v] >= 0) {
+        emb[3 * v] = (double)d1[v] + offset; emb[3 * v + 1] = (double)d2[v]; emb[3 * v + 2] = (double)d3[v];
+        done[v] = 1;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_first_undone(int64_t V, const unsigned char* __restrict__ done, int* first) {
+    const int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (v < V && !done[v]) atomicMin(first, (int)v);
+}
+}  // namespace
+
+// "" = the embedding is in ctx->d_emb (V x 3 doubles, device); "host" = this graph is one for the host's sweeps (a swarm of isolated
+// vertices, a path-like graph of tens of thousands of levels); anything else = an error text.
+static std::string nd_embed_device_impl(void* ctx, int64_t V);
+std::string nd_embed_device(void* ctx, int64_t V) {
+    NdBisectDevice& A = *(NdBisectDevice*)ctx;
+    if (getenv("LS_ND_HOST_EMBED")) { }                    // A/B and tests: the host's sweeps
+    else {
+        const std::string r = nd_embed_device_impl(ctx, V);
+        if (r != "host") return r;
+        if (A.d_emb) { int dev = 0; (void)hipGetDevice(&dev); (void)hipStreamSynchronize(A.st); if (!pool_give(dev, A.d_emb, A.d_emb_cap)) (void)hipFree(A.d_emb); A.d_emb = nullptr; }
+    }
+    // the host walks the pattern itself: it needs the column indices NOW
+    if (A.h_col_pending) {
+        if (hipMemcpyAsync(A.h_col_pending, A.d_col, sizeof(int32_t) * A.nnz, hipMemcpyDeviceToHost, A.st) != hipSuccess || hipStreamSynchronize(A.st) != hipSuccess)
+            return "nd_embed_device: copy of the pattern failed";
+        A.h_col_pending = nullptr;
+    }
+    return "host";
+}
+static std::string nd_embed_device_impl(void* ctx, int64_t V) {
+    NdBisectDevice& A = *(NdBisectDevice*)ctx;
+    hipStream_t st = A.st;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    size_t o_d[4];
+    for (int k = 0; k < 4; ++k) o_d[k] = take(sizeof(int) * V);
+    const int n_cnt = BFS_MAX_LEVELS + 2 * BFS_CHUNK + 8;
+    const size_t o_q0 = take(sizeof(int) * V), o_q1 = take(sizeof(int) * V), o_done = take(V), o_cnt = take(sizeof(int) * n_cnt), o_best = take(16), o_first = take(16);
+    size_t cap = off, ecap = sizeof(double) * 3 * (size_t)V;
+    char* base = (char*)pool_take(dev, off, &cap);
+    if (!base && pool_alloc(dev, (void**)&base, off) != hipSuccess) return "nd_embed_device: out of device memory";
+    struct Free { char* p; size_t bytes; int dev; hipStream_t st; ~Free() { (void)hipStreamSynchronize(st); if (!pool_give(dev, p, bytes)) (void)hipFree(p); } } guard{base, cap, dev, st};
+    double* emb = (double*)pool_take(dev, ecap, &ecap);
+    if (!emb && pool_alloc(dev, (void**)&emb, ecap) != hipSuccess) return "nd_embed_device: out of device memory";
+    A.d_emb = emb; A.d_emb_cap = ecap;               // (owned by the context from here on, whatever this function returns)
+    int* d[4];
+    for (int k = 0; k < 4; ++k) d[k] = (int*)(base + o_d[k]);
+    int* q[2] = {(int*)(base + o_q0), (int*)(base + o_q1)};
+    unsigned char* done = (unsigned char*)(base + o_done);
+    int* cnt = (int*)(base + o_cnt);
+    unsigned long long* best = (unsigned long long*)(base + o_best);
+    int* first = (int*)(base + o_first);
+    const unsigned gv = (unsigned)div_up(std::max<int64_t>(V, n_cnt), BLOCK);
+    bool failed = false, to_host = false;
+    struct Sweep { int levels, last; int64_t visited; };           // levels = index of the last non-empty level
+    std::vector<int> hc((size_t)BFS_CHUNK + 1);
+    auto sweep = [&](int start, int* dist, Sweep& h) {              // one breadth-first sweep
+        hipLaunchKernelGGL(k_bfs_init, dim3(gv), dim3(BLOCK), 0, st, V, dist, start, q[0], cnt, n_cnt);
+        h.visited = 1; h.levels = 0; h.last = start;
+        for (int lv = 0;; lv += BFS_CHUNK) {
+            for (int l = lv; l < lv + BFS_CHUNK; ++l)
+                hipLaunchKernelGGL(k_bfs_level, dim3(BFS_WG), dim3(BLOCK), 0, st, A.d_rowptr, A.d_col, dist, (const int*)q[l & 1], q[(l + 1) & 1], cnt, l);
+            // sizes of levels lv + 1 .. lv + BFS_CHUNK
+            if (hipMemcpyAsync(hc.data(), cnt + lv + 1, sizeof(int) * BFS_CHUNK, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { failed = true; return; }
+            bool ended = false;
+            for (int t = 0; t < BFS_CHUNK; ++t) {
+                if (hc[(size_t)t] == 0) { ended = true; break; }
+                h.visited += hc[(size_t)t]; h.levels = lv + 1 + t;
+            }
+            if (ended) break;
+            if (lv + BFS_CHUNK > BFS_MAX_LEVELS) { to_host = true; return; }
+        }
+        // the smallest index of the last level (its queue is intact: the launches behind it found it empty and wrote nothing)
+        int n_last = 1;
+        if (h.levels > 0) {
+            if (hipMemcpyAsync(&n_last, cnt + h.levels, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { failed = true; return; }
+        }
+        int init = 0x7fffffff;
+        if (hipMemcpyAsync(first, &init, sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess) { failed = true; return; }
+        hipLaunchKernelGGL(k_bfs_last, dim3(8), dim3(BLOCK), 0, st, (const int*)q[h.levels & 1], n_last, first);
+        if (hipMemcpyAsync(&h.last, first, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { failed = true; return; }
+    };
+    if (hipMemsetAsync(done, 0, (size_t)V, st) != hipSuccess || hipMemsetAsync(emb, 0, sizeof(double) * 3 * (size_t)V, st) != hipSuccess) return "nd_embed_device: memset failed";
+    double offset = 0.0;
+    int64_t remaining = V;
+    int seed = 0;
+    while (remaining > 0) {
+        Sweep h0, h1, h2, h3;
+        sweep(seed, d[0], h0);
+        if (failed) return "nd_embed_device: a device call failed";
+        if (to_host) return "host";
+        const int64_t comp = h0.visited;
+        if (comp <= 2 && remaining - comp > 4096) return "host";       // a swarm of isolated vertices: the host lays it out in index order
+        sweep(h0.last, d[1], h1);
+        if (!failed && !to_host) sweep(h1.last, d[2], h2);
+        if (failed) return "nd_embed_device: a device call failed";
+        if (to_host) return "host";
+        unsigned long long hbest = 0;
+        if (hipMemsetAsync(best, 0, sizeof(unsigned long long), st) != hipSuccess) return "nd_embed_device: memset failed";
+        hipLaunchKernelGGL(k_far_from_both, dim3(gv), dim3(BLOCK), 0, st, V, (const int*)d[0], (const int*)d[1], (const int*)d[2], best);
+        if (hipMemcpyAsync(&hbest, best, sizeof(hbest), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return "nd_embed_device: a device call failed";
+        const int p3 = hbest ? 0x7fffffff - (int)(unsigned)(hbest & 0xffffffffu) : seed;
+        sweep(p3, d[3], h3);
+        if (failed) return "nd_embed_device: a device call failed";
+        if (to_host) return "host";
+        hipLaunchKernelGGL(k_emb_write, dim3(gv), dim3(BLOCK), 0, st, V, (const int*)d[0], (const int*)d[1], (const int*)d[2], (const int*)d[3], offset, emb, done);
+        offset += (double)h1.levels + 2.0;                // (the largest d1 of the component = the last level of the sweep from p1)
+        remaining -= comp;
+        if (remaining > 0) {
+            int hfirst = 0x7fffffff;
+            if (hipMemcpyAsync(first, &hfirst, sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess) return "nd_embed_device: a device call failed";
+            hipLaunchKernelGGL(k_first_undone, dim3(gv), dim3(BLOCK), 0, st, V, (const unsigned char*)done, first);
+            if (hipMemcpyAsync(&hfirst, first, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return "nd_embed_device: a device call failed";
+            if (hfirst < 0 || hfirst >= V) return "nd_embed_device: inconsistent component count";
+            seed = hfirst;
+        }
+    }
+    if (hipGetLastError() != hipSuccess) return "nd_embed_device: a kernel launch failed";
+    return "";
+}
 
 // ordering = ND_ORDER_LONGEST: the longest axis of the caller's positions (averaged `smooth` times), or of `embedded` as it is.
 // ordering = ND_ORDER_MINSEP:  trial cuts over the position axes AND the three graph distances of `embedded` (both averaged `smooth`
@@ -350,6 +548,7 @@ std::string nd_bisect_device(void* ctx, int64_t V, int D, int smooth, const doub
         return "";
     }
     const bool minsep = ordering == ND_ORDER_MINSEP, has_pos = A.d_pos != nullptr;
+    if (A.d_emb) embedded = (const double*)A.d_emb;          // formed on the device (nd_embed_device): only ever used as a device-to-device source below
     if (!has_pos && !embedded) return "nd_bisect_device: neither positions nor an embedding";
     const int NA = (minsep && has_pos && embedded) ? 6 : 3;
     const int max_dom = 1 << (D - 1), nb = div_up(V, BCH);
@@ -400,11 +599,13 @@ std::string nd_bisect_device(void* ctx, int64_t V, int D, int smooth, const doub
         hipLaunchKernelGGL(k_f32_to_f64, dim3(div_up(3 * V, BLOCK)), dim3(BLOCK), 0, st, A.d_pos, 3 * V, pos);
         smooth_passes(pos, pos2, smooth);
         if (NA == 6) {
-            if (hipMemcpyAsync(posB, embedded, sizeof(double) * 3 * V, hipMemcpyHostToDevice, st) != hipSuccess) return "nd_bisect_device: copy failed";
+            if (hipMemcpyAsync(posB, A.d_emb ? (const void*)A.d_emb : (const void*)embedded, sizeof(double) * 3 * V, A.d_emb ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st) != hipSuccess)
+                return "nd_bisect_device: copy failed";
             smooth_passes(posB, pos2, smooth);            // (pos2 is scratch from here on)
         }
     } else {
-        if (hipMemcpyAsync(pos, embedded, sizeof(double) * 3 * V, hipMemcpyHostToDevice, st) != hipSuccess) return "nd_bisect_device: copy failed";
+        if (hipMemcpyAsync(pos, A.d_emb ? (const void*)A.d_emb : (const void*)embedded, sizeof(double) * 3 * V, A.d_emb ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st) != hipSuccess)
+            return "nd_bisect_device: copy failed";
         if (minsep) smooth_passes(pos, pos2, smooth);
     }
     // ---- the three coordinate orders: stable LSD radix sort of the ids by the 8 key bytes -> (coordinate, id) order -----------------
@@ -488,7 +689,9 @@ std::string ls::nd_plan_build_device(const int32_t* d_rowptr, const int32_t* d_c
     // profiles/r05_trial_cuts_on_device.txt)
     const bool host_rounds = ordering == ND_ORDER_MINSEP && host_trials;
     // (the trial cuts need the graph distances, i.e. the pattern on the host, before the rounds start; so does a matrix without positions)
-    const bool col_first = !d_positions || ordering == ND_ORDER_MINSEP;
+    // (round 6: the graph distances are breadth-first sweeps ON THE DEVICE, nd_embed_device -- the pattern crosses the bus during the rounds
+    //  in every case; the rare graphs the device hands back to the host's sweeps fetch it then)
+    const bool col_first = host_rounds;
     if (hipMemcpyAsync(h_rowptr, d_rowptr, sizeof(int32_t) * (V + 1), hipMemcpyDeviceToHost, st) != hipSuccess ||
         (col_first && hipMemcpyAsync(h_col, d_col, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost, st) != hipSuccess) ||
         hipStreamSynchronize(st) != hipSuccess)
@@ -510,7 +713,7 @@ std::string ls::nd_plan_build_device(const int32_t* d_rowptr, const int32_t* d_c
     NdBisectDevice ctx{d_rowptr, d_col, d_positions, nnz, st, col_first ? nullptr : h_col};
     const float given = 0.0f;                  // "positions were given": nd_plan_build only tests the pointer, the values are read on the device
     std::string err = nd_plan_build(V, h_rowptr, h_col, d_positions ? &given : nullptr, leaf_size, arity, smooth, out, nd_bisect_device, &ctx,
-                                    ordering == ND_ORDER_MINSEP ? ND_ORDER_MINSEP : ND_ORDER_LONGEST, defer_push_lists);
+                                    ordering == ND_ORDER_MINSEP ? ND_ORDER_MINSEP : ND_ORDER_LONGEST, defer_push_lists, nd_embed_device);
     if (timing) fprintf(stderr, "[nd_plan] returned (pool joined, temporaries released) %.3f s after its start; %.1f factor numbers per vertex, spread %.2f\n",
                         now_s() - t0, out.words_per_vertex, out.spread);
     if (!err.empty() || ordering != ND_ORDER_AUTO || out.spread <= nd_plan_suspect()) return err;
@@ -523,7 +726,7 @@ std::string ls::nd_plan_build_device(const int32_t* d_rowptr, const int32_t* d_c
         err = nd_plan_build(V, h_rowptr, h_col, d_positions ? h_pos.data() : nullptr, leaf_size, arity, smooth, B, nullptr, nullptr, ND_ORDER_MINSEP, defer_push_lists);
     } else {
         NdBisectDevice ctx2{d_rowptr, d_col, d_positions, nnz, st, nullptr};         // (h_col is complete: the first set of rounds has returned)
-        err = nd_plan_build(V, h_rowptr, h_col, d_positions ? &given : nullptr, leaf_size, arity, smooth, B, nd_bisect_device, &ctx2, ND_ORDER_MINSEP, defer_push_lists);
+        err = nd_plan_build(V, h_rowptr, h_col, d_positions ? &given : nullptr, leaf_size, arity, smooth, B, nd_bisect_device, &ctx2, ND_ORDER_MINSEP, defer_push_lists, nd_embed_device);
     }
     if (timing) fprintf(stderr, "[nd_plan] suspect dissection: tried graph distances as well: %.1f factor numbers per vertex, spread %.2f (%s), %.3f s after the start\n",
                         B.words_per_vertex, B.spread, err.empty() ? (B.words_per_vertex < out.words_per_vertex ? "taken" : "not taken") : err.c_str(), now_s() - t0);

@@ -14,6 +14,7 @@
 #include "common.h"
 #include "nd_plan.h"
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <string.h>
 #include <string>
@@ -490,7 +491,7 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 // defined in direct.hip: builds the handle from plan + factor arrays and takes ownership of the device arrays
 extern "C" int ls_direct_create(const ls_direct_arrays* A, int device, void* stream, ls_direct** out);
 int ls_direct_adopt(ls_direct* d, void* const* owned, const size_t* owned_bytes, int n_owned, const double* seconds3, const double* quality4);
-namespace ls { hipStream_t side_stream(int device, int which); }
+namespace ls { hipStream_t side_stream(int device, int which); extern std::atomic<long long> g_malloc_calls, g_malloc_us, g_malloc_bytes; }
 bool direct_tier_fits(int levels, int arity, const int* s, const int* b, const int* own_start, int tier_levels, bool sparse_leaves, int waves);
 bool direct_tier_full16(int64_t V, int arity, int levels, int tier_levels, int shard_count, int tier_waves);
 
@@ -909,6 +910,10 @@ static int direct_factor_impl(const int32_t* d_rowptr, const int32_t* d_col, con
     cleanup(false);
     const double t3 = now_s();
     lap("numeric factorisation + solve tables (overlapped)");
+    if (timing) {
+        const long long nc = ls::g_malloc_calls.exchange(0), us = ls::g_malloc_us.exchange(0), by = ls::g_malloc_bytes.exchange(0);
+        fprintf(stderr, "[ls_direct_factor]   allocations that missed the pool since the last report: %lld hipMalloc calls, %.1f MB, %.2f ms\n", nc, by / 1048576.0, us / 1e3);
+    }
     const double secs[3] = {t1 - t0, t2 - t1, t3 - t2};
     const double quality[4] = {(double)P.ordering, P.words_per_vertex, P.spread, P.words_other};
     return ls_direct_adopt(*out, owned.data(), owned_bytes.data(), (int)owned.size(), secs, quality);

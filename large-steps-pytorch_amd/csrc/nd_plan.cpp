@@ -168,7 +168,9 @@ int bfs(int64_t V, const int32_t* rowptr, const int32_t* col, int start, std::ve
     int last = start;
     float d = 0.0f;
     while (!frontier.empty()) {
-        last = frontier[0];
+        // "the last vertex reached" = the SMALLEST index of the last level: independent of the order a level is discovered in (the device's
+        // sweeps, csrc/nd_bisect.hip nd_embed_device, fill their queues through atomics), and what tests/nd_plan_statement.py states
+        last = *std::min_element(frontier.begin(), frontier.end());
         next.clear();
         d += 1.0f;
         for (int u : frontier)
@@ -231,7 +233,7 @@ int nd_plan_rounds(int64_t V, int leaf_size, int arity) {
 }
 
 std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, const float* pos_in, int leaf_size, int arity,
-                          int smooth, NdPlan& P, NdBisectFn bisect, void* bisect_ctx, int ordering, bool defer_push_lists) {
+                          int smooth, NdPlan& P, NdBisectFn bisect, void* bisect_ctx, int ordering, bool defer_push_lists, NdEmbedFn embed) {
     const auto t_start = std::chrono::steady_clock::now();
     const bool timing = getenv("LS_PLAN_TIMING") != nullptr;
     auto faults = [] { struct rusage u; getrusage(RUSAGE_SELF, &u); return (long)u.ru_minflt; };
@@ -263,10 +265,16 @@ std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, 
         if (pos_in || minsep)
             parallel_for(V, 65536, [&](int64_t lo, int64_t hi) { for (int64_t v = lo; v < hi; ++v) if (rowptr[v + 1] <= rowptr[v]) { empty_row = true; break; } });
         const bool all_rows = !empty_row;
-        if (!pos_in || minsep) graph_embedding(V, rowptr, col, emb);
+        bool emb_on_device = false;
+        if (!pos_in || minsep) {
+            const std::string how = embed ? embed(bisect_ctx, V) : std::string("host");
+            if (how.empty()) emb_on_device = true;
+            else if (how == "host") graph_embedding(V, rowptr, col, emb);
+            else return how;
+        }
         lap("positions");
         const int passes = minsep ? (all_rows ? smooth : 0) : ((pos_in && all_rows) ? smooth : 0);
-        const std::string err = bisect(bisect_ctx, V, D, passes, (!pos_in || minsep) ? emb.data() : nullptr, node.data(), minsep ? ND_ORDER_MINSEP : ND_ORDER_LONGEST);
+        const std::string err = bisect(bisect_ctx, V, D, passes, ((!pos_in || minsep) && !emb_on_device) ? emb.data() : nullptr, node.data(), minsep ? ND_ORDER_MINSEP : ND_ORDER_LONGEST);
         if (!err.empty()) return err;
     } else {
         // ---- coordinates: NA candidate axes per vertex. Axes 0-2: the caller's positions (averaged `smooth` times over the matrix

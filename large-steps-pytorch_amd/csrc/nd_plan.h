@@ -76,10 +76,14 @@ struct NdPlan {
 enum { ND_ORDER_AUTO = -1, ND_ORDER_LONGEST = 0, ND_ORDER_MINSEP = 1 };
 double nd_plan_suspect();                                    // the threshold on NdPlan::spread (environment LS_ND_SUSPECT)
 typedef std::string (*NdBisectFn)(void* ctx, int64_t V, int D, int smooth, const double* embedded, int64_t* node, int ordering);
+// embed: when given (with bisect), the graph-distance embedding is first asked of the callee too (csrc/nd_bisect.hip: breadth-first sweeps on
+// the device, the result stays there and the bisect callee reads it): "" = done, "host" = this graph is one for the host's own sweeps (the
+// callee has made sure rowptr / col are complete on the host), anything else = an error text.
+typedef std::string (*NdEmbedFn)(void* ctx, int64_t V);
 int nd_plan_rounds(int64_t V, int leaf_size, int arity);
 std::string nd_plan_build(int64_t V, const int32_t* rowptr, const int32_t* col, const float* pos, int leaf_size, int arity,
                           int smooth, NdPlan& out, NdBisectFn bisect = nullptr, void* bisect_ctx = nullptr, int ordering = ND_ORDER_LONGEST,
-                          bool defer_push_lists = false);
+                          bool defer_push_lists = false, NdEmbedFn embed = nullptr);
 // the push lists of the down sweep (push_ptr / push_tgt): the last stage of nd_plan_build, or -- with defer_push_lists -- called by
 // ls_direct_factor while the device factorises (the factorisation does not need them: ~3 ms off the constructor's critical path at 1M)
 void nd_plan_push_lists(NdPlan& P);

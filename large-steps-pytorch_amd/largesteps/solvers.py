@@ -399,11 +399,50 @@ class NestedDissectionSolver(Solver):
     positive definite, RuntimeError when the mesh does not dissect into fronts that fit the kernels.
     """
 
+    # A remesh loop tells the library its own period: when the previous solver of the same size class (same device, vertex count
+    # within ~9 %) served at least this many solves, the next construction asks for the trial cuts (ordering='trial-cuts': 10-25 ms more
+    # constructor, 5-12 % fewer factor numbers on rough closed scans -- the 250k cotangent config 0.102 -> 0.090 ms per solve, i.e.
+    # ~1500 solves to earn the longer construction back; the better of the two plans is kept, so a flat sheet only loses the time).
+    # Only where the trial cuts were measured to pay (100k .. 600k vertices) and only when the caller left `ordering` to the library.
+    AUTO_TRIAL_CUTS_AFTER = 1500
+    _served = {}                     # (device index, size class) -> solves the last closed solver of that class served
+    _suspect = {}                    # (device index, size class) -> True: the automatic rule ended up with the trial cuts for the last mesh of that class
+
+    @staticmethod
+    def _size_class(V):
+        import math
+        return int(round(8.0 * math.log2(max(int(V), 1))))
+
+    def _surface_key(self, csr):
+        """the size class + the bounding box of the positions, each extent to ~19 %: 'the same surface, remeshed' (a folded sheet and a flat
+        one of the same vertex count differ in it). One small reduction and a host read per construction."""
+        key = getattr(self, "_surface_key_cached", None)
+        if key is None:
+            box = ()
+            if csr.positions is not None and csr.V:
+                import math
+                p = csr.positions.detach()
+                ext = (p.amax(0) - p.amin(0)).tolist()
+                box = tuple(int(round(4.0 * math.log2(e))) if e > 0 and math.isfinite(e) else -999 for e in ext)
+            key = self._surface_key_cached = self._class_key + box
+        return key
+
     def __init__(self, M, leaf_size=None, arity=None, shard=(0, 1), ordering=None, tier_waves=0):
         import time
         csr = _native.csr_of(M)
         self._csr = csr
         self.last_info = None
+        self.solves_served = 0
+        self._class_key = (csr.device.index, self._size_class(csr.V))
+        self.ordering_requested = ordering
+        if ordering is None and not os.environ.get("LS_ND_ORDER"):
+            if 100_000 <= csr.V <= 600_000 and self._served.get(self._class_key, 0) >= self.AUTO_TRIAL_CUTS_AFTER:
+                ordering = "trial-cuts"
+            elif self._suspect.get(self._surface_key(csr)):
+                # the automatic rule found the previous mesh of this size class folded / rough (its longest-axis plan was built, found suspect and
+                # replaced by the trial-cut plan): a remesh of the same surface will be too -- ask for the trial cuts at once, one plan instead of two
+                ordering = "trial-cuts"
+        self.ordering_used = ordering
         # a matrix that was not built by compute_matrix: the factorisation needs M = M^T (up to rounding: 1e-6 of the largest entry)
         if not _native.is_symmetric(csr):
             raise ValueError("NestedDissectionSolver: the matrix is not symmetric")
@@ -415,6 +454,10 @@ class NestedDissectionSolver(Solver):
         self.build_seconds = time.perf_counter() - t0
         self.timings = self._direct.timings
         self.plan_quality = self._direct.plan_quality
+        if self.ordering_requested is None and self.ordering_used is None:
+            if len(self._suspect) > 64:
+                self._suspect.clear()
+            self._suspect[self._surface_key(csr)] = self.plan_quality["ordering"] == "trial-cuts"
 
     @_native.retry_on_oom
     def solve(self, b, backward=False):
@@ -426,9 +469,14 @@ class NestedDissectionSolver(Solver):
         if b.dim() not in (1, 2) or b.shape[0] != self._csr.V:
             raise ValueError(f"Invalid right-hand side shape {tuple(b.shape)}: expected ({self._csr.V}, k)")
         squeeze = b.dim() == 1
-        b32 = (b.detach().unsqueeze(1) if squeeze else b.detach()).contiguous()
-        x = torch.empty_like(b32)
-        if b32.shape[1] <= _KMAX:                        # the common case (k = 3 coordinates): one native call, no column loop
+        self.solves_served += 1
+        if not squeeze and b.is_contiguous():            # the common case: (V, k) contiguous as it is -- no view, no copy (the pointer is all the call takes)
+            b32 = b
+            x = torch.empty(b.shape, dtype=torch.float32, device=b.device)
+        else:
+            b32 = (b.detach().unsqueeze(1) if squeeze else b.detach()).contiguous()
+            x = torch.empty_like(b32)
+        if b32.shape[1] <= _KMAX:                        # k = 3 coordinates: one native call, no column loop
             self._direct.solve(b32, x)
         else:
             for c0 in range(0, b32.shape[1], _KMAX):
@@ -445,7 +493,23 @@ class NestedDissectionSolver(Solver):
     def close(self):
         """Free the factor now instead of when the object dies (a remesh loop that keeps the old solver alive while it builds the next one
         pays for both at once)."""
+        self._note_served()
         self._direct.close()
+
+    def _note_served(self):
+        key = getattr(self, "_class_key", None)
+        if key is not None and self.solves_served:
+            served = NestedDissectionSolver._served
+            if len(served) > 64:
+                served.clear()
+            served[key] = self.solves_served
+            self._class_key = None
+
+    def __del__(self):
+        try:
+            self._note_served()
+        except Exception:           # interpreter shutdown
+            pass
 
     def info(self):
         return self._direct.info()
@@ -506,9 +570,11 @@ class CholeskySolver(Solver):
         if self._impl is None:
             self._impl = IterativeCholeskySolver(M, rtol=rtol, max_iter=max_iter, chebyshev=chebyshev, patch_columns=patch_columns)
         self.method = "iterative" if isinstance(self._impl, IterativeCholeskySolver) else "nested-dissection"
+        # the facade adds nothing to a solve: the instance attribute shadows the method below, one Python frame and one retry wrapper less
+        # per call (an eager optimisation step at the reference's mesh sizes is host-bound)
+        self.solve = self._impl.solve
 
-    @_native.retry_on_oom
-    def solve(self, b, backward=False):
+    def solve(self, b, backward=False):                  # (documentation and the class-level contract; instances call _impl.solve directly)
         return self._impl.solve(b, backward=backward)
 
     @property

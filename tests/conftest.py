@@ -60,3 +60,17 @@ class Golden:
 @pytest.fixture(scope="session")
 def golden():
     return Golden()
+
+
+@pytest.fixture(autouse=True)
+def _forget_solver_history():
+    """The direct solver remembers, per size class / surface, how long the previous solver served and whether the automatic rule ended up with
+    the trial cuts (largesteps/solvers.py: a remesh loop tells the library its own period). Process-global heuristics: every test starts
+    without them."""
+    try:
+        from largesteps.solvers import NestedDissectionSolver
+        NestedDissectionSolver._served.clear()
+        NestedDissectionSolver._suspect.clear()
+    except Exception:
+        pass
+    yield

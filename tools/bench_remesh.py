@@ -73,4 +73,7 @@ tot = float(r.sum())
 print(f"{workload}: V={vu.shape[0]} (soup of {v_src.shape[0]} rows), remesh every {period} steps")
 print(f"  rebuild per remesh: remove_duplicates {r[0]:.2f} ms | compute_matrix + to_differential {r[1]:.2f} ms | solver constructor "
       f"(analysis + factorisation, first solve) {r[2]:.2f} ms | optimizer + targets {r[3]:.2f} ms | total {tot:.1f} ms")
+ctor = np.array(rebuild)[:, 2] * 1e3
+steady = ctor[skip:]
+print(f"  solver constructor per cycle (ms): {' '.join(f'{c:.1f}' for c in ctor)}   steady cycles: min {steady.min():.1f} median {np.median(steady):.1f} max {steady.max():.1f}")
 print(f"  optimisation step: {s:.3f} ms  -> amortised over the period: {s + tot / period:.3f} ms per step ({100 * tot / period / (s + tot / period):.1f} % rebuild)")
