@@ -666,11 +666,11 @@ def launch_ranks(args):
 
 
 # kernels of ONE rank per solve and the part of them above the cut level, measured on one MI355X with the plan that rank gets
-# (tools/shard_rank_time.py -> profiles/r05_run5_shard_rank_kernel_times.txt); the whole-job prediction adds one latency-bound all-reduce
-SHARD_MODEL_FILE = "r05_run5_shard_rank_kernel_times.txt"
+# (tools/shard_rank_time.py -> profiles/r06_run1_shard_rank_kernel_times.txt); the whole-job prediction adds one latency-bound all-reduce
+SHARD_MODEL_FILE = "r06_run1_shard_rank_kernel_times.txt"
 SHARD_MODEL_US = {
-    "cfg4_plane1m": {1: (196.8, 0.0), 2: (146.6, 12.3), 4: (125.7, 12.3), 8: (122.2, 41.6)},
-    "cfg5_plane4m": {1: (700.3, 0.0), 2: (407.8, 21.9), 4: (292.4, 21.2), 8: (260.8, 71.4)},
+    "cfg4_plane1m": {1: (191.5, 0.0), 2: (147.4, 12.6), 4: (125.2, 19.0), 8: (121.6, 55.6)},
+    "cfg5_plane4m": {1: (711.2, 0.0), 2: (405.3, 21.5), 4: (284.5, 21.5), 8: (252.1, 71.9)},
 }
 SHARD_MODEL_COLLECTIVE_US = (15.0, 30.0)
 

@@ -127,7 +127,7 @@ def test_plain_multi_gpu_start_launches_the_ranks_itself(monkeypatch):
 
 def test_shard_model_is_the_committed_table():
     """the N > 1 line carries DESIGN.md section 5's prediction for its N (so that a SCALE record tests the model): the rows are the
-    per-rank kernel times of the committed profiles/r05_run5_shard_rank_kernel_times.txt"""
+    per-rank kernel times of the committed profiles/r06_run1_shard_rank_kernel_times.txt"""
     bench = load_bench()
     text = open(os.path.join(ROOT, "profiles", bench.SHARD_MODEL_FILE)).read()
     for wl, rows in bench.SHARD_MODEL_US.items():
