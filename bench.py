@@ -501,6 +501,7 @@ def report_direct(args, solver, M, u, x, tv, v, f, cfg, ms, t_assemble):
     # cycle (scripts/main.py:137-169: the old matrix and its solver are gone when the new one is built): the measured solver is closed first,
     # so that -- as in that loop -- its factor arrays are in the library's pool when the next construction asks for them
     repeat_seconds = steady_seconds = None
+    steady_cycles = []
     if not args.no_extra_baselines:
         try:
             from largesteps.solvers import NestedDissectionSolver
@@ -513,13 +514,14 @@ def report_direct(args, solver, M, u, x, tv, v, f, cfg, ms, t_assemble):
         except Exception:
             repeat_seconds = None
         try:
-            # and the steady state of a remesh loop: the fourth construction of the process (the second one still meets host memory
-            # it touches for the first time)
-            for _ in range(2):
+            # and the steady state of a remesh loop: six further constructions (the process' first four still meet pools, allocator blocks
+            # and host pages they touch for the first time: profiles/r06_f4_remesh_cycle.txt); steady = their MEDIAN, all six are listed
+            for _ in range(6):
                 s3 = NestedDissectionSolver(M)
-                steady_seconds = s3.build_seconds
+                steady_cycles.append(s3.build_seconds)
                 s3.close()
                 del s3
+            steady_seconds = sorted(steady_cycles)[len(steady_cycles) // 2]
         except Exception:
             steady_seconds = None
     out = dict(
@@ -544,9 +546,10 @@ def report_direct(args, solver, M, u, x, tv, v, f, cfg, ms, t_assemble):
                     # factor words of the tier's subtrees, one workgroup (one CU) each: the heaviest one is the tier launches' time
                     tier_balance=tier_bal, tier_workgroups=inf["tier_workgroups"],
                     factor_seconds=getattr(solver, "build_seconds", None), factor_seconds_second_construction=repeat_seconds, factor_seconds_steady=steady_seconds,
+                    factor_seconds_cycles=steady_cycles,
                     factor_seconds_note="first: the process' first construction (code objects loaded, thread pool started, fresh heap); second: right after the measured "
-                                        "solver was closed (its buffers in the pool); steady: the LAST of two further constructions -- single samples of a quantity that "
-                                        "varies 25-45 ms from pass to pass at 1M (host-side analysis), so steady may exceed second; spread over 6+ cycles: tools/bench_remesh.py",
+                                        "solver was closed (its buffers in the pool); cycles: six further constructions back to back; steady: their median (the first "
+                                        "four constructions of a process are slower than its steady state); inside a remesh loop: tools/bench_remesh.py, tools/ctor_in_loop.py",
                     factor_stages_seconds=dict(symbolic_analysis=tm["plan_seconds"], layouts_host=tm["table_seconds"], numeric_device_and_solve_tables=tm["factor_seconds"]),
                     solve_bytes=solve_bytes, solve_gbs=solve_bytes / (ms * 1e-3) / 1e9,
                     solve_frac_of_8tbs=solve_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
