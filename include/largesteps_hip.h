@@ -333,6 +333,12 @@ int ls_direct_create(const ls_direct_arrays* arrays, int device, void* stream, l
  * both hold what the factorisation will use. Host only (no device is touched): the rule is a table of measured crossovers
  * (profiles/r03_leaf_size_sweep.txt), documented in DESIGN.md section 2.3 (table: docs/history_rounds_1_4.md). */
 int ls_direct_pick_tree(int64_t V, int* leaf_size, int* arity);
+/* Host only: the dynamic LDS (bytes) one workgroup of the tier kernels needs to walk a subtree of the `tier_levels` deepest levels of a plan
+ * (h_s / h_b / h_own_start: per node id, 1-based, level-major -- what ls_nd_plan_arrays returns), with `waves` = 4, 8 or 16 waves per workgroup;
+ * 0 = such a tier cannot be planned (a level mixing sparse and dense leaves). ls_direct_factor takes the 16-wave tier only while this is <= 160 KB
+ * and the 4-wave one while it is <= 150 KB. sparse_leaves != 0: leaves of at most 64 rows are stored as triangle + sparse block. */
+int ls_direct_tier_lds_bytes(int levels, int arity, const int32_t* h_s, const int32_t* h_b, const int32_t* h_own_start, int tier_levels,
+                             int sparse_leaves, int waves, size_t* h_bytes);
 /* Matrix in, solver out: symbolic analysis (bisection rounds on the device, csrc/nd_bisect.hip; tree, fronts and index lists on
  * host threads), numeric multifrontal factorisation in fp64 on the device with hand-written kernels (csrc/nd_factor.hip: products
  * on the fp64 matrix instruction, SPD inverses in registers), fp32 factor in the solve kernels' layouts, handle. This one call is the

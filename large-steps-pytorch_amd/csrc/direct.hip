@@ -1129,9 +1129,18 @@ static size_t plan_tier(const std::vector<NodeD>& nd, const std::vector<int64_t>
 
 // Host only, called by ls_direct_factor BEFORE it lays the factor out: would a tier of `tier_levels` levels (sparse or dense leaves)
 // fit the tier kernels' LDS budget on this tree? (s, b, own_start: per node id, 1-based, level-major.)
+static size_t direct_tier_lds(int levels, int arity, const int* s, const int* b, const int* own_start, int tier_levels, bool sparse_leaves, int waves);
 bool direct_tier_fits(int levels, int arity, const int* s, const int* b, const int* own_start, int tier_levels, bool sparse_leaves, int waves) {
     if (tier_levels <= 0) return true;
     if (tier_levels > levels || tier_levels > TIER_MAX_H) return false;
+    const size_t bytes = direct_tier_lds(levels, arity, s, b, own_start, tier_levels, sparse_leaves, waves);
+    return bytes && bytes <= (size_t)(waves == TIER_WAVES_FULL ? 160 : 150) * 1024;
+}
+
+// Host only: the dynamic LDS in bytes a tier workgroup of `waves` waves needs for this tree (0 = the tier cannot be planned). Exported as
+// ls_direct_tier_lds_bytes: the CPU tests hold the 1M-vertex closed scan against the 160 KB of a CU with it (round 6: its leaves' 83 boundary
+// rows once made the 16-wave plan 2668 floats per wave -- 4 % over -- and the solve fell back, silently, to 11 launches).
+static size_t direct_tier_lds(int levels, int arity, const int* s, const int* b, const int* own_start, int tier_levels, bool sparse_leaves, int waves) {
     std::vector<int64_t> level_off((size_t)levels + 1);
     int64_t cnt = 1, off = 1;
     for (int lv = 0; lv <= levels; ++lv) { level_off[lv] = off; off += cnt; cnt *= arity; }
@@ -1150,7 +1159,16 @@ bool direct_tier_fits(int levels, int arity, const int* s, const int* b, const i
     std::vector<TierWG> wgs;
     int vec = 0, tri = 0;
     const size_t region = plan_tier(nd, level_off, levels, arity, root, 0, level_off[root + 1] - level_off[root], items, wgs, vec, tri, waves);
-    return region && ((region + 3) & ~(size_t)3) * sizeof(float) * waves <= (waves == TIER_WAVES_FULL ? 160 : 150) * 1024;
+    return region ? ((region + 3) & ~(size_t)3) * sizeof(float) * waves : 0;
+}
+
+extern "C" int ls_direct_tier_lds_bytes(int levels, int arity, const int32_t* h_s, const int32_t* h_b, const int32_t* h_own_start, int tier_levels,
+                                        int sparse_leaves, int waves, size_t* h_bytes) {
+    LS_REQUIRE(h_s && h_b && h_own_start && h_bytes && levels >= 1 && levels <= 30 && (arity == 2 || arity == 4 || arity == 8) &&
+               tier_levels >= 1 && tier_levels <= levels && tier_levels <= TIER_MAX_H && (waves == TIER_WAVES || waves == TIER_WAVES_WIDE || waves == TIER_WAVES_FULL),
+               LS_E_INVALID, "ls_direct_tier_lds_bytes: bad argument (1 <= tier_levels <= min(levels, %d); waves 4, 8 or 16)", TIER_MAX_H);
+    *h_bytes = direct_tier_lds(levels, arity, h_s, h_b, h_own_start, tier_levels, sparse_leaves != 0, waves);
+    return LS_OK;
 }
 
 // One workgroup of SIXTEEN waves per CU walking a subtree one level taller (round 5): at 1M vertices the 256 subtrees below level 4

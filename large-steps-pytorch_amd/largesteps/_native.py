@@ -99,6 +99,7 @@ _SIGNATURES = {
     "ls_patch_plan_info": (c_int, [c_void_p] + [ctypes.POINTER(c_int)] * 5 + [ctypes.POINTER(c_i64)] * 3 + [ctypes.POINTER(ctypes.c_double)]),
     "ls_patch_plan_arrays": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ls_direct_level_words": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "ls_direct_tier_lds_bytes": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_size_t)]),
     "ls_direct_level_index_bytes": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "ls_direct_tier_balance": (c_int, [c_void_p, ctypes.POINTER(c_double * 4)]),
     "ls_direct_level_rows": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),

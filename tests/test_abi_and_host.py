@@ -291,3 +291,29 @@ def test_out_of_memory_in_torch_empties_the_pool_and_retries_once(native):
     from largesteps import geometry, normals, solvers
     for fn in (geometry.compute_matrix, normals.compute_vertex_normals, solvers.NestedDissectionSolver.solve, solvers.ConjugateGradientSolver.solve):
         assert hasattr(fn, "__wrapped__"), fn
+
+
+def test_direct_options_struct_and_argument_checks_without_a_device(native):
+    """ls_direct_options (round 6): the defaults, the size field, and the argument checks that come before any device call -- the constructor's
+    choices are arguments of the C ABI, not environment variables."""
+    import ctypes
+    lib = native.lib()
+    opt = native.DirectOptions()
+    native.check(lib.ls_direct_options_default(ctypes.byref(opt)))
+    assert ctypes.sizeof(native.DirectOptions) == 36 and opt.struct_bytes == 36
+    assert (opt.leaf_size, opt.arity, opt.tier_levels, opt.sparse_leaves, opt.shard_rank, opt.shard_count, opt.ordering, opt.tier_waves) == (0, 0, -1, 1, 0, 1, -1, 0)
+    with pytest.raises(ValueError, match="null"):
+        native.check(lib.ls_direct_options_default(None))
+    h = ctypes.c_void_p()
+    dummy = ctypes.c_void_p(16)          # never dereferenced: the checks below fail first
+    for field, value, what in (("ordering", 7, "ordering"), ("tier_waves", 5, "tier_waves"), ("struct_bytes", 0, "struct_bytes")):
+        bad = native.DirectOptions()
+        native.check(lib.ls_direct_options_default(ctypes.byref(bad)))
+        setattr(bad, field, value)
+        with pytest.raises(ValueError, match=what):
+            native.check(lib.ls_direct_factor_ex(dummy, dummy, dummy, 10, 10, None, ctypes.byref(bad), 0, None, ctypes.byref(h)))
+    with pytest.raises(ValueError, match="bad argument"):           # null matrix: refused before the device is touched
+        native.check(lib.ls_direct_factor_ex(None, None, None, 10, 10, None, None, 0, None, ctypes.byref(h)))
+    import os
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "largesteps_hip.h")).read()
+    assert "typedef struct ls_direct_options" in hdr and "int ls_direct_factor_ex(" in hdr and "#define LS_VERSION 110" in hdr

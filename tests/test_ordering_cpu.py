@@ -191,3 +191,40 @@ def test_automatic_choice_on_meshes_that_mislead_cutting_planes(name):
     assert auto.words_per_vertex <= 1.25 * min(axis.words_per_vertex, graph.words_per_vertex), (auto.words_per_vertex, axis.words_per_vertex, graph.words_per_vertex)
     assert auto.words_per_vertex <= axis.words_per_vertex and auto.spread <= 1.3
     assert int((auto.s + auto.b).max()) <= 8000            # the direct solver's front limit
+
+
+def _tier_lds(p, tier_levels, waves):
+    n = ctypes.c_size_t(0)
+    s32, b32, o32 = (np.ascontiguousarray(a, dtype=np.int32) for a in (p.s, p.b, p.own_start))
+    as_p = lambda a: a.ctypes.data_as(ctypes.c_void_p)   # noqa: E731
+    _native.check(_native.lib().ls_direct_tier_lds_bytes(int(p.levels), int(p.arity), as_p(s32), as_p(b32), as_p(o32), tier_levels, 1, waves, ctypes.byref(n)))
+    return n.value
+
+
+def test_one_million_vertex_closed_scan_fits_the_sixteen_wave_tier():
+    """Round 6's finding, held on the CPU: every mesh >= 800k vertices of rounds 1-5 was a plane (leaves of <= 37 boundary rows). The shipped
+    planner on cfg3's recipe at the headline size -- a closed noisy sphere, 998 562 vertices -- gives leaves of up to 83 boundary rows, a root
+    separator of ~3400 rows and subtrees 1.2-1.3x apart; with the down sweep's x_bnd BEHIND the leaf triangle in LDS its 16-wave tier needed
+    2668 floats per wave (limit 2560) and the solver fell back, silently, to 11 launches on three workgroups per CU (315 us per solve). With
+    x_bnd staged IN the triangle area the need is triangle + one vector whatever the boundary: the 4-level tier on 16 waves must fit 160 KB
+    (and the 3-level tier on 4 waves four workgroups' worth: 40 KB each)."""
+    v, f, _ = synthetic.config_mesh("cfg4b_sphere1m")
+    rowptr, col = pattern(f, v.shape[0])
+    p = native_plan(rowptr, col, v, 64, 4, ordering=-1)
+    assert p.levels == 8 and p.ordering == 1 and 200.0 < p.words_per_vertex < 235.0, (p.levels, p.ordering, p.words_per_vertex)
+    leaves = np.arange(p.level_off[p.levels - 1], p.level_off[p.levels])
+    assert p.s[leaves].max() <= 64 and p.b[leaves].max() > 64, "the case this test exists for: leaves with more boundary rows than a wave has lanes"
+    assert 3000 < p.s[1] < 4000
+    lds16 = _tier_lds(p, 4, 16)
+    assert 0 < lds16 <= 160 * 1024, lds16
+    lds4 = _tier_lds(p, 3, 4)
+    assert 0 < lds4 <= 40 * 1024, lds4                     # four workgroups per CU, as on the plane
+    # the plane of the same size, for scale: same budget, smaller boundaries
+    vp, fp, _ = synthetic.config_mesh("cfg4_plane1m")
+    rp, cp = pattern(fp, vp.shape[0])
+    pp = native_plan(rp, cp, vp, 64, 4, ordering=-1)
+    assert pp.b[np.arange(pp.level_off[7], pp.level_off[8])].max() < 64 and _tier_lds(pp, 4, 16) <= lds16
+    with pytest.raises(ValueError, match="tier_levels"):
+        _tier_lds(p, 9, 16)
+    with pytest.raises(ValueError, match="waves"):
+        _tier_lds(p, 3, 5)
