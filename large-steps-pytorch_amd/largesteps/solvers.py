@@ -394,7 +394,10 @@ class NestedDissectionSolver(Solver):
     inside each other) is recognised by its thick separators and dissected again with graph distances among the cutting directions
     (`plan_quality['ordering'] == 'trial-cuts'`). ordering='trial-cuts' (or LS_ND_ORDER=1) asks for those trial cuts always: 5-10 % fewer
     factor numbers on rough closed scans (the 250k cotangent config: 0.102 -> 0.090 ms per solve) for 10-25 ms more constructor --
-    worth it for a long captured run on one mesh; 'longest-axis' never tries them; None / 'auto' is the library's rule.
+    worth it for a long captured run on one mesh; 'longest-axis' never tries them; 'auto' is the library's rule for THIS matrix alone;
+    None (the default) is that rule plus what the process has learnt from its previous solvers of the same size class -- a surface the rule
+    found suspect once gets the trial cuts at once at its next construction (one plan instead of two: a remesh of a closed scan at 1M
+    vertices constructs in 78 ms instead of 150), and a size class whose previous solver served >= AUTO_TRIAL_CUTS_AFTER solves gets them too.
     tier_waves=4 / 8 / 16 picks the tier kernel's workgroup shape (0: the library's rule; A/B runs and tests). Raises ValueError when the matrix is not symmetric or not
     positive definite, RuntimeError when the mesh does not dissect into fronts that fit the kernels.
     """
